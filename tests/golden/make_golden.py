@@ -1,0 +1,425 @@
+"""Generates tests/golden/*.npz by running the UC-NeRF reference's own Python on seeded inputs.
+
+Run in the build container only (needs /root/reference):  python tests/golden/make_golden.py
+The reference has no tests/fixtures of its own; these captured vectors are what
+pins the oracle (oracle/ucnerf_oracle.py) and, through it, the HIP kernels.  Fixtures hold data only:
+inputs (including every random draw, captured by re-seeding) and the reference's outputs.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_import  # noqa: E402
+
+ref = _ref_import.load()
+torch.set_num_threads(1)   # fixtures must not depend on intra-op partitioning
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s %8.1f KB  %d arrays" % (name, os.path.getsize(path) / 1024, len(out)))
+
+
+def rand_pose(g, scale=0.15):
+    """Small random rotation (Rodrigues) + translation -> 4x4."""
+    w = (torch.rand(3, generator=g) - 0.5) * 2 * scale
+    th = w.norm()
+    k = w / th
+    Kx = torch.tensor([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = torch.eye(3) + torch.sin(th) * Kx + (1 - torch.cos(th)) * (Kx @ Kx)
+    M = torch.eye(4)
+    M[:3, :3] = R
+    M[:3, 3] = (torch.rand(3, generator=g) - 0.5) * 0.2
+    return M
+
+
+# ------------------------------------------------------------------ G1 ray generation
+def g1():
+    g = torch.Generator().manual_seed(101)
+    H, W = 16, 20
+    K = torch.tensor([[21.5, 0, 9.25], [0, 19.75, 8.5], [0, 0, 1]])
+    c2w = rand_pose(g)
+    dirs = ref.ray_utils.get_ray_directions(H, W, K)
+    ro, rd = ref.ray_utils.get_rays(dirs, c2w[:3, :4])
+    mo, md, mpix = ref.utils.get_rays_mvs(H, W, K, c2w, isRandom=False, chunk=64, idx=2)
+    fo, fd, fpix = ref.utils.get_rays_mvs(H, W, K, c2w, isRandom=False)
+    ho, hd = ref.helpers.get_rays(H, W, 23.0, c2w[:3, :4])
+    # 400x400 plumbing config: corner crop only (c1)
+    K4 = torch.tensor([[500., 0, 200], [0, 500, 200], [0, 0, 1]])
+    d4 = ref.ray_utils.get_ray_directions(400, 400, K4)
+    o4, r4 = ref.ray_utils.get_rays(d4, c2w[:3, :4])
+    sel = torch.tensor([0, 1, 399, 400, 79999, 159999])
+    save("g1_raygen", H=H, W=W, K=K, c2w=c2w, dirs=dirs, rays_o=ro, rays_d=rd, mvs_o=mo, mvs_d=md, mvs_pix=mpix,
+         mvs_full_d=fd, mvs_full_pix=fpix, gl_focal=23.0, gl_o=ho, gl_d=hd, K400=K4, sel400=sel, d400=r4[sel],
+         o400=o4[sel])
+
+
+# ------------------------------------------------------------------ G2 NDC ray warp
+def g2():
+    g = torch.Generator().manual_seed(102)
+    N = 64
+    ro = torch.randn(N, 3, generator=g) * 0.3
+    rd = torch.randn(N, 3, generator=g)
+    rd[:, 2] = -rd[:, 2].abs() - 0.2
+    o1, d1 = ref.ray_utils.get_ndc_rays(48, 64, [55.0, 57.5], 1.0, ro, rd)
+    o2, d2 = ref.helpers.ndc_rays(48, 64, 55.0, 1.0, ro, rd)
+    save("g2_ndc_rays", H=48, W=64, focal2=[55.0, 57.5], focal=55.0, near=1.0, rays_o=ro, rays_d=rd, o_ru=o1, d_ru=d1,
+         o_h=o2, d_h=d2)
+
+
+# ------------------------------------------------------------------ G3 depth sampling
+def g3():
+    g = torch.Generator().manual_seed(103)
+    N, S = 48, 64
+    rays = torch.cat([torch.randn(N, 3, generator=g) * 0.1, torch.randn(N, 3, generator=g),
+                      1.0 + torch.rand(N, 1, generator=g), 3.0 + torch.rand(N, 1, generator=g)], -1)
+    p0, _, _, z0 = ref.ray_utils.ray_marcher(rays, S, perturb=0)
+    pl, _, _, zl = ref.ray_utils.ray_marcher(rays, S, lindisp=True, perturb=0)
+    torch.manual_seed(7)
+    noise = torch.rand(N, S)
+    torch.manual_seed(7)
+    p1, _, _, z1 = ref.ray_utils.ray_marcher(rays, S, perturb=1.0)
+    torch.manual_seed(7)
+    p5, _, _, z5 = ref.ray_utils.ray_marcher(rays, S, perturb=0.5)
+    # live cascade sampler (utils/utils.py:684-706) via build_rays_test on a tiny scene
+    H, W, NS = 8, 12, 9
+    outputs = {}
+    for k, d in (("stage1", 4), ("stage2", 2), ("stage3", 1)):
+        lo = 1.0 + torch.rand(1, 1, H // d, W // d, generator=g)
+        outputs[k] = {"depth_values": torch.cat([lo, lo + 0.3, lo + 0.5 + torch.rand(1, 1, H // d, W // d, generator=g)], 1)}
+    K = torch.tensor([[10., 0, 6], [0, 10, 4], [0, 0, 1]])
+    c2w, w2c = rand_pose(g), rand_pose(g)
+    near_fars = torch.tensor([[1.0, 4.0], [1.0, 4.0]])
+    torch.manual_seed(11)
+    t_rand = torch.rand(32, NS)
+    torch.manual_seed(11)
+    pts, rdir, ndc, zc, ro, _ = ref.utils.build_rays_test(H, W, c2w, w2c, K, near_fars, near_fars[-1], NS, chunk=32,
+                                                          idx=1, outputs=outputs)
+    save("g3_sampling", rays=rays, S=S, z_det=z0, pts_det=p0, z_lindisp=zl, noise=noise, z_p1=z1, pts_p1=p1, z_p05=z5,
+         bt_H=H, bt_W=W, bt_NS=NS, bt_K=K, bt_c2w=c2w, bt_w2c=w2c, bt_near_fars=near_fars, bt_t_rand=t_rand,
+         bt_dv1=outputs["stage1"]["depth_values"], bt_dv2=outputs["stage2"]["depth_values"],
+         bt_dv3=outputs["stage3"]["depth_values"], bt_pts=pts, bt_dir=rdir, bt_z=zc, bt_o=ro,
+         bt_ndc1=ndc["stage1"], bt_ndc2=ndc["stage2"], bt_ndc3=ndc["stage3"], bt_ndc=ndc["ndc"])
+
+
+# ------------------------------------------------------------------ G4 projection to reference view
+def g4():
+    g = torch.Generator().manual_seed(104)
+    N, S = 24, 10
+    w2c = rand_pose(g)
+    K = torch.tensor([[31., 0.3, 20.], [0, 29., 16.], [0, 0, 1]])
+    pts = torch.randn(N, S, 3, generator=g) * 0.5 + torch.tensor([0., 0., 2.0])
+    # rows that hit the |z| < 1e-4 clamp: put camera-space z at +-5e-5 / 0
+    Rinv, t = w2c[:3, :3].T, w2c[:3, 3]
+    for i, zc in enumerate((5e-5, -5e-5, 0.0, 9.9e-5)):
+        pc = torch.tensor([0.3 * (i + 1), -0.2, zc])
+        pts[0, i] = (pc - t) @ Rinv.T
+    inv_scale = torch.tensor([39, 31])
+    nf = {}
+    for k in ("1", "2", "3"):
+        nf["near_" + k] = 0.5 + torch.rand(N, S, 1, generator=g)
+        nf["far_" + k] = 3.0 + torch.rand(N, S, 1, generator=g)
+    nf["near"], nf["far"] = torch.tensor(0.8), torch.tensor(4.5)
+    out = ref.utils.get_ndc_coordinate(w2c, K, pts.clone(), inv_scale, nf)
+    q2d = ref.utils.get_ndc_coordinate(w2c, K, pts.clone(), inv_scale, sample_2d=True)
+    save("g4_ndc_coord", w2c=w2c, K=K, pts=pts, inv_scale=inv_scale, q2d=q2d,
+         **{k: v for k, v in nf.items()}, **{"out_" + k: v for k, v in out.items()})
+
+
+# ------------------------------------------------------------------ G5 positional encodings
+def g5():
+    g = torch.Generator().manual_seed(105)
+    x = torch.cat([torch.rand(40, 3, generator=g), (torch.rand(24, 3, generator=g) - 0.5) * 1200.0])
+    e10, d10 = ref.models.get_embedder(10, 0)
+    e4, d4 = ref.models.get_embedder(4, 0)
+    h10, _ = ref.helpers.get_embedder(10, 0)
+    h4, _ = ref.helpers.get_embedder(4, 0)
+    x3 = x.reshape(8, 8, 3)
+    save("g5_embed", x=x, live10=e10(x), live4=e4(x), live10_3d=e10(x3), inter10=h10(x), inter4=h4(x), d10=d10, d4=d4)
+
+
+# ------------------------------------------------------------------ G6 the MLP
+def make_net(V):
+    """Seeded reference network; the V=7 one is shared by g6/g10/g11 (state_dict stored once, sd_v7.npz)."""
+    torch.manual_seed(600 + V)
+    return ref.models.UCNeRF(D=6, W=128, input_ch_pts=63, input_ch_views=27, input_ch_feat=24 + (V - 1) * 12 + 1,
+                             skips=[4], view_num=V)
+
+
+def g6():
+    save("sd_v7", **{k: v for k, v in make_net(7).state_dict().items()})
+    for V, tag in ((7, "v7"), (4, "v4")):
+        F = 24 + (V - 1) * 12 + 1
+        net = make_net(V)
+        g = torch.Generator().manual_seed(106 + V)
+        M = 96
+        x = torch.cat([torch.randn(M, 63, generator=g).clamp(-1, 1), torch.randn(M, F - 1, generator=g),
+                       torch.rand(M, 1, generator=g), torch.randn(M, 27, generator=g).clamp(-1, 1)], -1)
+        x.requires_grad_(True)
+        r = torch.randn(M, 4, generator=g)
+        out = net(x)
+        (out * r).sum().backward()
+        extra = {}
+        if V == 7:   # parameter grads for the shared network; names of params the reference leaves without grad
+            extra = {"grad." + k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+            extra["no_grad_names"] = np.array([k for k, p in net.named_parameters() if p.grad is None])
+        else:
+            extra = {"sd." + k: v for k, v in net.state_dict().items()}
+        save("g6_mlp_" + tag, V=V, x=x.detach(), r=r, out=out, grad_x=x.grad, **extra)
+
+
+# ------------------------------------------------------------------ G7 feature gather
+def tiny_scene(g, V=7, H=32, W=40, D=(6, 4, 2)):
+    vols = [torch.randn(1, 8, D[0], H // 4, W // 4, generator=g), torch.randn(1, 8, D[1], H // 2, W // 2, generator=g),
+            torch.randn(1, 8, D[2], H, W, generator=g)]
+    imgs = torch.rand(1, V - 1, 3, H, W, generator=g)
+    img_feat = torch.randn(V - 1, 1, 8, H, W, generator=g)
+    conf = torch.rand(H, W, generator=g).clamp(1e-3, 1)
+    K = torch.tensor([[30., 0, W / 2], [0, 30., H / 2], [0, 0, 1]])
+    w2cs = torch.stack([rand_pose(g, 0.05) for _ in range(V)])
+    return vols, imgs, img_feat, conf, K, w2cs
+
+
+def g7():
+    g = torch.Generator().manual_seed(107)
+    V, H, W = 7, 32, 40
+    vols, imgs, img_feat, conf, K, w2cs = tiny_scene(g, V, H, W)
+    N, S = 20, 12
+    pts = torch.randn(N, S, 3, generator=g) * torch.tensor([1.2, 1.0, 0.8]) + torch.tensor([0., 0., 2.2])
+    pts[0, :3] = torch.tensor([[50., 0, 1.0], [0, -50., 1.0], [0, 0, -1.0]])     # far outside / behind
+    inv_scale = torch.tensor([W - 1, H - 1])
+    nf = {}
+    for k in ("1", "2", "3"):
+        nf["near_" + k] = 1.0 + 0.5 * torch.rand(N, S, 1, generator=g)
+        nf["far_" + k] = 3.0 + 0.5 * torch.rand(N, S, 1, generator=g)
+    nf["near"], nf["far"] = torch.tensor(1.0), torch.tensor(4.0)
+    ndc = ref.utils.get_ndc_coordinate(w2cs[0], K, pts.clone(), inv_scale, nf)
+    # exact pixel centres / image edges in the stage grids
+    ndc["stage3"][1, 0] = torch.tensor([0.0, 0.0, 0.0])
+    ndc["stage3"][1, 1] = torch.tensor([1.0, 1.0, 1.0])
+    ndc["stage1"][1, 2] = torch.tensor([0.5, 0.5, 0.5])
+    for v in vols + [img_feat, conf]:
+        v.requires_grad_(True)
+    volume_feature = {"stage%d" % (i + 1): {"volume_feature_no_ref": vols[i]} for i in range(3)}
+    pose = {"w2cs": w2cs[1:].clone(), "intrinsics": K.repeat(V - 1, 1, 1)}
+    rf, cs = ref.utils.index_point_feature(volume_feature, conf.reshape(1, 1, 1, H, W), ndc)
+    cv = ref.utils.build_color_volume(pts, pose, imgs, None, img_feat, with_mask=True)
+    feats = ref.renderer.gen_pts_feats(imgs, volume_feature, pts, pose, ndc, 24 + 12 * (V - 1) + 1, img_feat,
+                                       confidence=conf)
+    r = torch.randn(feats.shape, generator=g)
+    (feats * r).sum().backward()
+    save("g7_gather", V=V, H=H, W=W, K=K, w2cs=w2cs, pts=pts, vol1=vols[0], vol2=vols[1], vol3=vols[2], imgs=imgs,
+         img_feat=img_feat, conf=conf, ndc1=ndc["stage1"], ndc2=ndc["stage2"], ndc3=ndc["stage3"], ndc=ndc["ndc"],
+         ray_feats=rf, conf_sampled=cs, color_volume=cv, feats=feats, r=r, g_vol1=vols[0].grad, g_vol2=vols[1].grad,
+         g_vol3=vols[2].grad, g_img_feat=img_feat.grad, g_conf=conf.grad)
+
+
+# ------------------------------------------------------------------ G8 sample_pdf
+def g8():
+    g = torch.Generator().manual_seed(108)
+    N, L, M = 160, 63, 128
+    z = torch.sort(1.0 + 3.0 * torch.rand(N, L + 1, generator=g), -1)[0]
+    bins = .5 * (z[:, 1:] + z[:, :-1])
+    w = torch.rand(N, L - 1, generator=g) ** 4
+    w[0] = 0.0                                  # all-zero weights
+    w[1] = 0.0; w[1, 17] = 1.0                  # one-hot
+    w[2] = 1e-9 * torch.rand(L - 1, generator=g)  # tiny totals
+    w[3] = 0.0; w[3, 0] = 5.0; w[3, -1] = 5.0   # mass at both ends
+    w[4] = 1e4 * torch.rand(L - 1, generator=g)
+    det = ref.ray_utils.sample_pdf(bins, w, M, det=True)
+    det_h = ref.helpers.sample_pdf(bins, w, M, det=True)
+    torch.manual_seed(21)
+    u = torch.rand(N, M)
+    # u exactly on cdf edges for some rows: recompute cdf the way the reference does
+    ww = w + 1e-5
+    cdf = torch.cat([torch.zeros(N, 1), torch.cumsum(ww / torch.sum(ww, -1, keepdim=True), -1)], -1)
+    u[5:40, :L] = cdf[5:40]
+    u[5:40, L:L + 8] = torch.tensor([0.0, 1.0, 0.99999994, 1e-8, 0.5, 0.25, 0.75, 1.0])
+    # monkeypatch torch.rand inside the reference call to return our u (captures the random branch)
+    orig = torch.rand
+    torch.rand = lambda *a, **k: u.clone()
+    try:
+        rnd = ref.ray_utils.sample_pdf(bins, w, M, det=False)
+    finally:
+        torch.rand = orig
+    inds = torch.searchsorted(cdf, u.contiguous(), right=True)
+    inds_det = torch.searchsorted(cdf, torch.linspace(0., 1., M).expand(N, M).contiguous(), right=True)
+    pyt = ref.ray_utils.sample_pdf(bins[:16], w[:16], M, det=False, pytest=True)
+    np.random.seed(0)
+    u_py = np.random.rand(16, M)
+    save("g8_sample_pdf", bins=bins, weights=w, M=M, samples_det=det, samples_det_helpers=det_h, u=u, samples_u=rnd,
+         cdf=cdf, inds_u=inds, inds_det=inds_det, samples_pytest=pyt, u_pytest=torch.Tensor(u_py))
+    # the ragged-length rowsum pin: sums of rows of every length 1..70
+    rows = {}
+    gg = torch.Generator().manual_seed(1108)
+    for n in list(range(1, 71)) + [127, 128, 190, 191]:
+        x = torch.rand(12, n, generator=gg) ** 3
+        rows["x%d" % n] = x
+        rows["s%d" % n] = torch.sum(x, -1)
+        rows["c%d" % n] = torch.cumsum(x, -1)
+    save("g8_rowsum", **rows)
+
+
+# ------------------------------------------------------------------ G9 compositing
+def g9():
+    g = torch.Generator().manual_seed(109)
+    out = {}
+    for S in (64, 192, 90):
+        N = 40
+        raw = torch.cat([torch.rand(N, S, 3, generator=g), torch.relu(torch.randn(N, S, 1, generator=g)) * 2], -1)
+        raw[0, :, 3] = 0.0                       # empty ray
+        raw[1, :, 3] = 50.0                      # saturated from the first sample
+        raw[2, :, 3] = 0.0; raw[2, S // 2, 3] = 30.0
+        z = torch.sort(1.0 + 3 * torch.rand(N, S, generator=g), -1)[0]
+        raw.requires_grad_(True)
+        for wb in (False, True):
+            res = ref.renderer.raw2outputs(raw, z, None, wb, "v2")
+            tag = "S%d_wb%d_" % (S, wb)
+            for name, t in zip(("rgb", "disp", "acc", "weights", "depth", "alpha", "var"), res):
+                out[tag + name] = t
+        r3, r1 = torch.randn(N, 3, generator=g), torch.randn(N, generator=g)
+        res = ref.renderer.raw2outputs(raw, z, None, False, "v2")
+        (res[0] * r3).sum().add((res[4] * r1).sum()).backward()
+        out.update({"S%d_raw" % S: raw.detach(), "S%d_z" % S: z, "S%d_r3" % S: r3, "S%d_r1" % S: r1,
+                    "S%d_graw" % S: raw.grad})
+        # nerf-pytorch style variant
+        rays_d = torch.randn(N, 3, generator=g)
+        rawh = torch.randn(N, S, 4, generator=g)
+        resh = ref.helpers.raw2outputs(rawh, z, rays_d, 0, False)
+        resw = ref.helpers.raw2outputs(rawh, z, rays_d, 0, True)
+        for name, t in zip(("rgb", "disp", "acc", "weights", "depth"), resh):
+            out["S%d_h_" % S + name] = t
+        out.update({"S%d_h_raw" % S: rawh, "S%d_h_rays_d" % S: rays_d, "S%d_h_rgb_wb" % S: resw[0]})
+        cosang = rays_d.norm(dim=-1)
+        out["S%d_dists" % S] = ref.renderer.depth2dist(z, cosang)
+    save("g9_composite", **out)
+
+
+# ------------------------------------------------------------------ G10 rendering(), first and second call
+class Args:
+    pass
+
+
+def mk_args(V):
+    a = Args()
+    a.view_num, a.feat_dim, a.img_downscale, a.use_color_volume, a.net_type = V, 24 + 12 * (V - 1) + 1, 1.0, False, "v2"
+    a.netchunk, a.multires, a.multires_views, a.i_embed = 1024, 10, 4, 0
+    return a
+
+
+def g10():
+    g = torch.Generator().manual_seed(110)
+    V, H, W = 7, 32, 40
+    vols, imgs, img_feat, conf, K, w2cs = tiny_scene(g, V, H, W)
+    net = make_net(V)
+    e_p, _ = ref.models.get_embedder(10, 0)
+    e_d, _ = ref.models.get_embedder(4, 0)
+    qfn = lambda pts, vd, f, fn: ref.renderer.run_network_mvs(pts, vd, f, fn, embed_fn=e_p, embeddirs_fn=e_d, netchunk=8)
+    N, S = 24, 12
+    c2w = rand_pose(g, 0.05)
+    xs, ys = torch.randint(0, W, (N,), generator=g).float(), torch.randint(0, H, (N,), generator=g).float()
+    dirs = torch.stack([(xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1], torch.ones_like(xs)], -1)
+    rays_d = dirs @ c2w[:3, :3].T
+    z = torch.sort(1.0 + 3.0 * torch.rand(N, S, generator=g), -1)[0]
+    pts = c2w[:3, 3].reshape(1, 1, 3) + rays_d[:, None] * z[..., None]
+    inv_scale = torch.tensor([W - 1, H - 1])
+    nf = {}
+    for k in ("1", "2", "3"):
+        nf["near_" + k] = torch.full((N, S, 1), 1.0)
+        nf["far_" + k] = torch.full((N, S, 1), 4.0)
+    nf["near"], nf["far"] = torch.tensor(1.0), torch.tensor(4.0)
+    ndc = ref.utils.get_ndc_coordinate(w2cs[0], K, pts.clone(), inv_scale, nf)
+    volume_feature = {"stage%d" % (i + 1): {"volume_feature_no_ref": vols[i]} for i in range(3)}
+    pose = {"w2cs": w2cs.clone(), "intrinsics": K.repeat(V, 1, 1)}
+    a = mk_args(V)
+    with torch.no_grad():
+        rgb1, d1 = ref.renderer.rendering(a, pose, pts, ndc, z, rays_d, volume_feature, imgs, network_fn=net,
+                                          img_feat=img_feat, network_query_fn=qfn, confidence=conf)
+        n_after = pose["w2cs"].shape[0]
+        rgb2, d2 = ref.renderer.rendering(a, pose, pts, ndc, z, rays_d, volume_feature, imgs, network_fn=net,
+                                          img_feat=img_feat, network_query_fn=qfn, confidence=conf)
+        rgbw, _ = ref.renderer.rendering(a, {"w2cs": w2cs.clone(), "intrinsics": K.repeat(V, 1, 1)}, pts, ndc, z,
+                                         rays_d, volume_feature, imgs, network_fn=net, img_feat=img_feat,
+                                         network_query_fn=qfn, white_bkgd=True, confidence=conf)
+    save("g10_rendering", V=V, H=H, W=W, K=K, w2cs=w2cs, c2w=c2w, xs=xs, ys=ys, z=z, pts=pts, rays_d=rays_d,
+         vol1=vols[0], vol2=vols[1], vol3=vols[2], imgs=imgs, img_feat=img_feat, conf=conf,
+         ndc1=ndc["stage1"], ndc2=ndc["stage2"], ndc3=ndc["stage3"], ndc=ndc["ndc"], rgb_first=rgb1, depth_first=d1,
+         rgb_second=rgb2, depth_second=d2, rgb_white=rgbw, n_w2cs_after_first=n_after)
+
+
+# ------------------------------------------------------------------ G11 coarse -> fine composition
+def g11():
+    g = torch.Generator().manual_seed(111)
+    V, H, W = 7, 32, 40
+    vols, imgs, img_feat, conf, K, _ = tiny_scene(g, V, H, W)
+    w2cs = torch.eye(4).repeat(V, 1, 1)
+    w2cs[:, 0, 3] = 0.01 * torch.arange(V)
+    net = make_net(V)
+    # scale sigma head so that weights are non-trivial along the ray
+    with torch.no_grad():
+        net.nerf.alpha_linear.weight.mul_(0.05); net.nerf.alpha_linear_1.weight.mul_(0.05)
+        net.nerf.alpha_linear.bias.add_(0.05); net.nerf.alpha_linear_1.bias.add_(0.05)
+    e_p, _ = ref.models.get_embedder(10, 0)
+    e_d, _ = ref.models.get_embedder(4, 0)
+    qfn = lambda pts, vd, f, fn: ref.renderer.run_network_mvs(pts, vd, f, fn, embed_fn=e_p, embeddirs_fn=e_d, netchunk=64)
+    N, NC, NF = 128, 64, 128
+    c2w = torch.eye(4)
+    xs, ys = torch.randint(0, W, (N,), generator=g).float(), torch.randint(0, H, (N,), generator=g).float()
+    ro, rd, _ = None, None, None
+    dirs = torch.stack([(xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1], torch.ones_like(xs)], -1)
+    rd = dirs @ c2w[:3, :3].T
+    rays = torch.cat([c2w[:3, 3].expand(N, 3), rd, torch.full((N, 1), 1.0), torch.full((N, 1), 4.0)], -1)
+    volume_feature = {"stage%d" % (i + 1): {"volume_feature_no_ref": vols[i]} for i in range(3)}
+    inv_scale = torch.tensor([W - 1, H - 1])
+    a = mk_args(V)
+
+    def one_pass(z):
+        S = z.shape[1]
+        pts = rays[:, None, :3] + rays[:, None, 3:6] * z[..., None]
+        nf = {}
+        for k in ("1", "2", "3"):
+            nf["near_" + k] = torch.full((N, S, 1), 1.0); nf["far_" + k] = torch.full((N, S, 1), 4.0)
+        nf["near"], nf["far"] = torch.tensor(1.0), torch.tensor(4.0)
+        ndc = ref.utils.get_ndc_coordinate(w2cs[0], K, pts.clone(), inv_scale, nf)
+        pose = {"w2cs": w2cs.clone(), "intrinsics": K.repeat(V, 1, 1)}
+        # rendering() returns only (rgb, depth); recompose its body to also get weights/var
+        cos_angle = torch.norm(rd, dim=-1)
+        angle = ref.renderer.gen_dir_feature(pose["w2cs"][0], rd / cos_angle.unsqueeze(-1))
+        pose["w2cs"], pose["intrinsics"] = pose["w2cs"][1:], pose["intrinsics"][1:]
+        feats = ref.renderer.gen_pts_feats(imgs, volume_feature, pts, pose, ndc, a.feat_dim, img_feat, confidence=conf)
+        raw = qfn(ndc["ndc"], angle, feats, net)
+        rgb_map, disp, acc, w, depth, _, var = ref.renderer.raw2outputs(raw, z, None, False, "v2")
+        pose2 = {"w2cs": w2cs.clone(), "intrinsics": K.repeat(V, 1, 1)}
+        rgb_chk, depth_chk = ref.renderer.rendering(a, pose2, pts, ndc, z, rd, volume_feature, imgs, network_fn=net,
+                                                    img_feat=img_feat, network_query_fn=qfn, confidence=conf)
+        assert torch.equal(rgb_chk, rgb_map) and torch.equal(depth_chk, depth)
+        return rgb_map, depth, acc, w, var, raw
+
+    with torch.no_grad():
+        _, _, _, z_c = ref.ray_utils.ray_marcher(rays, NC, perturb=0)
+        c_rgb, c_depth, c_acc, c_w, c_var, c_raw = one_pass(z_c)
+        z_mid = .5 * (z_c[:, :-1] + z_c[:, 1:])
+        z_s = ref.ray_utils.sample_pdf(z_mid, c_w[:, 1:-1], NF, det=True)
+        z_f = torch.sort(torch.cat([z_s, z_c], -1), -1)[0]
+        f_rgb, f_depth, f_acc, f_w, f_var, f_raw = one_pass(z_f)
+    save("g11_coarse_fine", V=V, H=H, W=W, K=K, w2cs=w2cs, xs=xs, ys=ys, near=1.0, far=4.0, vol1=vols[0], vol2=vols[1],
+         vol3=vols[2], imgs=imgs, img_feat=img_feat, conf=conf, z_coarse=z_c, c_rgb=c_rgb, c_depth=c_depth,
+         c_weights=c_w, z_samples=z_s, z_fine=z_f, f_rgb=f_rgb, f_depth=f_depth, f_acc=f_acc, f_var=f_var,
+         f_weights=f_w, c_sigma=c_raw[..., 3], sigma_head_scale=0.05, sigma_head_bias=0.05)
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
+        if not only or fn.__name__ in only:
+            fn()
