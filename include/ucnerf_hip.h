@@ -1,0 +1,355 @@
+/*
+ * ucnerf_hip.h -- C ABI of libucnerf_hip.so: the MI355X (gfx950) implementation of UC-NeRF's
+ * ray-marching volume-render hot path.
+ *
+ * The reference (wrld/UC-NeRF) is pure Python/PyTorch and has no FFI of its own; each entry point below
+ * replaces one torch-op sequence of the reference's hot path (file:line cited per function, paths relative
+ * to the reference tree).  A binding for any host language only needs this header: plain pointers and
+ * sizes, no torch types.  The Python host side in uc_nerf_amd/ binds it with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the field name ends in _host;
+ *   - all arrays are dense, row-major, float32 unless stated; index outputs are int64 (as torch's);
+ *   - every function is asynchronous on `stream` (a hipStream_t passed as void*), allocates nothing,
+ *     is re-entrant, and returns 0 on success or a negative UCNERF_E* code; ucnerf_last_error() returns
+ *     a thread-local description of the last failure;
+ *   - "sample" = one depth sample on one ray; M = N_rays * S samples, ray-major (sample s of ray r at
+ *     index r*S + s).
+ */
+#ifndef UCNERF_HIP_H
+#define UCNERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UCNERF_ABI_VERSION 1
+
+#define UCNERF_OK 0
+#define UCNERF_EINVAL (-1)   /* bad argument (null pointer, unsupported size/config) */
+#define UCNERF_EHIP (-2)     /* HIP runtime error at launch */
+
+const char* ucnerf_last_error(void);
+int ucnerf_abi_version(void);
+/* sizeof() of a params struct by name ("ucnerf_mlp_params", ...), -1 if unknown: lets a binding check its mirror. */
+int ucnerf_sizeof(const char* struct_name);
+/* Number of compute units of the current device (grid sizing for persistent kernels); <0 on error. */
+int ucnerf_device_cus(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * a1  ray generation -- data/ray_utils.py:12-53, utils/utils.py:217-271 (get_rays_mvs, deterministic and
+ *     given-pixel branches), utils/run_nerf_helpers.py:248-257 (OpenGL variant).
+ *     d_cam = ((x-K02)/K00, (y-K12)/K11, 1)  [opengl: ((x-W/2)/f, -(y-H/2)/f, -1)],  rays_d = d_cam @ R^T.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n;            /* rays to generate */
+    int32_t H, W;         /* image size (grid mode / opengl) */
+    int32_t grid_start;   /* grid mode (xs == NULL): first flattened row-major pixel index */
+    int32_t opengl;       /* 0: intrinsic-matrix +z convention, 1: single-focal -z convention */
+    float K[9];           /* 3x3 intrinsics, row-major (opengl: K[0] = focal) */
+    float c2w[12];        /* 3x4 camera-to-world, row-major */
+    const float* xs;      /* [n] pixel columns, or NULL for grid mode */
+    const float* ys;      /* [n] pixel rows */
+    float* rays_d;        /* [n,3] out */
+    float* rays_o;        /* [n,3] out or NULL (origin is c2w[:,3] for every ray) */
+    float* pix;           /* [2,n] out (row, col) or NULL */
+} ucnerf_ray_gen_params;
+int ucnerf_ray_gen(const ucnerf_ray_gen_params* p, void* stream);
+
+/* a2  LLFF NDC warp of rays -- data/ray_utils.py:56-94 (variant 0: focal[2], d2 = 1-o2),
+ *     utils/run_nerf_helpers.py:277-294 (variant 1: scalar focal, d2 = -2 near/o_z). */
+typedef struct {
+    int32_t n, H, W, variant;
+    float focal_x, focal_y, near;
+    const float* rays_o;  /* [n,3] */
+    const float* rays_d;  /* [n,3] */
+    float* out_o;         /* [n,3] */
+    float* out_d;         /* [n,3] */
+} ucnerf_ndc_rays_params;
+int ucnerf_ndc_rays(const ucnerf_ndc_rays_params* p, void* stream);
+
+/* view-direction feature of rendering() -- network/renderer.py:232-238,163-174:
+ *   cos = |d|,  angle = (d/cos) @ R_ref^T   (R_ref == NULL: angle = d/cos). */
+typedef struct {
+    int32_t n;
+    int32_t has_ref;
+    float w2c_ref[12];
+    const float* rays_d;  /* [n,3] */
+    float* angle;         /* [n,3] out */
+    float* cos_angle;     /* [n] out or NULL */
+} ucnerf_dir_feature_params;
+int ucnerf_dir_feature(const ucnerf_dir_feature_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a3  depth sampling -- data/ray_utils.py:152-197 (ray_marcher) and the live cascade sampler
+ *     utils/utils.py:393-397,684-706 (three uniform sets, sorted, stratified).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n, S;
+    int32_t lindisp;
+    float perturb;        /* > 0: z = lower + (upper-lower) * perturb * noise */
+    const float* rays;    /* [n,8] = (o, d, near, far) */
+    const float* noise;   /* [n,S] uniform [0,1) draws, required when perturb > 0 */
+    float* z;             /* [n,S] out */
+    float* pts;           /* [n,S,3] out or NULL */
+} ucnerf_sample_stratified_params;
+int ucnerf_sample_stratified(const ucnerf_sample_stratified_params* p, void* stream);
+
+typedef struct {
+    int32_t n, S;         /* S must be a multiple of 3, S <= 768 */
+    const float* near_far;/* [n,6] = (near_1, far_1, near_2, far_2, near_3, far_3) per ray */
+    const float* t_rand;  /* [n,S] uniform draws, or NULL for no jitter */
+    const float* rays_o;  /* [3] shared origin, used when pts != NULL */
+    const float* rays_d;  /* [n,3] */
+    float* z;             /* [n,S] out (sorted then jittered) */
+    float* pts;           /* [n,S,3] out or NULL */
+} ucnerf_sample_cascade_params;
+int ucnerf_sample_cascade(const ucnerf_sample_cascade_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a4  world -> reference-view normalised coordinates -- utils/utils.py:323-373 (get_ndc_coordinate).
+ *     p_cam = p R^T + T; |z|<1e-4 -> 1e-4; q = p_cam K^T; xy = q.xy/q.z / inv_scale;
+ *     z_k = (q.z - near_k)/(far_k - near_k) for k in {stage1, stage2, stage3, ndc}.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t m;            /* points */
+    int32_t has_w2c;
+    int32_t sample_2d;    /* 1: write only out_ndc = (x, y, raw z) */
+    int32_t nf_stride;    /* elements between consecutive points in near/far arrays: 1 (per point) or 0 (broadcast) */
+    float w2c[12];
+    float K[9];
+    float inv_scale[2];   /* (W-1, H-1) */
+    float near, far;      /* scene range for the 'ndc' copy */
+    const float* pts;     /* [m,3] */
+    const float* near_1; const float* far_1;   /* [m] (or [1] when nf_stride == 0) */
+    const float* near_2; const float* far_2;
+    const float* near_3; const float* far_3;
+    float* out_stage1;    /* [m,3] */
+    float* out_stage2;
+    float* out_stage3;
+    float* out_ndc;
+} ucnerf_ndc_project_params;
+int ucnerf_ndc_project(const ucnerf_ndc_project_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a5  positional encoding -- network/models.py:20-71 (layout 0, "live": [x | sin(2^k x) k<L | cos ...]),
+ *     utils/run_nerf_helpers.py:23-71 (layout 1, interleaved [x | sin f0 | cos f0 | sin f1 ...]).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t m;            /* 3-vectors */
+    int32_t n_freqs;
+    int32_t layout;
+    const float* x;       /* [m,3] */
+    float* out;           /* [m, 3 + 6*n_freqs] */
+} ucnerf_embed_params;
+int ucnerf_embed(const ucnerf_embed_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a7  feature gather -- network/renderer.py:177-212 (gen_pts_feats) = utils/utils.py:833-893
+ *     (index_point_feature: 3 trilinear volume lookups + bilinear confidence, align_corners=False, border)
+ *     + utils/utils.py:742-799 (build_color_volume: per source view bilinear rgb + in-mask + 8-ch image
+ *     features, align_corners=True, border).  Feature vector per sample, F = 24 + 12*V + 1:
+ *       [0:8] stage1 | [8:16] stage2 | [16:24] stage3 | [24:24+4V] (r,g,b,mask) x V | [..+8V] img_feat x V | conf
+ *     Sources are read in the reference's own layouts.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t m;                 /* samples */
+    int32_t V;                 /* source views (reference view_num - 1), 1..8 */
+    int32_t H, W;              /* image / confidence / img_feat size */
+    int32_t vol_d[3], vol_h[3], vol_w[3];   /* cascade volume sizes, 8 channels each */
+    int32_t out_tiled;         /* 0: feats [m,F] row-major; 1: [ceil(m/32)][F][32] (MLP tile layout) */
+    const float* pts;          /* [m,3] world points */
+    const float* ndc1;         /* [m,3] stage coordinates in ~[0,1] (ucnerf_ndc_project outputs) */
+    const float* ndc2;
+    const float* ndc3;
+    const float* vol[3];       /* [8,D,h,w] */
+    const float* conf;         /* [H,W] */
+    const float* imgs;         /* [V,3,H,W] */
+    const float* img_feat;     /* [V,8,H,W] */
+    const float* w2cs;         /* [V,12] rows 0..2 of each 4x4 */
+    const float* intrinsics;   /* [V,9] */
+    float* feats;              /* out */
+} ucnerf_feat_gather_params;
+int ucnerf_feat_gather_fwd(const ucnerf_feat_gather_params* p, void* stream);
+
+/* Backward of the gather w.r.t. its differentiable sources (the reference's autograd reaches the three
+ * volumes, img_feat and confidence through grid_sample; positions and images get no gradient,
+ * SURVEY.md 3.2).  Gradients are ACCUMULATED (atomic add) into the g_* buffers: zero them first. */
+typedef struct {
+    ucnerf_feat_gather_params fwd;   /* same geometry/inputs as the forward call (feats unused) */
+    const float* g_feats;            /* [m,F] row-major upstream gradient */
+    float* g_vol[3];                 /* [8,D,h,w] or NULL to skip */
+    float* g_conf;                   /* [H,W] or NULL */
+    float* g_img_feat;               /* [V,8,H,W] or NULL */
+} ucnerf_feat_gather_bwd_params;
+int ucnerf_feat_gather_bwd(const ucnerf_feat_gather_bwd_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a6 (+a5 fused)  the uncertainty-conditioned MLP -- network/models.py:138-184 driven by
+ *     network/renderer.py:78-106 (run_network_mvs; batchify's netchunk loop is unnecessary here).
+ *     Fixed architecture: D=6, W=128, skip after layer 4, multires 10 / 4 (63 + F + 27 inputs).
+ *     Weights are consumed as a pre-packed MFMA operand stream built by ucnerf_mlp_pack from the flat
+ *     parameter vector (concatenation of the reference state_dict tensors in state_dict order).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_src;        /* V = view_num - 1 */
+    int32_t pe_layout;    /* 0 live (network/models.py), 1 interleaved (run_nerf_helpers.py) */
+} ucnerf_mlp_config;
+
+/* Sizes: number of floats in the flat parameter vector and in the packed stream (<0 on bad config). */
+int64_t ucnerf_mlp_param_count(const ucnerf_mlp_config* cfg);
+int64_t ucnerf_mlp_stream_count(const ucnerf_mlp_config* cfg);
+/* Host-side: fills idx_host[stream_count] with the flat-parameter index feeding each stream slot (-1 = zero pad). */
+int ucnerf_mlp_pack_index(const ucnerf_mlp_config* cfg, int32_t* idx_host);
+/* Device-side: stream[i] = idx[i] >= 0 ? flat[idx[i]] : 0.  idx is the device copy of the table above. */
+int ucnerf_mlp_pack(const float* flat_params, const int32_t* idx, float* stream_out, int64_t n, void* stream);
+/* Transpose of the pack for gradients: g_flat[idx[i]] += g_stream[i] (g_flat zeroed by the caller). */
+int ucnerf_mlp_unpack_grad(const float* g_stream, const int32_t* idx, float* g_flat, int64_t n, void* stream);
+
+typedef struct {
+    ucnerf_mlp_config cfg;
+    int32_t m;                 /* samples */
+    int32_t S;                 /* samples per ray (view dir of sample s is dirs[s / S]); dirs_per_sample: ignored */
+    int32_t dirs_per_sample;   /* 1: dirs is [m,3] */
+    int32_t feats_tiled;       /* feats layout, see ucnerf_feat_gather_params.out_tiled */
+    int32_t max_blocks;        /* 0 = auto (persistent grid sized from the CU count) */
+    const float* pts;          /* [m,3] the 'ndc' coordinates fed to the positional encoding */
+    const float* dirs;         /* [m/S,3] or [m,3] view-direction feature */
+    const float* feats;        /* [m,F] or tiled */
+    const float* wstream;      /* packed weights (ucnerf_mlp_pack) */
+    float* raw;                /* [m,4] out: rgb (after sigmoid), sigma (after relu) */
+} ucnerf_mlp_params;
+int ucnerf_mlp_fwd(const ucnerf_mlp_params* p, void* stream);
+
+/* Backward: recomputes the forward per tile, returns d(feats) and accumulates d(packed weights).
+ * g_wstream must be zeroed by the caller; map it back with ucnerf_mlp_unpack_grad. */
+typedef struct {
+    ucnerf_mlp_params fwd;
+    const float* g_raw;        /* [m,4] */
+    float* g_feats;            /* [m,F] row-major out, or NULL */
+    float* g_wstream;          /* [stream_count] accumulated */
+    float* workspace;          /* scratch, ucnerf_mlp_bwd_workspace_floats() floats */
+} ucnerf_mlp_bwd_params;
+int64_t ucnerf_mlp_bwd_workspace_floats(const ucnerf_mlp_config* cfg, int32_t m);
+int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a9  alpha compositing -- network/renderer.py:25-36,109-140 (variant 0 "live": alpha = 1-exp(-sigma),
+ *     rgb/sigma already activated, dists ignored) and utils/run_nerf_helpers.py:343-390 (variant 1:
+ *     alpha = 1-exp(-relu(sigma+noise)*dists), rgb = sigmoid(raw), dists = dz*|d|, last = 1e10).
+ *     T_i = prod_{j<i} (1-alpha_j+1e-10), w = alpha*T.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n, S;
+    int32_t variant;
+    int32_t white_bkgd;
+    const float* raw;      /* [n,S,4] */
+    const float* z;        /* [n,S] */
+    const float* rays_d;   /* [n,3]  (variant 1) */
+    const float* noise;    /* [n,S] or NULL (variant 1) */
+    float* rgb_map;        /* [n,3] */
+    float* depth_map;      /* [n] */
+    float* acc_map;        /* [n] or NULL */
+    float* disp_map;       /* [n] or NULL */
+    float* weights;        /* [n,S] or NULL */
+    float* var;            /* [n] unbiased variance of the weights, or NULL (variant 0 only) */
+} ucnerf_composite_params;
+int ucnerf_composite_fwd(const ucnerf_composite_params* p, void* stream);
+
+typedef struct {
+    ucnerf_composite_params fwd;   /* inputs as in the forward call; outputs unused */
+    const float* g_rgb;        /* [n,3] or NULL */
+    const float* g_depth;      /* [n] or NULL */
+    const float* g_acc;        /* [n] or NULL */
+    const float* g_weights;    /* [n,S] or NULL */
+    float* g_raw;              /* [n,S,4] out */
+} ucnerf_composite_bwd_params;
+int ucnerf_composite_bwd(const ucnerf_composite_bwd_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a8  inverse-CDF sampling -- data/ray_utils.py:98-141 == utils/run_nerf_helpers.py:298-341, with the
+ *     uniform draws u given, and the sorted merge of data/ray_utils.py:219.
+ *     Reproduces torch-CPU's accumulation orders (vectorised row sum, float64 cumsum) so that
+ *     inds == torch.searchsorted(cdf, u, right=True) bit for bit.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n;
+    int32_t n_bins;        /* L = bins per ray; weights per ray = L-1; 2 <= L <= 1024 */
+    int32_t n_samples;     /* M draws per ray, M <= 1024 */
+    int32_t u_stride;      /* n_samples (per-ray draws) or 0 (one shared row, e.g. linspace) */
+    int32_t n_merge;       /* z_merge entries per ray (0: no merge), n_merge + M <= 2048 */
+    const float* bins;     /* [n,L] */
+    const float* weights;  /* [n,L-1] */
+    const float* u;        /* [n,M] or [M] */
+    const float* z_merge;  /* [n,n_merge] values to merge with the samples, or NULL */
+    float* samples;        /* [n,M] out or NULL */
+    int64_t* inds;         /* [n,M] out or NULL */
+    float* cdf;            /* [n,L] out or NULL */
+    float* z_sorted;       /* [n,n_merge+M] out: sort(cat(samples, z_merge)), or NULL */
+} ucnerf_sample_pdf_params;
+int ucnerf_sample_pdf(const ucnerf_sample_pdf_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a10  one fused render pass -- network/renderer.py:215-255 (rendering) with the projection of
+ *      utils/utils.py:716-724 in front: rays + depths -> world points -> stage coordinates -> features ->
+ *      PE + MLP -> composite.  Source views = pose entries 1..V of the reference's pose_ref
+ *      (the in-place trim of renderer.py:241-243 is host-side behaviour and stays in the Python mirror).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n, S;
+    int32_t white_bkgd;
+    int32_t max_blocks;        /* MLP persistent grid cap, 0 = auto */
+    ucnerf_mlp_config cfg;
+    /* geometry */
+    const float* rays_o;       /* [3] shared origin */
+    const float* rays_d;       /* [n,3] */
+    const float* z;            /* [n,S] */
+    float w2c_ref[12];         /* reference view: projection for the stage/ndc coordinates */
+    float K_ref[9];
+    float w2c_dir[12];         /* rotation used for the view-direction feature (pose_ref['w2cs'][0] at call time) */
+    float near, far;           /* scene range */
+    const float* near_far;     /* [n,6] per-ray cascade ranges, or NULL: all stages use (near, far) */
+    /* gather sources, see ucnerf_feat_gather_params */
+    int32_t H, W;
+    int32_t vol_d[3], vol_h[3], vol_w[3];
+    const float* vol[3];
+    const float* conf;
+    const float* imgs;
+    const float* img_feat;
+    const float* w2cs;         /* [V,12] source views */
+    const float* intrinsics;   /* [V,9] */
+    const float* wstream;
+    /* workspace: ucnerf_render_workspace_floats(n, S, V) floats */
+    float* workspace;
+    /* outputs */
+    float* rgb_map;            /* [n,3] */
+    float* depth_map;          /* [n] */
+    float* acc_map;            /* [n] or NULL */
+    float* weights;            /* [n,S] or NULL */
+    float* var;                /* [n] or NULL */
+    float* raw;                /* [n,S,4] or NULL (kept for backward) */
+    float* feats;              /* [n*S,F] row-major or NULL (kept for backward) */
+} ucnerf_render_params;
+int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V);
+int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream);
+
+/* Backward of one render pass: d(rgb_map, depth_map) -> d(packed weights), d(volumes, img_feat, conf). */
+typedef struct {
+    ucnerf_render_params fwd;      /* as in the forward call; raw must hold the forward's raw output */
+    const float* g_rgb;            /* [n,3] */
+    const float* g_depth;          /* [n] or NULL */
+    float* g_wstream;              /* accumulated, zeroed by caller */
+    float* g_vol[3];               /* accumulated or NULL */
+    float* g_conf;
+    float* g_img_feat;
+    float* workspace;              /* ucnerf_render_bwd_workspace_floats(n, S, V) floats */
+} ucnerf_render_bwd_params;
+int64_t ucnerf_render_bwd_workspace_floats(int32_t n, int32_t S, int32_t V);
+int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UCNERF_HIP_H */

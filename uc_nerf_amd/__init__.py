@@ -1,0 +1,29 @@
+"""uc_nerf_amd -- MI355X (gfx950) implementation of UC-NeRF's ray-marching volume-render hot path.
+
+Layers:
+  csrc/ + include/ucnerf_hip.h   hand-written HIP kernels behind a C ABI (libucnerf_hip.so)
+  _lib.py, ops.py                ctypes binding and torch-tensor wrappers (plumbing)
+  network/, utils/, data/        mirrors of the reference's Python call surface for this path
+  pipeline.py, parallel.py       the fused coarse+fine renderer and ray-sharded multi-GPU driver
+
+GPU only: there is no CPU or PyTorch fallback; calls on CPU tensors raise.
+"""
+__version__ = "0.1.0"
+
+
+def install_dropin():
+    """Registers this package's mirrors under the reference's module names (`network.renderer`,
+    `network.models`, `utils.utils`, `utils.run_nerf_helpers`, `data.ray_utils`) so that the reference's
+    train.py imports resolve here unchanged.  See INTEGRATION.md."""
+    import importlib
+    import sys
+    import types
+    for pkg in ("network", "utils", "data"):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = []
+            sys.modules[pkg] = m
+    for name in ("network.renderer", "network.models", "utils.utils", "utils.run_nerf_helpers", "data.ray_utils"):
+        mod = importlib.import_module("uc_nerf_amd." + name)
+        sys.modules[name] = mod
+        setattr(sys.modules[name.split(".")[0]], name.split(".")[1], mod)

@@ -1,0 +1,188 @@
+"""ctypes binding of libucnerf_hip.so (the C ABI declared in include/ucnerf_hip.h).
+
+There is no CPU fallback anywhere in this package: if the library is missing or a call fails, a
+RuntimeError is raised.  Struct mirrors are checked against the library's own sizeof() table at load time.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libucnerf_hip.so")
+
+fp = C.POINTER(C.c_float)
+i32 = C.c_int32
+f32 = C.c_float
+vp = C.c_void_p     # device pointers travel as integers
+
+
+class RayGenParams(C.Structure):
+    _fields_ = [("n", i32), ("H", i32), ("W", i32), ("grid_start", i32), ("opengl", i32), ("K", f32 * 9),
+                ("c2w", f32 * 12), ("xs", vp), ("ys", vp), ("rays_d", vp), ("rays_o", vp), ("pix", vp)]
+
+
+class NdcRaysParams(C.Structure):
+    _fields_ = [("n", i32), ("H", i32), ("W", i32), ("variant", i32), ("focal_x", f32), ("focal_y", f32),
+                ("near", f32), ("rays_o", vp), ("rays_d", vp), ("out_o", vp), ("out_d", vp)]
+
+
+class DirFeatureParams(C.Structure):
+    _fields_ = [("n", i32), ("has_ref", i32), ("w2c_ref", f32 * 12), ("rays_d", vp), ("angle", vp), ("cos_angle", vp)]
+
+
+class SampleStratifiedParams(C.Structure):
+    _fields_ = [("n", i32), ("S", i32), ("lindisp", i32), ("perturb", f32), ("rays", vp), ("noise", vp), ("z", vp),
+                ("pts", vp)]
+
+
+class SampleCascadeParams(C.Structure):
+    _fields_ = [("n", i32), ("S", i32), ("near_far", vp), ("t_rand", vp), ("rays_o", vp), ("rays_d", vp), ("z", vp),
+                ("pts", vp)]
+
+
+class NdcProjectParams(C.Structure):
+    _fields_ = [("m", i32), ("has_w2c", i32), ("sample_2d", i32), ("nf_stride", i32), ("w2c", f32 * 12), ("K", f32 * 9),
+                ("inv_scale", f32 * 2), ("near", f32), ("far", f32), ("pts", vp), ("near_1", vp), ("far_1", vp),
+                ("near_2", vp), ("far_2", vp), ("near_3", vp), ("far_3", vp), ("out_stage1", vp), ("out_stage2", vp),
+                ("out_stage3", vp), ("out_ndc", vp)]
+
+
+class EmbedParams(C.Structure):
+    _fields_ = [("m", i32), ("n_freqs", i32), ("layout", i32), ("x", vp), ("out", vp)]
+
+
+class FeatGatherParams(C.Structure):
+    _fields_ = [("m", i32), ("V", i32), ("H", i32), ("W", i32), ("vol_d", i32 * 3), ("vol_h", i32 * 3),
+                ("vol_w", i32 * 3), ("out_tiled", i32), ("pts", vp), ("ndc1", vp), ("ndc2", vp), ("ndc3", vp),
+                ("vol", vp * 3), ("conf", vp), ("imgs", vp), ("img_feat", vp), ("w2cs", vp), ("intrinsics", vp),
+                ("feats", vp)]
+
+
+class FeatGatherBwdParams(C.Structure):
+    _fields_ = [("fwd", FeatGatherParams), ("g_feats", vp), ("g_vol", vp * 3), ("g_conf", vp), ("g_img_feat", vp)]
+
+
+class MlpConfig(C.Structure):
+    _fields_ = [("n_src", i32), ("pe_layout", i32)]
+
+
+class MlpParams(C.Structure):
+    _fields_ = [("cfg", MlpConfig), ("m", i32), ("S", i32), ("dirs_per_sample", i32), ("feats_tiled", i32),
+                ("max_blocks", i32), ("pts", vp), ("dirs", vp), ("feats", vp), ("wstream", vp), ("raw", vp)]
+
+
+class MlpBwdParams(C.Structure):
+    _fields_ = [("fwd", MlpParams), ("g_raw", vp), ("g_feats", vp), ("g_wstream", vp), ("workspace", vp)]
+
+
+class CompositeParams(C.Structure):
+    _fields_ = [("n", i32), ("S", i32), ("variant", i32), ("white_bkgd", i32), ("raw", vp), ("z", vp), ("rays_d", vp),
+                ("noise", vp), ("rgb_map", vp), ("depth_map", vp), ("acc_map", vp), ("disp_map", vp), ("weights", vp),
+                ("var", vp)]
+
+
+class CompositeBwdParams(C.Structure):
+    _fields_ = [("fwd", CompositeParams), ("g_rgb", vp), ("g_depth", vp), ("g_acc", vp), ("g_weights", vp),
+                ("g_raw", vp)]
+
+
+class SamplePdfParams(C.Structure):
+    _fields_ = [("n", i32), ("n_bins", i32), ("n_samples", i32), ("u_stride", i32), ("n_merge", i32), ("bins", vp),
+                ("weights", vp), ("u", vp), ("z_merge", vp), ("samples", vp), ("inds", vp), ("cdf", vp),
+                ("z_sorted", vp)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("n", i32), ("S", i32), ("white_bkgd", i32), ("max_blocks", i32), ("cfg", MlpConfig), ("rays_o", vp),
+                ("rays_d", vp), ("z", vp), ("w2c_ref", f32 * 12), ("K_ref", f32 * 9), ("w2c_dir", f32 * 12),
+                ("near", f32), ("far", f32), ("near_far", vp), ("H", i32), ("W", i32), ("vol_d", i32 * 3),
+                ("vol_h", i32 * 3), ("vol_w", i32 * 3), ("vol", vp * 3), ("conf", vp), ("imgs", vp), ("img_feat", vp),
+                ("w2cs", vp), ("intrinsics", vp), ("wstream", vp), ("workspace", vp), ("rgb_map", vp),
+                ("depth_map", vp), ("acc_map", vp), ("weights", vp), ("var", vp), ("raw", vp), ("feats", vp)]
+
+
+class RenderBwdParams(C.Structure):
+    _fields_ = [("fwd", RenderParams), ("g_rgb", vp), ("g_depth", vp), ("g_wstream", vp), ("g_vol", vp * 3),
+                ("g_conf", vp), ("g_img_feat", vp), ("workspace", vp)]
+
+
+STRUCTS = {
+    "ucnerf_ray_gen_params": RayGenParams, "ucnerf_ndc_rays_params": NdcRaysParams,
+    "ucnerf_dir_feature_params": DirFeatureParams, "ucnerf_sample_stratified_params": SampleStratifiedParams,
+    "ucnerf_sample_cascade_params": SampleCascadeParams, "ucnerf_ndc_project_params": NdcProjectParams,
+    "ucnerf_embed_params": EmbedParams, "ucnerf_feat_gather_params": FeatGatherParams,
+    "ucnerf_feat_gather_bwd_params": FeatGatherBwdParams, "ucnerf_mlp_config": MlpConfig,
+    "ucnerf_mlp_params": MlpParams, "ucnerf_mlp_bwd_params": MlpBwdParams, "ucnerf_composite_params": CompositeParams,
+    "ucnerf_composite_bwd_params": CompositeBwdParams, "ucnerf_sample_pdf_params": SamplePdfParams,
+    "ucnerf_render_params": RenderParams, "ucnerf_render_bwd_params": RenderBwdParams,
+}
+
+# every symbol include/ucnerf_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "ucnerf_last_error": (C.c_char_p, []),
+    "ucnerf_abi_version": (C.c_int, []),
+    "ucnerf_sizeof": (C.c_int, [C.c_char_p]),
+    "ucnerf_device_cus": (C.c_int, []),
+    "ucnerf_ray_gen": (C.c_int, [_P, _P]),
+    "ucnerf_ndc_rays": (C.c_int, [_P, _P]),
+    "ucnerf_dir_feature": (C.c_int, [_P, _P]),
+    "ucnerf_sample_stratified": (C.c_int, [_P, _P]),
+    "ucnerf_sample_cascade": (C.c_int, [_P, _P]),
+    "ucnerf_ndc_project": (C.c_int, [_P, _P]),
+    "ucnerf_embed": (C.c_int, [_P, _P]),
+    "ucnerf_feat_gather_fwd": (C.c_int, [_P, _P]),
+    "ucnerf_feat_gather_bwd": (C.c_int, [_P, _P]),
+    "ucnerf_mlp_param_count": (C.c_int64, [_P]),
+    "ucnerf_mlp_stream_count": (C.c_int64, [_P]),
+    "ucnerf_mlp_pack_index": (C.c_int, [_P, _P]),
+    "ucnerf_mlp_pack": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "ucnerf_mlp_unpack_grad": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "ucnerf_mlp_fwd": (C.c_int, [_P, _P]),
+    "ucnerf_mlp_bwd_workspace_floats": (C.c_int64, [_P, C.c_int32]),
+    "ucnerf_mlp_bwd": (C.c_int, [_P, _P]),
+    "ucnerf_composite_fwd": (C.c_int, [_P, _P]),
+    "ucnerf_composite_bwd": (C.c_int, [_P, _P]),
+    "ucnerf_sample_pdf": (C.c_int, [_P, _P]),
+    "ucnerf_render_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "ucnerf_render_fused_fwd": (C.c_int, [_P, _P]),
+    "ucnerf_render_bwd_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "ucnerf_render_fused_bwd": (C.c_int, [_P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads the library once; raises if it is absent or its ABI does not match this binding."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("uc_nerf_amd: %s is missing -- build it with `python -m uc_nerf_amd.build` "
+                           "(there is no CPU or PyTorch fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise RuntimeError("uc_nerf_amd: %s does not export %s" % (LIB_PATH, name)) from e
+        fn.restype, fn.argtypes = res, args
+    if L.ucnerf_abi_version() != 1:
+        raise RuntimeError("uc_nerf_amd: ABI version mismatch")
+    for cname, cls in STRUCTS.items():
+        got = L.ucnerf_sizeof(cname.encode())
+        if got != C.sizeof(cls):
+            raise RuntimeError("uc_nerf_amd: struct %s is %d bytes in the library, %d in the binding"
+                               % (cname, got, C.sizeof(cls)))
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("uc_nerf_amd: %s failed (%d): %s" % (what, rc, lib().ucnerf_last_error().decode()))
+
+
+def call(name, params, stream):
+    """Invokes an `int f(const params*, stream)` entry point."""
+    check(getattr(lib(), name)(C.addressof(params), C.c_void_p(stream)), name)

@@ -1,0 +1,228 @@
+// K4: per-sample feature gather (network/renderer.py:177-212 = utils/utils.py:833-893 + :742-799 of the
+// reference), forward and backward.
+//
+// Work is split into "units": 0,1,2 = the three cascade volumes (8 channels, trilinear, align_corners=False),
+// 3 = confidence (bilinear, align_corners=False, sampled with the stage-3 grid), 4.. = one per source view
+// (world point -> view pixel; bilinear rgb + in-mask + 8 image-feature channels, align_corners=True).
+// blockIdx.y selects the unit, so every wave runs one code path and consecutive lanes are consecutive
+// samples of a ray (neighbouring voxels -> L2 locality).  grid_sample semantics restated:
+//   align_corners=False: i = ((g+1)*size - 1)/2;  align_corners=True: i = (g+1)/2*(size-1);
+//   border padding: clamp i to [0, size-1] before floor/frac; a corner index == size gets weight 0.
+#include "common.h"
+
+namespace ucnerf {
+
+__device__ __forceinline__ float unnorm(float g, int size, bool align) {
+    float i = align ? (g + 1.f) / 2.f * (float)(size - 1) : ((g + 1.f) * (float)size - 1.f) / 2.f;
+    return fminf(fmaxf(i, 0.f), (float)(size - 1));
+}
+
+struct Lerp {        // one axis of a (bi|tri)linear footprint
+    int i0, i1;      // corner indices (i1 clamped into range; its weight is 0 when it was out of range)
+    float w0, w1;
+};
+
+__device__ __forceinline__ Lerp axis(float g, int size, bool align) {
+    const float x = unnorm(g, size, align);
+    const float f = floorf(x);
+    Lerp a;
+    a.i0 = (int)f;
+    a.w1 = x - f;
+    a.w0 = 1.f - a.w1;
+    a.i1 = a.i0 + 1;
+    if (a.i1 > size - 1) { a.i1 = size - 1; a.w1 = 0.f; }
+    return a;
+}
+
+// feature f of sample s in the output tensor
+__device__ __forceinline__ size_t out_index(const ucnerf_feat_gather_params& p, int F, int s, int f) {
+    return p.out_tiled ? ((size_t)(s >> 5) * F + f) * 32 + (s & 31) : (size_t)s * F + f;
+}
+
+// world point -> (gx, gy) in [-1,1] of source view `v` (get_ndc_coordinate with sample_2d=True, then *2-1)
+__device__ __forceinline__ void project_view(const ucnerf_feat_gather_params& p, int v, int s, float* gx, float* gy) {
+    const float* M = p.w2cs + 12 * v;
+    const float* K = p.intrinsics + 9 * v;
+    const float x = p.pts[3 * (size_t)s], y = p.pts[3 * (size_t)s + 1], z = p.pts[3 * (size_t)s + 2];
+    const float cx = x * M[0] + y * M[1] + z * M[2] + M[3];
+    const float cy = x * M[4] + y * M[5] + z * M[6] + M[7];
+    float cz = x * M[8] + y * M[9] + z * M[10] + M[11];
+    if (fabsf(cz) < 1e-4f) cz = 1e-4f;
+    const float qx = cx * K[0] + cy * K[1] + cz * K[2];
+    const float qy = cx * K[3] + cy * K[4] + cz * K[5];
+    const float qz = cx * K[6] + cy * K[7] + cz * K[8];
+    *gx = (qx / qz + 0.0f) / (float)(p.W - 1) * 2.0f - 1.0f;
+    *gy = (qy / qz + 0.0f) / (float)(p.H - 1) * 2.0f - 1.0f;
+}
+
+__global__ void __launch_bounds__(256) feat_gather_fwd_kernel(ucnerf_feat_gather_params p) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= p.m) return;
+    const int unit = blockIdx.y;
+    const int F = 24 + 12 * p.V + 1;
+    if (unit < 3) {
+        const float* g = (unit == 0 ? p.ndc1 : unit == 1 ? p.ndc2 : p.ndc3) + 3 * (size_t)s;
+        const int D = p.vol_d[unit], h = p.vol_h[unit], w = p.vol_w[unit];
+        const Lerp ax = axis(g[0] * 2.f - 1.0f, w, false), ay = axis(g[1] * 2.f - 1.0f, h, false),
+                   az = axis(g[2] * 2.f - 1.0f, D, false);
+        const float* vol = p.vol[unit];
+        const size_t cs = (size_t)D * h * w;
+        const size_t o00 = ((size_t)az.i0 * h + ay.i0) * w, o01 = ((size_t)az.i0 * h + ay.i1) * w,
+                     o10 = ((size_t)az.i1 * h + ay.i0) * w, o11 = ((size_t)az.i1 * h + ay.i1) * w;
+        const float w00 = az.w0 * ay.w0, w01 = az.w0 * ay.w1, w10 = az.w1 * ay.w0, w11 = az.w1 * ay.w1;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float* vc = vol + c * cs;
+            float acc = vc[o00 + ax.i0] * (w00 * ax.w0);
+            acc += vc[o00 + ax.i1] * (w00 * ax.w1);
+            acc += vc[o01 + ax.i0] * (w01 * ax.w0);
+            acc += vc[o01 + ax.i1] * (w01 * ax.w1);
+            acc += vc[o10 + ax.i0] * (w10 * ax.w0);
+            acc += vc[o10 + ax.i1] * (w10 * ax.w1);
+            acc += vc[o11 + ax.i0] * (w11 * ax.w0);
+            acc += vc[o11 + ax.i1] * (w11 * ax.w1);
+            p.feats[out_index(p, F, s, 8 * unit + c)] = acc;
+        }
+    } else if (unit == 3) {
+        const float* g = p.ndc3 + 3 * (size_t)s;
+        const Lerp ax = axis(g[0] * 2.f - 1.0f, p.W, false), ay = axis(g[1] * 2.f - 1.0f, p.H, false);
+        const float* c = p.conf;
+        float acc = c[(size_t)ay.i0 * p.W + ax.i0] * (ay.w0 * ax.w0);
+        acc += c[(size_t)ay.i0 * p.W + ax.i1] * (ay.w0 * ax.w1);
+        acc += c[(size_t)ay.i1 * p.W + ax.i0] * (ay.w1 * ax.w0);
+        acc += c[(size_t)ay.i1 * p.W + ax.i1] * (ay.w1 * ax.w1);
+        p.feats[out_index(p, F, s, F - 1)] = acc;
+    } else {
+        const int v = unit - 4;
+        float gx, gy;
+        project_view(p, v, s, &gx, &gy);
+        const Lerp ax = axis(gx, p.W, true), ay = axis(gy, p.H, true);
+        const size_t hw = (size_t)p.H * p.W;
+        const size_t o00 = (size_t)ay.i0 * p.W + ax.i0, o01 = (size_t)ay.i0 * p.W + ax.i1,
+                     o10 = (size_t)ay.i1 * p.W + ax.i0, o11 = (size_t)ay.i1 * p.W + ax.i1;
+        const float w00 = ay.w0 * ax.w0, w01 = ay.w0 * ax.w1, w10 = ay.w1 * ax.w0, w11 = ay.w1 * ax.w1;
+        const float* img = p.imgs + (size_t)v * 3 * hw;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* ic = img + c * hw;
+            float acc = ic[o00] * w00; acc += ic[o01] * w01; acc += ic[o10] * w10; acc += ic[o11] * w11;
+            p.feats[out_index(p, F, s, 24 + 4 * v + c)] = acc;
+        }
+        const bool in = gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f;      // utils/utils.py:791-792
+        p.feats[out_index(p, F, s, 24 + 4 * v + 3)] = in ? 1.f : 0.f;
+        const float* ft = p.img_feat + (size_t)v * 8 * hw;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float* fc = ft + c * hw;
+            float acc = fc[o00] * w00; acc += fc[o01] * w01; acc += fc[o10] * w10; acc += fc[o11] * w11;
+            p.feats[out_index(p, F, s, 24 + 4 * p.V + 8 * v + c)] = acc;
+        }
+    }
+}
+
+// Backward: scatter g_feats through the same footprints (float atomics; accumulates into the g_* buffers).
+__global__ void __launch_bounds__(256) feat_gather_bwd_kernel(ucnerf_feat_gather_bwd_params bp) {
+    const ucnerf_feat_gather_params& p = bp.fwd;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= p.m) return;
+    const int unit = blockIdx.y;
+    const int F = 24 + 12 * p.V + 1;
+    const float* gf = bp.g_feats + (size_t)s * F;
+    if (unit < 3) {
+        float* gv = bp.g_vol[unit];
+        if (!gv) return;
+        const float* g = (unit == 0 ? p.ndc1 : unit == 1 ? p.ndc2 : p.ndc3) + 3 * (size_t)s;
+        const int D = p.vol_d[unit], h = p.vol_h[unit], w = p.vol_w[unit];
+        const Lerp ax = axis(g[0] * 2.f - 1.0f, w, false), ay = axis(g[1] * 2.f - 1.0f, h, false),
+                   az = axis(g[2] * 2.f - 1.0f, D, false);
+        const size_t cs = (size_t)D * h * w;
+        const size_t o00 = ((size_t)az.i0 * h + ay.i0) * w, o01 = ((size_t)az.i0 * h + ay.i1) * w,
+                     o10 = ((size_t)az.i1 * h + ay.i0) * w, o11 = ((size_t)az.i1 * h + ay.i1) * w;
+        const float w00 = az.w0 * ay.w0, w01 = az.w0 * ay.w1, w10 = az.w1 * ay.w0, w11 = az.w1 * ay.w1;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float* vc = gv + c * cs;
+            const float gc = gf[8 * unit + c];
+            atomicAdd(vc + o00 + ax.i0, gc * (w00 * ax.w0));
+            if (ax.w1 != 0.f) atomicAdd(vc + o00 + ax.i1, gc * (w00 * ax.w1));
+            if (w01 != 0.f) {
+                atomicAdd(vc + o01 + ax.i0, gc * (w01 * ax.w0));
+                if (ax.w1 != 0.f) atomicAdd(vc + o01 + ax.i1, gc * (w01 * ax.w1));
+            }
+            if (w10 != 0.f) {
+                atomicAdd(vc + o10 + ax.i0, gc * (w10 * ax.w0));
+                if (ax.w1 != 0.f) atomicAdd(vc + o10 + ax.i1, gc * (w10 * ax.w1));
+            }
+            if (w11 != 0.f) {
+                atomicAdd(vc + o11 + ax.i0, gc * (w11 * ax.w0));
+                if (ax.w1 != 0.f) atomicAdd(vc + o11 + ax.i1, gc * (w11 * ax.w1));
+            }
+        }
+    } else if (unit == 3) {
+        if (!bp.g_conf) return;
+        const float* g = p.ndc3 + 3 * (size_t)s;
+        const Lerp ax = axis(g[0] * 2.f - 1.0f, p.W, false), ay = axis(g[1] * 2.f - 1.0f, p.H, false);
+        const float gc = gf[F - 1];
+        atomicAdd(bp.g_conf + (size_t)ay.i0 * p.W + ax.i0, gc * (ay.w0 * ax.w0));
+        atomicAdd(bp.g_conf + (size_t)ay.i0 * p.W + ax.i1, gc * (ay.w0 * ax.w1));
+        atomicAdd(bp.g_conf + (size_t)ay.i1 * p.W + ax.i0, gc * (ay.w1 * ax.w0));
+        atomicAdd(bp.g_conf + (size_t)ay.i1 * p.W + ax.i1, gc * (ay.w1 * ax.w1));
+    } else {
+        if (!bp.g_img_feat) return;
+        const int v = unit - 4;
+        float gx, gy;
+        project_view(p, v, s, &gx, &gy);
+        const Lerp ax = axis(gx, p.W, true), ay = axis(gy, p.H, true);
+        const size_t hw = (size_t)p.H * p.W;
+        const size_t o00 = (size_t)ay.i0 * p.W + ax.i0, o01 = (size_t)ay.i0 * p.W + ax.i1,
+                     o10 = (size_t)ay.i1 * p.W + ax.i0, o11 = (size_t)ay.i1 * p.W + ax.i1;
+        const float w00 = ay.w0 * ax.w0, w01 = ay.w0 * ax.w1, w10 = ay.w1 * ax.w0, w11 = ay.w1 * ax.w1;
+        float* ft = bp.g_img_feat + (size_t)v * 8 * hw;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float* fc = ft + c * hw;
+            const float gc = gf[24 + 4 * p.V + 8 * v + c];
+            atomicAdd(fc + o00, gc * w00); atomicAdd(fc + o01, gc * w01);
+            atomicAdd(fc + o10, gc * w10); atomicAdd(fc + o11, gc * w11);
+        }
+    }
+}
+
+static int check_geometry(const ucnerf_feat_gather_params* p, const char* who) {
+    UCNERF_REQUIRE(p->pts && p->ndc1 && p->ndc2 && p->ndc3, "%s: null sample coordinates", who);
+    UCNERF_REQUIRE(p->V >= 1 && p->V <= 8, "%s: V = %d outside 1..8", who, p->V);
+    UCNERF_REQUIRE(p->H >= 2 && p->W >= 2, "%s: image size %dx%d", who, p->H, p->W);
+    for (int k = 0; k < 3; ++k)
+        UCNERF_REQUIRE(p->vol_d[k] >= 1 && p->vol_h[k] >= 1 && p->vol_w[k] >= 1, "%s: volume %d has an empty dimension", who, k);
+    UCNERF_REQUIRE(p->w2cs && p->intrinsics, "%s: null camera arrays", who);
+    return UCNERF_OK;
+}
+
+}  // namespace ucnerf
+
+using namespace ucnerf;
+
+extern "C" {
+
+int ucnerf_feat_gather_fwd(const ucnerf_feat_gather_params* p, void* stream) {
+    UCNERF_REQUIRE(p, "feat_gather_fwd: null params");
+    int rc = check_geometry(p, "feat_gather_fwd");
+    if (rc) return rc;
+    UCNERF_REQUIRE(p->vol[0] && p->vol[1] && p->vol[2] && p->conf && p->imgs && p->img_feat && p->feats,
+                   "feat_gather_fwd: null source/output pointer");
+    if (p->m <= 0) return UCNERF_OK;
+    hipLaunchKernelGGL(feat_gather_fwd_kernel, dim3(cdiv(p->m, 256), 4 + p->V), dim3(256), 0, (hipStream_t)stream, *p);
+    return check_launch("feat_gather_fwd");
+}
+
+int ucnerf_feat_gather_bwd(const ucnerf_feat_gather_bwd_params* bp, void* stream) {
+    UCNERF_REQUIRE(bp && bp->g_feats, "feat_gather_bwd: null params/g_feats");
+    int rc = check_geometry(&bp->fwd, "feat_gather_bwd");
+    if (rc) return rc;
+    if (bp->fwd.m <= 0) return UCNERF_OK;
+    hipLaunchKernelGGL(feat_gather_bwd_kernel, dim3(cdiv(bp->fwd.m, 256), 4 + bp->fwd.V), dim3(256), 0,
+                       (hipStream_t)stream, *bp);
+    return check_launch("feat_gather_bwd");
+}
+
+}  // extern "C"

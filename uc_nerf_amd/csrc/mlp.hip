@@ -1,0 +1,426 @@
+// K5+K6: positional encoding + the uncertainty-conditioned MLP, forward (network/models.py:138-184,
+// network/renderer.py:78-106 of the reference), on v_mfma_f32_32x32x2_f32.
+//
+// One wave owns a tile of 32 samples for the whole network.  Activations never leave the wave's
+// registers (layout: mlp_layout.h); weights stream from L2 as one float4 per lane per k-step.
+// A 256-thread block = 4 independent waves; the grid is persistent (waves stride over tiles).
+#include "common.h"
+#include "mlp_layout.h"
+
+#include <vector>
+
+namespace ucnerf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// host: pack index
+// ------------------------------------------------------------------------------------------------
+// One GEMM section: k-steps [t][lane][nt] at `off`, bias block [h][nt][r] at `off_bias`.
+// row_base[n] = flat offset of weight row n (rows >= 64 may belong to a second matrix), col_h{0,1}[t] = column
+// consumed by lane-half h at k-step t (-1 = zero pad).
+static void fill_section(int32_t* idx, int64_t off, int64_t off_bias, int64_t p_bias_lo, int64_t p_bias_hi,
+                         const std::vector<int64_t>& row_base, const std::vector<int>& col_h0,
+                         const std::vector<int>& col_h1) {
+    for (int h = 0; h < 2; ++h)
+        for (int nt = 0; nt < 4; ++nt)
+            for (int r = 0; r < 16; ++r) {
+                int n = acc_feature(nt, r, h);
+                idx[off_bias + (h * 4 + nt) * 16 + r] = (int32_t)(p_bias_hi >= 0 && n >= 64 ? p_bias_hi + n - 64 : p_bias_lo + n);
+            }
+    for (size_t t = 0; t < col_h0.size(); ++t)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int nt = 0; nt < 4; ++nt) {
+                int n = 32 * nt + (lane & 31);
+                int col = (lane >> 5) ? col_h1[t] : col_h0[t];
+                idx[off + (int64_t)t * KSTEP_FLOATS + lane * 4 + nt] = col < 0 ? -1 : (int32_t)(row_base[n] + (int64_t)col);
+            }
+}
+
+static int build_pack_index(const ucnerf_mlp_config* cfg, int32_t* idx) {
+    MlpLayout L;
+    if (!mlp_layout(cfg->n_src, &L)) return -1;
+    const int v = L.v, W = MLP_W;
+    for (int64_t i = 0; i < L.total; ++i) idx[i] = -1;
+    auto rows = [&](int64_t base, int K) {
+        std::vector<int64_t> rb(128);
+        for (int n = 0; n < 128; ++n) rb[n] = base + (int64_t)n * K;
+        return rb;
+    };
+    auto nat_cols = [&](int ks, int K, int h) {
+        std::vector<int> c(ks);
+        for (int t = 0; t < ks; ++t) c[t] = 2 * t + h < K ? 2 * t + h : -1;
+        return c;
+    };
+    auto acc_cols = [&](int h, int base) {
+        std::vector<int> c(KS_HID);
+        for (int t = 0; t < KS_HID; ++t) c[t] = base + acc_feature(t >> 4, t & 15, h);
+        return c;
+    };
+    auto pe_cols = [&](int ks, int nf, int h, int base) {
+        std::vector<int> c(ks);
+        for (int t = 0; t < ks; ++t) {
+            int kind, a;
+            pe_slot(t, h, nf, &kind, &a);
+            int col = pe_column(kind, a, nf, cfg->pe_layout);
+            c[t] = col < 0 ? -1 : base + col;
+        }
+        return c;
+    };
+    auto cat = [](std::vector<int> a, const std::vector<int>& b) { a.insert(a.end(), b.begin(), b.end()); return a; };
+    auto bias_off = [&](int sec) { return L.off_const + (int64_t)sec * 128; };
+    // bias nets
+    fill_section(idx, L.off_sec[SEC_BD], bias_off(SEC_BD), L.p_bdb, -1, rows(L.p_bdw, 24 + 4 * v),
+                 nat_cols(L.kd, 24 + 4 * v, 0), nat_cols(L.kd, 24 + 4 * v, 1));
+    fill_section(idx, L.off_sec[SEC_BC], bias_off(SEC_BC), L.p_bcb, -1, rows(L.p_bcw, 8 * v), nat_cols(L.kc, 8 * v, 0),
+                 nat_cols(L.kc, 8 * v, 1));
+    // trunk
+    fill_section(idx, L.off_sec[SEC_L0], bias_off(SEC_L0), L.p_lb[0], -1, rows(L.p_lw[0], MLP_PE_PTS),
+                 pe_cols(KS_PE_PTS, 10, 0, 0), pe_cols(KS_PE_PTS, 10, 1, 0));
+    for (int i = 1; i < 5; ++i)
+        fill_section(idx, L.off_sec[SEC_L0 + i], bias_off(SEC_L0 + i), L.p_lb[i], -1, rows(L.p_lw[i], W), acc_cols(0, 0),
+                     acc_cols(1, 0));
+    fill_section(idx, L.off_sec[SEC_L0 + 5], bias_off(SEC_L0 + 5), L.p_lb[5], -1, rows(L.p_lw[5], W + MLP_PE_PTS),
+                 cat(pe_cols(KS_PE_PTS, 10, 0, 0), acc_cols(0, MLP_PE_PTS)),
+                 cat(pe_cols(KS_PE_PTS, 10, 1, 0), acc_cols(1, MLP_PE_PTS)));
+    fill_section(idx, L.off_sec[SEC_FT], bias_off(SEC_FT), L.p_fb, -1, rows(L.p_fw, W), acc_cols(0, 0), acc_cols(1, 0));
+    {   // views_linears (rows 0..63) stacked on view_confi_linears (rows 64..127); input [feature 128 | dir PE 27]
+        std::vector<int64_t> rb(128);
+        for (int n = 0; n < 64; ++n) {
+            rb[n] = L.p_vw + (int64_t)n * (W + MLP_PE_DIR);
+            rb[64 + n] = L.p_vcw + (int64_t)n * (W + MLP_PE_DIR);
+        }
+        fill_section(idx, L.off_sec[SEC_VC], bias_off(SEC_VC), L.p_vb, L.p_vcb, rb,
+                     cat(acc_cols(0, 0), pe_cols(KS_PE_DIR, 4, 0, W)), cat(acc_cols(1, 0), pe_cols(KS_PE_DIR, 4, 1, W)));
+    }
+    // wrap: the ring prefetch of a tile's last k-steps lands on the first k-steps of the next tile
+    for (int64_t i = 0; i < (int64_t)RING * KSTEP_FLOATS; ++i) idx[L.off_wrap + i] = idx[i];
+    // heads: [h][nt][r][4] + 4 biases
+    const int64_t off_hb = L.off_const + N_SEC * 128, off_ha = off_hb + 516;
+    for (int h = 0; h < 2; ++h)
+        for (int nt = 0; nt < 4; ++nt)
+            for (int r = 0; r < 16; ++r) {
+                int f = acc_feature(nt, r, h);
+                int64_t o = ((h * 4 + nt) * 16 + r) * 4;
+                for (int c = 0; c < 3; ++c) idx[off_hb + o + c] = (int32_t)(L.p_crw + c * W + f);   // confi_rgb_linear
+                idx[off_hb + o + 3] = (int32_t)(L.p_a1w + f);                                         // alpha_linear_1
+                if (f < 64) for (int c = 0; c < 3; ++c) idx[off_ha + o + c] = (int32_t)(L.p_rw + c * 64 + f);  // rgb_linear
+                else idx[off_ha + o + 3] = (int32_t)(L.p_aw + f - 64);                                 // alpha_linear
+            }
+    for (int c = 0; c < 3; ++c) { idx[off_hb + 512 + c] = (int32_t)(L.p_crb + c); idx[off_ha + 512 + c] = (int32_t)(L.p_rb + c); }
+    idx[off_hb + 512 + 3] = (int32_t)L.p_a1b;
+    idx[off_ha + 512 + 3] = (int32_t)L.p_ab;
+    return 0;
+}
+
+__global__ void pack_kernel(const float* __restrict__ flat, const int32_t* __restrict__ idx, float* __restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { int32_t k = idx[i]; out[i] = k >= 0 ? flat[k] : 0.f; }
+}
+
+__global__ void unpack_grad_kernel(const float* __restrict__ g, const int32_t* __restrict__ idx, float* __restrict__ gflat, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { int32_t k = idx[i]; if (k >= 0) atomicAdd(gflat + k, g[i]); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// device: forward
+// ------------------------------------------------------------------------------------------------
+struct MlpGeom {      // MlpLayout subset the kernel needs (32-bit is plenty: the stream is < 1 MB)
+    int F, kd, kc, f_img, off_const;
+};
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// The weight stream is walked strictly in order by every wave: `A` points at this lane's float4 of the
+// current k-step, `ring` holds the next RING k-steps already in flight.  sched_barrier(0) after each
+// k-step keeps hipcc from hoisting the whole layer's loads (which spills) -- the ring IS the prefetch.
+struct Stream {
+    const f32x4* __restrict__ A;
+    f32x4 ring[RING];
+};
+
+#define KSTEP(S, T, BVAL, ACC)                                   \
+    {                                                            \
+        const f32x4 a_ = (S).ring[(T) & (RING - 1)];             \
+        (S).ring[(T) & (RING - 1)] = (S).A[((T) + RING) * 64];   \
+        const float b_ = (BVAL);                                 \
+        (ACC)[0] = MFMA(a_.x, b_, (ACC)[0]);                     \
+        (ACC)[1] = MFMA(a_.y, b_, (ACC)[1]);                     \
+        (ACC)[2] = MFMA(a_.z, b_, (ACC)[2]);                     \
+        (ACC)[3] = MFMA(a_.w, b_, (ACC)[3]);                     \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    }
+
+// accumulators <- bias block of section `sec` (LDS copy of the constants)
+__device__ __forceinline__ void init_bias(const float* cst, int sec, int h, f32x16 (&acc)[4]) {
+    const f32x4* b = reinterpret_cast<const f32x4*>(cst + sec * 128 + h * 64);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = b[nt * 4 + q];
+            acc[nt][4 * q] = v.x; acc[nt][4 * q + 1] = v.y; acc[nt][4 * q + 2] = v.z; acc[nt][4 * q + 3] = v.w;
+        }
+}
+
+// 64 k-steps whose B operands are the registers of an accumulator-layout activation set
+__device__ __forceinline__ void gemm_hidden(Stream& S, const f32x16 (&x)[4], f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int t = 0; t < KS_HID; ++t) KSTEP(S, t, x[t >> 4][t & 15], acc)
+    S.A += KS_HID * 64;
+}
+
+// KS k-steps whose B operands sit in a per-lane register array (encodings)
+template <int KS>
+__device__ __forceinline__ void gemm_regs(Stream& S, const float (&x)[KS], f32x16 (&acc)[4]) {
+    static_assert(KS % RING == 0, "sections are multiples of the ring depth");
+#pragma unroll
+    for (int t = 0; t < KS; ++t) KSTEP(S, t, x[t], acc)
+    S.A += KS * 64;
+}
+
+// KS k-steps whose B operands come from this wave's LDS stash (slot t at stash[t*64 + lane])
+template <int KS>
+__device__ __forceinline__ void gemm_stash(Stream& S, const float* stash, int lane, f32x16 (&acc)[4]) {
+    float b[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i) b[i] = stash[i * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+        const float bv = b[t & (RING - 1)];
+        if (t + RING < KS) b[t & (RING - 1)] = stash[(t + RING) * 64 + lane];
+        KSTEP(S, t, bv, acc)
+    }
+    S.A += KS * 64;
+}
+
+// ks (runtime, multiple of RING) k-steps whose B operands stream from global memory: element t at xb[t * xstride]
+__device__ __forceinline__ void gemm_mem(Stream& S, const float* __restrict__ xb, int xstride, int ks, f32x16 (&acc)[4]) {
+    float b[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i) b[i] = xb[(size_t)i * xstride];
+    for (int t0 = 0; t0 < ks; t0 += RING) {
+        const bool more = t0 + RING < ks;
+#pragma unroll
+        for (int i = 0; i < RING; ++i) {
+            const float bv = b[i];
+            if (more) b[i] = xb[(size_t)(t0 + RING + i) * xstride];
+            KSTEP(S, i, bv, acc)
+        }
+        S.A += RING * 64;
+    }
+}
+
+// 4-wide heads on the VALU: out4 = sum_f x[f] * Wh[f][0..3] over this lane's 64 features, then both halves
+__device__ __forceinline__ f32x4 head4(const float* hd, int h, const f32x16 (&x)[4]) {
+    const f32x4* w = reinterpret_cast<const f32x4*>(hd) + h * 64;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const f32x4 wv = w[nt * 16 + r];
+            const float xv = x[nt][r];
+            s.x = fmaf(xv, wv.x, s.x); s.y = fmaf(xv, wv.y, s.y); s.z = fmaf(xv, wv.z, s.z); s.w = fmaf(xv, wv.w, s.w);
+        }
+    s.x += __shfl_xor(s.x, 32); s.y += __shfl_xor(s.y, 32); s.z += __shfl_xor(s.z, 32); s.w += __shfl_xor(s.w, 32);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(hd + 512);
+    s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    return s;
+}
+
+// Positional encoding of a 3-vector in the k-step order of mlp_layout.h (this lane-half's slots).
+template <int NF, int KS>
+__device__ __forceinline__ void encode(const float (&x)[3], int h, float (&pe)[KS]) {
+    constexpr int half = 3 * NF / 2;
+#pragma unroll
+    for (int q = 0; q < half; ++q) {
+        const int a = 2 * q + h;
+        const int fr = a / 3, c = a - 3 * fr;
+        const float xc = c == 0 ? x[0] : (c == 1 ? x[1] : x[2]);
+        float s, co;
+        sincosf(xc * (float)(1 << fr), &s, &co);
+        pe[q] = s;
+        pe[half + q] = co;
+    }
+    pe[2 * half] = h ? x[2] : x[0];
+    pe[2 * half + 1] = h ? 0.f : x[1];
+#pragma unroll
+    for (int q = 2 * half + 2; q < KS; ++q) pe[q] = 0.f;
+}
+
+#define EPILOGUE_RELU_MOD(DST, ACC, MOD)                                               \
+    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                   \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) (DST)[nt][r] = fmaxf((ACC)[nt][r] * (MOD)[nt][r], 0.f);
+
+template <bool TILED>
+__global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, MlpGeom g, int n_tiles) {
+    __shared__ __attribute__((aligned(16))) float cst[CONST_FLOATS];
+    __shared__ __attribute__((aligned(16))) float pe_stash[4][KS_PE_PTS * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const float* __restrict__ ws = p.wstream;
+    const int n_waves = gridDim.x * 4;
+    float* stash = pe_stash[wave];
+
+    for (int i = threadIdx.x; i < CONST_FLOATS; i += 256) cst[i] = ws[g.off_const + i];
+    __syncthreads();
+    const float* hb = cst + N_SEC * 128;
+    const float* ha = hb + 516;
+
+    const f32x4* const A0 = reinterpret_cast<const f32x4*>(ws) + lane;
+    Stream S;
+#pragma unroll
+    for (int i = 0; i < RING; ++i) S.ring[i] = A0[i * 64];
+
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += n_waves) {
+        S.A = A0;
+        const int s_raw = tile * 32 + j;
+        const int s = s_raw < p.m ? s_raw : p.m - 1;
+        // feature f of sample s lives at fb[f * fstride]
+        const float* fb;
+        int fstride;
+        if (TILED) { fb = p.feats + (size_t)(s >> 5) * g.F * 32 + (s & 31); fstride = 32; }
+        else { fb = p.feats + (size_t)s * g.F; fstride = 1; }
+
+        f32x16 bd[4], hin[4], acc[4];
+
+        // ---- depth-bias net: bd = W_d [volume feats | colours+masks] + b      (models.py:150)
+        init_bias(cst, SEC_BD, h, bd);
+        gemm_mem(S, fb + (size_t)h * fstride, 2 * fstride, g.kd, bd);
+
+        // ---- point encoding, stashed in LDS for the skip connection; layer 0
+        {
+            float pe[KS_PE_PTS];
+            const float x[3] = {p.pts[3 * (size_t)s], p.pts[3 * (size_t)s + 1], p.pts[3 * (size_t)s + 2]};
+            encode<10, KS_PE_PTS>(x, h, pe);
+#pragma unroll
+            for (int t = 0; t < KS_PE_PTS; ++t) stash[t * 64 + lane] = pe[t];
+            init_bias(cst, SEC_L0, h, acc);
+            gemm_regs<KS_PE_PTS>(S, pe, acc);
+        }
+        EPILOGUE_RELU_MOD(hin, acc, bd)
+
+        // ---- layers 1..4                                                        (models.py:153-155)
+#pragma unroll 1
+        for (int l = 1; l < 5; ++l) {
+            init_bias(cst, SEC_L0 + l, h, acc);
+            gemm_hidden(S, hin, acc);
+            EPILOGUE_RELU_MOD(hin, acc, bd)
+        }
+
+        // ---- layer 5 on [pe | h]                                                (models.py:156-157)
+        init_bias(cst, SEC_L0 + 5, h, acc);
+        gemm_stash<KS_PE_PTS>(S, stash, lane, acc);
+        gemm_hidden(S, hin, acc);
+        EPILOGUE_RELU_MOD(hin, acc, bd)
+
+        // ---- base heads: confi_rgb_linear, alpha_linear_1                       (models.py:161-162)
+        const f32x4 base = head4(hb, h, hin);
+
+        // ---- confidence-bias net, feature_linear(h * b_c)                       (models.py:151,164)
+        init_bias(cst, SEC_BC, h, bd);
+        gemm_mem(S, fb + (size_t)(g.f_img + h) * fstride, 2 * fstride, g.kc, bd);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hin[nt][r] = hin[nt][r] * bd[nt][r];
+        init_bias(cst, SEC_FT, h, acc);
+        gemm_hidden(S, hin, acc);
+
+        // ---- views_linears | view_confi_linears on [feature | dir encoding], relu   (models.py:166-173)
+        init_bias(cst, SEC_VC, h, hin);
+        gemm_hidden(S, acc, hin);
+        {
+            const size_t ray = p.dirs_per_sample ? (size_t)s : (size_t)(s / p.S);
+            const float d[3] = {p.dirs[3 * ray], p.dirs[3 * ray + 1], p.dirs[3 * ray + 2]};
+            float pd[KS_PE_DIR];
+            encode<4, KS_PE_DIR>(d, h, pd);
+            gemm_regs<KS_PE_DIR>(S, pd, hin);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hin[nt][r] = fmaxf(hin[nt][r], 0.f);
+
+        // ---- adapt heads (rgb_linear on rows 0..63, alpha_linear on rows 64..127), uncertainty blend
+        const f32x4 adapt = head4(ha, h, hin);
+        const float conf = fb[(size_t)(g.F - 1) * fstride];
+        const float u = 1.f - conf, omu = 1.f - u;          // models.py:149,177-178
+        f32x4 out;
+        out.x = 1.f / (1.f + expf(-(base.x * omu + adapt.x * u)));
+        out.y = 1.f / (1.f + expf(-(base.y * omu + adapt.y * u)));
+        out.z = 1.f / (1.f + expf(-(base.z * omu + adapt.z * u)));
+        out.w = fmaxf(adapt.w * omu + base.w * u, 0.f);
+        if (h == 0 && s_raw < p.m) reinterpret_cast<f32x4*>(p.raw)[s_raw] = out;
+    }
+}
+
+static MlpGeom geom_of(const MlpLayout& L) {
+    MlpGeom g;
+    g.F = L.F; g.kd = L.kd; g.kc = L.kc; g.f_img = 24 + 4 * L.v; g.off_const = (int)L.off_const;
+    return g;
+}
+
+}  // namespace ucnerf
+
+using namespace ucnerf;
+
+extern "C" {
+
+int64_t ucnerf_mlp_param_count(const ucnerf_mlp_config* cfg) {
+    MlpLayout L;
+    if (!cfg || !mlp_layout(cfg->n_src, &L)) return fail(UCNERF_EINVAL, "mlp: n_src must be in 1..8");
+    return L.n_params;
+}
+
+int64_t ucnerf_mlp_stream_count(const ucnerf_mlp_config* cfg) {
+    MlpLayout L;
+    if (!cfg || !mlp_layout(cfg->n_src, &L)) return fail(UCNERF_EINVAL, "mlp: n_src must be in 1..8");
+    return L.total;
+}
+
+int ucnerf_mlp_pack_index(const ucnerf_mlp_config* cfg, int32_t* idx_host) {
+    UCNERF_REQUIRE(cfg && idx_host, "mlp_pack_index: null pointer");
+    UCNERF_REQUIRE(cfg->pe_layout == 0 || cfg->pe_layout == 1, "mlp_pack_index: pe_layout %d", cfg->pe_layout);
+    UCNERF_REQUIRE(build_pack_index(cfg, idx_host) == 0, "mlp_pack_index: n_src %d outside 1..8", cfg->n_src);
+    return UCNERF_OK;
+}
+
+int ucnerf_mlp_pack(const float* flat, const int32_t* idx, float* out, int64_t n, void* stream) {
+    UCNERF_REQUIRE(flat && idx && out && n > 0, "mlp_pack: bad arguments");
+    hipLaunchKernelGGL(pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, flat, idx, out, n);
+    return check_launch("mlp_pack");
+}
+
+int ucnerf_mlp_unpack_grad(const float* g, const int32_t* idx, float* gflat, int64_t n, void* stream) {
+    UCNERF_REQUIRE(g && idx && gflat && n > 0, "mlp_unpack_grad: bad arguments");
+    hipLaunchKernelGGL(unpack_grad_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, g, idx, gflat, n);
+    return check_launch("mlp_unpack_grad");
+}
+
+int ucnerf_mlp_fwd(const ucnerf_mlp_params* p, void* stream) {
+    UCNERF_REQUIRE(p && p->pts && p->dirs && p->feats && p->wstream && p->raw, "mlp_fwd: null pointer");
+    MlpLayout L;
+    UCNERF_REQUIRE(mlp_layout(p->cfg.n_src, &L), "mlp_fwd: n_src %d outside 1..8", p->cfg.n_src);
+    UCNERF_REQUIRE(p->m >= 0, "mlp_fwd: m < 0");
+    UCNERF_REQUIRE(p->dirs_per_sample || p->S > 0, "mlp_fwd: S must be > 0 when dirs are per ray");
+    UCNERF_REQUIRE(((uintptr_t)p->wstream & 15) == 0 && ((uintptr_t)p->raw & 15) == 0, "mlp_fwd: wstream/raw must be 16-byte aligned");
+    if (p->m == 0) return UCNERF_OK;
+    const int n_tiles = cdiv(p->m, 32);
+    int cus = device_cus();
+    if (cus <= 0) return fail(UCNERF_EHIP, "mlp_fwd: no device");
+    int blocks = cdiv(n_tiles, 4);
+    int cap = p->max_blocks > 0 ? p->max_blocks : cus * 2;
+    if (blocks > cap) blocks = cap;
+    MlpGeom g = geom_of(L);
+    if (p->feats_tiled)
+        hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, g, n_tiles);
+    else
+        hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, g, n_tiles);
+    return check_launch("mlp_fwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,341 @@
+// K1/K2/K3 + a2/a5 small per-ray / per-sample kernels (HBM-bound, one thread per element).
+#include "common.h"
+
+namespace ucnerf {
+
+thread_local char g_err[512] = "";
+char* last_error_buf() { return g_err; }
+
+int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        cus = prop.multiProcessorCount;
+    }
+    return cus;
+}
+
+// ------------------------------------------------------------------------------------------- a1
+__global__ void ray_gen_kernel(ucnerf_ray_gen_params p) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    float x, y;
+    if (p.xs) {
+        x = p.xs[i];
+        y = p.ys[i];
+    } else {                                   // row-major pixel grid (meshgrid 'ij', flattened)
+        int idx = p.grid_start + i;
+        y = (float)(idx / p.W);
+        x = (float)(idx % p.W);
+    }
+    float dx, dy, dz;
+    if (p.opengl) {                            // utils/run_nerf_helpers.py:252
+        float f = p.K[0];
+        dx = (x - p.W * .5f) / f;
+        dy = -(y - p.H * .5f) / f;
+        dz = -1.0f;
+    } else {                                   // data/ray_utils.py:27, utils/utils.py:259-261
+        dx = (x - p.K[2]) / p.K[0];
+        dy = (y - p.K[5]) / p.K[4];
+        dz = 1.0f;
+    }
+    const float* R = p.c2w;
+    p.rays_d[3 * i + 0] = dx * R[0] + dy * R[1] + dz * R[2];
+    p.rays_d[3 * i + 1] = dx * R[4] + dy * R[5] + dz * R[6];
+    p.rays_d[3 * i + 2] = dx * R[8] + dy * R[9] + dz * R[10];
+    if (p.rays_o) {
+        p.rays_o[3 * i + 0] = R[3];
+        p.rays_o[3 * i + 1] = R[7];
+        p.rays_o[3 * i + 2] = R[11];
+    }
+    if (p.pix) {
+        p.pix[i] = y;
+        p.pix[p.n + i] = x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- a2
+__global__ void ndc_rays_kernel(ucnerf_ndc_rays_params p) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    float ox = p.rays_o[3 * i], oy = p.rays_o[3 * i + 1], oz = p.rays_o[3 * i + 2];
+    float dx = p.rays_d[3 * i], dy = p.rays_d[3 * i + 1], dz = p.rays_d[3 * i + 2];
+    float t = -(p.near + oz) / dz;
+    ox = ox + t * dx; oy = oy + t * dy; oz = oz + t * dz;
+    float sx = -1.f / (p.W / (2.f * p.focal_x)), sy = -1.f / (p.H / (2.f * p.focal_y));
+    float ox_oz = ox / oz, oy_oz = oy / oz;
+    float o2 = 1.f + 2.f * p.near / oz;
+    p.out_o[3 * i] = sx * ox_oz;
+    p.out_o[3 * i + 1] = sy * oy_oz;
+    p.out_o[3 * i + 2] = o2;
+    p.out_d[3 * i] = sx * (dx / dz - ox_oz);
+    p.out_d[3 * i + 1] = sy * (dy / dz - oy_oz);
+    p.out_d[3 * i + 2] = p.variant == 0 ? 1.f - o2 : -2.f * p.near / oz;
+}
+
+// ------------------------------------------------------------------------------- view-dir feature
+__global__ void dir_feature_kernel(ucnerf_dir_feature_params p) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    float dx = p.rays_d[3 * i], dy = p.rays_d[3 * i + 1], dz = p.rays_d[3 * i + 2];
+    float c = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx /= c; dy /= c; dz /= c;
+    if (p.cos_angle) p.cos_angle[i] = c;
+    if (p.has_ref) {
+        const float* R = p.w2c_ref;
+        p.angle[3 * i] = dx * R[0] + dy * R[1] + dz * R[2];
+        p.angle[3 * i + 1] = dx * R[4] + dy * R[5] + dz * R[6];
+        p.angle[3 * i + 2] = dx * R[8] + dy * R[9] + dz * R[10];
+    } else {
+        p.angle[3 * i] = dx; p.angle[3 * i + 1] = dy; p.angle[3 * i + 2] = dz;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- a3
+// torch.linspace(0, 1, S)[i]: ATen computes start + step*i below the midpoint and end - step*(S-1-i) above.
+__device__ __forceinline__ float linspace01(int i, int S) {
+    if (S == 1) return 0.f;
+    float step = 1.0f / (float)(S - 1);
+    return i < S / 2 ? step * (float)i : 1.0f - step * (float)(S - 1 - i);
+}
+
+__device__ __forceinline__ float z_at(float near, float far, int i, int S, int lindisp) {
+    float t = linspace01(i, S);
+    return lindisp ? 1.f / (1.f / near * (1.f - t) + 1.f / far * t) : near * (1.f - t) + far * t;
+}
+
+__global__ void sample_stratified_kernel(ucnerf_sample_stratified_params p) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)p.n * p.S) return;
+    int r = (int)(idx / p.S), s = (int)(idx % p.S);
+    const float* ray = p.rays + 8 * (size_t)r;
+    float near = ray[6], far = ray[7];
+    float z = z_at(near, far, s, p.S, p.lindisp);
+    if (p.perturb > 0.f) {
+        float zl = s > 0 ? z_at(near, far, s - 1, p.S, p.lindisp) : z;
+        float zu = s + 1 < p.S ? z_at(near, far, s + 1, p.S, p.lindisp) : z;
+        float lower = s > 0 ? .5f * (zl + z) : z;         // mids = .5*(z[:-1] + z[1:])
+        float upper = s + 1 < p.S ? .5f * (z + zu) : z;
+        z = lower + (upper - lower) * (p.perturb * p.noise[idx]);
+    }
+    p.z[idx] = z;
+    if (p.pts) {
+        p.pts[3 * idx] = ray[0] + ray[3] * z;
+        p.pts[3 * idx + 1] = ray[1] + ray[4] * z;
+        p.pts[3 * idx + 2] = ray[2] + ray[5] * z;
+    }
+}
+
+// Live cascade sampler: one 64-thread block per ray; the S values are sorted in LDS (bitonic, padded to a
+// power of two), then stratified.  S <= 768.
+__global__ void __launch_bounds__(64) sample_cascade_kernel(ucnerf_sample_cascade_params p) {
+    __shared__ float zs[1024];
+    int r = blockIdx.x;
+    int S = p.S, n3 = S / 3;
+    int P = 1;
+    while (P < S) P <<= 1;
+    const float* nf = p.near_far + 6 * (size_t)r;
+    for (int i = threadIdx.x; i < P; i += 64) {
+        float v = __builtin_inff();
+        if (i < S) {
+            int k = i / n3, j = i % n3;
+            float t = linspace01(j, n3);
+            v = nf[2 * k] * (1.0f - t) + nf[2 * k + 1] * t;       // utils/utils.py:396
+        }
+        zs[i] = v;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += 64) {
+                int l = i ^ j;
+                if (l > i) {
+                    float a = zs[i], b = zs[l];
+                    bool up = (i & k) == 0;
+                    if ((a > b) == up) { zs[i] = b; zs[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int s = threadIdx.x; s < S; s += 64) {
+        float z = zs[s];
+        if (p.t_rand) {
+            float lower = s > 0 ? .5f * (z + zs[s - 1]) : z;      // mids = .5*(z[1:] + z[:-1])
+            float upper = s + 1 < S ? .5f * (zs[s + 1] + z) : z;
+            z = lower + (upper - lower) * p.t_rand[(size_t)r * S + s];
+        }
+        size_t o = (size_t)r * S + s;
+        p.z[o] = z;
+        if (p.pts) {
+            p.pts[3 * o] = p.rays_o[0] + z * p.rays_d[3 * r];
+            p.pts[3 * o + 1] = p.rays_o[1] + z * p.rays_d[3 * r + 1];
+            p.pts[3 * o + 2] = p.rays_o[2] + z * p.rays_d[3 * r + 2];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- a4
+__global__ void ndc_project_kernel(ucnerf_ndc_project_params p) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.m) return;
+    float x = p.pts[3 * (size_t)i], y = p.pts[3 * (size_t)i + 1], z = p.pts[3 * (size_t)i + 2];
+    if (p.has_w2c) {
+        const float* M = p.w2c;
+        float cx = x * M[0] + y * M[1] + z * M[2] + M[3];
+        float cy = x * M[4] + y * M[5] + z * M[6] + M[7];
+        float cz = x * M[8] + y * M[9] + z * M[10] + M[11];
+        if (fabsf(cz) < 1e-4f) cz = 1e-4f;
+        x = cx; y = cy; z = cz;
+    }
+    const float* K = p.K;
+    float qx = x * K[0] + y * K[1] + z * K[2];
+    float qy = x * K[3] + y * K[4] + z * K[5];
+    float qz = x * K[6] + y * K[7] + z * K[8];
+    float u = (qx / qz + 0.0f) / p.inv_scale[0];
+    float v = (qy / qz + 0.0f) / p.inv_scale[1];
+    size_t o = 3 * (size_t)i;
+    if (p.sample_2d) {
+        p.out_ndc[o] = u; p.out_ndc[o + 1] = v; p.out_ndc[o + 2] = qz;
+        return;
+    }
+    size_t k = (size_t)i * p.nf_stride;
+    float* outs[3] = {p.out_stage1, p.out_stage2, p.out_stage3};
+    const float* nears[3] = {p.near_1, p.near_2, p.near_3};
+    const float* fars[3] = {p.far_1, p.far_2, p.far_3};
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (!outs[s]) continue;
+        float n = nears[s][k], f = fars[s][k];
+        outs[s][o] = u; outs[s][o + 1] = v; outs[s][o + 2] = (qz - n) / (f - n);
+    }
+    if (p.out_ndc) {
+        p.out_ndc[o] = u; p.out_ndc[o + 1] = v; p.out_ndc[o + 2] = (qz - p.near) / (p.far - p.near);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- a5
+__global__ void embed_kernel(ucnerf_embed_params p) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (vector, freq slot)
+    int L = p.n_freqs;
+    if (idx >= (long long)p.m * (L + 1)) return;
+    int v = (int)(idx / (L + 1)), k = (int)(idx % (L + 1));
+    int D = 3 + 6 * L;
+    const float* x = p.x + 3 * (size_t)v;
+    float* o = p.out + (size_t)v * D;
+    if (k == L) {
+        o[0] = x[0]; o[1] = x[1]; o[2] = x[2];
+        return;
+    }
+    float f = (float)(1 << k);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s, co;
+        sincosf(x[c] * f, &s, &co);
+        if (p.layout == 0) {                 // [x | sin(f0..) | cos(f0..)], 3 per frequency
+            o[3 + 3 * k + c] = s;
+            o[3 + 3 * L + 3 * k + c] = co;
+        } else {                             // [x | sin f0 | cos f0 | sin f1 | ...]
+            o[3 + 6 * k + c] = s;
+            o[3 + 6 * k + 3 + c] = co;
+        }
+    }
+}
+
+}  // namespace ucnerf
+
+using namespace ucnerf;
+
+extern "C" {
+
+const char* ucnerf_last_error(void) { return last_error_buf(); }
+int ucnerf_abi_version(void) { return UCNERF_ABI_VERSION; }
+int ucnerf_device_cus(void) { return device_cus(); }
+
+int ucnerf_sizeof(const char* name) {
+#define SZ(T) if (!strcmp(name, #T)) return (int)sizeof(T)
+    SZ(ucnerf_ray_gen_params); SZ(ucnerf_ndc_rays_params); SZ(ucnerf_dir_feature_params);
+    SZ(ucnerf_sample_stratified_params); SZ(ucnerf_sample_cascade_params); SZ(ucnerf_ndc_project_params);
+    SZ(ucnerf_embed_params); SZ(ucnerf_feat_gather_params); SZ(ucnerf_feat_gather_bwd_params);
+    SZ(ucnerf_mlp_config); SZ(ucnerf_mlp_params); SZ(ucnerf_mlp_bwd_params); SZ(ucnerf_composite_params);
+    SZ(ucnerf_composite_bwd_params); SZ(ucnerf_sample_pdf_params); SZ(ucnerf_render_params);
+    SZ(ucnerf_render_bwd_params);
+#undef SZ
+    return -1;
+}
+
+int ucnerf_ray_gen(const ucnerf_ray_gen_params* p, void* stream) {
+    UCNERF_REQUIRE(p && p->rays_d, "ray_gen: null params/rays_d");
+    UCNERF_REQUIRE(p->n >= 0, "ray_gen: n < 0");
+    UCNERF_REQUIRE((p->xs == nullptr) == (p->ys == nullptr), "ray_gen: xs and ys must both be given or both NULL");
+    UCNERF_REQUIRE(p->xs || (p->W > 0 && p->H > 0 && p->grid_start >= 0 &&
+                             (long long)p->grid_start + p->n <= (long long)p->H * p->W),
+                   "ray_gen: grid range [%d, %d) outside %dx%d", p->grid_start, p->grid_start + p->n, p->H, p->W);
+    if (p->n == 0) return UCNERF_OK;
+    hipLaunchKernelGGL(ray_gen_kernel, dim3(cdiv(p->n, 256)), dim3(256), 0, (hipStream_t)stream, *p);
+    return check_launch("ray_gen");
+}
+
+int ucnerf_ndc_rays(const ucnerf_ndc_rays_params* p, void* stream) {
+    UCNERF_REQUIRE(p && p->rays_o && p->rays_d && p->out_o && p->out_d, "ndc_rays: null pointer");
+    UCNERF_REQUIRE(p->variant == 0 || p->variant == 1, "ndc_rays: variant %d", p->variant);
+    if (p->n <= 0) return UCNERF_OK;
+    hipLaunchKernelGGL(ndc_rays_kernel, dim3(cdiv(p->n, 256)), dim3(256), 0, (hipStream_t)stream, *p);
+    return check_launch("ndc_rays");
+}
+
+int ucnerf_dir_feature(const ucnerf_dir_feature_params* p, void* stream) {
+    UCNERF_REQUIRE(p && p->rays_d && p->angle, "dir_feature: null pointer");
+    if (p->n <= 0) return UCNERF_OK;
+    hipLaunchKernelGGL(dir_feature_kernel, dim3(cdiv(p->n, 256)), dim3(256), 0, (hipStream_t)stream, *p);
+    return check_launch("dir_feature");
+}
+
+int ucnerf_sample_stratified(const ucnerf_sample_stratified_params* p, void* stream) {
+    UCNERF_REQUIRE(p && p->rays && p->z, "sample_stratified: null pointer");
+    UCNERF_REQUIRE(p->S >= 1, "sample_stratified: S = %d", p->S);
+    UCNERF_REQUIRE(!(p->perturb > 0.f) || p->noise, "sample_stratified: perturb > 0 needs noise draws");
+    if (p->n <= 0) return UCNERF_OK;
+    hipLaunchKernelGGL(sample_stratified_kernel, dim3(cdiv((long long)p->n * p->S, 256)), dim3(256), 0,
+                       (hipStream_t)stream, *p);
+    return check_launch("sample_stratified");
+}
+
+int ucnerf_sample_cascade(const ucnerf_sample_cascade_params* p, void* stream) {
+    UCNERF_REQUIRE(p && p->near_far && p->z, "sample_cascade: null pointer");
+    UCNERF_REQUIRE(p->S >= 3 && p->S % 3 == 0 && p->S <= 768, "sample_cascade: S = %d (multiple of 3, <= 768)", p->S);
+    UCNERF_REQUIRE(!p->pts || (p->rays_o && p->rays_d), "sample_cascade: pts needs rays_o and rays_d");
+    if (p->n <= 0) return UCNERF_OK;
+    hipLaunchKernelGGL(sample_cascade_kernel, dim3(p->n), dim3(64), 0, (hipStream_t)stream, *p);
+    return check_launch("sample_cascade");
+}
+
+int ucnerf_ndc_project(const ucnerf_ndc_project_params* p, void* stream) {
+    UCNERF_REQUIRE(p && p->pts, "ndc_project: null pointer");
+    UCNERF_REQUIRE(p->nf_stride == 0 || p->nf_stride == 1, "ndc_project: nf_stride %d", p->nf_stride);
+    if (p->sample_2d) {
+        UCNERF_REQUIRE(p->out_ndc, "ndc_project: sample_2d needs out_ndc");
+    } else {
+        UCNERF_REQUIRE(p->out_stage1 || p->out_stage2 || p->out_stage3 || p->out_ndc, "ndc_project: no outputs");
+        UCNERF_REQUIRE((!p->out_stage1 || (p->near_1 && p->far_1)) && (!p->out_stage2 || (p->near_2 && p->far_2)) &&
+                           (!p->out_stage3 || (p->near_3 && p->far_3)),
+                       "ndc_project: stage output without its near/far arrays");
+    }
+    if (p->m <= 0) return UCNERF_OK;
+    hipLaunchKernelGGL(ndc_project_kernel, dim3(cdiv(p->m, 256)), dim3(256), 0, (hipStream_t)stream, *p);
+    return check_launch("ndc_project");
+}
+
+int ucnerf_embed(const ucnerf_embed_params* p, void* stream) {
+    UCNERF_REQUIRE(p && p->x && p->out, "embed: null pointer");
+    UCNERF_REQUIRE(p->n_freqs >= 0 && p->n_freqs <= 30, "embed: n_freqs %d", p->n_freqs);
+    UCNERF_REQUIRE(p->layout == 0 || p->layout == 1, "embed: layout %d", p->layout);
+    if (p->m <= 0) return UCNERF_OK;
+    hipLaunchKernelGGL(embed_kernel, dim3(cdiv((long long)p->m * (p->n_freqs + 1), 256)), dim3(256), 0,
+                       (hipStream_t)stream, *p);
+    return check_launch("embed");
+}
+
+}  // extern "C"

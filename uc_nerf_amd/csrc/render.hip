@@ -1,0 +1,145 @@
+// a10: one render pass = projection -> feature gather -> PE + MLP -> composite, chained on one stream
+// (network/renderer.py:215-255 with utils/utils.py:716-724 in front).  Host-side orchestration only:
+// every stage is one of the library's own kernels; intermediates live in the caller's workspace.
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace ucnerf {
+
+struct PointsArgs {
+    int n, S;
+    const float* rays_o;
+    const float* rays_d;
+    const float* z;
+    float w2c[12];
+    float K[9];
+    float inv_w, inv_h;        // W-1, H-1
+    float near, far;
+    const float* near_far;     // [n,6] or NULL
+    float* pts;
+    float* ndc1;
+    float* ndc2;
+    float* ndc3;
+    float* ndc;
+};
+
+// world point of every sample + its four normalised copies (utils/utils.py:716, :333-367)
+__global__ void __launch_bounds__(256) render_points_kernel(PointsArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.n * a.S) return;
+    const int r = (int)(idx / a.S);
+    const float z = a.z[idx];
+    const float x = a.rays_o[0] + z * a.rays_d[3 * r], y = a.rays_o[1] + z * a.rays_d[3 * r + 1],
+                w = a.rays_o[2] + z * a.rays_d[3 * r + 2];
+    const size_t o = 3 * (size_t)idx;
+    a.pts[o] = x; a.pts[o + 1] = y; a.pts[o + 2] = w;
+    const float* M = a.w2c;
+    const float cx = x * M[0] + y * M[1] + w * M[2] + M[3];
+    const float cy = x * M[4] + y * M[5] + w * M[6] + M[7];
+    float cz = x * M[8] + y * M[9] + w * M[10] + M[11];
+    if (fabsf(cz) < 1e-4f) cz = 1e-4f;
+    const float* K = a.K;
+    const float qx = cx * K[0] + cy * K[1] + cz * K[2];
+    const float qy = cx * K[3] + cy * K[4] + cz * K[5];
+    const float qz = cx * K[6] + cy * K[7] + cz * K[8];
+    const float u = (qx / qz + 0.0f) / a.inv_w, v = (qy / qz + 0.0f) / a.inv_h;
+    float n1 = a.near, f1 = a.far, n2 = a.near, f2 = a.far, n3 = a.near, f3 = a.far;
+    if (a.near_far) {
+        const float* nf = a.near_far + 6 * (size_t)r;
+        n1 = nf[0]; f1 = nf[1]; n2 = nf[2]; f2 = nf[3]; n3 = nf[4]; f3 = nf[5];
+    }
+    a.ndc1[o] = u; a.ndc1[o + 1] = v; a.ndc1[o + 2] = (qz - n1) / (f1 - n1);
+    a.ndc2[o] = u; a.ndc2[o + 1] = v; a.ndc2[o + 2] = (qz - n2) / (f2 - n2);
+    a.ndc3[o] = u; a.ndc3[o + 1] = v; a.ndc3[o + 2] = (qz - n3) / (f3 - n3);
+    a.ndc[o] = u; a.ndc[o + 1] = v; a.ndc[o + 2] = (qz - a.near) / (a.far - a.near);
+}
+
+struct Workspace {
+    float *pts, *ndc1, *ndc2, *ndc3, *ndc, *angle, *feats, *raw;
+};
+
+static inline size_t align4(size_t x) { return (x + 3) & ~(size_t)3; }
+
+static size_t carve(float* base, int n, int S, int V, Workspace* w) {
+    const size_t M = (size_t)n * S, F = 24 + 12 * V + 1;
+    const size_t tiles = (M + 31) / 32;
+    size_t o = 0;
+    auto take = [&](size_t k) { float* r = base ? base + o : nullptr; o += align4(k); return r; };
+    w->pts = take(3 * M); w->ndc1 = take(3 * M); w->ndc2 = take(3 * M); w->ndc3 = take(3 * M); w->ndc = take(3 * M);
+    w->angle = take(3 * (size_t)n);
+    w->raw = take(4 * M);
+    w->feats = take(tiles * 32 * F);
+    return o;
+}
+
+static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace* w) {
+    const int V = p->cfg.n_src;
+    carve(p->workspace, p->n, p->S, V, w);
+    const long long M = (long long)p->n * p->S;
+    PointsArgs a;
+    a.n = p->n; a.S = p->S; a.rays_o = p->rays_o; a.rays_d = p->rays_d; a.z = p->z;
+    memcpy(a.w2c, p->w2c_ref, sizeof(a.w2c));
+    memcpy(a.K, p->K_ref, sizeof(a.K));
+    a.inv_w = (float)(p->W - 1); a.inv_h = (float)(p->H - 1);
+    a.near = p->near; a.far = p->far; a.near_far = p->near_far;
+    a.pts = w->pts; a.ndc1 = w->ndc1; a.ndc2 = w->ndc2; a.ndc3 = w->ndc3; a.ndc = w->ndc;
+    hipLaunchKernelGGL(render_points_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, a);
+    int rc = check_launch("render_points");
+    if (rc) return rc;
+
+    ucnerf_feat_gather_params g;
+    memset(&g, 0, sizeof(g));
+    g.m = (int)M; g.V = V; g.H = p->H; g.W = p->W;
+    for (int k = 0; k < 3; ++k) { g.vol_d[k] = p->vol_d[k]; g.vol_h[k] = p->vol_h[k]; g.vol_w[k] = p->vol_w[k]; g.vol[k] = p->vol[k]; }
+    g.pts = w->pts; g.ndc1 = w->ndc1; g.ndc2 = w->ndc2; g.ndc3 = w->ndc3;
+    g.conf = p->conf; g.imgs = p->imgs; g.img_feat = p->img_feat; g.w2cs = p->w2cs; g.intrinsics = p->intrinsics;
+    const bool keep_feats = p->feats != nullptr;        // caller wants row-major features (for the backward)
+    g.out_tiled = keep_feats ? 0 : 1;
+    g.feats = keep_feats ? p->feats : w->feats;
+    if ((rc = ucnerf_feat_gather_fwd(&g, st))) return rc;
+
+    ucnerf_dir_feature_params d;
+    memset(&d, 0, sizeof(d));
+    d.n = p->n; d.has_ref = 1; memcpy(d.w2c_ref, p->w2c_dir, sizeof(d.w2c_ref));
+    d.rays_d = p->rays_d; d.angle = w->angle; d.cos_angle = nullptr;
+    if ((rc = ucnerf_dir_feature(&d, st))) return rc;
+
+    ucnerf_mlp_params m;
+    memset(&m, 0, sizeof(m));
+    m.cfg = p->cfg; m.m = (int)M; m.S = p->S; m.dirs_per_sample = 0; m.feats_tiled = g.out_tiled; m.max_blocks = p->max_blocks;
+    m.pts = w->ndc; m.dirs = w->angle; m.feats = g.feats; m.wstream = p->wstream;
+    m.raw = p->raw ? p->raw : w->raw;
+    if ((rc = ucnerf_mlp_fwd(&m, st))) return rc;
+
+    ucnerf_composite_params c;
+    memset(&c, 0, sizeof(c));
+    c.n = p->n; c.S = p->S; c.variant = 0; c.white_bkgd = p->white_bkgd;
+    c.raw = m.raw; c.z = p->z;
+    c.rgb_map = p->rgb_map; c.depth_map = p->depth_map; c.acc_map = p->acc_map; c.weights = p->weights; c.var = p->var;
+    return ucnerf_composite_fwd(&c, st);
+}
+
+}  // namespace ucnerf
+
+using namespace ucnerf;
+
+extern "C" {
+
+int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V) {
+    if (n < 0 || S < 1 || V < 1 || V > 8) return fail(UCNERF_EINVAL, "render_workspace: bad sizes n=%d S=%d V=%d", n, S, V);
+    Workspace w;
+    return (int64_t)carve(nullptr, n, S, V, &w);
+}
+
+int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream) {
+    UCNERF_REQUIRE(p && p->rays_o && p->rays_d && p->z && p->workspace && p->wstream && p->rgb_map && p->depth_map,
+                   "render_fused_fwd: null pointer");
+    UCNERF_REQUIRE(p->S >= 1 && p->S <= 1024, "render_fused_fwd: S = %d outside 1..1024", p->S);
+    UCNERF_REQUIRE((long long)p->n * p->S < (1ll << 31), "render_fused_fwd: n*S overflows int32");
+    UCNERF_REQUIRE(((uintptr_t)p->workspace & 15) == 0, "render_fused_fwd: workspace must be 16-byte aligned");
+    if (p->n <= 0) return UCNERF_OK;
+    Workspace w;
+    return run_forward(p, (hipStream_t)stream, &w);
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+// K8 + K9: inverse-CDF sampling with bit-exact searchsorted indices, and the sorted merge of the fine
+// depths with the coarse ones (data/ray_utils.py:98-141,219 of the reference).
+//
+// One 64-lane wave (= one block) per ray; everything lives in LDS.  To make
+// inds == torch.searchsorted(cdf, u, right=True) bit for bit the cdf must be bit-identical to torch-CPU's:
+//   * sum(weights + 1e-5) follows ATen's cascade_sum for a contiguous float32 row (8-lane vectors, four
+//     interleaved partial accumulators with cascade levels, tail first, lanes folded left to right);
+//   * pdf = w / sum with IEEE division;
+//   * cumsum accumulates sequentially in float64 and rounds every output to float32.
+// This file must be compiled with -ffp-contract=off.
+#include "common.h"
+
+namespace ucnerf {
+
+constexpr int PDF_MAX_BINS = 1024;
+constexpr int PDF_MAX_SORT = 2048;
+
+// ATen multi_row_sum + row_sum over `n` items item(i), i < n, for ONE vector lane.
+template <class Item>
+__device__ float aten_row_sum(int n, Item item) {
+    const int n_groups = n / 4;
+    int ceil_log2 = 0;
+    while ((1 << ceil_log2) < n_groups) ++ceil_log2;
+    const int power = ceil_log2 / 4 > 4 ? ceil_log2 / 4 : 4;
+    const int step = 1 << power, mask = step - 1;
+    float acc[4][4];
+    for (int a = 0; a < 4; ++a) for (int k = 0; k < 4; ++k) acc[a][k] = 0.f;
+    int i = 0;
+    while (i + step <= n_groups) {
+        for (int s = 0; s < step; ++s, ++i)
+            for (int k = 0; k < 4; ++k) acc[0][k] += item(4 * i + k);
+        for (int lv = 1; lv < 4; ++lv) {
+            for (int k = 0; k < 4; ++k) { acc[lv][k] += acc[lv - 1][k]; acc[lv - 1][k] = 0.f; }
+            if (i & (mask << (lv * power))) break;
+        }
+    }
+    for (; i < n_groups; ++i)
+        for (int k = 0; k < 4; ++k) acc[0][k] += item(4 * i + k);
+    for (int lv = 1; lv < 4; ++lv)
+        for (int k = 0; k < 4; ++k) acc[0][k] += acc[lv][k];
+    for (int r = n_groups * 4; r < n; ++r) acc[0][0] += item(r);
+    acc[0][0] += acc[0][1];
+    acc[0][0] += acc[0][2];
+    acc[0][0] += acc[0][3];
+    return acc[0][0];
+}
+
+__global__ void __launch_bounds__(64) sample_pdf_kernel(ucnerf_sample_pdf_params p) {
+    __shared__ float w[PDF_MAX_BINS];       // weights + 1e-5, then pdf
+    __shared__ float cdf[PDF_MAX_BINS];
+    __shared__ float srt[PDF_MAX_SORT];
+    __shared__ float lane_part[8];
+    __shared__ float total;
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    const int L = p.n_bins, n = L - 1, M = p.n_samples;
+    const float* wr = p.weights + (size_t)ray * n;
+    const float* bins = p.bins + (size_t)ray * L;
+
+    for (int i = lane; i < n; i += 64) w[i] = wr[i] + 1e-5f;
+    __syncthreads();
+
+    // ---- torch.sum(weights, -1)
+    if (n < 8) {
+        if (lane == 0) total = aten_row_sum(n, [&](int i) { return w[i]; });
+    } else {
+        const int nv = n / 8;
+        if (lane < 8) lane_part[lane] = aten_row_sum(nv, [&](int i) { return w[8 * i + lane]; });
+        __syncthreads();
+        if (lane == 0) {
+            float acc = 0.f;
+            for (int k = nv * 8; k < n; ++k) acc += w[k];
+            for (int k = 0; k < 8; ++k) acc += lane_part[k];
+            total = acc;
+        }
+    }
+    __syncthreads();
+    const float tot = total;
+    for (int i = lane; i < n; i += 64) w[i] = w[i] / tot;
+    __syncthreads();
+
+    // ---- cdf = [0, cumsum(pdf)] with a float64 running sum
+    if (lane == 0) {
+        double run = 0.0;
+        cdf[0] = 0.f;
+        for (int i = 0; i < n; ++i) { run += (double)w[i]; cdf[i + 1] = (float)run; }
+    }
+    __syncthreads();
+    if (p.cdf) for (int i = lane; i < L; i += 64) p.cdf[(size_t)ray * L + i] = cdf[i];
+
+    // ---- invert
+    const float* ur = p.u + (size_t)ray * p.u_stride;
+    for (int m = lane; m < M; m += 64) {
+        const float u = ur[m];
+        int lo = 0, hi = L;                          // first index with cdf[idx] > u  (right=True)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const int below = lo - 1 > 0 ? lo - 1 : 0;
+        const int above = lo < L - 1 ? lo : L - 1;
+        const float c0 = cdf[below], c1 = cdf[above];
+        const float b0 = bins[below], b1 = bins[above];
+        float denom = c1 - c0;
+        if (denom < 1e-5f) denom = 1.f;
+        const float t = (u - c0) / denom;
+        const float smp = b0 + t * (b1 - b0);
+        if (p.samples) p.samples[(size_t)ray * M + m] = smp;
+        if (p.inds) p.inds[(size_t)ray * M + m] = (int64_t)lo;
+        if (p.z_sorted) srt[m] = smp;
+    }
+
+    // ---- sort(cat(samples, z_merge)): bitonic network over the padded LDS buffer
+    if (p.z_sorted) {
+        const int tot_n = M + p.n_merge;
+        int P = 1;
+        while (P < tot_n) P <<= 1;
+        for (int i = lane; i < P - M; i += 64)
+            srt[M + i] = i < p.n_merge ? p.z_merge[(size_t)ray * p.n_merge + i] : __builtin_inff();
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = lane; i < P; i += 64) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const float a = srt[i], b = srt[l];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) { srt[i] = b; srt[l] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int i = lane; i < tot_n; i += 64) p.z_sorted[(size_t)ray * tot_n + i] = srt[i];
+    }
+}
+
+}  // namespace ucnerf
+
+using namespace ucnerf;
+
+extern "C" int ucnerf_sample_pdf(const ucnerf_sample_pdf_params* p, void* stream) {
+    UCNERF_REQUIRE(p && p->bins && p->weights && p->u, "sample_pdf: null pointer");
+    UCNERF_REQUIRE(p->n_bins >= 2 && p->n_bins <= PDF_MAX_BINS, "sample_pdf: n_bins = %d outside 2..%d", p->n_bins, PDF_MAX_BINS);
+    UCNERF_REQUIRE(p->n_samples >= 1 && p->n_samples <= 1024, "sample_pdf: n_samples = %d outside 1..1024", p->n_samples);
+    UCNERF_REQUIRE(p->u_stride == 0 || p->u_stride == p->n_samples, "sample_pdf: u_stride must be 0 or n_samples");
+    UCNERF_REQUIRE(p->n_merge >= 0 && p->n_merge + p->n_samples <= PDF_MAX_SORT, "sample_pdf: n_merge + n_samples > %d", PDF_MAX_SORT);
+    UCNERF_REQUIRE(!p->z_sorted || p->n_merge == 0 || p->z_merge, "sample_pdf: z_sorted with n_merge > 0 needs z_merge");
+    UCNERF_REQUIRE(p->samples || p->inds || p->cdf || p->z_sorted, "sample_pdf: no outputs requested");
+    if (p->n <= 0) return UCNERF_OK;
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3(p->n), dim3(64), 0, (hipStream_t)stream, *p);
+    return check_launch("sample_pdf");
+}

@@ -1,0 +1,479 @@
+"""Torch-facing wrappers of the HIP entry points: tensors in, tensors out, on the caller's current stream.
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); every computation is a kernel of
+libucnerf_hip.so.  All functions require float32 tensors on a ROCm device and raise otherwise.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def _dev(t):
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise RuntimeError("uc_nerf_amd: expected a tensor on a ROCm device, got %s"
+                           % (t.device if torch.is_tensor(t) else type(t)))
+    return t.device
+
+
+def _f32(t, name="tensor"):
+    _dev(t)
+    if t.dtype != torch.float32:
+        raise RuntimeError("uc_nerf_amd: %s must be float32, got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _mat(dst, src, rows, cols):
+    """Copies the top-left rows x cols block of a (host or device) matrix into a ctypes float array."""
+    m = torch.as_tensor(src, dtype=torch.float32).detach().cpu()
+    for r in range(rows):
+        for c in range(cols):
+            dst[r * cols + c] = float(m[r, c])
+
+
+def _launch(name, params, device):
+    with torch.cuda.device(device):
+        L.call(name, params, _stream())
+
+
+# ------------------------------------------------------------------------------------------------ a1/a2
+def ray_gen(K, c2w, xs=None, ys=None, H=0, W=0, grid_start=0, n=None, opengl=False, want_origin=False, want_pix=False,
+            device=None):
+    """Pinhole rays.  Either (xs, ys) pixel lists or a row-major grid range [grid_start, grid_start+n) of an
+    HxW image.  Returns (rays_d[n,3], rays_o[n,3] or None, pix[2,n] or None)."""
+    p = L.RayGenParams()
+    if xs is not None:
+        xs, ys = _f32(xs, "xs"), _f32(ys, "ys")
+        device, n = xs.device, xs.numel()
+        p.xs, p.ys = _ptr(xs), _ptr(ys)
+    else:
+        if device is None:
+            raise RuntimeError("uc_nerf_amd.ray_gen: grid mode needs a device")
+        n = H * W - grid_start if n is None else n
+    p.n, p.H, p.W, p.grid_start, p.opengl = n, H, W, grid_start, int(opengl)
+    if opengl:
+        p.K[0] = float(K)
+    else:
+        _mat(p.K, K, 3, 3)
+    _mat(p.c2w, c2w, 3, 4)
+    rays_d = torch.empty(n, 3, device=device)
+    rays_o = torch.empty(n, 3, device=device) if want_origin else None
+    pix = torch.empty(2, n, device=device) if want_pix else None
+    p.rays_d, p.rays_o, p.pix = _ptr(rays_d), _ptr(rays_o), _ptr(pix)
+    _launch("ucnerf_ray_gen", p, device)
+    return rays_d, rays_o, pix
+
+
+def ndc_rays(H, W, focal_x, focal_y, near, rays_o, rays_d, variant):
+    rays_o, rays_d = _f32(rays_o.reshape(-1, 3)), _f32(rays_d.reshape(-1, 3))
+    p = L.NdcRaysParams()
+    p.n, p.H, p.W, p.variant = rays_o.shape[0], int(H), int(W), variant
+    p.focal_x, p.focal_y, p.near = float(focal_x), float(focal_y), float(near)
+    out_o, out_d = torch.empty_like(rays_o), torch.empty_like(rays_d)
+    p.rays_o, p.rays_d, p.out_o, p.out_d = _ptr(rays_o), _ptr(rays_d), _ptr(out_o), _ptr(out_d)
+    _launch("ucnerf_ndc_rays", p, rays_o.device)
+    return out_o, out_d
+
+
+def dir_feature(rays_d, w2c_ref=None):
+    """Returns (angle[n,3], cos_angle[n]): normalised direction rotated into the reference camera."""
+    rays_d = _f32(rays_d, "rays_d")
+    p = L.DirFeatureParams()
+    p.n, p.has_ref = rays_d.shape[0], int(w2c_ref is not None)
+    if w2c_ref is not None:
+        _mat(p.w2c_ref, w2c_ref, 3, 4)
+    angle = torch.empty_like(rays_d)
+    cos = torch.empty(rays_d.shape[0], device=rays_d.device)
+    p.rays_d, p.angle, p.cos_angle = _ptr(rays_d), _ptr(angle), _ptr(cos)
+    _launch("ucnerf_dir_feature", p, rays_d.device)
+    return angle, cos
+
+
+# ------------------------------------------------------------------------------------------------ a3
+def sample_stratified(rays, S, lindisp=False, perturb=0.0, noise=None, want_pts=True):
+    rays = _f32(rays, "rays")
+    n = rays.shape[0]
+    p = L.SampleStratifiedParams()
+    p.n, p.S, p.lindisp, p.perturb = n, int(S), int(lindisp), float(perturb)
+    if perturb > 0:
+        if noise is None:
+            noise = torch.rand(n, S, device=rays.device)
+        noise = _f32(noise, "noise")
+    z = torch.empty(n, S, device=rays.device)
+    pts = torch.empty(n, S, 3, device=rays.device) if want_pts else None
+    p.rays, p.noise, p.z, p.pts = _ptr(rays), _ptr(noise if perturb > 0 else None), _ptr(z), _ptr(pts)
+    _launch("ucnerf_sample_stratified", p, rays.device)
+    return z, pts
+
+
+def sample_cascade(near_far, S, t_rand=None, rays_o=None, rays_d=None):
+    """near_far [n,6] per-ray cascade ranges -> sorted + stratified depths [n,S] (and points when rays given)."""
+    near_far = _f32(near_far, "near_far")
+    n = near_far.shape[0]
+    p = L.SampleCascadeParams()
+    p.n, p.S = n, int(S)
+    t_rand = _f32(t_rand) if t_rand is not None else None
+    z = torch.empty(n, S, device=near_far.device)
+    pts = None
+    if rays_d is not None:
+        rays_o, rays_d = _f32(rays_o.reshape(-1)[:3]), _f32(rays_d)
+        pts = torch.empty(n, S, 3, device=near_far.device)
+    p.near_far, p.t_rand, p.rays_o, p.rays_d, p.z, p.pts = (_ptr(near_far), _ptr(t_rand), _ptr(rays_o), _ptr(rays_d),
+                                                            _ptr(z), _ptr(pts))
+    _launch("ucnerf_sample_cascade", p, near_far.device)
+    return z, pts
+
+
+# ------------------------------------------------------------------------------------------------ a4
+def ndc_project(pts, w2c, K, inv_scale, near_far=None, sample_2d=False):
+    """get_ndc_coordinate.  pts [N,S,3].  near_far: dict with near_1..far_3 ([N,S,1] tensors or scalars) and
+    near/far scalars.  Returns dict(stage1, stage2, stage3, ndc) or a single tensor when sample_2d."""
+    pts = _f32(pts, "pts")
+    shp = pts.shape
+    m = pts.numel() // 3
+    p = L.NdcProjectParams()
+    p.m, p.has_w2c, p.sample_2d = m, int(w2c is not None), int(sample_2d)
+    if w2c is not None:
+        _mat(p.w2c, w2c, 3, 4)
+    _mat(p.K, K, 3, 3)
+    s = torch.as_tensor(inv_scale, dtype=torch.float32).detach().cpu().reshape(-1)
+    p.inv_scale[0], p.inv_scale[1] = float(s[0]), float(s[1])
+    p.pts = _ptr(pts)
+    dev = pts.device
+    if sample_2d:
+        out = torch.empty(shp, device=dev)
+        p.out_ndc = _ptr(out)
+        _launch("ucnerf_ndc_project", p, dev)
+        return out
+    keep, strides = [], set()
+    for k in ("near_1", "far_1", "near_2", "far_2", "near_3", "far_3"):
+        v = near_far[k]
+        if torch.is_tensor(v) and v.numel() == m:
+            v = _f32(v.to(dev).reshape(-1))
+            strides.add(1)
+        else:
+            v = torch.as_tensor(v, dtype=torch.float32).reshape(-1)[:1].to(dev).contiguous()
+            strides.add(0)
+        keep.append(v)
+        setattr(p, k, _ptr(v))
+    if len(strides) != 1:
+        raise RuntimeError("uc_nerf_amd.ndc_project: stage near/far must be all per-sample or all scalar")
+    p.nf_stride = strides.pop()
+    p.near, p.far = float(near_far["near"]), float(near_far["far"])
+    outs = {k: torch.empty(shp, device=dev) for k in ("stage1", "stage2", "stage3", "ndc")}
+    p.out_stage1, p.out_stage2, p.out_stage3, p.out_ndc = (_ptr(outs["stage1"]), _ptr(outs["stage2"]),
+                                                           _ptr(outs["stage3"]), _ptr(outs["ndc"]))
+    _launch("ucnerf_ndc_project", p, dev)
+    return outs
+
+
+# ------------------------------------------------------------------------------------------------ a5
+def embed(x, n_freqs, layout=0):
+    x = _f32(x, "x")
+    if x.shape[-1] != 3:
+        raise RuntimeError("uc_nerf_amd.embed: last dimension must be 3")
+    out = torch.empty(*x.shape[:-1], 3 + 6 * n_freqs, device=x.device)
+    p = L.EmbedParams()
+    p.m, p.n_freqs, p.layout, p.x, p.out = x.numel() // 3, n_freqs, layout, _ptr(x), _ptr(out)
+    _launch("ucnerf_embed", p, x.device)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ a7
+class GatherSources:
+    """The gather's read-only geometry + source tensors, normalised to the layouts the kernels read."""
+
+    def __init__(self, vols, conf, imgs, img_feat, w2cs, intrinsics):
+        self.vols = [_f32(v, "volume").reshape(v.shape[-4:]) for v in vols]           # [8,D,h,w]
+        for v in self.vols:
+            if v.shape[0] != 8:
+                raise RuntimeError("uc_nerf_amd: cascade volumes must have 8 channels")
+        H, W = conf.shape[-2:]
+        self.H, self.W = int(H), int(W)
+        self.conf = _f32(conf, "confidence").reshape(H, W)
+        self.imgs = _f32(imgs, "imgs").reshape(-1, 3, H, W)                            # [V,3,H,W]
+        self.V = self.imgs.shape[0]
+        self.img_feat = _f32(img_feat, "img_feat").reshape(self.V, 8, H, W)
+        dev = self.conf.device
+        self.w2cs = torch.as_tensor(w2cs, dtype=torch.float32)[:, :3, :4].reshape(-1, 12).to(dev).contiguous()
+        self.intrinsics = torch.as_tensor(intrinsics, dtype=torch.float32).reshape(-1, 9).to(dev).contiguous()
+        if self.w2cs.shape[0] != self.V or self.intrinsics.shape[0] != self.V:
+            raise RuntimeError("uc_nerf_amd: %d source images but %d poses / %d intrinsics"
+                               % (self.V, self.w2cs.shape[0], self.intrinsics.shape[0]))
+        self.F = 24 + 12 * self.V + 1
+        self.device = dev
+
+    def fill(self, p):
+        p.V, p.H, p.W = self.V, self.H, self.W
+        for k, v in enumerate(self.vols):
+            p.vol_d[k], p.vol_h[k], p.vol_w[k] = v.shape[1], v.shape[2], v.shape[3]
+            p.vol[k] = _ptr(v)
+        p.conf, p.imgs, p.img_feat = _ptr(self.conf), _ptr(self.imgs), _ptr(self.img_feat)
+        p.w2cs, p.intrinsics = _ptr(self.w2cs), _ptr(self.intrinsics)
+
+
+def feat_gather_fwd(src, pts, ndc1, ndc2, ndc3, tiled=False):
+    pts, ndc1, ndc2, ndc3 = _f32(pts), _f32(ndc1), _f32(ndc2), _f32(ndc3)
+    m = pts.numel() // 3
+    p = L.FeatGatherParams()
+    src.fill(p)
+    p.m, p.out_tiled = m, int(tiled)
+    feats = torch.empty(((m + 31) // 32) * 32 * src.F if tiled else m * src.F, device=pts.device)
+    p.pts, p.ndc1, p.ndc2, p.ndc3, p.feats = _ptr(pts), _ptr(ndc1), _ptr(ndc2), _ptr(ndc3), _ptr(feats)
+    _launch("ucnerf_feat_gather_fwd", p, pts.device)
+    return feats if tiled else feats.view(*pts.shape[:-1], src.F)
+
+
+def feat_gather_bwd(src, pts, ndc1, ndc2, ndc3, g_feats, need=(True, True, True, True, True)):
+    """Returns grads (g_vol1, g_vol2, g_vol3, g_conf, g_img_feat); entries not needed are None."""
+    pts, ndc1, ndc2, ndc3, g_feats = _f32(pts), _f32(ndc1), _f32(ndc2), _f32(ndc3), _f32(g_feats)
+    bp = L.FeatGatherBwdParams()
+    src.fill(bp.fwd)
+    bp.fwd.m = pts.numel() // 3
+    bp.fwd.pts, bp.fwd.ndc1, bp.fwd.ndc2, bp.fwd.ndc3 = _ptr(pts), _ptr(ndc1), _ptr(ndc2), _ptr(ndc3)
+    bp.g_feats = _ptr(g_feats)
+    gv = [torch.zeros_like(v) if need[k] else None for k, v in enumerate(src.vols)]
+    gc = torch.zeros_like(src.conf) if need[3] else None
+    gi = torch.zeros_like(src.img_feat) if need[4] else None
+    for k in range(3):
+        bp.g_vol[k] = _ptr(gv[k])
+    bp.g_conf, bp.g_img_feat = _ptr(gc), _ptr(gi)
+    _launch("ucnerf_feat_gather_bwd", bp, pts.device)
+    return gv[0], gv[1], gv[2], gc, gi
+
+
+class _FeatGather(torch.autograd.Function):
+    """Differentiable w.r.t. the three volumes, confidence and img_feat (never positions: SURVEY 3.2)."""
+
+    @staticmethod
+    def forward(ctx, vol1, vol2, vol3, conf, img_feat, imgs, w2cs, intrinsics, pts, ndc1, ndc2, ndc3):
+        src = GatherSources([vol1, vol2, vol3], conf, imgs, img_feat, w2cs, intrinsics)
+        ctx.src, ctx.shapes = src, (vol1.shape, vol2.shape, vol3.shape, conf.shape, img_feat.shape)
+        ctx.save_for_backward(pts, ndc1, ndc2, ndc3)
+        return feat_gather_fwd(src, pts, ndc1, ndc2, ndc3)
+
+    @staticmethod
+    def backward(ctx, g):
+        pts, ndc1, ndc2, ndc3 = ctx.saved_tensors
+        need = ctx.needs_input_grad[:5]
+        grads = feat_gather_bwd(ctx.src, pts, ndc1, ndc2, ndc3, g.reshape(-1, ctx.src.F), need)
+        out = [x.reshape(s) if x is not None else None for x, s in zip(grads, ctx.shapes)]
+        return tuple(out) + (None,) * 7
+
+
+def feat_gather(vols, conf, img_feat, imgs, w2cs, intrinsics, pts, ndc1, ndc2, ndc3):
+    return _FeatGather.apply(vols[0], vols[1], vols[2], conf, img_feat, imgs, w2cs, intrinsics, pts, ndc1, ndc2, ndc3)
+
+
+# ------------------------------------------------------------------------------------------------ a6
+class PackedWeights:
+    """Pack index (host-built by the library, cached on device) + packing of a flat parameter vector."""
+    _cache = {}
+
+    def __init__(self, n_src, pe_layout, device):
+        self.cfg = L.MlpConfig(n_src, pe_layout)
+        lib = L.lib()
+        self.n_params = lib.ucnerf_mlp_param_count(C.addressof(self.cfg))
+        self.n_stream = lib.ucnerf_mlp_stream_count(C.addressof(self.cfg))
+        if self.n_params < 0 or self.n_stream < 0:
+            raise RuntimeError("uc_nerf_amd: unsupported MLP config n_src=%d: %s"
+                               % (n_src, lib.ucnerf_last_error().decode()))
+        idx = torch.empty(self.n_stream, dtype=torch.int32)
+        L.check(lib.ucnerf_mlp_pack_index(C.addressof(self.cfg), C.c_void_p(idx.data_ptr())), "ucnerf_mlp_pack_index")
+        self.idx_host = idx
+        self.idx = idx.to(device)
+        self.device = device
+
+    @classmethod
+    def get(cls, n_src, pe_layout, device):
+        key = (n_src, pe_layout, str(device))
+        if key not in cls._cache:
+            cls._cache[key] = cls(n_src, pe_layout, device)
+        return cls._cache[key]
+
+    def pack(self, flat):
+        flat = _f32(flat, "flat parameters")
+        if flat.numel() != self.n_params:
+            raise RuntimeError("uc_nerf_amd: flat parameter vector has %d floats, expected %d"
+                               % (flat.numel(), self.n_params))
+        out = torch.empty(self.n_stream, device=flat.device)
+        with torch.cuda.device(flat.device):
+            L.check(L.lib().ucnerf_mlp_pack(_ptr(flat), _ptr(self.idx), _ptr(out), self.n_stream, _stream()), "ucnerf_mlp_pack")
+        return out
+
+    def unpack_grad(self, g_stream):
+        g_flat = torch.zeros(self.n_params, device=g_stream.device)
+        with torch.cuda.device(g_stream.device):
+            L.check(L.lib().ucnerf_mlp_unpack_grad(_ptr(g_stream), _ptr(self.idx), _ptr(g_flat), self.n_stream, _stream()),
+                    "ucnerf_mlp_unpack_grad")
+        return g_flat
+
+
+def mlp_fwd(pw, wstream, pts, dirs, feats, S, feats_tiled=False, max_blocks=0):
+    """pts [m,3] (any leading shape), dirs [m/S,3] or [m,3], feats [m,F] or tiled buffer -> raw [m,4]."""
+    pts, dirs, feats = _f32(pts, "pts"), _f32(dirs, "dirs"), _f32(feats, "feats")
+    m = pts.numel() // 3
+    p = L.MlpParams()
+    p.cfg = pw.cfg
+    p.m, p.S = m, int(S)
+    n_dirs = dirs.numel() // 3
+    if n_dirs == m:
+        p.dirs_per_sample = 1
+    elif S > 0 and n_dirs * S == m:
+        p.dirs_per_sample = 0
+    else:
+        raise RuntimeError("uc_nerf_amd.mlp_fwd: %d directions for %d samples (S=%d)" % (n_dirs, m, S))
+    F = 24 + 12 * pw.cfg.n_src + 1
+    need = ((m + 31) // 32) * 32 * F if feats_tiled else m * F
+    if feats.numel() != need:
+        raise RuntimeError("uc_nerf_amd.mlp_fwd: feats has %d floats, expected %d" % (feats.numel(), need))
+    p.feats_tiled, p.max_blocks = int(feats_tiled), int(max_blocks)
+    raw = torch.empty(m, 4, device=pts.device)
+    p.pts, p.dirs, p.feats, p.wstream, p.raw = _ptr(pts), _ptr(dirs), _ptr(feats), _ptr(wstream), _ptr(raw)
+    _launch("ucnerf_mlp_fwd", p, pts.device)
+    return raw
+
+
+# ------------------------------------------------------------------------------------------------ a9
+def composite_fwd(raw, z, variant=0, white_bkgd=False, rays_d=None, noise=None, want_var=True):
+    raw, z = _f32(raw, "raw"), _f32(z, "z")
+    n, S = z.shape
+    dev = z.device
+    p = L.CompositeParams()
+    p.n, p.S, p.variant, p.white_bkgd = n, S, variant, int(white_bkgd)
+    out = dict(rgb=torch.empty(n, 3, device=dev), depth=torch.empty(n, device=dev), acc=torch.empty(n, device=dev),
+               disp=torch.empty(n, device=dev), weights=torch.empty(n, S, device=dev))
+    if variant == 0 and want_var and S >= 2:
+        out["var"] = torch.empty(n, device=dev)
+    rays_d = _f32(rays_d) if rays_d is not None else None
+    noise = _f32(noise) if noise is not None else None
+    p.raw, p.z, p.rays_d, p.noise = _ptr(raw), _ptr(z), _ptr(rays_d), _ptr(noise)
+    p.rgb_map, p.depth_map, p.acc_map, p.disp_map = _ptr(out["rgb"]), _ptr(out["depth"]), _ptr(out["acc"]), _ptr(out["disp"])
+    p.weights, p.var = _ptr(out["weights"]), _ptr(out.get("var"))
+    _launch("ucnerf_composite_fwd", p, dev)
+    return out
+
+
+def composite_bwd(raw, z, g_rgb=None, g_depth=None, g_acc=None, g_weights=None, white_bkgd=False):
+    raw, z = _f32(raw), _f32(z)
+    n, S = z.shape
+    bp = L.CompositeBwdParams()
+    bp.fwd.n, bp.fwd.S, bp.fwd.variant, bp.fwd.white_bkgd = n, S, 0, int(white_bkgd)
+    bp.fwd.raw, bp.fwd.z = _ptr(raw), _ptr(z)
+    gs = [_f32(g) if g is not None else None for g in (g_rgb, g_depth, g_acc, g_weights)]
+    bp.g_rgb, bp.g_depth, bp.g_acc, bp.g_weights = (_ptr(g) for g in gs)
+    g_raw = torch.empty_like(raw)
+    bp.g_raw = _ptr(g_raw)
+    _launch("ucnerf_composite_bwd", bp, z.device)
+    return g_raw
+
+
+class _Composite(torch.autograd.Function):
+    """raw2outputs (live variant): differentiable w.r.t. raw through rgb_map, depth_map, acc_map and weights."""
+
+    @staticmethod
+    def forward(ctx, raw, z, white_bkgd):
+        out = composite_fwd(raw, z, 0, white_bkgd)
+        ctx.save_for_backward(raw, z)
+        ctx.white_bkgd = white_bkgd
+        var = out.get("var", torch.zeros_like(out["acc"]))
+        ctx.mark_non_differentiable(out["disp"], var)
+        return out["rgb"], out["depth"], out["acc"], out["weights"], out["disp"], var
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_acc, g_weights, _g_disp, _g_var):
+        raw, z = ctx.saved_tensors
+        g_raw = composite_bwd(raw, z, g_rgb, g_depth, g_acc, g_weights, ctx.white_bkgd)
+        return g_raw, None, None
+
+
+def composite(raw, z, white_bkgd=False):
+    return _Composite.apply(raw, z, bool(white_bkgd))
+
+
+# ------------------------------------------------------------------------------------------------ a8
+def sample_pdf(bins, weights, u, z_merge=None, want_inds=True, want_cdf=False):
+    """Returns dict(samples[n,M], inds[n,M] int64, cdf[n,L] (opt), z_sorted[n,M+n_merge] (when z_merge given))."""
+    bins, weights, u = _f32(bins, "bins"), _f32(weights, "weights"), _f32(u, "u")
+    n, Lb = bins.shape
+    if weights.shape != (n, Lb - 1):
+        raise RuntimeError("uc_nerf_amd.sample_pdf: weights must be [n, n_bins-1]")
+    M = u.shape[-1]
+    dev = bins.device
+    p = L.SamplePdfParams()
+    p.n, p.n_bins, p.n_samples = n, Lb, M
+    if u.numel() == n * M:
+        p.u_stride = M
+    elif u.numel() == M:
+        p.u_stride = 0          # one shared row of draws (e.g. linspace)
+    else:
+        raise RuntimeError("uc_nerf_amd.sample_pdf: u must be [n, M] or [M]")
+    out = {"samples": torch.empty(n, M, device=dev)}
+    if want_inds:
+        out["inds"] = torch.empty(n, M, dtype=torch.int64, device=dev)
+    if want_cdf:
+        out["cdf"] = torch.empty(n, Lb, device=dev)
+    if z_merge is not None:
+        z_merge = _f32(z_merge, "z_merge")
+        p.n_merge = z_merge.shape[1]
+        out["z_sorted"] = torch.empty(n, M + p.n_merge, device=dev)
+    p.bins, p.weights, p.u, p.z_merge = _ptr(bins), _ptr(weights), _ptr(u), _ptr(z_merge)
+    p.samples, p.inds, p.cdf, p.z_sorted = _ptr(out["samples"]), _ptr(out.get("inds")), _ptr(out.get("cdf")), _ptr(out.get("z_sorted"))
+    _launch("ucnerf_sample_pdf", p, dev)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ a10
+class RenderPass:
+    """Pre-bound arguments of ucnerf_render_fused_fwd for one scene; call it with (rays_d, z)."""
+
+    def __init__(self, src, pw, wstream, rays_o, w2c_ref, K_ref, w2c_dir, near, far, white_bkgd=False, max_blocks=0):
+        self.src, self.pw, self.wstream = src, pw, wstream
+        self.rays_o = _f32(rays_o.reshape(-1)[:3].clone(), "rays_o")
+        self.p = p = L.RenderParams()
+        src.fill(p)
+        p.cfg = pw.cfg
+        p.white_bkgd, p.max_blocks = int(white_bkgd), int(max_blocks)
+        _mat(p.w2c_ref, w2c_ref, 3, 4)
+        _mat(p.K_ref, K_ref, 3, 3)
+        _mat(p.w2c_dir, w2c_dir, 3, 4)
+        p.near, p.far = float(near), float(far)
+        p.rays_o, p.wstream = _ptr(self.rays_o), _ptr(wstream)
+        self._ws = None
+
+    def __call__(self, rays_d, z, near_far=None, want=("acc", "weights", "var"), keep=()):
+        rays_d, z = _f32(rays_d, "rays_d"), _f32(z, "z")
+        n, S = z.shape
+        dev = z.device
+        p = self.p
+        p.n, p.S = n, S
+        need = L.lib().ucnerf_render_workspace_floats(n, S, self.src.V)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, device=dev)
+        near_far = _f32(near_far) if near_far is not None else None
+        out = {"rgb": torch.empty(n, 3, device=dev), "depth": torch.empty(n, device=dev)}
+        if "acc" in want:
+            out["acc"] = torch.empty(n, device=dev)
+        if "weights" in want:
+            out["weights"] = torch.empty(n, S, device=dev)
+        if "var" in want and S >= 2:
+            out["var"] = torch.empty(n, device=dev)
+        if "raw" in keep:
+            out["raw"] = torch.empty(n, S, 4, device=dev)
+        if "feats" in keep:
+            out["feats"] = torch.empty(n * S, self.src.F, device=dev)
+        p.rays_d, p.z, p.near_far, p.workspace = _ptr(rays_d), _ptr(z), _ptr(near_far), _ptr(self._ws)
+        p.rgb_map, p.depth_map, p.acc_map = _ptr(out["rgb"]), _ptr(out["depth"]), _ptr(out.get("acc"))
+        p.weights, p.var, p.raw, p.feats = _ptr(out.get("weights")), _ptr(out.get("var")), _ptr(out.get("raw")), _ptr(out.get("feats"))
+        _launch("ucnerf_render_fused_fwd", p, dev)
+        return out
