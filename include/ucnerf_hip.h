@@ -37,6 +37,12 @@ int ucnerf_abi_version(void);
 int ucnerf_sizeof(const char* struct_name);
 /* Number of compute units of the current device (grid sizing for persistent kernels); <0 on error. */
 int ucnerf_device_cus(void);
+/* HIP timing events for measuring kernels inside a call chain (bench harness): create / record on a stream /
+ * elapsed milliseconds between two recorded events (waits for `stop`) / destroy. */
+void* ucnerf_event_create(void);
+int ucnerf_event_record(void* event, void* stream);
+int ucnerf_event_elapsed_ms(void* start, void* stop, float* ms_host);
+int ucnerf_event_destroy(void* event);
 
 /* ------------------------------------------------------------------------------------------------
  * a1  ray generation -- data/ray_utils.py:12-53, utils/utils.py:217-271 (get_rays_mvs, deterministic and
@@ -280,8 +286,11 @@ typedef struct {
     int32_t n_samples;     /* M draws per ray, M <= 1024 */
     int32_t u_stride;      /* n_samples (per-ray draws) or 0 (one shared row, e.g. linspace) */
     int32_t n_merge;       /* z_merge entries per ray (0: no merge), n_merge + M <= 2048 */
+    int32_t from_coarse;   /* 1: the hierarchical recipe of data/ray_utils.py:216-217 in one call -- z_merge holds the
+                              coarse depths z[n,S], weights the coarse weights w[n,S]; bins = .5*(z[:-1]+z[1:]) (so
+                              n_bins = S-1) and the pdf uses w[:, 1:-1].  bins may then be NULL. */
     const float* bins;     /* [n,L] */
-    const float* weights;  /* [n,L-1] */
+    const float* weights;  /* [n,L-1]  (from_coarse: [n,S]) */
     const float* u;        /* [n,M] or [M] */
     const float* z_merge;  /* [n,n_merge] values to merge with the samples, or NULL */
     float* samples;        /* [n,M] out or NULL */
@@ -331,6 +340,9 @@ typedef struct {
     float* var;                /* [n] or NULL */
     float* raw;                /* [n,S,4] or NULL (kept for backward) */
     float* feats;              /* [n*S,F] row-major or NULL (kept for backward) */
+    /* optional timing hooks: events (ucnerf_event_create) recorded on `stream` right before / after the MLP kernel */
+    void* ev_mlp_start;
+    void* ev_mlp_stop;
 } ucnerf_render_params;
 int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream);

@@ -86,7 +86,8 @@ class CompositeBwdParams(C.Structure):
 
 
 class SamplePdfParams(C.Structure):
-    _fields_ = [("n", i32), ("n_bins", i32), ("n_samples", i32), ("u_stride", i32), ("n_merge", i32), ("bins", vp),
+    _fields_ = [("n", i32), ("n_bins", i32), ("n_samples", i32), ("u_stride", i32), ("n_merge", i32), ("from_coarse", i32),
+                ("bins", vp),
                 ("weights", vp), ("u", vp), ("z_merge", vp), ("samples", vp), ("inds", vp), ("cdf", vp),
                 ("z_sorted", vp)]
 
@@ -97,7 +98,8 @@ class RenderParams(C.Structure):
                 ("near", f32), ("far", f32), ("near_far", vp), ("H", i32), ("W", i32), ("vol_d", i32 * 3),
                 ("vol_h", i32 * 3), ("vol_w", i32 * 3), ("vol", vp * 3), ("conf", vp), ("imgs", vp), ("img_feat", vp),
                 ("w2cs", vp), ("intrinsics", vp), ("wstream", vp), ("workspace", vp), ("rgb_map", vp),
-                ("depth_map", vp), ("acc_map", vp), ("weights", vp), ("var", vp), ("raw", vp), ("feats", vp)]
+                ("depth_map", vp), ("acc_map", vp), ("weights", vp), ("var", vp), ("raw", vp), ("feats", vp),
+                ("ev_mlp_start", vp), ("ev_mlp_stop", vp)]
 
 
 class RenderBwdParams(C.Structure):
@@ -123,6 +125,10 @@ SYMBOLS = {
     "ucnerf_abi_version": (C.c_int, []),
     "ucnerf_sizeof": (C.c_int, [C.c_char_p]),
     "ucnerf_device_cus": (C.c_int, []),
+    "ucnerf_event_create": (C.c_void_p, []),
+    "ucnerf_event_record": (C.c_int, [_P, _P]),
+    "ucnerf_event_elapsed_ms": (C.c_int, [_P, _P, _P]),
+    "ucnerf_event_destroy": (C.c_int, [_P]),
     "ucnerf_ray_gen": (C.c_int, [_P, _P]),
     "ucnerf_ndc_rays": (C.c_int, [_P, _P]),
     "ucnerf_dir_feature": (C.c_int, [_P, _P]),

@@ -189,7 +189,9 @@ using namespace ucnerf;
 extern "C" {
 
 int ucnerf_composite_fwd(const ucnerf_composite_params* p, void* stream) {
-    UCNERF_REQUIRE(p && p->raw && p->z && p->rgb_map && p->depth_map, "composite_fwd: null pointer");
+    UCNERF_REQUIRE(p, "composite_fwd: null params");
+    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->raw && p->z && p->rgb_map && p->depth_map, "composite_fwd: null pointer");
     UCNERF_REQUIRE(p->S >= 1 && p->S <= 1024, "composite_fwd: S = %d outside 1..1024", p->S);
     UCNERF_REQUIRE(p->variant == 0 || (p->variant == 1 && p->rays_d), "composite_fwd: variant %d (variant 1 needs rays_d)", p->variant);
     UCNERF_REQUIRE(!p->var || (p->variant == 0 && p->S >= 2), "composite_fwd: var needs the live variant and S >= 2");
@@ -207,7 +209,9 @@ int ucnerf_composite_fwd(const ucnerf_composite_params* p, void* stream) {
 }
 
 int ucnerf_composite_bwd(const ucnerf_composite_bwd_params* bp, void* stream) {
-    UCNERF_REQUIRE(bp && bp->fwd.raw && bp->fwd.z && bp->g_raw, "composite_bwd: null pointer");
+    UCNERF_REQUIRE(bp, "composite_bwd: null params");
+    if (bp->fwd.n <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(bp->fwd.raw && bp->fwd.z && bp->g_raw, "composite_bwd: null pointer");
     const ucnerf_composite_params& p = bp->fwd;
     UCNERF_REQUIRE(p.variant == 0, "composite_bwd: only the live variant (network/renderer.py) has a backward");
     UCNERF_REQUIRE(p.S >= 1 && p.S <= 1024, "composite_bwd: S = %d outside 1..1024", p.S);

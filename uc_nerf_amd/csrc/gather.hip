@@ -206,6 +206,7 @@ extern "C" {
 
 int ucnerf_feat_gather_fwd(const ucnerf_feat_gather_params* p, void* stream) {
     UCNERF_REQUIRE(p, "feat_gather_fwd: null params");
+    if (p->m <= 0) return UCNERF_OK;
     int rc = check_geometry(p, "feat_gather_fwd");
     if (rc) return rc;
     UCNERF_REQUIRE(p->vol[0] && p->vol[1] && p->vol[2] && p->conf && p->imgs && p->img_feat && p->feats,
@@ -216,7 +217,9 @@ int ucnerf_feat_gather_fwd(const ucnerf_feat_gather_params* p, void* stream) {
 }
 
 int ucnerf_feat_gather_bwd(const ucnerf_feat_gather_bwd_params* bp, void* stream) {
-    UCNERF_REQUIRE(bp && bp->g_feats, "feat_gather_bwd: null params/g_feats");
+    UCNERF_REQUIRE(bp, "feat_gather_bwd: null params");
+    if (bp->fwd.m <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(bp->g_feats, "feat_gather_bwd: null g_feats");
     int rc = check_geometry(&bp->fwd, "feat_gather_bwd");
     if (rc) return rc;
     if (bp->fwd.m <= 0) return UCNERF_OK;

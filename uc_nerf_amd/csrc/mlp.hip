@@ -402,7 +402,9 @@ int ucnerf_mlp_unpack_grad(const float* g, const int32_t* idx, float* gflat, int
 }
 
 int ucnerf_mlp_fwd(const ucnerf_mlp_params* p, void* stream) {
-    UCNERF_REQUIRE(p && p->pts && p->dirs && p->feats && p->wstream && p->raw, "mlp_fwd: null pointer");
+    UCNERF_REQUIRE(p, "mlp_fwd: null params");
+    if (p->m == 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->pts && p->dirs && p->feats && p->wstream && p->raw, "mlp_fwd: null pointer");
     MlpLayout L;
     UCNERF_REQUIRE(mlp_layout(p->cfg.n_src, &L), "mlp_fwd: n_src %d outside 1..8", p->cfg.n_src);
     UCNERF_REQUIRE(p->m >= 0, "mlp_fwd: m < 0");

@@ -254,6 +254,27 @@ const char* ucnerf_last_error(void) { return last_error_buf(); }
 int ucnerf_abi_version(void) { return UCNERF_ABI_VERSION; }
 int ucnerf_device_cus(void) { return device_cus(); }
 
+void* ucnerf_event_create(void) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { fail(UCNERF_EHIP, "event_create failed"); return nullptr; }
+    return (void*)e;
+}
+int ucnerf_event_record(void* event, void* stream) {
+    UCNERF_REQUIRE(event, "event_record: null event");
+    hipError_t e = hipEventRecord((hipEvent_t)event, (hipStream_t)stream);
+    return e == hipSuccess ? UCNERF_OK : fail(UCNERF_EHIP, "event_record: %s", hipGetErrorString(e));
+}
+int ucnerf_event_elapsed_ms(void* start, void* stop, float* ms_host) {
+    UCNERF_REQUIRE(start && stop && ms_host, "event_elapsed_ms: null argument");
+    hipError_t e = hipEventSynchronize((hipEvent_t)stop);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms_host, (hipEvent_t)start, (hipEvent_t)stop);
+    return e == hipSuccess ? UCNERF_OK : fail(UCNERF_EHIP, "event_elapsed_ms: %s", hipGetErrorString(e));
+}
+int ucnerf_event_destroy(void* event) {
+    if (event) hipEventDestroy((hipEvent_t)event);
+    return UCNERF_OK;
+}
+
 int ucnerf_sizeof(const char* name) {
 #define SZ(T) if (!strcmp(name, #T)) return (int)sizeof(T)
     SZ(ucnerf_ray_gen_params); SZ(ucnerf_ndc_rays_params); SZ(ucnerf_dir_feature_params);
@@ -267,8 +288,10 @@ int ucnerf_sizeof(const char* name) {
 }
 
 int ucnerf_ray_gen(const ucnerf_ray_gen_params* p, void* stream) {
-    UCNERF_REQUIRE(p && p->rays_d, "ray_gen: null params/rays_d");
+    UCNERF_REQUIRE(p, "ray_gen: null params");
     UCNERF_REQUIRE(p->n >= 0, "ray_gen: n < 0");
+    if (p->n == 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->rays_d, "ray_gen: null rays_d");
     UCNERF_REQUIRE((p->xs == nullptr) == (p->ys == nullptr), "ray_gen: xs and ys must both be given or both NULL");
     UCNERF_REQUIRE(p->xs || (p->W > 0 && p->H > 0 && p->grid_start >= 0 &&
                              (long long)p->grid_start + p->n <= (long long)p->H * p->W),
@@ -279,7 +302,9 @@ int ucnerf_ray_gen(const ucnerf_ray_gen_params* p, void* stream) {
 }
 
 int ucnerf_ndc_rays(const ucnerf_ndc_rays_params* p, void* stream) {
-    UCNERF_REQUIRE(p && p->rays_o && p->rays_d && p->out_o && p->out_d, "ndc_rays: null pointer");
+    UCNERF_REQUIRE(p, "ndc_rays: null params");
+    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->rays_o && p->rays_d && p->out_o && p->out_d, "ndc_rays: null pointer");
     UCNERF_REQUIRE(p->variant == 0 || p->variant == 1, "ndc_rays: variant %d", p->variant);
     if (p->n <= 0) return UCNERF_OK;
     hipLaunchKernelGGL(ndc_rays_kernel, dim3(cdiv(p->n, 256)), dim3(256), 0, (hipStream_t)stream, *p);
@@ -287,14 +312,18 @@ int ucnerf_ndc_rays(const ucnerf_ndc_rays_params* p, void* stream) {
 }
 
 int ucnerf_dir_feature(const ucnerf_dir_feature_params* p, void* stream) {
-    UCNERF_REQUIRE(p && p->rays_d && p->angle, "dir_feature: null pointer");
+    UCNERF_REQUIRE(p, "dir_feature: null params");
+    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->rays_d && p->angle, "dir_feature: null pointer");
     if (p->n <= 0) return UCNERF_OK;
     hipLaunchKernelGGL(dir_feature_kernel, dim3(cdiv(p->n, 256)), dim3(256), 0, (hipStream_t)stream, *p);
     return check_launch("dir_feature");
 }
 
 int ucnerf_sample_stratified(const ucnerf_sample_stratified_params* p, void* stream) {
-    UCNERF_REQUIRE(p && p->rays && p->z, "sample_stratified: null pointer");
+    UCNERF_REQUIRE(p, "sample_stratified: null params");
+    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->rays && p->z, "sample_stratified: null pointer");
     UCNERF_REQUIRE(p->S >= 1, "sample_stratified: S = %d", p->S);
     UCNERF_REQUIRE(!(p->perturb > 0.f) || p->noise, "sample_stratified: perturb > 0 needs noise draws");
     if (p->n <= 0) return UCNERF_OK;
@@ -304,7 +333,9 @@ int ucnerf_sample_stratified(const ucnerf_sample_stratified_params* p, void* str
 }
 
 int ucnerf_sample_cascade(const ucnerf_sample_cascade_params* p, void* stream) {
-    UCNERF_REQUIRE(p && p->near_far && p->z, "sample_cascade: null pointer");
+    UCNERF_REQUIRE(p, "sample_cascade: null params");
+    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->near_far && p->z, "sample_cascade: null pointer");
     UCNERF_REQUIRE(p->S >= 3 && p->S % 3 == 0 && p->S <= 768, "sample_cascade: S = %d (multiple of 3, <= 768)", p->S);
     UCNERF_REQUIRE(!p->pts || (p->rays_o && p->rays_d), "sample_cascade: pts needs rays_o and rays_d");
     if (p->n <= 0) return UCNERF_OK;
@@ -313,7 +344,9 @@ int ucnerf_sample_cascade(const ucnerf_sample_cascade_params* p, void* stream) {
 }
 
 int ucnerf_ndc_project(const ucnerf_ndc_project_params* p, void* stream) {
-    UCNERF_REQUIRE(p && p->pts, "ndc_project: null pointer");
+    UCNERF_REQUIRE(p, "ndc_project: null params");
+    if (p->m <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->pts, "ndc_project: null pts");
     UCNERF_REQUIRE(p->nf_stride == 0 || p->nf_stride == 1, "ndc_project: nf_stride %d", p->nf_stride);
     if (p->sample_2d) {
         UCNERF_REQUIRE(p->out_ndc, "ndc_project: sample_2d needs out_ndc");
@@ -329,7 +362,9 @@ int ucnerf_ndc_project(const ucnerf_ndc_project_params* p, void* stream) {
 }
 
 int ucnerf_embed(const ucnerf_embed_params* p, void* stream) {
-    UCNERF_REQUIRE(p && p->x && p->out, "embed: null pointer");
+    UCNERF_REQUIRE(p, "embed: null params");
+    if (p->m <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->x && p->out, "embed: null pointer");
     UCNERF_REQUIRE(p->n_freqs >= 0 && p->n_freqs <= 30, "embed: n_freqs %d", p->n_freqs);
     UCNERF_REQUIRE(p->layout == 0 || p->layout == 1, "embed: layout %d", p->layout);
     if (p->m <= 0) return UCNERF_OK;

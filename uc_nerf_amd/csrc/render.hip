@@ -109,7 +109,9 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
     m.cfg = p->cfg; m.m = (int)M; m.S = p->S; m.dirs_per_sample = 0; m.feats_tiled = g.out_tiled; m.max_blocks = p->max_blocks;
     m.pts = w->ndc; m.dirs = w->angle; m.feats = g.feats; m.wstream = p->wstream;
     m.raw = p->raw ? p->raw : w->raw;
+    if (p->ev_mlp_start && (rc = ucnerf_event_record(p->ev_mlp_start, st))) return rc;
     if ((rc = ucnerf_mlp_fwd(&m, st))) return rc;
+    if (p->ev_mlp_stop && (rc = ucnerf_event_record(p->ev_mlp_stop, st))) return rc;
 
     ucnerf_composite_params c;
     memset(&c, 0, sizeof(c));
@@ -132,7 +134,9 @@ int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V) {
 }
 
 int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream) {
-    UCNERF_REQUIRE(p && p->rays_o && p->rays_d && p->z && p->workspace && p->wstream && p->rgb_map && p->depth_map,
+    UCNERF_REQUIRE(p, "render_fused_fwd: null params");
+    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->rays_o && p->rays_d && p->z && p->workspace && p->wstream && p->rgb_map && p->depth_map,
                    "render_fused_fwd: null pointer");
     UCNERF_REQUIRE(p->S >= 1 && p->S <= 1024, "render_fused_fwd: S = %d outside 1..1024", p->S);
     UCNERF_REQUIRE((long long)p->n * p->S < (1ll << 31), "render_fused_fwd: n*S overflows int32");

@@ -49,14 +49,22 @@ __global__ void __launch_bounds__(64) sample_pdf_kernel(ucnerf_sample_pdf_params
     __shared__ float w[PDF_MAX_BINS];       // weights + 1e-5, then pdf
     __shared__ float cdf[PDF_MAX_BINS];
     __shared__ float srt[PDF_MAX_SORT];
+    __shared__ float bins[PDF_MAX_BINS];
     __shared__ float lane_part[8];
     __shared__ float total;
     const int ray = blockIdx.x, lane = threadIdx.x;
     const int L = p.n_bins, n = L - 1, M = p.n_samples;
-    const float* wr = p.weights + (size_t)ray * n;
-    const float* bins = p.bins + (size_t)ray * L;
-
-    for (int i = lane; i < n; i += 64) w[i] = wr[i] + 1e-5f;
+    if (p.from_coarse) {        // bins = mid-points of the coarse depths, weights = w[1:-1]   (data/ray_utils.py:216-217)
+        const float* zc = p.z_merge + (size_t)ray * p.n_merge;
+        const float* wr = p.weights + (size_t)ray * p.n_merge + 1;
+        for (int i = lane; i < L; i += 64) bins[i] = .5f * (zc[i] + zc[i + 1]);
+        for (int i = lane; i < n; i += 64) w[i] = wr[i] + 1e-5f;
+    } else {
+        const float* wr = p.weights + (size_t)ray * n;
+        const float* br = p.bins + (size_t)ray * L;
+        for (int i = lane; i < L; i += 64) bins[i] = br[i];
+        for (int i = lane; i < n; i += 64) w[i] = wr[i] + 1e-5f;
+    }
     __syncthreads();
 
     // ---- torch.sum(weights, -1)
@@ -138,7 +146,13 @@ __global__ void __launch_bounds__(64) sample_pdf_kernel(ucnerf_sample_pdf_params
 using namespace ucnerf;
 
 extern "C" int ucnerf_sample_pdf(const ucnerf_sample_pdf_params* p, void* stream) {
-    UCNERF_REQUIRE(p && p->bins && p->weights && p->u, "sample_pdf: null pointer");
+    UCNERF_REQUIRE(p, "sample_pdf: null params");
+    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->weights && p->u, "sample_pdf: null pointer");
+    if (p->from_coarse)
+        UCNERF_REQUIRE(p->z_merge && p->n_merge == p->n_bins + 1, "sample_pdf: from_coarse needs z_merge with n_merge == n_bins + 1");
+    else
+        UCNERF_REQUIRE(p->bins, "sample_pdf: null bins");
     UCNERF_REQUIRE(p->n_bins >= 2 && p->n_bins <= PDF_MAX_BINS, "sample_pdf: n_bins = %d outside 2..%d", p->n_bins, PDF_MAX_BINS);
     UCNERF_REQUIRE(p->n_samples >= 1 && p->n_samples <= 1024, "sample_pdf: n_samples = %d outside 1..1024", p->n_samples);
     UCNERF_REQUIRE(p->u_stride == 0 || p->u_stride == p->n_samples, "sample_pdf: u_stride must be 0 or n_samples");
