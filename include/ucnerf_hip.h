@@ -96,7 +96,8 @@ typedef struct {
     int32_t n, S;
     int32_t lindisp;
     float perturb;        /* > 0: z = lower + (upper-lower) * perturb * noise */
-    const float* rays;    /* [n,8] = (o, d, near, far) */
+    float near, far;      /* used when rays == NULL: every ray samples [near, far] (pts must be NULL) */
+    const float* rays;    /* [n,8] = (o, d, near, far), or NULL */
     const float* noise;   /* [n,S] uniform [0,1) draws, required when perturb > 0 */
     float* z;             /* [n,S] out */
     float* pts;           /* [n,S,3] out or NULL */

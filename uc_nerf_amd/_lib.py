@@ -30,7 +30,7 @@ class DirFeatureParams(C.Structure):
 
 
 class SampleStratifiedParams(C.Structure):
-    _fields_ = [("n", i32), ("S", i32), ("lindisp", i32), ("perturb", f32), ("rays", vp), ("noise", vp), ("z", vp),
+    _fields_ = [("n", i32), ("S", i32), ("lindisp", i32), ("perturb", f32), ("near", f32), ("far", f32), ("rays", vp), ("noise", vp), ("z", vp),
                 ("pts", vp)]
 
 
@@ -163,6 +163,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64 (same SONAME as the system one).  Device pointers and streams
+    # handed over by torch are only meaningful inside THAT runtime instance, so it has to be the one our
+    # library binds to: make sure it is resident before dlopen() resolves libucnerf_hip.so's dependency.
+    import torch
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):
+        C.CDLL(tl, mode=C.RTLD_GLOBAL)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("uc_nerf_amd: %s is missing -- build it with `python -m uc_nerf_amd.build` "
                            "(there is no CPU or PyTorch fallback)" % LIB_PATH)

@@ -110,8 +110,8 @@ __global__ void sample_stratified_kernel(ucnerf_sample_stratified_params p) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)p.n * p.S) return;
     int r = (int)(idx / p.S), s = (int)(idx % p.S);
-    const float* ray = p.rays + 8 * (size_t)r;
-    float near = ray[6], far = ray[7];
+    const float* ray = p.rays ? p.rays + 8 * (size_t)r : nullptr;
+    const float near = ray ? ray[6] : p.near, far = ray ? ray[7] : p.far;
     float z = z_at(near, far, s, p.S, p.lindisp);
     if (p.perturb > 0.f) {
         float zl = s > 0 ? z_at(near, far, s - 1, p.S, p.lindisp) : z;
@@ -323,7 +323,8 @@ int ucnerf_dir_feature(const ucnerf_dir_feature_params* p, void* stream) {
 int ucnerf_sample_stratified(const ucnerf_sample_stratified_params* p, void* stream) {
     UCNERF_REQUIRE(p, "sample_stratified: null params");
     if (p->n <= 0) return UCNERF_OK;
-    UCNERF_REQUIRE(p->rays && p->z, "sample_stratified: null pointer");
+    UCNERF_REQUIRE(p->z, "sample_stratified: null z");
+    UCNERF_REQUIRE(p->rays || !p->pts, "sample_stratified: pts output needs the rays array");
     UCNERF_REQUIRE(p->S >= 1, "sample_stratified: S = %d", p->S);
     UCNERF_REQUIRE(!(p->perturb > 0.f) || p->noise, "sample_stratified: perturb > 0 needs noise draws");
     if (p->n <= 0) return UCNERF_OK;

@@ -100,19 +100,24 @@ def dir_feature(rays_d, w2c_ref=None):
 
 
 # ------------------------------------------------------------------------------------------------ a3
-def sample_stratified(rays, S, lindisp=False, perturb=0.0, noise=None, want_pts=True):
-    rays = _f32(rays, "rays")
-    n = rays.shape[0]
+def sample_stratified(rays, S, lindisp=False, perturb=0.0, noise=None, want_pts=True, n=None, near=None, far=None,
+                      device=None):
+    """ray_marcher depths.  Either `rays` [n,8] (per-ray near/far, optional points) or n + scalar near/far."""
     p = L.SampleStratifiedParams()
+    if rays is not None:
+        rays = _f32(rays, "rays")
+        n, device = rays.shape[0], rays.device
+    else:
+        p.near, p.far, want_pts = float(near), float(far), False
     p.n, p.S, p.lindisp, p.perturb = n, int(S), int(lindisp), float(perturb)
     if perturb > 0:
         if noise is None:
-            noise = torch.rand(n, S, device=rays.device)
+            noise = torch.rand(n, S, device=device)
         noise = _f32(noise, "noise")
-    z = torch.empty(n, S, device=rays.device)
-    pts = torch.empty(n, S, 3, device=rays.device) if want_pts else None
+    z = torch.empty(n, S, device=device)
+    pts = torch.empty(n, S, 3, device=device) if want_pts else None
     p.rays, p.noise, p.z, p.pts = _ptr(rays), _ptr(noise if perturb > 0 else None), _ptr(z), _ptr(pts)
-    _launch("ucnerf_sample_stratified", p, rays.device)
+    _launch("ucnerf_sample_stratified", p, device)
     return z, pts
 
 
@@ -402,16 +407,23 @@ def composite(raw, z, white_bkgd=False):
 
 
 # ------------------------------------------------------------------------------------------------ a8
-def sample_pdf(bins, weights, u, z_merge=None, want_inds=True, want_cdf=False):
-    """Returns dict(samples[n,M], inds[n,M] int64, cdf[n,L] (opt), z_sorted[n,M+n_merge] (when z_merge given))."""
-    bins, weights, u = _f32(bins, "bins"), _f32(weights, "weights"), _f32(u, "u")
-    n, Lb = bins.shape
-    if weights.shape != (n, Lb - 1):
-        raise RuntimeError("uc_nerf_amd.sample_pdf: weights must be [n, n_bins-1]")
+def sample_pdf(bins, weights, u, z_merge=None, want_inds=True, want_cdf=False, from_coarse=False):
+    """Returns dict(samples[n,M], inds[n,M] int64, cdf[n,L] (opt), z_sorted[n,M+n_merge] (when z_merge given)).
+    from_coarse: bins=None, weights = coarse weights [n,S], z_merge = coarse depths [n,S] (mid-point bins, w[1:-1])."""
+    weights, u = _f32(weights, "weights"), _f32(u, "u")
+    if from_coarse:
+        n, Lb = weights.shape[0], weights.shape[1] - 1
+        if z_merge is None or tuple(z_merge.shape) != tuple(weights.shape):
+            raise RuntimeError("uc_nerf_amd.sample_pdf: from_coarse needs z_merge with the weights' shape")
+    else:
+        bins = _f32(bins, "bins")
+        n, Lb = bins.shape
+        if weights.shape != (n, Lb - 1):
+            raise RuntimeError("uc_nerf_amd.sample_pdf: weights must be [n, n_bins-1]")
     M = u.shape[-1]
-    dev = bins.device
+    dev = weights.device
     p = L.SamplePdfParams()
-    p.n, p.n_bins, p.n_samples = n, Lb, M
+    p.n, p.n_bins, p.n_samples, p.from_coarse = n, Lb, M, int(from_coarse)
     if u.numel() == n * M:
         p.u_stride = M
     elif u.numel() == M:
@@ -427,7 +439,7 @@ def sample_pdf(bins, weights, u, z_merge=None, want_inds=True, want_cdf=False):
         z_merge = _f32(z_merge, "z_merge")
         p.n_merge = z_merge.shape[1]
         out["z_sorted"] = torch.empty(n, M + p.n_merge, device=dev)
-    p.bins, p.weights, p.u, p.z_merge = _ptr(bins), _ptr(weights), _ptr(u), _ptr(z_merge)
+    p.bins, p.weights, p.u, p.z_merge = _ptr(None if from_coarse else bins), _ptr(weights), _ptr(u), _ptr(z_merge)
     p.samples, p.inds, p.cdf, p.z_sorted = _ptr(out["samples"]), _ptr(out.get("inds")), _ptr(out.get("cdf")), _ptr(out.get("z_sorted"))
     _launch("ucnerf_sample_pdf", p, dev)
     return out
@@ -451,7 +463,7 @@ class RenderPass:
         p.rays_o, p.wstream = _ptr(self.rays_o), _ptr(wstream)
         self._ws = None
 
-    def __call__(self, rays_d, z, near_far=None, want=("acc", "weights", "var"), keep=()):
+    def __call__(self, rays_d, z, near_far=None, want=("acc", "weights", "var"), keep=(), events=None):
         rays_d, z = _f32(rays_d, "rays_d"), _f32(z, "z")
         n, S = z.shape
         dev = z.device
@@ -475,5 +487,30 @@ class RenderPass:
         p.rays_d, p.z, p.near_far, p.workspace = _ptr(rays_d), _ptr(z), _ptr(near_far), _ptr(self._ws)
         p.rgb_map, p.depth_map, p.acc_map = _ptr(out["rgb"]), _ptr(out["depth"]), _ptr(out.get("acc"))
         p.weights, p.var, p.raw, p.feats = _ptr(out.get("weights")), _ptr(out.get("var")), _ptr(out.get("raw")), _ptr(out.get("feats"))
+        p.ev_mlp_start, p.ev_mlp_stop = events if events is not None else (None, None)
         _launch("ucnerf_render_fused_fwd", p, dev)
         return out
+
+
+# ------------------------------------------------------------------------------------------------ timing
+class Event:
+    """HIP timing event created by the library (usable with any stream the kernels run on)."""
+
+    def __init__(self):
+        self.h = L.lib().ucnerf_event_create()
+        if not self.h:
+            raise RuntimeError("uc_nerf_amd: event_create failed")
+
+    def record(self):
+        L.check(L.lib().ucnerf_event_record(self.h, _stream()), "ucnerf_event_record")
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float(0)
+        L.check(L.lib().ucnerf_event_elapsed_ms(self.h, stop.h, C.addressof(ms)), "ucnerf_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            L.lib().ucnerf_event_destroy(self.h)
+        except Exception:
+            pass

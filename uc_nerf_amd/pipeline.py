@@ -1,0 +1,52 @@
+"""The 64 coarse + 128 fine hierarchical renderer composed from the library's entry points
+(ray_marcher -> render -> sample_pdf on mid-points with w[1:-1] -> sorted merge -> render).
+
+Six library calls per batch, all on the caller's stream:
+  ray_gen -> sample_stratified -> render_fused_fwd (coarse) -> sample_pdf(+merge) -> render_fused_fwd (fine)
+"""
+import torch
+
+from . import ops
+
+
+def flat_params_of(state_dict):
+    """Concatenates a reference-style UCNeRF state_dict (state_dict order) into the flat vector the packer reads."""
+    return torch.cat([v.reshape(-1) for v in state_dict.values()]).float()
+
+
+class CoarseFineRenderer:
+    """scene: dict with K[3,3], c2w[4,4] (target camera), w2cs[V,4,4] + intrinsics[V,3,3] (index 0 = reference
+    view, 1.. = source views), near, far, vols (3 x [1,8,D,h,w]), imgs [1,V-1,3,H,W], img_feat [V-1,1,8,H,W],
+    confidence [H,W]; tensors already on the device.  flat_params: the MLP's flat parameter vector (device)."""
+
+    def __init__(self, scene, flat_params, n_coarse=64, n_fine=128, white_bkgd=False, pe_layout=0, max_blocks=0):
+        dev = scene["confidence"].device
+        self.scene, self.dev = scene, dev
+        self.n_coarse, self.n_fine = n_coarse, n_fine
+        self.src = ops.GatherSources(scene["vols"], scene["confidence"], scene["imgs"], scene["img_feat"],
+                                     scene["w2cs"][1:], scene["intrinsics"][1:])
+        self.pw = ops.PackedWeights.get(self.src.V, pe_layout, dev)
+        self.wstream = self.pw.pack(flat_params)
+        w2c_ref = scene["w2cs"][0]
+        self.pass_ = ops.RenderPass(self.src, self.pw, self.wstream, scene["c2w"][:3, 3].to(dev), w2c_ref,
+                                    scene["intrinsics"][0], w2c_ref, scene["near"], scene["far"], white_bkgd, max_blocks)
+        self.u_det = torch.linspace(0., 1., n_fine, device=dev)
+
+    def set_params(self, flat_params):
+        self.wstream.copy_(self.pw.pack(flat_params))
+
+    def render(self, xs, ys, perturb=0.0, noise=None, u=None, events=None):
+        """xs, ys: pixel coordinates [n] (device, float32).  events: optional [(start, stop), (start, stop)]
+        Event pairs recorded around the coarse and the fine MLP launches."""
+        sc = self.scene
+        rays_d, _, _ = ops.ray_gen(sc["K"], sc["c2w"], xs=xs, ys=ys)
+        n = rays_d.shape[0]
+        z_c, _ = ops.sample_stratified(None, self.n_coarse, perturb=perturb, noise=noise, n=n, near=sc["near"],
+                                       far=sc["far"], device=self.dev)
+        ev = [(a.h, b.h) for a, b in events] if events else (None, None)
+        coarse = self.pass_(rays_d, z_c, want=("weights",), events=ev[0])
+        hs = ops.sample_pdf(None, coarse["weights"], self.u_det if u is None else u, z_merge=z_c, want_inds=False,
+                            from_coarse=True)
+        out = self.pass_(rays_d, hs["z_sorted"], want=("acc", "weights", "var"), events=ev[1])
+        out.update(z_coarse=z_c, z_fine=hs["z_sorted"], z_samples=hs["samples"], coarse=coarse, rays_d=rays_d)
+        return out
