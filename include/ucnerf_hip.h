@@ -230,14 +230,18 @@ typedef struct {
 } ucnerf_mlp_params;
 int ucnerf_mlp_fwd(const ucnerf_mlp_params* p, void* stream);
 
-/* Backward: recomputes the forward per tile, returns d(feats) and accumulates d(packed weights).
- * g_wstream must be zeroed by the caller; map it back with ucnerf_mlp_unpack_grad. */
+/* Backward (autograd of network/models.py:138-184): re-runs the forward keeping the per-layer activations, then
+ * walks the layers backwards with fp32-MFMA GEMMs.  Produces d(feats) and ACCUMULATES the parameter gradients
+ * into g_flat, a vector laid out exactly like the flat parameter vector (zero it first).  The three parameter
+ * sets the reference never uses (pts_bias_confidence_1, feature_linear_1, confi_linear) get no contribution.
+ * Positions and view directions receive no gradient (the reference path is non-differentiable there). */
 typedef struct {
-    ucnerf_mlp_params fwd;
-    const float* g_raw;        /* [m,4] */
-    float* g_feats;            /* [m,F] row-major out, or NULL */
-    float* g_wstream;          /* [stream_count] accumulated */
-    float* workspace;          /* scratch, ucnerf_mlp_bwd_workspace_floats() floats */
+    ucnerf_mlp_params fwd;     /* forward arguments; feats must be row-major [m,F]; raw is not written */
+    const float* g_raw;        /* [m,4] upstream gradient */
+    const float* flat_params;  /* [param_count] the parameters the wstream was packed from */
+    float* g_feats;            /* [m,F] row-major out (every column written) */
+    float* g_flat;             /* [param_count] accumulated */
+    float* workspace;          /* scratch, ucnerf_mlp_bwd_workspace_floats() floats, 16-byte aligned */
 } ucnerf_mlp_bwd_params;
 int64_t ucnerf_mlp_bwd_workspace_floats(const ucnerf_mlp_config* cfg, int32_t m);
 int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* p, void* stream);
@@ -348,16 +352,19 @@ typedef struct {
 int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream);
 
-/* Backward of one render pass: d(rgb_map, depth_map) -> d(packed weights), d(volumes, img_feat, conf). */
+/* Backward of one render pass: d(rgb_map, depth_map) -> d(parameters), d(volumes, img_feat, confidence).
+ * fwd.raw and fwd.feats must point at the buffers the forward call filled (keep them); all g_* outputs are
+ * ACCUMULATED (zero them first). */
 typedef struct {
-    ucnerf_render_params fwd;      /* as in the forward call; raw must hold the forward's raw output */
+    ucnerf_render_params fwd;
     const float* g_rgb;            /* [n,3] */
     const float* g_depth;          /* [n] or NULL */
-    float* g_wstream;              /* accumulated, zeroed by caller */
+    const float* flat_params;      /* [param_count] */
+    float* g_flat;                 /* [param_count] accumulated */
     float* g_vol[3];               /* accumulated or NULL */
     float* g_conf;
     float* g_img_feat;
-    float* workspace;              /* ucnerf_render_bwd_workspace_floats(n, S, V) floats */
+    float* workspace;              /* ucnerf_render_bwd_workspace_floats(n, S, V) floats, 16-byte aligned */
 } ucnerf_render_bwd_params;
 int64_t ucnerf_render_bwd_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* p, void* stream);

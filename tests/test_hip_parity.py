@@ -293,3 +293,85 @@ def test_composite_sample_counts_vs_oracle(S):
     close(out["weights"], want[3], 2e-6, 2e-5)
     if S >= 2:
         close(out["var"], want[6], 1e-6, 1e-4)
+
+
+# ---------------------------------------------------------------------------------------------- a6 backward
+@pytest.mark.parametrize("n_src,m,S", [(6, 96, 1), (3, 45, 9), (6, 2100, 3)])
+def test_mlp_backward_vs_oracle_autograd(n_src, m, S, sd_v7):
+    """Parameter and feature gradients of sum(raw * r) against autograd through the CPU oracle (which
+    tests/test_oracle_golden.py pins to the reference's own gradients, G6)."""
+    from uc_nerf_amd.synthetic import init_ucnerf_state_dict
+    sd = sd_v7 if n_src == 6 else init_ucnerf_state_dict(seed=9, n_src=n_src)
+    gen = torch.Generator().manual_seed(m)
+    F = 24 + 12 * n_src + 1
+    pts = torch.rand(m, 3, generator=gen)
+    feats = torch.randn(m, F, generator=gen)
+    feats[:, -1] = torch.rand(m, generator=gen)
+    dirs = torch.nn.functional.normalize(torch.randn(m // S, 3, generator=gen), dim=-1)
+    r = torch.randn(m, 4, generator=gen)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    fo = feats.clone().requires_grad_(True)
+    out = O.run_network_mvs(p, pts.view(m // S, S, 3), dirs, fo.view(m // S, S, F), n_src=n_src).reshape(m, 4)
+    (out * r).sum().backward()
+
+    pw = ops().PackedWeights.get(n_src, 0, torch.device(DEV))
+    flat = dev(flat_params(sd)).requires_grad_(True)
+    fd = dev(feats).requires_grad_(True)
+    raw = ops().mlp(flat, fd, dev(pts), dev(dirs), pw, S)
+    (raw * dev(r)).sum().backward()
+    gs = fo.grad.abs().max().item()
+    close(fd.grad, fo.grad, 2e-4 * gs, 2e-3)
+    off = 0
+    for k, v in sd.items():
+        n = v.numel()
+        got = flat.grad[off:off + n].view(v.shape).cpu()
+        off += n
+        if p[k].grad is None:
+            assert torch.count_nonzero(got) == 0, k            # the reference leaves these without gradient
+        else:
+            want = p[k].grad
+            torch.testing.assert_close(got, want, atol=2e-4 * want.abs().max().item() + 1e-7, rtol=2e-3, msg=lambda s_: k + ": " + s_)
+
+
+def test_render_pass_backward_reaches_volumes_features_confidence_and_parameters():
+    from uc_nerf_amd import ops as P
+    from uc_nerf_amd.pipeline import flat_params_of
+    from uc_nerf_amd.synthetic import init_ucnerf_state_dict, make_scene, scene_to
+    from test_hip_pipeline import oracle_pass
+    scene = make_scene(seed=21, H=32, W=40, small_volumes=True)
+    scene["c2w"][:3, 3] = torch.tensor([0.03, 0.01, -0.02])
+    sd = init_ucnerf_state_dict(seed=6, sigma_scale=0.1, sigma_bias=0.02)
+    gen = torch.Generator().manual_seed(77)
+    N, S = 40, 24
+    xs, ys = torch.randint(0, 40, (N,), generator=gen).float(), torch.randint(1, 31, (N,), generator=gen).float()
+    _, rays_d, _ = O.get_rays_mvs_pixels(xs, ys, scene["K"], scene["c2w"])
+    z = torch.sort(1.0 + 3.0 * torch.rand(N, S, generator=gen), -1)[0]
+    r3, r1 = torch.randn(N, 3, generator=gen), torch.randn(N, generator=gen)
+    # oracle with autograd
+    leaves = scene["vols"] + [scene["img_feat"], scene["confidence"]]
+    for t in leaves:
+        t.requires_grad_(True)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    want = oracle_pass(p, scene, rays_d, z)
+    ((want["rgb"] * r3).sum() + (want["depth"] * r1).sum()).backward()
+    # device
+    sc = scene_to({k: (v.detach() if torch.is_tensor(v) else [t.detach() for t in v] if isinstance(v, list) else v)
+                   for k, v in scene.items()}, torch.device(DEV))
+    src = P.GatherSources(sc["vols"], sc["confidence"], sc["imgs"], sc["img_feat"], sc["w2cs"][1:], sc["intrinsics"][1:])
+    pw = P.PackedWeights.get(src.V, 0, torch.device(DEV))
+    flat = flat_params_of(sd).to(DEV)
+    rp = P.RenderPass(src, pw, pw.pack(flat), sc["c2w"][:3, 3], sc["w2cs"][0], sc["intrinsics"][0], sc["w2cs"][0],
+                      scene["near"], scene["far"])
+    kept = rp(dev(rays_d), dev(z), keep=("raw", "feats"))
+    g_flat, gv1, gv2, gv3, gc, gi = rp.backward(dev(rays_d), dev(z), kept, dev(r3), dev(r1), flat)
+    for got, t in zip((gv1, gv2, gv3, gi, gc), leaves):
+        w = t.grad
+        torch.testing.assert_close(got.cpu().reshape(w.shape), w, atol=3e-4 * w.abs().max().item() + 1e-7, rtol=3e-3)
+    off = 0
+    for k, v in sd.items():
+        n = v.numel()
+        got = g_flat[off:off + n].view(v.shape).cpu()
+        off += n
+        if p[k].grad is not None:
+            w = p[k].grad
+            torch.testing.assert_close(got, w, atol=3e-4 * w.abs().max().item() + 1e-7, rtol=3e-3, msg=lambda s_: k + ": " + s_)

@@ -71,7 +71,7 @@ class MlpParams(C.Structure):
 
 
 class MlpBwdParams(C.Structure):
-    _fields_ = [("fwd", MlpParams), ("g_raw", vp), ("g_feats", vp), ("g_wstream", vp), ("workspace", vp)]
+    _fields_ = [("fwd", MlpParams), ("g_raw", vp), ("flat_params", vp), ("g_feats", vp), ("g_flat", vp), ("workspace", vp)]
 
 
 class CompositeParams(C.Structure):
@@ -103,8 +103,8 @@ class RenderParams(C.Structure):
 
 
 class RenderBwdParams(C.Structure):
-    _fields_ = [("fwd", RenderParams), ("g_rgb", vp), ("g_depth", vp), ("g_wstream", vp), ("g_vol", vp * 3),
-                ("g_conf", vp), ("g_img_feat", vp), ("workspace", vp)]
+    _fields_ = [("fwd", RenderParams), ("g_rgb", vp), ("g_depth", vp), ("flat_params", vp), ("g_flat", vp),
+                ("g_vol", vp * 3), ("g_conf", vp), ("g_img_feat", vp), ("workspace", vp)]
 
 
 STRUCTS = {

@@ -255,8 +255,21 @@ __device__ __forceinline__ void encode(const float (&x)[3], int h, float (&pe)[K
     _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                   \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) (DST)[nt][r] = fmaxf((ACC)[nt][r] * (MOD)[nt][r], 0.f);
 
-template <bool TILED>
-__global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, MlpGeom g, int n_tiles) {
+// accumulator-layout activation set -> row-major [m,128] (lane = sample, 4 consecutive features per float4)
+__device__ __forceinline__ void save_rows(float* buf, int s, int h, bool valid, const f32x16 (&x)[4]) {
+    if (!valid) return;
+    f32x4* row = reinterpret_cast<f32x4*>(buf + (size_t)s * 128);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = {x[nt][4 * q], x[nt][4 * q + 1], x[nt][4 * q + 2], x[nt][4 * q + 3]};
+            row[8 * nt + 2 * q + h] = v;
+        }
+}
+
+template <bool TILED, bool SAVE>
+__global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, MlpGeom g, int n_tiles, MlpSaved sv) {
     __shared__ __attribute__((aligned(16))) float cst[CONST_FLOATS];
     __shared__ __attribute__((aligned(16))) float pe_stash[4][KS_PE_PTS * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -279,6 +292,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
         S.A = A0;
         const int s_raw = tile * 32 + j;
         const int s = s_raw < p.m ? s_raw : p.m - 1;
+        const bool valid = s_raw < p.m;
         // feature f of sample s lives at fb[f * fstride]
         const float* fb;
         int fstride;
@@ -290,6 +304,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
         // ---- depth-bias net: bd = W_d [volume feats | colours+masks] + b      (models.py:150)
         init_bias(cst, SEC_BD, h, bd);
         gemm_mem(S, fb + (size_t)h * fstride, 2 * fstride, g.kd, bd);
+        if (SAVE) save_rows(sv.bd, s, h, valid, bd);
 
         // ---- point encoding, stashed in LDS for the skip connection; layer 0
         {
@@ -302,6 +317,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
             gemm_regs<KS_PE_PTS>(S, pe, acc);
         }
         EPILOGUE_RELU_MOD(hin, acc, bd)
+        if (SAVE) save_rows(sv.h[0], s, h, valid, hin);
 
         // ---- layers 1..4                                                        (models.py:153-155)
 #pragma unroll 1
@@ -309,6 +325,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
             init_bias(cst, SEC_L0 + l, h, acc);
             gemm_hidden(S, hin, acc);
             EPILOGUE_RELU_MOD(hin, acc, bd)
+            if (SAVE) save_rows(sv.h[l], s, h, valid, hin);
         }
 
         // ---- layer 5 on [pe | h]                                                (models.py:156-157)
@@ -316,6 +333,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
         gemm_stash<KS_PE_PTS>(S, stash, lane, acc);
         gemm_hidden(S, hin, acc);
         EPILOGUE_RELU_MOD(hin, acc, bd)
+        if (SAVE) save_rows(sv.h[5], s, h, valid, hin);
 
         // ---- base heads: confi_rgb_linear, alpha_linear_1                       (models.py:161-162)
         const f32x4 base = head4(hb, h, hin);
@@ -323,12 +341,14 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
         // ---- confidence-bias net, feature_linear(h * b_c)                       (models.py:151,164)
         init_bias(cst, SEC_BC, h, bd);
         gemm_mem(S, fb + (size_t)(g.f_img + h) * fstride, 2 * fstride, g.kc, bd);
+        if (SAVE) save_rows(sv.bc, s, h, valid, bd);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) hin[nt][r] = hin[nt][r] * bd[nt][r];
         init_bias(cst, SEC_FT, h, acc);
         gemm_hidden(S, hin, acc);
+        if (SAVE) save_rows(sv.ft, s, h, valid, acc);
 
         // ---- views_linears | view_confi_linears on [feature | dir encoding], relu   (models.py:166-173)
         init_bias(cst, SEC_VC, h, hin);
@@ -344,6 +364,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) hin[nt][r] = fmaxf(hin[nt][r], 0.f);
+        if (SAVE) save_rows(sv.vc, s, h, valid, hin);
 
         // ---- adapt heads (rgb_linear on rows 0..63, alpha_linear on rows 64..127), uncertainty blend
         const f32x4 adapt = head4(ha, h, hin);
@@ -354,7 +375,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
         out.y = 1.f / (1.f + expf(-(base.y * omu + adapt.y * u)));
         out.z = 1.f / (1.f + expf(-(base.z * omu + adapt.z * u)));
         out.w = fmaxf(adapt.w * omu + base.w * u, 0.f);
-        if (h == 0 && s_raw < p.m) reinterpret_cast<f32x4*>(p.raw)[s_raw] = out;
+        if (h == 0 && valid) reinterpret_cast<f32x4*>(p.raw)[s_raw] = out;
     }
 }
 
@@ -362,6 +383,37 @@ static MlpGeom geom_of(const MlpLayout& L) {
     MlpGeom g;
     g.F = L.F; g.kd = L.kd; g.kc = L.kc; g.f_img = 24 + 4 * L.v; g.off_const = (int)L.off_const;
     return g;
+}
+
+// Launches the forward; `save` (optional) receives the activations the backward needs.
+int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st) {
+    UCNERF_REQUIRE(p, "mlp_fwd: null params");
+    if (p->m == 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->pts && p->dirs && p->feats && p->wstream && p->raw, "mlp_fwd: null pointer");
+    MlpLayout L;
+    UCNERF_REQUIRE(mlp_layout(p->cfg.n_src, &L), "mlp_fwd: n_src %d outside 1..8", p->cfg.n_src);
+    UCNERF_REQUIRE(p->m >= 0, "mlp_fwd: m < 0");
+    UCNERF_REQUIRE(p->dirs_per_sample || p->S > 0, "mlp_fwd: S must be > 0 when dirs are per ray");
+    UCNERF_REQUIRE(((uintptr_t)p->wstream & 15) == 0 && ((uintptr_t)p->raw & 15) == 0, "mlp_fwd: wstream/raw must be 16-byte aligned");
+    const int n_tiles = cdiv(p->m, 32);
+    int cus = device_cus();
+    if (cus <= 0) return fail(UCNERF_EHIP, "mlp_fwd: no device");
+    int blocks = cdiv(n_tiles, 4);
+    int cap = p->max_blocks > 0 ? p->max_blocks : cus * 2;
+    if (blocks > cap) blocks = cap;
+    MlpGeom g = geom_of(L);
+    MlpSaved sv;
+    memset(&sv, 0, sizeof(sv));
+    if (save) sv = *save;
+    dim3 grid(blocks), block(256);
+    if (save) {
+        if (p->feats_tiled) hipLaunchKernelGGL((mlp_fwd_kernel<true, true>), grid, block, 0, st, *p, g, n_tiles, sv);
+        else hipLaunchKernelGGL((mlp_fwd_kernel<false, true>), grid, block, 0, st, *p, g, n_tiles, sv);
+    } else {
+        if (p->feats_tiled) hipLaunchKernelGGL((mlp_fwd_kernel<true, false>), grid, block, 0, st, *p, g, n_tiles, sv);
+        else hipLaunchKernelGGL((mlp_fwd_kernel<false, false>), grid, block, 0, st, *p, g, n_tiles, sv);
+    }
+    return check_launch("mlp_fwd");
 }
 
 }  // namespace ucnerf
@@ -401,28 +453,6 @@ int ucnerf_mlp_unpack_grad(const float* g, const int32_t* idx, float* gflat, int
     return check_launch("mlp_unpack_grad");
 }
 
-int ucnerf_mlp_fwd(const ucnerf_mlp_params* p, void* stream) {
-    UCNERF_REQUIRE(p, "mlp_fwd: null params");
-    if (p->m == 0) return UCNERF_OK;
-    UCNERF_REQUIRE(p->pts && p->dirs && p->feats && p->wstream && p->raw, "mlp_fwd: null pointer");
-    MlpLayout L;
-    UCNERF_REQUIRE(mlp_layout(p->cfg.n_src, &L), "mlp_fwd: n_src %d outside 1..8", p->cfg.n_src);
-    UCNERF_REQUIRE(p->m >= 0, "mlp_fwd: m < 0");
-    UCNERF_REQUIRE(p->dirs_per_sample || p->S > 0, "mlp_fwd: S must be > 0 when dirs are per ray");
-    UCNERF_REQUIRE(((uintptr_t)p->wstream & 15) == 0 && ((uintptr_t)p->raw & 15) == 0, "mlp_fwd: wstream/raw must be 16-byte aligned");
-    if (p->m == 0) return UCNERF_OK;
-    const int n_tiles = cdiv(p->m, 32);
-    int cus = device_cus();
-    if (cus <= 0) return fail(UCNERF_EHIP, "mlp_fwd: no device");
-    int blocks = cdiv(n_tiles, 4);
-    int cap = p->max_blocks > 0 ? p->max_blocks : cus * 2;
-    if (blocks > cap) blocks = cap;
-    MlpGeom g = geom_of(L);
-    if (p->feats_tiled)
-        hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, g, n_tiles);
-    else
-        hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, g, n_tiles);
-    return check_launch("mlp_fwd");
-}
+int ucnerf_mlp_fwd(const ucnerf_mlp_params* p, void* stream) { return launch_mlp_fwd(p, nullptr, (hipStream_t)stream); }
 
 }  // extern "C"

@@ -1,14 +1,476 @@
-// K6 backward + the fused render backward.  (Placeholder bodies: the symbols exist so the ABI is complete;
-// they report an error until the backward kernels land.)
+// K6 backward: gradients of the UC-NeRF MLP w.r.t. its parameters and its gathered features
+// (autograd of network/models.py:138-184; positions / view directions get no gradient).
+//
+// Layer-by-layer from activations saved by the forward kernel (mlp.hip, SAVE variant), all row-major
+// [m,128].  Two hand-written fp32-MFMA GEMM kernels do the heavy lifting:
+//   gemm_nn:  G_in[m x N]  = G_out[m x K] * W[K x N]           data gradient  (lane = sample, as the forward)
+//   gemm_tn:  gW[No x Ki] += G_out[m x No]^T * X[m x Ki]        weight gradient (contraction over samples;
+//             row-major activations put FEATURES on lanes, so both MFMA operands are coalesced loads and the
+//             accumulator tile maps to 128-byte row segments of the weight matrix -> well-shaped float atomics)
+// plus small fused element-wise kernels between them.  Weight gradients are accumulated straight into the
+// flat parameter-gradient vector (same layout as the flat parameter vector), so no unpacking is needed.
 #include "common.h"
+#include "mlp_layout.h"
+
+namespace ucnerf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st);
+
+// 4 consecutive parameters (parameter tensors are only 4-byte aligned inside the flat vector)
+__device__ __forceinline__ f32x4 ld4(const float* p) { return f32x4{p[0], p[1], p[2], p[3]}; }
+
+// ------------------------------------------------------------------------------------------------
+// gemm_nn: C[s][n] (=|+=) sum_k A[s][k] W[k][n],  K = 8*KQ, n < N <= 32*NT
+// ------------------------------------------------------------------------------------------------
+struct NnArgs {
+    const float* A; int lda;
+    const float* W; int ldw;
+    float* C; int ldc;
+    int m, N, accumulate;
+};
+
+template <int KQ, int NT>
+__global__ void __launch_bounds__(256) gemm_nn_kernel(NnArgs a, int n_tiles) {
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int n_waves = gridDim.x * 4;
+    for (int tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += n_waves) {
+        const int s_raw = tile * 32 + j;
+        const int s = s_raw < a.m ? s_raw : a.m - 1;
+        const f32x4* arow = reinterpret_cast<const f32x4*>(a.A + (size_t)s * a.lda) + h;     // float4 #(2q + h)
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        // stage = one group of 8 k: this lane-half's 4 activations + the 4 weight rows it pairs with
+        f32x4 xa = arow[0];
+        float w[4][NT];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = 32 * nt + j;
+                w[c][nt] = col < a.N ? a.W[(size_t)(4 * h + c) * a.ldw + col] : 0.f;
+            }
+#pragma unroll 2
+        for (int q = 0; q < KQ; ++q) {
+            f32x4 xn = xa;
+            float wn[4][NT];
+            if (q + 1 < KQ) {
+                xn = arow[2 * (q + 1)];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int col = 32 * nt + j;
+                        wn[c][nt] = col < a.N ? a.W[(size_t)(8 * (q + 1) + 4 * h + c) * a.ldw + col] : 0.f;
+                    }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = MFMA(w[c][nt], xa[c], acc[nt]);
+            if (q + 1 < KQ) {
+                xa = xn;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) w[c][nt] = wn[c][nt];
+            }
+        }
+        if (s_raw < a.m) {
+            float* crow = a.C + (size_t)s * a.ldc;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (col < a.N) crow[col] = a.accumulate ? crow[col] + acc[nt][r] : acc[nt][r];
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn: gW[n][k] += sum_s G[s][n] X[s / xdiv][k];  gb[n] += sum_s G[s][n]
+// block = 4 waves, wave w owns output rows 32w..32w+31; grid.x = sample chunks of CH
+// ------------------------------------------------------------------------------------------------
+struct TnArgs {
+    const float* G; int ldg;
+    const float* X; int ldx; int xdiv;
+    float* gW; int ldw;
+    float* gb;
+    int m, Nout, Kin;
+};
+
+constexpr int TN_CHUNK = 1024;
+
+template <int KT>
+__global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const int nt = threadIdx.x >> 6;
+    if (32 * nt >= a.Nout) return;
+    const int s0 = blockIdx.x * TN_CHUNK;
+    const int s1 = s0 + TN_CHUNK < a.m ? s0 + TN_CHUNK : a.m;
+    const bool row_ok = 32 * nt + i < a.Nout;
+    f32x16 acc[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[kt][r] = 0.f;
+    float colsum = 0.f;
+    auto load = [&](int s, float& ga, float (&xb)[KT]) {
+        const bool ok = s < s1;
+        const int sc = ok ? s : s1 - 1;
+        ga = ok && row_ok ? a.G[(size_t)sc * a.ldg + 32 * nt + i] : 0.f;
+        const float* xr = a.X + (size_t)(sc / a.xdiv) * a.ldx;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) xb[kt] = ok && 32 * kt + i < a.Kin ? xr[32 * kt + i] : 0.f;
+    };
+    float ga[4], xb[4][KT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load(s0 + 2 * u + h, ga[u], xb[u]);
+    for (int s = s0; s < s1; s += 8) {           // 4 k-steps (8 samples) per iteration, next 4 prefetched
+        float gn[4], xn[4][KT];
+        const bool more = s + 8 < s1;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load(s + 8 + 2 * u + h, gn[u], xn[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            colsum += ga[u];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) acc[kt] = MFMA(ga[u], xb[u][kt], acc[kt]);
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ga[u] = gn[u];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) xb[u][kt] = xn[u][kt];
+            }
+        }
+    }
+    // D[row][col]: row = (r&3) + 8(r>>2) + 4h (output feature), col = lane&31 (input feature)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h, k = 32 * kt + i;
+            if (n < a.Nout && k < a.Kin) atomicAdd(a.gW + (size_t)n * a.ldw + k, acc[kt][r]);
+        }
+    if (a.gb) {
+        colsum += __shfl_xor(colsum, 32);
+        if (h == 0 && row_ok) atomicAdd(a.gb + 32 * nt + i, colsum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// element-wise stages
+// ------------------------------------------------------------------------------------------------
+// Output stage (models.py:177-178 backwards) + both 4-wide heads.  32 lanes per sample (4 features each).
+struct HeadArgs {
+    int m, F;
+    const float* raw;     // [m,4] forward output
+    const float* g_raw;   // [m,4]
+    const float* feats; int ldf;    // conf = feats[s][F-1]
+    const float* h5;      // [m,128]
+    const float* vc;      // [m,128] (post-relu)
+    const float* w_crgb;  // confi_rgb_linear.weight [3,128]
+    const float* w_a1;    // alpha_linear_1.weight [1,128]
+    const float* w_rgb;   // rgb_linear.weight [3,64]
+    const float* w_a;     // alpha_linear.weight [1,64]
+    const float* b_crgb; const float* b_a1; const float* b_rgb; const float* b_a;
+    float* g_base;        // [m,4]  d/d(base rgb, base sigma)
+    float* g_adapt;       // [m,4]
+    float* g_vc;          // [m,128] gradient at the pre-relu output of views/view_confi linears
+    float* g_feats; int ldgf;       // writes column F-1 (confidence)
+};
+
+__global__ void __launch_bounds__(256) head_bwd_kernel(HeadArgs a) {
+    const int s = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int c = threadIdx.x & 31;                      // features 4c..4c+3
+    if (s >= a.m) return;
+    const f32x4 hv = reinterpret_cast<const f32x4*>(a.h5 + (size_t)s * 128)[c];
+    const f32x4 vv = reinterpret_cast<const f32x4*>(a.vc + (size_t)s * 128)[c];
+    float base[4], adapt[4];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const f32x4 w = ld4(a.w_crgb + o * 128 + 4 * c);
+        base[o] = hv.x * w.x + hv.y * w.y + hv.z * w.z + hv.w * w.w;
+    }
+    {
+        const f32x4 w = ld4(a.w_a1 + 4 * c);
+        base[3] = hv.x * w.x + hv.y * w.y + hv.z * w.z + hv.w * w.w;
+    }
+    f32x4 wr[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, wa = {0, 0, 0, 0};
+    if (c < 16) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) wr[o] = ld4(a.w_rgb + o * 64 + 4 * c);
+    } else {
+        wa = ld4(a.w_a + 4 * (c - 16));
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) adapt[o] = vv.x * wr[o].x + vv.y * wr[o].y + vv.z * wr[o].z + vv.w * wr[o].w;
+    adapt[3] = vv.x * wa.x + vv.y * wa.y + vv.z * wa.z + vv.w * wa.w;
+#pragma unroll
+    for (int d = 16; d > 0; d >>= 1)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) { base[o] += __shfl_xor(base[o], d); adapt[o] += __shfl_xor(adapt[o], d); }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) { base[o] += a.b_crgb[o]; adapt[o] += a.b_rgb[o]; }
+    base[3] += a.b_a1[0]; adapt[3] += a.b_a[0];
+
+    const f32x4 raw = reinterpret_cast<const f32x4*>(a.raw)[s];
+    const f32x4 gr = reinterpret_cast<const f32x4*>(a.g_raw)[s];
+    const float conf = a.feats[(size_t)s * a.ldf + a.F - 1];
+    const float u = 1.f - conf, omu = 1.f - u;
+    const float gp[4] = {gr.x * raw.x * (1.f - raw.x), gr.y * raw.y * (1.f - raw.y), gr.z * raw.z * (1.f - raw.z),
+                         raw.w > 0.f ? gr.w : 0.f};
+    const float gb4[4] = {gp[0] * omu, gp[1] * omu, gp[2] * omu, gp[3] * u};
+    const float ga4[4] = {gp[0] * u, gp[1] * u, gp[2] * u, gp[3] * omu};
+    if (c == 0) {
+        reinterpret_cast<f32x4*>(a.g_base)[s] = f32x4{gb4[0], gb4[1], gb4[2], gb4[3]};
+        reinterpret_cast<f32x4*>(a.g_adapt)[s] = f32x4{ga4[0], ga4[1], ga4[2], ga4[3]};
+        const float gu = gp[0] * (adapt[0] - base[0]) + gp[1] * (adapt[1] - base[1]) + gp[2] * (adapt[2] - base[2]) +
+                         gp[3] * (base[3] - adapt[3]);
+        a.g_feats[(size_t)s * a.ldgf + a.F - 1] = -gu;          // u = 1 - confidence
+    }
+    // g_vc = relu'(vc) * (W_head^T g_adapt)
+    f32x4 g;
+    g.x = ga4[0] * wr[0].x + ga4[1] * wr[1].x + ga4[2] * wr[2].x + ga4[3] * wa.x;
+    g.y = ga4[0] * wr[0].y + ga4[1] * wr[1].y + ga4[2] * wr[2].y + ga4[3] * wa.y;
+    g.z = ga4[0] * wr[0].z + ga4[1] * wr[1].z + ga4[2] * wr[2].z + ga4[3] * wa.z;
+    g.w = ga4[0] * wr[0].w + ga4[1] * wr[1].w + ga4[2] * wr[2].w + ga4[3] * wa.w;
+    g.x = vv.x > 0.f ? g.x : 0.f; g.y = vv.y > 0.f ? g.y : 0.f; g.z = vv.z > 0.f ? g.z : 0.f; g.w = vv.w > 0.f ? g.w : 0.f;
+    reinterpret_cast<f32x4*>(a.g_vc + (size_t)s * 128)[c] = g;
+}
+
+// gx = h5 * bc  (input of feature_linear)
+__global__ void __launch_bounds__(256) mul_kernel(const f32x4* x, const f32x4* y, f32x4* o, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 a = x[i], b = y[i];
+        o[i] = f32x4{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w};
+    }
+}
+
+// after feature_linear: g_h5 = g_g * bc + W_basehead^T g_base ;  g_bc = g_g * h5
+struct BcSplitArgs {
+    size_t n4;
+    const f32x4* g_g; const f32x4* bc; const f32x4* h5;
+    const float* g_base;     // [m,4]
+    const float* w_crgb; const float* w_a1;
+    f32x4* g_h5; f32x4* g_bc;
+};
+
+__global__ void __launch_bounds__(256) bc_split_kernel(BcSplitArgs a) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) {
+        const size_t s = i >> 5;
+        const int c = (int)(i & 31);
+        const f32x4 g = a.g_g[i], b = a.bc[i], h = a.h5[i];
+        const f32x4 gb = reinterpret_cast<const f32x4*>(a.g_base)[s];
+        const f32x4 w0 = ld4(a.w_crgb + 4 * c), w1 = ld4(a.w_crgb + 128 + 4 * c), w2 = ld4(a.w_crgb + 256 + 4 * c),
+                    w3 = ld4(a.w_a1 + 4 * c);
+        f32x4 o;
+        o.x = g.x * b.x + gb.x * w0.x + gb.y * w1.x + gb.z * w2.x + gb.w * w3.x;
+        o.y = g.y * b.y + gb.x * w0.y + gb.y * w1.y + gb.z * w2.y + gb.w * w3.y;
+        o.z = g.z * b.z + gb.x * w0.z + gb.y * w1.z + gb.z * w2.z + gb.w * w3.z;
+        o.w = g.w * b.w + gb.x * w0.w + gb.y * w1.w + gb.z * w2.w + gb.w * w3.w;
+        a.g_h5[i] = o;
+        a.g_bc[i] = f32x4{g.x * h.x, g.y * h.y, g.z * h.z, g.w * h.w};
+    }
+}
+
+// trunk layer: g_pre = g_h * [h > 0];  g_y = g_pre * bd;  g_bd (+)= g_pre * y, with y = h / bd where h > 0
+__global__ void __launch_bounds__(256) relu_mod_bwd_kernel(const f32x4* g_h, const f32x4* hh, const f32x4* bd, f32x4* g_y,
+                                                            f32x4* g_bd, int first, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 g = g_h[i], h = hh[i], b = bd[i];
+        f32x4 acc = first ? f32x4{0.f, 0.f, 0.f, 0.f} : g_bd[i];
+        f32x4 y;
+#define ONE(C)                                            \
+        {                                                 \
+            const bool on = h.C > 0.f;                    \
+            const float gp = on ? g.C : 0.f;              \
+            y.C = gp * b.C;                               \
+            acc.C += on ? gp * (h.C / b.C) : 0.f;         \
+        }
+        ONE(x) ONE(y) ONE(z) ONE(w)
+#undef ONE
+        g_y[i] = y;
+        g_bd[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------------
+struct BwdWork {
+    MlpSaved sv;
+    float *pep, *ped, *g1, *g2, *g3, *gbd, *gx, *g_base, *g_adapt, *raw;
+};
+
+static size_t carve_bwd(float* base, int m, int n_dirs, BwdWork* w) {
+    size_t o = 0;
+    auto take = [&](size_t k) { float* r = base ? base + o : nullptr; o += (k + 3) & ~(size_t)3; return r; };
+    const size_t M = (size_t)m;
+    w->sv.bd = take(M * 128);
+    for (int l = 0; l < 6; ++l) w->sv.h[l] = take(M * 128);
+    w->sv.bc = take(M * 128); w->sv.ft = take(M * 128); w->sv.vc = take(M * 128);
+    w->pep = take(M * 63); w->ped = take((size_t)n_dirs * 27);
+    w->g1 = take(M * 128); w->g2 = take(M * 128); w->g3 = take(M * 128); w->gbd = take(M * 128); w->gx = take(M * 128);
+    w->g_base = take(M * 4); w->g_adapt = take(M * 4); w->raw = take(M * 4);
+    return o;
+}
+
+static int run_nn(hipStream_t st, int m, const float* A, int lda, int K, const float* W, int ldw, int N, float* C, int ldc,
+                  bool accumulate) {
+    NnArgs a{A, lda, W, ldw, C, ldc, m, N, accumulate ? 1 : 0};
+    const int n_tiles = cdiv(m, 32);
+    int blocks = cdiv(n_tiles, 4);
+    const int cap = device_cus() * 4;
+    if (blocks > cap) blocks = cap;
+    const bool wide = N > 64;
+    if (K == 128) {
+        if (wide) hipLaunchKernelGGL((gemm_nn_kernel<16, 4>), dim3(blocks), dim3(256), 0, st, a, n_tiles);
+        else hipLaunchKernelGGL((gemm_nn_kernel<16, 2>), dim3(blocks), dim3(256), 0, st, a, n_tiles);
+    } else if (K == 64) {
+        if (wide) hipLaunchKernelGGL((gemm_nn_kernel<8, 4>), dim3(blocks), dim3(256), 0, st, a, n_tiles);
+        else hipLaunchKernelGGL((gemm_nn_kernel<8, 2>), dim3(blocks), dim3(256), 0, st, a, n_tiles);
+    } else {
+        return fail(UCNERF_EINVAL, "mlp_bwd: gemm_nn K = %d", K);
+    }
+    return check_launch("mlp_bwd gemm_nn");
+}
+
+static int run_tn(hipStream_t st, int m, const float* G, int ldg, int Nout, const float* X, int ldx, int xdiv, int Kin, float* gW,
+                  int ldw, float* gb) {
+    for (int k0 = 0; k0 < Kin; k0 += 128) {               // at most 4 accumulator tiles per launch
+        const int kin = Kin - k0 < 128 ? Kin - k0 : 128;
+        TnArgs a{G, ldg, X + k0, ldx, xdiv, gW + k0, ldw, k0 == 0 ? gb : nullptr, m, Nout, kin};
+        dim3 grid(cdiv(m, TN_CHUNK)), block(256);
+        const int kt = cdiv(kin, 32);
+        if (kt == 1) hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, block, 0, st, a);
+        else if (kt == 2) hipLaunchKernelGGL(gemm_tn_kernel<2>, grid, block, 0, st, a);
+        else if (kt == 3) hipLaunchKernelGGL(gemm_tn_kernel<3>, grid, block, 0, st, a);
+        else hipLaunchKernelGGL(gemm_tn_kernel<4>, grid, block, 0, st, a);
+        int rc = check_launch("mlp_bwd gemm_tn");
+        if (rc) return rc;
+    }
+    return UCNERF_OK;
+}
+
+#define RUN(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+}  // namespace ucnerf
 
 using namespace ucnerf;
 
 extern "C" {
 
-int64_t ucnerf_mlp_bwd_workspace_floats(const ucnerf_mlp_config*, int32_t) { return 0; }
-int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params*, void*) { return fail(UCNERF_EINVAL, "mlp_bwd: not implemented yet"); }
-int64_t ucnerf_render_bwd_workspace_floats(int32_t, int32_t, int32_t) { return 0; }
-int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params*, void*) { return fail(UCNERF_EINVAL, "render_fused_bwd: not implemented yet"); }
-
+int64_t ucnerf_mlp_bwd_workspace_floats(const ucnerf_mlp_config* cfg, int32_t m) {
+    MlpLayout L;
+    if (!cfg || !mlp_layout(cfg->n_src, &L) || m < 0) return fail(UCNERF_EINVAL, "mlp_bwd_workspace: bad arguments");
+    BwdWork w;
+    return (int64_t)carve_bwd(nullptr, m, m, &w);      // upper bound (direction rows <= m)
 }
+
+int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
+    UCNERF_REQUIRE(bp, "mlp_bwd: null params");
+    const ucnerf_mlp_params& f = bp->fwd;
+    if (f.m <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(f.pts && f.dirs && f.feats && f.wstream && bp->g_raw && bp->flat_params && bp->g_flat && bp->g_feats &&
+                       bp->workspace, "mlp_bwd: null pointer");
+    UCNERF_REQUIRE(!f.feats_tiled, "mlp_bwd: features must be row-major [m,F]");
+    UCNERF_REQUIRE(f.cfg.pe_layout == 0 || f.cfg.pe_layout == 1, "mlp_bwd: pe_layout %d", f.cfg.pe_layout);
+    UCNERF_REQUIRE(((uintptr_t)bp->workspace & 15) == 0 && ((uintptr_t)bp->g_raw & 15) == 0, "mlp_bwd: workspace/g_raw must be 16-byte aligned");
+    MlpLayout L;
+    UCNERF_REQUIRE(mlp_layout(f.cfg.n_src, &L), "mlp_bwd: n_src %d outside 1..8", f.cfg.n_src);
+    hipStream_t st = (hipStream_t)stream;
+    const int m = f.m, v = L.v, F = L.F, n_mvs = 24 + 4 * v, n_img = 8 * v;
+    const int n_dirs = f.dirs_per_sample ? m : m / f.S;
+    const int xdiv_dir = f.dirs_per_sample ? 1 : f.S;
+    BwdWork w;
+    carve_bwd(bp->workspace, m, n_dirs, &w);
+    const float* P = bp->flat_params;
+    float* G = bp->g_flat;
+    const size_t n4 = (size_t)m * 32;
+    const int ew_blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+
+    // 0. forward with the activations kept; encodings as explicit matrices for the weight-gradient GEMMs
+    ucnerf_mlp_params fw = f;
+    fw.raw = w.raw;
+    RUN(launch_mlp_fwd(&fw, &w.sv, st));
+    ucnerf_embed_params e;
+    e.m = m; e.n_freqs = 10; e.layout = f.cfg.pe_layout; e.x = f.pts; e.out = w.pep;
+    RUN(ucnerf_embed(&e, st));
+    e.m = n_dirs; e.n_freqs = 4; e.x = f.dirs; e.out = w.ped;
+    RUN(ucnerf_embed(&e, st));
+
+    // 1. output stage + heads: g_base, g_adapt, d/d(confidence), g_vc -> g1
+    HeadArgs ha;
+    ha.m = m; ha.F = F; ha.raw = w.raw; ha.g_raw = bp->g_raw; ha.feats = f.feats; ha.ldf = F; ha.h5 = w.sv.h[5]; ha.vc = w.sv.vc;
+    ha.w_crgb = P + L.p_crw; ha.w_a1 = P + L.p_a1w; ha.w_rgb = P + L.p_rw; ha.w_a = P + L.p_aw;
+    ha.b_crgb = P + L.p_crb; ha.b_a1 = P + L.p_a1b; ha.b_rgb = P + L.p_rb; ha.b_a = P + L.p_ab;
+    ha.g_base = w.g_base; ha.g_adapt = w.g_adapt; ha.g_vc = w.g1; ha.g_feats = bp->g_feats; ha.ldgf = F;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(cdiv(m, 8)), dim3(256), 0, st, ha);
+    RUN(check_launch("mlp_bwd head"));
+    // head weights: rgb_linear [3,64] <- g_adapt[:, :3]^T vc[:, :64]; alpha_linear [1,64] <- g_adapt[:, 3]^T vc[:, 64:]
+    RUN(run_tn(st, m, w.g_adapt, 4, 3, w.sv.vc, 128, 1, 64, G + L.p_rw, 64, G + L.p_rb));
+    RUN(run_tn(st, m, w.g_adapt + 3, 4, 1, w.sv.vc + 64, 128, 1, 64, G + L.p_aw, 64, G + L.p_ab));
+    RUN(run_tn(st, m, w.g_base, 4, 3, w.sv.h[5], 128, 1, 128, G + L.p_crw, 128, G + L.p_crb));
+    RUN(run_tn(st, m, w.g_base + 3, 4, 1, w.sv.h[5], 128, 1, 128, G + L.p_a1w, 128, G + L.p_a1b));
+
+    // 2. views_linears / view_confi_linears: weights [64,155] on [f | dir encoding]; g_f -> g2
+    const int KV = MLP_W + MLP_PE_DIR;
+    RUN(run_tn(st, m, w.g1, 128, 64, w.sv.ft, 128, 1, 128, G + L.p_vw, KV, G + L.p_vb));
+    RUN(run_tn(st, m, w.g1, 128, 64, w.ped, 27, xdiv_dir, 27, G + L.p_vw + 128, KV, nullptr));
+    RUN(run_tn(st, m, w.g1 + 64, 128, 64, w.sv.ft, 128, 1, 128, G + L.p_vcw, KV, G + L.p_vcb));
+    RUN(run_tn(st, m, w.g1 + 64, 128, 64, w.ped, 27, xdiv_dir, 27, G + L.p_vcw + 128, KV, nullptr));
+    RUN(run_nn(st, m, w.g1, 128, 64, P + L.p_vw, KV, 128, w.g2, 128, false));
+    RUN(run_nn(st, m, w.g1 + 64, 128, 64, P + L.p_vcw, KV, 128, w.g2, 128, true));
+
+    // 3. feature_linear on gx = h5 * bc: weights, then g_g -> g1
+    hipLaunchKernelGGL(mul_kernel, dim3(ew_blocks), dim3(256), 0, st, (const f32x4*)w.sv.h[5], (const f32x4*)w.sv.bc, (f32x4*)w.gx, n4);
+    RUN(check_launch("mlp_bwd mul"));
+    RUN(run_tn(st, m, w.g2, 128, 128, w.gx, 128, 1, 128, G + L.p_fw, 128, G + L.p_fb));
+    RUN(run_nn(st, m, w.g2, 128, 128, P + L.p_fw, 128, 128, w.g1, 128, false));
+
+    // 4. g_h5 -> g2, g_bc -> g3; confidence-bias net
+    BcSplitArgs bs;
+    bs.n4 = n4; bs.g_g = (const f32x4*)w.g1; bs.bc = (const f32x4*)w.sv.bc; bs.h5 = (const f32x4*)w.sv.h[5];
+    bs.g_base = w.g_base; bs.w_crgb = P + L.p_crw; bs.w_a1 = P + L.p_a1w; bs.g_h5 = (f32x4*)w.g2; bs.g_bc = (f32x4*)w.g3;
+    hipLaunchKernelGGL(bc_split_kernel, dim3(ew_blocks), dim3(256), 0, st, bs);
+    RUN(check_launch("mlp_bwd bc_split"));
+    RUN(run_tn(st, m, w.g3, 128, 128, f.feats + n_mvs, F, 1, n_img, G + L.p_bcw, n_img, G + L.p_bcb));
+    RUN(run_nn(st, m, w.g3, 128, 128, P + L.p_bcw, n_img, n_img, bp->g_feats + n_mvs, F, false));
+
+    // 5. trunk, layers 5..0:  g_h (g2) -> g_y (g1), g_bd accumulates; weights; g_h of the layer below -> g2
+    for (int l = 5; l >= 0; --l) {
+        hipLaunchKernelGGL(relu_mod_bwd_kernel, dim3(ew_blocks), dim3(256), 0, st, (const f32x4*)w.g2, (const f32x4*)w.sv.h[l],
+                           (const f32x4*)w.sv.bd, (f32x4*)w.g1, (f32x4*)w.gbd, l == 5 ? 1 : 0, n4);
+        RUN(check_launch("mlp_bwd relu_mod"));
+        if (l == 0) {
+            RUN(run_tn(st, m, w.g1, 128, 128, w.pep, 63, 1, 63, G + L.p_lw[0], 63, G + L.p_lb[0]));
+        } else if (l == 5) {
+            RUN(run_tn(st, m, w.g1, 128, 128, w.pep, 63, 1, 63, G + L.p_lw[5], 191, G + L.p_lb[5]));
+            RUN(run_tn(st, m, w.g1, 128, 128, w.sv.h[4], 128, 1, 128, G + L.p_lw[5] + 63, 191, nullptr));
+            RUN(run_nn(st, m, w.g1, 128, 128, P + L.p_lw[5] + 63, 191, 128, w.g2, 128, false));
+        } else {
+            RUN(run_tn(st, m, w.g1, 128, 128, w.sv.h[l - 1], 128, 1, 128, G + L.p_lw[l], 128, G + L.p_lb[l]));
+            RUN(run_nn(st, m, w.g1, 128, 128, P + L.p_lw[l], 128, 128, w.g2, 128, false));
+        }
+    }
+
+    // 6. depth-bias net
+    RUN(run_tn(st, m, w.gbd, 128, 128, f.feats, F, 1, n_mvs, G + L.p_bdw, n_mvs, G + L.p_bdb));
+    RUN(run_nn(st, m, w.gbd, 128, 128, P + L.p_bdw, n_mvs, n_mvs, bp->g_feats, F, false));
+    return UCNERF_OK;
+}
+
+}  // extern "C"

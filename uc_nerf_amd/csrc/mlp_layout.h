@@ -84,6 +84,15 @@ inline bool mlp_layout(int v, MlpLayout* L) {
     return true;
 }
 
+// Activations the training forward keeps for the backward, all row-major [m,128] float32.
+struct MlpSaved {
+    float* bd;      // depth-bias net output b_d
+    float* h[6];    // trunk activations h_l = relu((W_l x + b_l) * b_d)
+    float* bc;      // confidence-bias net output b_c
+    float* ft;      // feature_linear output f
+    float* vc;      // relu([views_linears | view_confi_linears]([f | dir encoding]))
+};
+
 // Encoding argument handled by k-step t of lane-half h: a in [0, 3*n_freqs) = 3*freq + coord; returns
 // kind 0 = sin(arg a), 1 = cos(arg a), 2 = raw coordinate `a`, 3 = zero pad.
 __host__ __device__ inline void pe_slot(int t, int h, int n_freqs, int* kind, int* a) {
@@ -96,7 +105,7 @@ __host__ __device__ inline void pe_slot(int t, int h, int n_freqs, int* kind, in
 }
 
 // column of the reference's encoded vector for a slot (layout 0 = network/models.py, 1 = run_nerf_helpers.py)
-inline int pe_column(int kind, int a, int n_freqs, int layout) {
+__host__ __device__ inline int pe_column(int kind, int a, int n_freqs, int layout) {
     if (kind == 2) return a;
     if (kind == 3) return -1;
     int fr = a / 3, c = a % 3;

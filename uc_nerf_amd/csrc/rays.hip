@@ -271,7 +271,7 @@ int ucnerf_event_elapsed_ms(void* start, void* stop, float* ms_host) {
     return e == hipSuccess ? UCNERF_OK : fail(UCNERF_EHIP, "event_elapsed_ms: %s", hipGetErrorString(e));
 }
 int ucnerf_event_destroy(void* event) {
-    if (event) hipEventDestroy((hipEvent_t)event);
+    if (event) (void)hipEventDestroy((hipEvent_t)event);
     return UCNERF_OK;
 }
 

@@ -72,9 +72,7 @@ static size_t carve(float* base, int n, int S, int V, Workspace* w) {
     return o;
 }
 
-static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace* w) {
-    const int V = p->cfg.n_src;
-    carve(p->workspace, p->n, p->S, V, w);
+static int launch_points(const ucnerf_render_params* p, hipStream_t st, Workspace* w) {
     const long long M = (long long)p->n * p->S;
     PointsArgs a;
     a.n = p->n; a.S = p->S; a.rays_o = p->rays_o; a.rays_d = p->rays_d; a.z = p->z;
@@ -84,31 +82,45 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
     a.near = p->near; a.far = p->far; a.near_far = p->near_far;
     a.pts = w->pts; a.ndc1 = w->ndc1; a.ndc2 = w->ndc2; a.ndc3 = w->ndc3; a.ndc = w->ndc;
     hipLaunchKernelGGL(render_points_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, a);
-    int rc = check_launch("render_points");
-    if (rc) return rc;
+    return check_launch("render_points");
+}
 
-    ucnerf_feat_gather_params g;
-    memset(&g, 0, sizeof(g));
-    g.m = (int)M; g.V = V; g.H = p->H; g.W = p->W;
-    for (int k = 0; k < 3; ++k) { g.vol_d[k] = p->vol_d[k]; g.vol_h[k] = p->vol_h[k]; g.vol_w[k] = p->vol_w[k]; g.vol[k] = p->vol[k]; }
-    g.pts = w->pts; g.ndc1 = w->ndc1; g.ndc2 = w->ndc2; g.ndc3 = w->ndc3;
-    g.conf = p->conf; g.imgs = p->imgs; g.img_feat = p->img_feat; g.w2cs = p->w2cs; g.intrinsics = p->intrinsics;
-    const bool keep_feats = p->feats != nullptr;        // caller wants row-major features (for the backward)
-    g.out_tiled = keep_feats ? 0 : 1;
-    g.feats = keep_feats ? p->feats : w->feats;
-    if ((rc = ucnerf_feat_gather_fwd(&g, st))) return rc;
+static void gather_geometry(const ucnerf_render_params* p, const Workspace* w, ucnerf_feat_gather_params* g) {
+    memset(g, 0, sizeof(*g));
+    g->m = p->n * p->S; g->V = p->cfg.n_src; g->H = p->H; g->W = p->W;
+    for (int k = 0; k < 3; ++k) { g->vol_d[k] = p->vol_d[k]; g->vol_h[k] = p->vol_h[k]; g->vol_w[k] = p->vol_w[k]; g->vol[k] = p->vol[k]; }
+    g->pts = w->pts; g->ndc1 = w->ndc1; g->ndc2 = w->ndc2; g->ndc3 = w->ndc3;
+    g->conf = p->conf; g->imgs = p->imgs; g->img_feat = p->img_feat; g->w2cs = p->w2cs; g->intrinsics = p->intrinsics;
+}
 
+static void mlp_args(const ucnerf_render_params* p, const Workspace* w, const float* feats, int tiled, float* raw, ucnerf_mlp_params* m) {
+    memset(m, 0, sizeof(*m));
+    m->cfg = p->cfg; m->m = p->n * p->S; m->S = p->S; m->dirs_per_sample = 0; m->feats_tiled = tiled; m->max_blocks = p->max_blocks;
+    m->pts = w->ndc; m->dirs = w->angle; m->feats = feats; m->wstream = p->wstream; m->raw = raw;
+}
+
+static int launch_dirs(const ucnerf_render_params* p, hipStream_t st, Workspace* w) {
     ucnerf_dir_feature_params d;
     memset(&d, 0, sizeof(d));
     d.n = p->n; d.has_ref = 1; memcpy(d.w2c_ref, p->w2c_dir, sizeof(d.w2c_ref));
     d.rays_d = p->rays_d; d.angle = w->angle; d.cos_angle = nullptr;
-    if ((rc = ucnerf_dir_feature(&d, st))) return rc;
+    return ucnerf_dir_feature(&d, st);
+}
 
+static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace* w) {
+    const int V = p->cfg.n_src;
+    carve(p->workspace, p->n, p->S, V, w);
+    int rc = launch_points(p, st, w);
+    if (rc) return rc;
+    ucnerf_feat_gather_params g;
+    gather_geometry(p, w, &g);
+    const bool keep_feats = p->feats != nullptr;        // caller wants row-major features (for the backward)
+    g.out_tiled = keep_feats ? 0 : 1;
+    g.feats = keep_feats ? p->feats : w->feats;
+    if ((rc = ucnerf_feat_gather_fwd(&g, st))) return rc;
+    if ((rc = launch_dirs(p, st, w))) return rc;
     ucnerf_mlp_params m;
-    memset(&m, 0, sizeof(m));
-    m.cfg = p->cfg; m.m = (int)M; m.S = p->S; m.dirs_per_sample = 0; m.feats_tiled = g.out_tiled; m.max_blocks = p->max_blocks;
-    m.pts = w->ndc; m.dirs = w->angle; m.feats = g.feats; m.wstream = p->wstream;
-    m.raw = p->raw ? p->raw : w->raw;
+    mlp_args(p, w, g.feats, g.out_tiled, p->raw ? p->raw : w->raw, &m);
     if (p->ev_mlp_start && (rc = ucnerf_event_record(p->ev_mlp_start, st))) return rc;
     if ((rc = ucnerf_mlp_fwd(&m, st))) return rc;
     if (p->ev_mlp_stop && (rc = ucnerf_event_record(p->ev_mlp_stop, st))) return rc;
@@ -131,6 +143,67 @@ int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V) {
     if (n < 0 || S < 1 || V < 1 || V > 8) return fail(UCNERF_EINVAL, "render_workspace: bad sizes n=%d S=%d V=%d", n, S, V);
     Workspace w;
     return (int64_t)carve(nullptr, n, S, V, &w);
+}
+
+// backward workspace = [forward-style carve (points, coordinates, directions)] [g_raw 4M] [g_feats M*F] [mlp_bwd scratch]
+static size_t carve_bwd_render(float* base, int n, int S, int V, Workspace* w, float** g_raw, float** g_feats, float** mlp_ws) {
+    size_t o = carve(base, n, S, V, w);
+    const size_t M = (size_t)n * S, F = 24 + 12 * V + 1;
+    ucnerf_mlp_config cfg{V, 0};
+    const size_t mlp = (size_t)ucnerf_mlp_bwd_workspace_floats(&cfg, (int)M);
+    auto take = [&](size_t k) { float* r = base ? base + o : nullptr; o += align4(k); return r; };
+    *g_raw = take(4 * M); *g_feats = take(M * F); *mlp_ws = take(mlp);
+    return o;
+}
+
+int64_t ucnerf_render_bwd_workspace_floats(int32_t n, int32_t S, int32_t V) {
+    if (n < 0 || S < 1 || V < 1 || V > 8) return fail(UCNERF_EINVAL, "render_bwd_workspace: bad sizes n=%d S=%d V=%d", n, S, V);
+    Workspace w;
+    float *a, *b, *c;
+    return (int64_t)carve_bwd_render(nullptr, n, S, V, &w, &a, &b, &c);
+}
+
+int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* bp, void* stream) {
+    UCNERF_REQUIRE(bp, "render_fused_bwd: null params");
+    const ucnerf_render_params* p = &bp->fwd;
+    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->rays_o && p->rays_d && p->z && p->wstream && p->raw && p->feats && bp->g_rgb && bp->flat_params && bp->g_flat &&
+                       bp->workspace, "render_fused_bwd: null pointer (fwd.raw and fwd.feats must hold the forward's outputs)");
+    UCNERF_REQUIRE(((uintptr_t)bp->workspace & 15) == 0, "render_fused_bwd: workspace must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int V = p->cfg.n_src;
+    Workspace w;
+    float *g_raw, *g_feats, *mlp_ws;
+    carve_bwd_render(bp->workspace, p->n, p->S, V, &w, &g_raw, &g_feats, &mlp_ws);
+    int rc;
+    ucnerf_render_params q = *p;            // points / coordinates / directions are recomputed into OUR workspace
+    q.workspace = bp->workspace;
+    if ((rc = launch_points(&q, st, &w))) return rc;
+    if ((rc = launch_dirs(&q, st, &w))) return rc;
+
+    ucnerf_composite_bwd_params cb;
+    memset(&cb, 0, sizeof(cb));
+    cb.fwd.n = p->n; cb.fwd.S = p->S; cb.fwd.variant = 0; cb.fwd.white_bkgd = p->white_bkgd; cb.fwd.raw = p->raw; cb.fwd.z = p->z;
+    cb.g_rgb = bp->g_rgb; cb.g_depth = bp->g_depth; cb.g_raw = g_raw;
+    if ((rc = ucnerf_composite_bwd(&cb, st))) return rc;
+
+    ucnerf_mlp_bwd_params mb;
+    memset(&mb, 0, sizeof(mb));
+    mlp_args(&q, &w, p->feats, 0, nullptr, &mb.fwd);
+    mb.fwd.raw = g_raw;                      // placeholder (not written by the backward)
+    mb.g_raw = g_raw; mb.flat_params = bp->flat_params; mb.g_feats = g_feats; mb.g_flat = bp->g_flat; mb.workspace = mlp_ws;
+    if ((rc = ucnerf_mlp_bwd(&mb, st))) return rc;
+
+    if (bp->g_vol[0] || bp->g_vol[1] || bp->g_vol[2] || bp->g_conf || bp->g_img_feat) {
+        ucnerf_feat_gather_bwd_params gb;
+        memset(&gb, 0, sizeof(gb));
+        gather_geometry(&q, &w, &gb.fwd);
+        gb.g_feats = g_feats;
+        for (int k = 0; k < 3; ++k) gb.g_vol[k] = bp->g_vol[k];
+        gb.g_conf = bp->g_conf; gb.g_img_feat = bp->g_img_feat;
+        if ((rc = ucnerf_feat_gather_bwd(&gb, st))) return rc;
+    }
+    return UCNERF_OK;
 }
 
 int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream) {

@@ -349,6 +349,55 @@ def mlp_fwd(pw, wstream, pts, dirs, feats, S, feats_tiled=False, max_blocks=0):
     return raw
 
 
+def mlp_bwd(pw, wstream, flat, pts, dirs, feats, S, g_raw):
+    """Gradients of sum(raw * g_raw) w.r.t. feats [m,F] and the flat parameter vector."""
+    pts, dirs, feats, g_raw, flat = _f32(pts), _f32(dirs), _f32(feats), _f32(g_raw), _f32(flat)
+    m = pts.numel() // 3
+    F = 24 + 12 * pw.cfg.n_src + 1
+    bp = L.MlpBwdParams()
+    p = bp.fwd
+    p.cfg = pw.cfg
+    p.m, p.S = m, int(S)
+    n_dirs = dirs.numel() // 3
+    if n_dirs == m:
+        p.dirs_per_sample = 1
+    elif S > 0 and n_dirs * S == m:
+        p.dirs_per_sample = 0
+    else:
+        raise RuntimeError("uc_nerf_amd.mlp_bwd: %d directions for %d samples (S=%d)" % (n_dirs, m, S))
+    if feats.numel() != m * F or g_raw.numel() != m * 4:
+        raise RuntimeError("uc_nerf_amd.mlp_bwd: feats must be [m,%d] row-major and g_raw [m,4]" % F)
+    need = L.lib().ucnerf_mlp_bwd_workspace_floats(C.addressof(pw.cfg), m)
+    ws = torch.empty(need, device=pts.device)
+    g_feats = torch.empty(m, F, device=pts.device)
+    g_flat = torch.zeros(pw.n_params, device=pts.device)
+    p.pts, p.dirs, p.feats, p.wstream, p.raw = _ptr(pts), _ptr(dirs), _ptr(feats), _ptr(wstream), _ptr(g_raw)
+    bp.g_raw, bp.flat_params, bp.g_feats, bp.g_flat, bp.workspace = _ptr(g_raw), _ptr(flat), _ptr(g_feats), _ptr(g_flat), _ptr(ws)
+    _launch("ucnerf_mlp_bwd", bp, pts.device)
+    return g_feats, g_flat
+
+
+class _MLP(torch.autograd.Function):
+    """raw = MLP(PE(pts), feats, PE(dirs)); differentiable w.r.t. the flat parameters and feats."""
+
+    @staticmethod
+    def forward(ctx, flat, feats, pts, dirs, pw, S):
+        ws = pw.pack(flat)
+        ctx.pw, ctx.S = pw, S
+        ctx.save_for_backward(flat, feats, pts, dirs, ws)
+        return mlp_fwd(pw, ws, pts, dirs, feats.reshape(-1, feats.shape[-1]), S)
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        flat, feats, pts, dirs, ws = ctx.saved_tensors
+        g_feats, g_flat = mlp_bwd(ctx.pw, ws, flat, pts, dirs, feats.reshape(-1, feats.shape[-1]), ctx.S, g_raw)
+        return g_flat, g_feats.view(feats.shape), None, None, None, None
+
+
+def mlp(flat, feats, pts, dirs, pw, S):
+    return _MLP.apply(flat, feats, pts, dirs, pw, S)
+
+
 # ------------------------------------------------------------------------------------------------ a9
 def composite_fwd(raw, z, variant=0, white_bkgd=False, rays_d=None, noise=None, want_var=True):
     raw, z = _f32(raw, "raw"), _f32(z, "z")
@@ -490,6 +539,33 @@ class RenderPass:
         p.ev_mlp_start, p.ev_mlp_stop = events if events is not None else (None, None)
         _launch("ucnerf_render_fused_fwd", p, dev)
         return out
+
+    def backward(self, rays_d, z, kept, g_rgb, g_depth, flat, near_far=None, need=(True, True, True, True, True)):
+        """Backward of the last-style forward call: `kept` = its outputs with keep=("raw", "feats").
+        Returns (g_flat, g_vol1, g_vol2, g_vol3, g_conf, g_img_feat)."""
+        rays_d, z, flat, g_rgb = _f32(rays_d), _f32(z), _f32(flat), _f32(g_rgb)
+        n, S = z.shape
+        dev = z.device
+        bp = L.RenderBwdParams()
+        C.memmove(C.addressof(bp.fwd), C.addressof(self.p), C.sizeof(L.RenderParams))
+        p = bp.fwd
+        p.n, p.S = n, S
+        near_far = _f32(near_far) if near_far is not None else None
+        p.rays_d, p.z, p.near_far = _ptr(rays_d), _ptr(z), _ptr(near_far)
+        p.raw, p.feats = _ptr(kept["raw"]), _ptr(kept["feats"])
+        p.ev_mlp_start = p.ev_mlp_stop = None
+        ws = torch.empty(L.lib().ucnerf_render_bwd_workspace_floats(n, S, self.src.V), device=dev)
+        g_flat = torch.zeros(self.pw.n_params, device=dev)
+        gv = [torch.zeros_like(v) if need[k] else None for k, v in enumerate(self.src.vols)]
+        gc = torch.zeros_like(self.src.conf) if need[3] else None
+        gi = torch.zeros_like(self.src.img_feat) if need[4] else None
+        g_depth = _f32(g_depth) if g_depth is not None else None
+        bp.g_rgb, bp.g_depth, bp.flat_params, bp.g_flat, bp.workspace = _ptr(g_rgb), _ptr(g_depth), _ptr(flat), _ptr(g_flat), _ptr(ws)
+        for k in range(3):
+            bp.g_vol[k] = _ptr(gv[k])
+        bp.g_conf, bp.g_img_feat = _ptr(gc), _ptr(gi)
+        _launch("ucnerf_render_fused_bwd", bp, dev)
+        return g_flat, gv[0], gv[1], gv[2], gc, gi
 
 
 # ------------------------------------------------------------------------------------------------ timing
