@@ -167,6 +167,8 @@ typedef struct {
     int32_t H, W;              /* image / confidence / img_feat size */
     int32_t vol_d[3], vol_h[3], vol_w[3];   /* cascade volume sizes, 8 channels each */
     int32_t out_tiled;         /* 0: feats [m,F] row-major; 1: [ceil(m/32)][F][32] (MLP tile layout) */
+    int32_t unit_mask;         /* 0 = everything; else bit k selects unit k: 0..2 cascade volumes, 3 confidence,
+                                  4+i source view i (rgb+mask and image features).  Sources of unselected units may be NULL. */
     const float* pts;          /* [m,3] world points */
     const float* ndc1;         /* [m,3] stage coordinates in ~[0,1] (ucnerf_ndc_project outputs) */
     const float* ndc2;
@@ -222,6 +224,11 @@ typedef struct {
     int32_t dirs_per_sample;   /* 1: dirs is [m,3] */
     int32_t feats_tiled;       /* feats layout, see ucnerf_feat_gather_params.out_tiled */
     int32_t max_blocks;        /* 0 = auto (persistent grid sized from the CU count) */
+    int32_t encoded;           /* 1: pts / dirs rows already hold the 63 / 27 encoded values (cfg.pe_layout order), as in
+                                  UCNeRF.forward(x) of the reference; implies dirs_per_sample, row-major feats */
+    int32_t pts_stride;        /* floats between consecutive rows of pts / dirs / row-major feats; 0 = dense (3 or 63, */
+    int32_t dirs_stride;       /*   3 or 27, F).  Lets all three point into one [m, 63+F+27] matrix. */
+    int32_t feat_stride;
     const float* pts;          /* [m,3] the 'ndc' coordinates fed to the positional encoding */
     const float* dirs;         /* [m/S,3] or [m,3] view-direction feature */
     const float* feats;        /* [m,F] or tiled */
@@ -239,7 +246,8 @@ typedef struct {
     ucnerf_mlp_params fwd;     /* forward arguments; feats must be row-major [m,F]; raw is not written */
     const float* g_raw;        /* [m,4] upstream gradient */
     const float* flat_params;  /* [param_count] the parameters the wstream was packed from */
-    float* g_feats;            /* [m,F] row-major out (every column written) */
+    float* g_feats;            /* [m,F] out, rows g_feat_stride floats apart (every one of the F columns written) */
+    int32_t g_feat_stride;     /* 0 = F */
     float* g_flat;             /* [param_count] accumulated */
     float* workspace;          /* scratch, ucnerf_mlp_bwd_workspace_floats() floats, 16-byte aligned */
 } ucnerf_mlp_bwd_params;

@@ -1,0 +1,272 @@
+"""The reference's Python call surface (network.renderer, network.models, utils.utils, utils.run_nerf_helpers,
+data.ray_utils) as served by uc_nerf_amd, exercised the way train.py uses it and compared with the reference's
+golden vectors."""
+import types
+
+import pytest
+import torch
+
+from conftest import load_golden, state_dict_from
+from oracle import ucnerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(t):
+    return t.to(DEV) if torch.is_tensor(t) else t
+
+
+def close(a, b, atol=1e-5, rtol=1e-5):
+    torch.testing.assert_close(a.cpu(), b.cpu(), atol=atol, rtol=rtol, equal_nan=True)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import uc_nerf_amd
+    uc_nerf_amd.install_dropin()
+    import data.ray_utils as ray_utils
+    import network.models as models
+    import network.renderer as renderer
+    import utils.run_nerf_helpers as helpers
+    import utils.utils as utils
+    return types.SimpleNamespace(models=models, renderer=renderer, utils=utils, helpers=helpers, ray_utils=ray_utils)
+
+
+def make_model(mods, V, sd):
+    m = mods.models.UCNeRF(D=6, W=128, input_ch_pts=63, input_ch_views=27, input_ch_feat=24 + 12 * (V - 1) + 1, skips=[4],
+                           view_num=V)
+    m.load_state_dict(sd)                       # reference checkpoints load unchanged (names, shapes, order)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("tag", ["v7", "v4"])
+def test_ucnerf_forward_on_encoded_input_matches_reference_output_and_grads(mods, tag, sd_v7):
+    """G6: UCNeRF.forward(x) on the reference's own 187-wide (or 151-wide) input rows, output and gradients."""
+    g = load_golden("g6_mlp_" + tag)
+    V = g["V"]
+    sd = sd_v7 if tag == "v7" else state_dict_from(g)
+    net = make_model(mods, V, sd)
+    x = dev(g["x"]).requires_grad_(True)
+    out = net(x)
+    scale = g["out"].abs().max().item()
+    close(out, g["out"], 2e-5 * max(1.0, scale), 1e-4)
+    (out * dev(g["r"])).sum().backward()
+    F = 24 + 12 * (V - 1) + 1
+    gx = g["grad_x"]
+    close(x.grad[:, 63:63 + F], gx[:, 63:63 + F], 2e-4 * gx.abs().max().item(), 2e-3)
+    assert torch.count_nonzero(x.grad[:, :63]) == 0 and torch.count_nonzero(x.grad[:, 63 + F:]) == 0
+    if tag == "v7":
+        no_grad = set(g["no_grad_names"].tolist())
+        for k, p in net.named_parameters():
+            if k in no_grad:
+                assert p.grad is None or torch.count_nonzero(p.grad) == 0, k
+            else:
+                w = g["grad." + k]
+                torch.testing.assert_close(p.grad.cpu(), w, atol=2e-4 * w.abs().max().item() + 1e-7, rtol=2e-3, msg=lambda s: k + ": " + s)
+
+
+def test_reference_init_policy_and_unsupported_configs_fail_loudly(mods):
+    torch.manual_seed(0)
+    net = mods.models.UCNeRF(D=6, W=128, input_ch_pts=63, input_ch_views=27, input_ch_feat=97, skips=[4], view_num=7)
+    sd = net.state_dict()
+    assert sum(v.numel() for v in sd.values()) == 181642
+    for k in ("nerf.alpha_linear.bias", "nerf.pts_linears.3.bias", "nerf.rgb_linear.bias"):
+        assert torch.count_nonzero(sd[k]) == 0                 # weights_init applied (zero bias)
+    for k in ("nerf.alpha_linear_1.bias", "nerf.pts_bias_confidence.bias"):
+        assert torch.count_nonzero(sd[k]) > 0                  # nn.Linear default init kept (models.py:107-118)
+    with pytest.raises(NotImplementedError):
+        mods.models.UCNeRF(D=8, W=256, input_ch_pts=63, input_ch_views=27, input_ch_feat=97, skips=[4], view_num=7)
+    with pytest.raises(RuntimeError):                          # GPU only: no CPU fallback
+        net(torch.zeros(4, 187))
+    assert torch.equal(net.forward_uncertainty(torch.tensor([0.25])), torch.tensor([0.75]))
+    with pytest.raises(AttributeError):
+        net.forward_alpha(torch.zeros(1, 160))
+
+
+def _ndc(g):
+    return {"stage1": dev(g["ndc1"]), "stage2": dev(g["ndc2"]), "stage3": dev(g["ndc3"]), "ndc": dev(g["ndc"])}
+
+
+def test_rendering_first_and_second_call_with_pose_trim(mods, sd_v7):
+    """G10: rendering() as train.py calls it; the in-place trim of pose_ref changes the second call's view feature."""
+    g = load_golden("g10_rendering")
+    V = g["V"]
+    net = make_model(mods, V, sd_v7)
+    args = types.SimpleNamespace(view_num=V, feat_dim=24 + 12 * (V - 1) + 1, img_downscale=1.0, use_color_volume=False,
+                                 net_type="v2", netchunk=8, multires=10, multires_views=4, i_embed=0)
+    e_p, d_p = mods.models.get_embedder(10, 0)
+    e_d, d_d = mods.models.get_embedder(4, 0)
+    assert (d_p, d_d) == (63, 27)
+    qfn = lambda pts, vd, f, fn: mods.renderer.run_network_mvs(pts, vd, f, fn, embed_fn=e_p, embeddirs_fn=e_d, netchunk=8)
+    vf = {"stage%d" % (i + 1): {"volume_feature_no_ref": dev(g["vol%d" % (i + 1)])} for i in range(3)}
+    pose = {"w2cs": dev(g["w2cs"]).clone(), "intrinsics": dev(g["K"]).repeat(V, 1, 1)}
+    kw = dict(network_fn=net, img_feat=dev(g["img_feat"]), network_query_fn=qfn, confidence=dev(g["conf"]))
+    with torch.no_grad():
+        rgb1, d1 = mods.renderer.rendering(args, pose, dev(g["pts"]), _ndc(g), dev(g["z"]), dev(g["rays_d"]), vf, dev(g["imgs"]), **kw)
+        assert pose["w2cs"].shape[0] == V - 1 == g["n_w2cs_after_first"]
+        rgb2, d2 = mods.renderer.rendering(args, pose, dev(g["pts"]), _ndc(g), dev(g["z"]), dev(g["rays_d"]), vf, dev(g["imgs"]), **kw)
+        pose = {"w2cs": dev(g["w2cs"]).clone(), "intrinsics": dev(g["K"]).repeat(V, 1, 1)}
+        rgbw, _ = mods.renderer.rendering(args, pose, dev(g["pts"]), _ndc(g), dev(g["z"]), dev(g["rays_d"]), vf, dev(g["imgs"]),
+                                          white_bkgd=True, **kw)
+    close(rgb1, g["rgb_first"], 1e-4, 0); close(d1, g["depth_first"], 1e-4, 1e-4)
+    close(rgb2, g["rgb_second"], 1e-4, 0); close(d2, g["depth_second"], 1e-4, 1e-4)
+    close(rgbw, g["rgb_white"], 1e-4, 0)
+    # the generic (non-fused) run_network_mvs branch: explicit embed -> cat -> batchify over UCNeRF.forward(x)
+    e_h, _ = mods.helpers.get_embedder(10, 0)          # interleaved layout cannot fuse with the live dir embedder
+    feats = mods.renderer.gen_pts_feats(dev(g["imgs"]), vf, dev(g["pts"]), {"w2cs": dev(g["w2cs"])[1:], "intrinsics": dev(g["K"]).repeat(V - 1, 1, 1)},
+                                        _ndc(g), args.feat_dim, dev(g["img_feat"]), confidence=dev(g["conf"]))
+    angle = mods.renderer.gen_dir_feature(dev(g["w2cs"])[0], torch.nn.functional.normalize(dev(g["rays_d"]), dim=-1))
+    fused = mods.renderer.run_network_mvs(_ndc(g)["ndc"], angle, feats, net, e_p, e_d, netchunk=8)
+    generic = mods.renderer.run_network_mvs(_ndc(g)["ndc"], angle[:, None].expand(-1, feats.shape[1], -1).contiguous(), feats,
+                                            lambda x: net(x), e_p, e_d, netchunk=5)
+    close(generic, fused, 1e-5, 1e-5)
+
+
+def test_training_step_through_rendering_updates_parameters_and_sources(mods, sd_v7):
+    """A train.py-shaped step: rendering -> img2mse -> backward -> Adam; gradients reach the MLP, the cascade
+    volumes, img_feats and the confidence map, and match autograd through the oracle."""
+    g = load_golden("g10_rendering")
+    V = g["V"]
+    net = make_model(mods, V, sd_v7)
+    args = types.SimpleNamespace(view_num=V, feat_dim=97, img_downscale=1.0, use_color_volume=False, net_type="v2")
+    e_p, _ = mods.models.get_embedder(10, 0)
+    e_d, _ = mods.models.get_embedder(4, 0)
+    qfn = lambda pts, vd, f, fn: mods.renderer.run_network_mvs(pts, vd, f, fn, embed_fn=e_p, embeddirs_fn=e_d)
+    vols = [dev(g["vol%d" % k]).requires_grad_(True) for k in (1, 2, 3)]
+    img_feat, conf = dev(g["img_feat"]).requires_grad_(True), dev(g["conf"]).requires_grad_(True)
+    vf = {"stage%d" % (i + 1): {"volume_feature_no_ref": vols[i]} for i in range(3)}
+    target = torch.rand(g["pts"].shape[0], 3, generator=torch.Generator().manual_seed(1))
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    losses = []
+    for it in range(3):
+        pose = {"w2cs": dev(g["w2cs"]).clone(), "intrinsics": dev(g["K"]).repeat(V, 1, 1)}
+        rgb, depth = mods.renderer.rendering(args, pose, dev(g["pts"]), _ndc(g), dev(g["z"]), dev(g["rays_d"]), vf, dev(g["imgs"]),
+                                             network_fn=net, img_feat=img_feat, network_query_fn=qfn, confidence=conf)
+        loss = mods.utils.img2mse(rgb, dev(target)) * 5.0 + 0.05 * torch.mean((depth - 2.0) ** 2)
+        opt.zero_grad()
+        for t in vols + [img_feat, conf]:
+            t.grad = None
+        loss.backward()
+        if it == 0:
+            # oracle autograd on identical inputs
+            p = {k: v.clone().requires_grad_(True) for k, v in sd_v7.items()}
+            ov = [g["vol%d" % k].clone().requires_grad_(True) for k in (1, 2, 3)]
+            oi, oc = g["img_feat"].clone().requires_grad_(True), g["conf"].clone().requires_grad_(True)
+            ndc = {"stage1": g["ndc1"], "stage2": g["ndc2"], "stage3": g["ndc3"], "ndc": g["ndc"]}
+            orgb, odepth = O.rendering(p, {"w2cs": g["w2cs"].clone(), "intrinsics": g["K"].repeat(V, 1, 1)}, g["pts"], ndc,
+                                       g["z"], g["rays_d"], ov, g["imgs"], oi, oc, V)
+            (torch.mean((orgb - target) ** 2) * 5.0 + 0.05 * torch.mean((odepth - 2.0) ** 2)).backward()
+            close(loss.detach(), (torch.mean((orgb - target) ** 2) * 5.0 + 0.05 * torch.mean((odepth - 2.0) ** 2)).detach(), 1e-5, 1e-4)
+            for got, want in zip(vols + [img_feat, conf], ov + [oi, oc]):
+                w = want.grad
+                torch.testing.assert_close(got.grad.cpu(), w, atol=3e-4 * w.abs().max().item() + 1e-8, rtol=3e-3)
+            for k, q in net.named_parameters():
+                if p[k].grad is not None:
+                    w = p[k].grad
+                    torch.testing.assert_close(q.grad.cpu(), w, atol=3e-4 * w.abs().max().item() + 1e-8, rtol=3e-3, msg=lambda s: k + ": " + s)
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
+
+
+def test_ray_builders_and_helpers_against_reference_vectors(mods, monkeypatch):
+    g = load_golden("g3_sampling")
+    H, W, NS = g["bt_H"], g["bt_W"], g["bt_NS"]
+    outputs = {"stage%d" % k: {"depth_values": dev(g["bt_dv%d" % k])} for k in (1, 2, 3)}
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: dev(g["bt_t_rand"]).clone())      # the reference's draws
+    pts, rd, ndc, z, ro, par = mods.utils.build_rays_test(H, W, dev(g["bt_c2w"]), dev(g["bt_w2c"]), dev(g["bt_K"]),
+                                                          dev(g["bt_near_fars"]), dev(g["bt_near_fars"])[-1], NS, chunk=32,
+                                                          idx=1, outputs=outputs)
+    monkeypatch.undo()
+    close(z, g["bt_z"], 1e-6, 1e-6); close(pts, g["bt_pts"], 1e-5, 1e-5); close(rd, g["bt_dir"]); close(ro, g["bt_o"])
+    for k, name in (("stage1", "bt_ndc1"), ("stage2", "bt_ndc2"), ("stage3", "bt_ndc3"), ("ndc", "bt_ndc")):
+        close(ndc[k], g[name], 2e-5, 2e-5)
+    assert set(par) == {"w2c_ref", "intrinsic_ref", "inv_scale", "near", "far", "pad"}
+    # ray_marcher / get_ray_directions / get_rays / ndc helpers
+    p, o, d, zz = mods.ray_utils.ray_marcher(dev(g["rays"]), g["S"])
+    close(zz, g["z_det"], 1e-6, 1e-6); close(p, g["pts_det"], 1e-6, 1e-6)
+    g1 = load_golden("g1_raygen")
+    dirs = mods.ray_utils.get_ray_directions(g1["H"], g1["W"], dev(g1["K"]))
+    close(dirs, g1["dirs"], 1e-6, 1e-6)
+    ro, rdd = mods.ray_utils.get_rays(dirs, dev(g1["c2w"])[:3, :4])
+    close(rdd, g1["rays_d"]); close(ro, g1["rays_o"])
+    ho, hd = mods.helpers.get_rays(g1["H"], g1["W"], g1["gl_focal"], dev(g1["c2w"])[:3, :4])
+    close(hd, g1["gl_d"]); close(ho, g1["gl_o"])
+    g2 = load_golden("g2_ndc_rays")
+    o1, d1 = mods.ray_utils.get_ndc_rays(g2["H"], g2["W"], g2["focal2"].tolist(), g2["near"], dev(g2["rays_o"]), dev(g2["rays_d"]))
+    close(o1, g2["o_ru"], 1e-5, 1e-5); close(d1, g2["d_ru"], 1e-5, 1e-5)
+    o2, d2 = mods.helpers.ndc_rays(g2["H"], g2["W"], g2["focal"], g2["near"], dev(g2["rays_o"]), dev(g2["rays_d"]))
+    close(o2, g2["o_h"], 1e-5, 1e-5); close(d2, g2["d_h"], 1e-5, 1e-5)
+    # sample_pdf det / pytest branches, both modules
+    g8 = load_golden("g8_sample_pdf")
+    for mod in (mods.ray_utils, mods.helpers):
+        assert torch.equal(mod.sample_pdf(dev(g8["bins"]), dev(g8["weights"]), g8["M"], det=True).cpu(), g8["samples_det"])
+        assert torch.equal(mod.sample_pdf(dev(g8["bins"][:16]), dev(g8["weights"][:16]), g8["M"], det=False, pytest=True).cpu(),
+                           g8["samples_pytest"])
+    # nerf-pytorch style raw2outputs + both embedders
+    g9 = load_golden("g9_composite")
+    res = mods.helpers.raw2outputs(dev(g9["S64_h_raw"]), dev(g9["S64_z"]), dev(g9["S64_h_rays_d"]))
+    for name, t in zip(("rgb", "disp", "acc", "weights", "depth"), res):
+        close(t, g9["S64_h_" + name], 2e-6, 2e-5)
+    g5 = load_golden("g5_embed")
+    close(mods.models.get_embedder(10, 0)[0](dev(g5["x"])), g5["live10"], 2e-6, 0)
+    close(mods.helpers.get_embedder(10, 0)[0](dev(g5["x"])), g5["inter10"], 2e-6, 0)
+    assert isinstance(mods.models.get_embedder(10, -1)[0], torch.nn.Identity)
+
+
+def test_gather_halves_match_reference(mods):
+    g = load_golden("g7_gather")
+    V = g["V"]
+    vf = {"stage%d" % (i + 1): {"volume_feature_no_ref": dev(g["vol%d" % (i + 1)])} for i in range(3)}
+    ndc = {"stage1": dev(g["ndc1"]), "stage2": dev(g["ndc2"]), "stage3": dev(g["ndc3"]), "ndc": dev(g["ndc"])}
+    rf, cs = mods.utils.index_point_feature(vf, dev(g["conf"]).reshape(1, 1, 1, g["H"], g["W"]), ndc)
+    close(rf, g["ray_feats"], 2e-5, 1e-5); close(cs, g["conf_sampled"], 1e-5, 1e-5)
+    pose = {"w2cs": dev(g["w2cs"])[1:], "intrinsics": dev(g["K"]).repeat(V - 1, 1, 1)}
+    cv = mods.utils.build_color_volume(dev(g["pts"]), pose, dev(g["imgs"]), None, dev(g["img_feat"]), with_mask=True)
+    close(cv, g["color_volume"], 2e-5, 1e-5)
+
+
+def test_build_rays_training_sampler_contract(mods):
+    """build_rays: 9-tuple, patch rays first, sparse-depth rays last, colours gathered at the sampled pixels."""
+    H, W, V, NS = 64, 80, 4, 9
+    gen = torch.Generator().manual_seed(0)
+    imgs = torch.rand(1, V, 3, H, W, generator=gen).to(DEV)
+    conf = torch.rand(H, W, generator=gen).clamp(1e-3, 1).to(DEV)
+    coords = torch.stack([torch.randint(0, H, (17,), generator=gen), torch.randint(0, W, (17,), generator=gen)], -1).float().to(DEV)
+    outputs = {}
+    for k, d in (("stage1", 4), ("stage2", 2), ("stage3", 1)):
+        lo = 1.0 + torch.rand(1, 1, H // d, W // d, generator=gen)
+        outputs[k] = {"depth_values": torch.cat([lo, lo + 0.5, lo + 1.0], 1).to(DEV)}
+    K = torch.tensor([[60., 0, W / 2], [0, 60., H / 2], [0, 0, 1]]).to(DEV)
+    eye = torch.eye(4).to(DEV)
+    pose_ref = {"w2cs": eye.repeat(V, 1, 1), "intrinsics": K.repeat(V, 1, 1), "near_fars": torch.tensor([[1.0, 4.0]] * V).to(DEV)}
+    args = types.SimpleNamespace(patch_num=4, patch_size=6)
+    out = mods.utils.build_rays(args, imgs, conf, None, coords, pose_ref, eye.repeat(V, 1, 1), eye.repeat(V, 1, 1), K.repeat(V, 1, 1),
+                                200, NS, with_depth=True, outputs=outputs)
+    pts, rd, colors, ndc, z, ro, rdep, par, pix = out
+    R = 200 + 17
+    assert pts.shape == (R, NS, 3) and rd.shape == (R, 3) and colors.shape == (R, 3) and z.shape == (R, NS) and pix.shape == (2, R)
+    assert rdep is None and set(ndc) == {"stage1", "stage2", "stage3", "ndc"}
+    assert torch.equal(pix[:, -17:].float(), coords.t())
+    assert torch.equal(colors, imgs[0, 0][:, pix[0], pix[1]].t())
+    first = pix[:, :36].reshape(2, 6, 6)                          # first patch is a contiguous 6x6 block
+    assert torch.all(first[0, 1:] - first[0, :-1] == 1) and torch.all(first[1, :, 1:] - first[1, :, :-1] == 1)
+    assert torch.all(z[:, 1:] >= z[:, :-1] - 1e-4)
+    with pytest.raises(UnboundLocalError):
+        mods.utils.build_rays(args, imgs, conf, None, coords, pose_ref, eye.repeat(V, 1, 1), eye.repeat(V, 1, 1), K.repeat(V, 1, 1),
+                              200, NS, with_depth=False, outputs=outputs)
+
+
+def test_create_ucnerf_contract(mods):
+    args = types.SimpleNamespace(multires=10, multires_views=4, i_embed=0, netdepth=6, netwidth=128, feat_dim=97, net_type="v2",
+                                 view_num=7, netchunk=1024, perturb=1.0, N_samples=90, use_viewdirs=True, white_bkgd=False,
+                                 raw_noise_std=0.0, ckpt=None, device=DEV)
+    train, test, start, grad_vars = mods.models.create_ucnerf(args, dir_embedder=True, pts_embedder=True)
+    assert set(train) == {"network_query_fn", "perturb", "N_samples", "network_fn", "network_mvs", "use_viewdirs", "white_bkgd",
+                          "raw_noise_std"}
+    assert start == 0 and test["perturb"] is False and len(grad_vars) == 36
+    mods.utils.filter_keys(train)
+    assert "N_samples" not in train
+    train.pop("network_mvs")
+    assert next(train["network_fn"].parameters()).is_cuda

@@ -52,7 +52,7 @@ class EmbedParams(C.Structure):
 
 class FeatGatherParams(C.Structure):
     _fields_ = [("m", i32), ("V", i32), ("H", i32), ("W", i32), ("vol_d", i32 * 3), ("vol_h", i32 * 3),
-                ("vol_w", i32 * 3), ("out_tiled", i32), ("pts", vp), ("ndc1", vp), ("ndc2", vp), ("ndc3", vp),
+                ("vol_w", i32 * 3), ("out_tiled", i32), ("unit_mask", i32), ("pts", vp), ("ndc1", vp), ("ndc2", vp), ("ndc3", vp),
                 ("vol", vp * 3), ("conf", vp), ("imgs", vp), ("img_feat", vp), ("w2cs", vp), ("intrinsics", vp),
                 ("feats", vp)]
 
@@ -67,11 +67,13 @@ class MlpConfig(C.Structure):
 
 class MlpParams(C.Structure):
     _fields_ = [("cfg", MlpConfig), ("m", i32), ("S", i32), ("dirs_per_sample", i32), ("feats_tiled", i32),
-                ("max_blocks", i32), ("pts", vp), ("dirs", vp), ("feats", vp), ("wstream", vp), ("raw", vp)]
+                ("max_blocks", i32), ("encoded", i32), ("pts_stride", i32), ("dirs_stride", i32), ("feat_stride", i32),
+                ("pts", vp), ("dirs", vp), ("feats", vp), ("wstream", vp), ("raw", vp)]
 
 
 class MlpBwdParams(C.Structure):
-    _fields_ = [("fwd", MlpParams), ("g_raw", vp), ("flat_params", vp), ("g_feats", vp), ("g_flat", vp), ("workspace", vp)]
+    _fields_ = [("fwd", MlpParams), ("g_raw", vp), ("flat_params", vp), ("g_feats", vp), ("g_feat_stride", i32),
+                ("g_flat", vp), ("workspace", vp)]
 
 
 class CompositeParams(C.Structure):

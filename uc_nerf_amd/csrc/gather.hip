@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(256) feat_gather_fwd_kernel(ucnerf_feat_gather
     if (s >= p.m) return;
     const int unit = blockIdx.y;
     const int F = 24 + 12 * p.V + 1;
+    if (p.unit_mask && !((p.unit_mask >> unit) & 1)) return;
     if (unit < 3) {
         const float* g = (unit == 0 ? p.ndc1 : unit == 1 ? p.ndc2 : p.ndc3) + 3 * (size_t)s;
         const int D = p.vol_d[unit], h = p.vol_h[unit], w = p.vol_w[unit];
@@ -127,6 +128,7 @@ __global__ void __launch_bounds__(256) feat_gather_bwd_kernel(ucnerf_feat_gather
     if (s >= p.m) return;
     const int unit = blockIdx.y;
     const int F = 24 + 12 * p.V + 1;
+    if (p.unit_mask && !((p.unit_mask >> unit) & 1)) return;
     const float* gf = bp.g_feats + (size_t)s * F;
     if (unit < 3) {
         float* gv = bp.g_vol[unit];
@@ -189,12 +191,17 @@ __global__ void __launch_bounds__(256) feat_gather_bwd_kernel(ucnerf_feat_gather
 }
 
 static int check_geometry(const ucnerf_feat_gather_params* p, const char* who) {
-    UCNERF_REQUIRE(p->pts && p->ndc1 && p->ndc2 && p->ndc3, "%s: null sample coordinates", who);
+    const int mask = p->unit_mask ? p->unit_mask : ~0;
     UCNERF_REQUIRE(p->V >= 1 && p->V <= 8, "%s: V = %d outside 1..8", who, p->V);
     UCNERF_REQUIRE(p->H >= 2 && p->W >= 2, "%s: image size %dx%d", who, p->H, p->W);
+    const float* nd[3] = {p->ndc1, p->ndc2, p->ndc3};
     for (int k = 0; k < 3; ++k)
-        UCNERF_REQUIRE(p->vol_d[k] >= 1 && p->vol_h[k] >= 1 && p->vol_w[k] >= 1, "%s: volume %d has an empty dimension", who, k);
-    UCNERF_REQUIRE(p->w2cs && p->intrinsics, "%s: null camera arrays", who);
+        if (mask & (1 << k)) {
+            UCNERF_REQUIRE(nd[k], "%s: null stage-%d coordinates", who, k + 1);
+            UCNERF_REQUIRE(p->vol_d[k] >= 1 && p->vol_h[k] >= 1 && p->vol_w[k] >= 1, "%s: volume %d has an empty dimension", who, k);
+        }
+    if (mask & 8) UCNERF_REQUIRE(p->ndc3, "%s: the confidence lookup needs stage-3 coordinates", who);
+    if (mask & (((1 << p->V) - 1) << 4)) UCNERF_REQUIRE(p->pts && p->w2cs && p->intrinsics, "%s: null points / camera arrays", who);
     return UCNERF_OK;
 }
 
@@ -209,8 +216,11 @@ int ucnerf_feat_gather_fwd(const ucnerf_feat_gather_params* p, void* stream) {
     if (p->m <= 0) return UCNERF_OK;
     int rc = check_geometry(p, "feat_gather_fwd");
     if (rc) return rc;
-    UCNERF_REQUIRE(p->vol[0] && p->vol[1] && p->vol[2] && p->conf && p->imgs && p->img_feat && p->feats,
-                   "feat_gather_fwd: null source/output pointer");
+    const int mask = p->unit_mask ? p->unit_mask : ~0;
+    for (int k = 0; k < 3; ++k) UCNERF_REQUIRE(!(mask & (1 << k)) || p->vol[k], "feat_gather_fwd: null volume %d", k);
+    UCNERF_REQUIRE(!(mask & 8) || p->conf, "feat_gather_fwd: null confidence");
+    UCNERF_REQUIRE(!(mask & (((1 << p->V) - 1) << 4)) || (p->imgs && p->img_feat), "feat_gather_fwd: null images / image features");
+    UCNERF_REQUIRE(p->feats, "feat_gather_fwd: null output");
     if (p->m <= 0) return UCNERF_OK;
     hipLaunchKernelGGL(feat_gather_fwd_kernel, dim3(cdiv(p->m, 256), 4 + p->V), dim3(256), 0, (hipStream_t)stream, *p);
     return check_launch("feat_gather_fwd");

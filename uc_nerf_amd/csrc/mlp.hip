@@ -129,6 +129,7 @@ __global__ void unpack_grad_kernel(const float* __restrict__ g, const int32_t* _
 // ------------------------------------------------------------------------------------------------
 struct MlpGeom {      // MlpLayout subset the kernel needs (32-bit is plenty: the stream is < 1 MB)
     int F, kd, kc, f_img, off_const;
+    int pts_stride, dirs_stride, feat_stride, pe_layout;
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -251,6 +252,21 @@ __device__ __forceinline__ void encode(const float (&x)[3], int h, float (&pe)[K
     for (int q = 2 * half + 2; q < KS; ++q) pe[q] = 0.f;
 }
 
+// Encoded-input mode: the encoding already sits in memory (reference column order); pick this lane-half's slots.
+template <int NF, int KS>
+__device__ __forceinline__ void load_encoded(const float* __restrict__ row, int h, int layout, float (&pe)[KS]) {
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+        int k0, a0, k1, a1;
+        pe_slot(t, 0, NF, &k0, &a0);
+        pe_slot(t, 1, NF, &k1, &a1);
+        const int c0 = layout == 0 ? pe_column(k0, a0, NF, 0) : pe_column(k0, a0, NF, 1);
+        const int c1 = layout == 0 ? pe_column(k1, a1, NF, 0) : pe_column(k1, a1, NF, 1);
+        const int c = h ? c1 : c0;
+        pe[t] = c >= 0 ? row[c] : 0.f;
+    }
+}
+
 #define EPILOGUE_RELU_MOD(DST, ACC, MOD)                                               \
     _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                   \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) (DST)[nt][r] = fmaxf((ACC)[nt][r] * (MOD)[nt][r], 0.f);
@@ -268,7 +284,7 @@ __device__ __forceinline__ void save_rows(float* buf, int s, int h, bool valid, 
         }
 }
 
-template <bool TILED, bool SAVE>
+template <bool TILED, bool SAVE, bool ENC>
 __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, MlpGeom g, int n_tiles, MlpSaved sv) {
     __shared__ __attribute__((aligned(16))) float cst[CONST_FLOATS];
     __shared__ __attribute__((aligned(16))) float pe_stash[4][KS_PE_PTS * 64];
@@ -297,7 +313,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
         const float* fb;
         int fstride;
         if (TILED) { fb = p.feats + (size_t)(s >> 5) * g.F * 32 + (s & 31); fstride = 32; }
-        else { fb = p.feats + (size_t)s * g.F; fstride = 1; }
+        else { fb = p.feats + (size_t)s * g.feat_stride; fstride = 1; }
 
         f32x16 bd[4], hin[4], acc[4];
 
@@ -309,8 +325,13 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
         // ---- point encoding, stashed in LDS for the skip connection; layer 0
         {
             float pe[KS_PE_PTS];
-            const float x[3] = {p.pts[3 * (size_t)s], p.pts[3 * (size_t)s + 1], p.pts[3 * (size_t)s + 2]};
-            encode<10, KS_PE_PTS>(x, h, pe);
+            const float* prow = p.pts + (size_t)s * g.pts_stride;
+            if (ENC) {
+                load_encoded<10, KS_PE_PTS>(prow, h, g.pe_layout, pe);
+            } else {
+                const float x[3] = {prow[0], prow[1], prow[2]};
+                encode<10, KS_PE_PTS>(x, h, pe);
+            }
 #pragma unroll
             for (int t = 0; t < KS_PE_PTS; ++t) stash[t * 64 + lane] = pe[t];
             init_bias(cst, SEC_L0, h, acc);
@@ -355,9 +376,14 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
         gemm_hidden(S, acc, hin);
         {
             const size_t ray = p.dirs_per_sample ? (size_t)s : (size_t)(s / p.S);
-            const float d[3] = {p.dirs[3 * ray], p.dirs[3 * ray + 1], p.dirs[3 * ray + 2]};
+            const float* drow = p.dirs + ray * g.dirs_stride;
             float pd[KS_PE_DIR];
-            encode<4, KS_PE_DIR>(d, h, pd);
+            if (ENC) {
+                load_encoded<4, KS_PE_DIR>(drow, h, g.pe_layout, pd);
+            } else {
+                const float d[3] = {drow[0], drow[1], drow[2]};
+                encode<4, KS_PE_DIR>(d, h, pd);
+            }
             gemm_regs<KS_PE_DIR>(S, pd, hin);
         }
 #pragma unroll
@@ -382,6 +408,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
 static MlpGeom geom_of(const MlpLayout& L) {
     MlpGeom g;
     g.F = L.F; g.kd = L.kd; g.kc = L.kc; g.f_img = 24 + 4 * L.v; g.off_const = (int)L.off_const;
+    g.pts_stride = g.dirs_stride = 3; g.feat_stride = L.F; g.pe_layout = 0;
     return g;
 }
 
@@ -402,17 +429,22 @@ int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t
     int cap = p->max_blocks > 0 ? p->max_blocks : cus * 2;
     if (blocks > cap) blocks = cap;
     MlpGeom g = geom_of(L);
+    UCNERF_REQUIRE(p->cfg.pe_layout == 0 || p->cfg.pe_layout == 1, "mlp_fwd: pe_layout %d", p->cfg.pe_layout);
+    UCNERF_REQUIRE(!p->encoded || (p->dirs_per_sample && !p->feats_tiled), "mlp_fwd: encoded inputs need per-sample dirs and row-major feats");
+    UCNERF_REQUIRE(p->pts_stride >= 0 && p->dirs_stride >= 0 && p->feat_stride >= 0, "mlp_fwd: negative stride");
+    g.pe_layout = p->cfg.pe_layout;
+    g.pts_stride = p->pts_stride ? p->pts_stride : (p->encoded ? MLP_PE_PTS : 3);
+    g.dirs_stride = p->dirs_stride ? p->dirs_stride : (p->encoded ? MLP_PE_DIR : 3);
+    g.feat_stride = p->feat_stride ? p->feat_stride : L.F;
     MlpSaved sv;
     memset(&sv, 0, sizeof(sv));
     if (save) sv = *save;
     dim3 grid(blocks), block(256);
-    if (save) {
-        if (p->feats_tiled) hipLaunchKernelGGL((mlp_fwd_kernel<true, true>), grid, block, 0, st, *p, g, n_tiles, sv);
-        else hipLaunchKernelGGL((mlp_fwd_kernel<false, true>), grid, block, 0, st, *p, g, n_tiles, sv);
-    } else {
-        if (p->feats_tiled) hipLaunchKernelGGL((mlp_fwd_kernel<true, false>), grid, block, 0, st, *p, g, n_tiles, sv);
-        else hipLaunchKernelGGL((mlp_fwd_kernel<false, false>), grid, block, 0, st, *p, g, n_tiles, sv);
-    }
+#define LAUNCH(T, SV, E) hipLaunchKernelGGL((mlp_fwd_kernel<T, SV, E>), grid, block, 0, st, *p, g, n_tiles, sv)
+    if (p->encoded) { if (save) LAUNCH(false, true, true); else LAUNCH(false, false, true); }
+    else if (save) { if (p->feats_tiled) LAUNCH(true, true, false); else LAUNCH(false, true, false); }
+    else { if (p->feats_tiled) LAUNCH(true, false, false); else LAUNCH(false, false, false); }
+#undef LAUNCH
     return check_launch("mlp_fwd");
 }
 

@@ -395,6 +395,8 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     const int m = f.m, v = L.v, F = L.F, n_mvs = 24 + 4 * v, n_img = 8 * v;
     const int n_dirs = f.dirs_per_sample ? m : m / f.S;
     const int xdiv_dir = f.dirs_per_sample ? 1 : f.S;
+    const int ldf = f.feat_stride ? f.feat_stride : F;            // row stride of feats
+    const int ldgf = bp->g_feat_stride ? bp->g_feat_stride : F;   // row stride of g_feats
     BwdWork w;
     carve_bwd(bp->workspace, m, n_dirs, &w);
     const float* P = bp->flat_params;
@@ -406,18 +408,27 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     ucnerf_mlp_params fw = f;
     fw.raw = w.raw;
     RUN(launch_mlp_fwd(&fw, &w.sv, st));
-    ucnerf_embed_params e;
-    e.m = m; e.n_freqs = 10; e.layout = f.cfg.pe_layout; e.x = f.pts; e.out = w.pep;
-    RUN(ucnerf_embed(&e, st));
-    e.m = n_dirs; e.n_freqs = 4; e.x = f.dirs; e.out = w.ped;
-    RUN(ucnerf_embed(&e, st));
+    const float *pep = w.pep, *ped = w.ped;      // encodings as matrices: [m,63] and [n_dirs,27]
+    int ld_pep = 63, ld_ped = 27;
+    if (f.encoded) {                              // already in memory (UCNeRF.forward(x) of the reference)
+        pep = f.pts; ld_pep = f.pts_stride ? f.pts_stride : 63;
+        ped = f.dirs; ld_ped = f.dirs_stride ? f.dirs_stride : 27;
+    } else {
+        UCNERF_REQUIRE((f.pts_stride == 0 || f.pts_stride == 3) && (f.dirs_stride == 0 || f.dirs_stride == 3),
+                       "mlp_bwd: strided raw pts/dirs are not supported");
+        ucnerf_embed_params e;
+        e.m = m; e.n_freqs = 10; e.layout = f.cfg.pe_layout; e.x = f.pts; e.out = w.pep;
+        RUN(ucnerf_embed(&e, st));
+        e.m = n_dirs; e.n_freqs = 4; e.x = f.dirs; e.out = w.ped;
+        RUN(ucnerf_embed(&e, st));
+    }
 
     // 1. output stage + heads: g_base, g_adapt, d/d(confidence), g_vc -> g1
     HeadArgs ha;
-    ha.m = m; ha.F = F; ha.raw = w.raw; ha.g_raw = bp->g_raw; ha.feats = f.feats; ha.ldf = F; ha.h5 = w.sv.h[5]; ha.vc = w.sv.vc;
+    ha.m = m; ha.F = F; ha.raw = w.raw; ha.g_raw = bp->g_raw; ha.feats = f.feats; ha.ldf = ldf; ha.h5 = w.sv.h[5]; ha.vc = w.sv.vc;
     ha.w_crgb = P + L.p_crw; ha.w_a1 = P + L.p_a1w; ha.w_rgb = P + L.p_rw; ha.w_a = P + L.p_aw;
     ha.b_crgb = P + L.p_crb; ha.b_a1 = P + L.p_a1b; ha.b_rgb = P + L.p_rb; ha.b_a = P + L.p_ab;
-    ha.g_base = w.g_base; ha.g_adapt = w.g_adapt; ha.g_vc = w.g1; ha.g_feats = bp->g_feats; ha.ldgf = F;
+    ha.g_base = w.g_base; ha.g_adapt = w.g_adapt; ha.g_vc = w.g1; ha.g_feats = bp->g_feats; ha.ldgf = ldgf;
     hipLaunchKernelGGL(head_bwd_kernel, dim3(cdiv(m, 8)), dim3(256), 0, st, ha);
     RUN(check_launch("mlp_bwd head"));
     // head weights: rgb_linear [3,64] <- g_adapt[:, :3]^T vc[:, :64]; alpha_linear [1,64] <- g_adapt[:, 3]^T vc[:, 64:]
@@ -429,9 +440,9 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     // 2. views_linears / view_confi_linears: weights [64,155] on [f | dir encoding]; g_f -> g2
     const int KV = MLP_W + MLP_PE_DIR;
     RUN(run_tn(st, m, w.g1, 128, 64, w.sv.ft, 128, 1, 128, G + L.p_vw, KV, G + L.p_vb));
-    RUN(run_tn(st, m, w.g1, 128, 64, w.ped, 27, xdiv_dir, 27, G + L.p_vw + 128, KV, nullptr));
+    RUN(run_tn(st, m, w.g1, 128, 64, ped, ld_ped, xdiv_dir, 27, G + L.p_vw + 128, KV, nullptr));
     RUN(run_tn(st, m, w.g1 + 64, 128, 64, w.sv.ft, 128, 1, 128, G + L.p_vcw, KV, G + L.p_vcb));
-    RUN(run_tn(st, m, w.g1 + 64, 128, 64, w.ped, 27, xdiv_dir, 27, G + L.p_vcw + 128, KV, nullptr));
+    RUN(run_tn(st, m, w.g1 + 64, 128, 64, ped, ld_ped, xdiv_dir, 27, G + L.p_vcw + 128, KV, nullptr));
     RUN(run_nn(st, m, w.g1, 128, 64, P + L.p_vw, KV, 128, w.g2, 128, false));
     RUN(run_nn(st, m, w.g1 + 64, 128, 64, P + L.p_vcw, KV, 128, w.g2, 128, true));
 
@@ -447,8 +458,8 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     bs.g_base = w.g_base; bs.w_crgb = P + L.p_crw; bs.w_a1 = P + L.p_a1w; bs.g_h5 = (f32x4*)w.g2; bs.g_bc = (f32x4*)w.g3;
     hipLaunchKernelGGL(bc_split_kernel, dim3(ew_blocks), dim3(256), 0, st, bs);
     RUN(check_launch("mlp_bwd bc_split"));
-    RUN(run_tn(st, m, w.g3, 128, 128, f.feats + n_mvs, F, 1, n_img, G + L.p_bcw, n_img, G + L.p_bcb));
-    RUN(run_nn(st, m, w.g3, 128, 128, P + L.p_bcw, n_img, n_img, bp->g_feats + n_mvs, F, false));
+    RUN(run_tn(st, m, w.g3, 128, 128, f.feats + n_mvs, ldf, 1, n_img, G + L.p_bcw, n_img, G + L.p_bcb));
+    RUN(run_nn(st, m, w.g3, 128, 128, P + L.p_bcw, n_img, n_img, bp->g_feats + n_mvs, ldgf, false));
 
     // 5. trunk, layers 5..0:  g_h (g2) -> g_y (g1), g_bd accumulates; weights; g_h of the layer below -> g2
     for (int l = 5; l >= 0; --l) {
@@ -456,9 +467,9 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
                            (const f32x4*)w.sv.bd, (f32x4*)w.g1, (f32x4*)w.gbd, l == 5 ? 1 : 0, n4);
         RUN(check_launch("mlp_bwd relu_mod"));
         if (l == 0) {
-            RUN(run_tn(st, m, w.g1, 128, 128, w.pep, 63, 1, 63, G + L.p_lw[0], 63, G + L.p_lb[0]));
+            RUN(run_tn(st, m, w.g1, 128, 128, pep, ld_pep, 1, 63, G + L.p_lw[0], 63, G + L.p_lb[0]));
         } else if (l == 5) {
-            RUN(run_tn(st, m, w.g1, 128, 128, w.pep, 63, 1, 63, G + L.p_lw[5], 191, G + L.p_lb[5]));
+            RUN(run_tn(st, m, w.g1, 128, 128, pep, ld_pep, 1, 63, G + L.p_lw[5], 191, G + L.p_lb[5]));
             RUN(run_tn(st, m, w.g1, 128, 128, w.sv.h[4], 128, 1, 128, G + L.p_lw[5] + 63, 191, nullptr));
             RUN(run_nn(st, m, w.g1, 128, 128, P + L.p_lw[5] + 63, 191, 128, w.g2, 128, false));
         } else {
@@ -468,8 +479,8 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     }
 
     // 6. depth-bias net
-    RUN(run_tn(st, m, w.gbd, 128, 128, f.feats, F, 1, n_mvs, G + L.p_bdw, n_mvs, G + L.p_bdb));
-    RUN(run_nn(st, m, w.gbd, 128, 128, P + L.p_bdw, n_mvs, n_mvs, bp->g_feats, F, false));
+    RUN(run_tn(st, m, w.gbd, 128, 128, f.feats, ldf, 1, n_mvs, G + L.p_bdw, n_mvs, G + L.p_bdb));
+    RUN(run_nn(st, m, w.gbd, 128, 128, P + L.p_bdw, n_mvs, n_mvs, bp->g_feats, ldgf, false));
     return UCNERF_OK;
 }
 

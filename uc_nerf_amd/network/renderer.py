@@ -1,0 +1,102 @@
+"""Drop-in for the reference's network/renderer.py: same function names, argument orders and return arities;
+every computation is a libucnerf_hip.so kernel (feature gather, fused PE+MLP, compositing) with autograd support.
+"""
+import torch
+
+from .. import ops
+
+
+def depth2dist(z_vals, cos_angle):
+    """network/renderer.py:6-15 (rendering() computes it but raw2alpha ignores it; plain tensor plumbing)."""
+    d = z_vals[..., 1:] - z_vals[..., :-1]
+    d = torch.cat([d, torch.full_like(z_vals[..., :1], 1e10)], -1)
+    return d * cos_angle.unsqueeze(-1)
+
+
+def raw2alpha(sigma, dist, net_type):
+    """network/renderer.py:25-36 -> (alpha, weights, softmax(sigma)).  Weights come from the compositing kernel."""
+    n, S = sigma.shape
+    raw = torch.cat([torch.zeros(n, S, 3, device=sigma.device), sigma.unsqueeze(-1)], -1)
+    _, _, _, weights, _, _ = ops.composite(raw, torch.zeros_like(sigma), False)
+    return 1. - torch.exp(-sigma), weights, torch.softmax(sigma, 1)
+
+
+def batchify(fn, chunk):
+    """network/renderer.py:57-75."""
+    if chunk is None:
+        return fn
+
+    def ret(inputs, alpha_only):
+        f = fn.forward_alpha if alpha_only else fn
+        return torch.cat([f(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
+
+    return ret
+
+
+def _fusable(fn, embed_fn, embeddirs_fn):
+    return (hasattr(fn, "forward_raw") and getattr(embed_fn, "n_freqs", None) == 10
+            and getattr(embeddirs_fn, "n_freqs", None) == 4
+            and getattr(embed_fn, "layout", None) == getattr(embeddirs_fn, "layout", -1))
+
+
+def run_network_mvs(pts, viewdirs, alpha_feat, fn, embed_fn, embeddirs_fn, netchunk=1024):
+    """network/renderer.py:78-106.  With this package's UCNeRF and embedders the encodings, the concatenation and the
+    netchunk loop disappear into one fused kernel launch (netchunk is accepted and ignored); any other `fn` gets
+    the reference's embed -> cat -> batchify sequence."""
+    if viewdirs is not None and alpha_feat is not None and _fusable(fn, embed_fn, embeddirs_fn):
+        return fn.forward_raw(pts, viewdirs, alpha_feat, embed_fn.layout)
+    if embed_fn is not None:
+        pts = embed_fn(pts)
+    if alpha_feat is not None:
+        pts = torch.cat((pts, alpha_feat), dim=-1)
+    if viewdirs is not None:
+        if viewdirs.dim() != 3:
+            viewdirs = viewdirs[:, None].expand(-1, pts.shape[1], -1)
+        if embeddirs_fn is not None:
+            viewdirs = embeddirs_fn(viewdirs.contiguous())
+        pts = torch.cat([pts, viewdirs], -1)
+    out = batchify(fn, netchunk)(pts, viewdirs is None)
+    return out.reshape(list(pts.shape[:-1]) + [out.shape[-1]])
+
+
+def raw2outputs(raw, z_vals, dists, white_bkgd=False, net_type='v2'):
+    """network/renderer.py:109-140 -> (rgb_map, disp_map, acc_map, weights, depth_map, weights, var)."""
+    rgb, depth, acc, weights, disp, var = ops.composite(raw[..., :4], z_vals, white_bkgd)
+    return rgb, disp, acc, weights, depth, weights, var
+
+
+def gen_dir_feature(w2c_ref, rays_dir):
+    """network/renderer.py:163-174: rays_dir @ R_ref^T."""
+    return rays_dir @ w2c_ref[:3, :3].t()
+
+
+def gen_pts_feats(imgs, volume_feature, rays_pts, pose_ref, rays_ndc, feat_dim, img_feat=None, near_fars=None,
+                  img_downscale=1.0, use_color_volume=False, net_type='v0', confidence=None):
+    """network/renderer.py:177-212 (use_color_volume=False): [N,S,feat_dim] from ONE gather launch."""
+    if use_color_volume:
+        raise NotImplementedError("uc_nerf_amd: use_color_volume=True is not on the reference's live path")
+    vols = [volume_feature["stage%d" % k]["volume_feature_no_ref"] for k in (1, 2, 3)]
+    feats = ops.feat_gather(vols, confidence, img_feat, imgs, pose_ref['w2cs'], pose_ref['intrinsics'], rays_pts,
+                            rays_ndc['stage1'], rays_ndc['stage2'], rays_ndc['stage3'])
+    if feats.shape[-1] != feat_dim:
+        raise RuntimeError("uc_nerf_amd.gen_pts_feats: feat_dim %d but the sources give %d" % (feat_dim, feats.shape[-1]))
+    return feats
+
+
+def rendering(args, pose_ref, rays_pts, rays_ndc, depth_candidates, rays_dir, volume_feature=None, imgs=None,
+              network_fn=None, near_fars=None, img_feat=None, network_query_fn=None, white_bkgd=False, confidence=None,
+              **kwargs):
+    """network/renderer.py:215-255 -> (rgb_map [N,3], depth_map [N]), including the in-place trim of pose_ref."""
+    if pose_ref is not None:
+        angle, _ = ops.dir_feature(rays_dir, pose_ref['w2cs'][0])
+    else:
+        angle, _ = ops.dir_feature(rays_dir, None)
+    if pose_ref['w2cs'].shape[0] == args.view_num:          # renderer.py:241-243: callers observe this mutation
+        pose_ref['w2cs'] = pose_ref['w2cs'][1:]
+        pose_ref['intrinsics'] = pose_ref['intrinsics'][1:]
+    input_feat = gen_pts_feats(imgs, volume_feature, rays_pts, pose_ref, rays_ndc, args.feat_dim, img_feat, near_fars,
+                               args.img_downscale, args.use_color_volume, args.net_type, confidence=confidence)
+    raw = network_query_fn(rays_ndc['ndc'], angle, input_feat, network_fn)
+    rgb_map, disp_map, acc_map, weights, depth_map, alpha, var = raw2outputs(raw, depth_candidates, None, white_bkgd,
+                                                                           args.net_type)
+    return rgb_map, depth_map

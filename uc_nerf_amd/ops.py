@@ -196,83 +196,118 @@ def embed(x, n_freqs, layout=0):
 
 # ------------------------------------------------------------------------------------------------ a7
 class GatherSources:
-    """The gather's read-only geometry + source tensors, normalised to the layouts the kernels read."""
+    """The gather's read-only geometry + source tensors, normalised to the layouts the kernels read.
+    Any of `vols`, `conf`, `imgs` may be None: the corresponding units are masked out (their feature columns are
+    left unwritten), which is how index_point_feature / build_color_volume run on the same kernel."""
 
-    def __init__(self, vols, conf, imgs, img_feat, w2cs, intrinsics):
-        self.vols = [_f32(v, "volume").reshape(v.shape[-4:]) for v in vols]           # [8,D,h,w]
-        for v in self.vols:
-            if v.shape[0] != 8:
-                raise RuntimeError("uc_nerf_amd: cascade volumes must have 8 channels")
-        H, W = conf.shape[-2:]
-        self.H, self.W = int(H), int(W)
-        self.conf = _f32(conf, "confidence").reshape(H, W)
-        self.imgs = _f32(imgs, "imgs").reshape(-1, 3, H, W)                            # [V,3,H,W]
-        self.V = self.imgs.shape[0]
-        self.img_feat = _f32(img_feat, "img_feat").reshape(self.V, 8, H, W)
-        dev = self.conf.device
-        self.w2cs = torch.as_tensor(w2cs, dtype=torch.float32)[:, :3, :4].reshape(-1, 12).to(dev).contiguous()
-        self.intrinsics = torch.as_tensor(intrinsics, dtype=torch.float32).reshape(-1, 9).to(dev).contiguous()
-        if self.w2cs.shape[0] != self.V or self.intrinsics.shape[0] != self.V:
-            raise RuntimeError("uc_nerf_amd: %d source images but %d poses / %d intrinsics"
-                               % (self.V, self.w2cs.shape[0], self.intrinsics.shape[0]))
+    def __init__(self, vols, conf, imgs, img_feat, w2cs, intrinsics, hw=None):
+        self.mask = 0
+        dev = None
+        self.vols = [None, None, None]
+        if vols is not None:
+            self.vols = [_f32(v, "volume").reshape(v.shape[-4:]) for v in vols]       # [8,D,h,w]
+            for v in self.vols:
+                if v.shape[0] != 8:
+                    raise RuntimeError("uc_nerf_amd: cascade volumes must have 8 channels")
+            self.mask |= 0b111
+            dev = self.vols[0].device
+        self.conf = None
+        if conf is not None:
+            hw = tuple(conf.shape[-2:])
+            self.conf = _f32(conf, "confidence").reshape(hw)
+            self.mask |= 0b1000
+            dev = self.conf.device
+        self.imgs = self.img_feat = self.w2cs = self.intrinsics = None
+        self.V = 1
+        if imgs is not None:
+            hw = tuple(imgs.shape[-2:])
+            self.imgs = _f32(imgs, "imgs").reshape(-1, 3, *hw)                         # [V,3,H,W]
+            self.V = self.imgs.shape[0]
+            dev = self.imgs.device
+            self.img_feat = (_f32(img_feat, "img_feat").reshape(self.V, 8, *hw) if img_feat is not None
+                             else torch.zeros(self.V, 8, *hw, device=dev))
+            self.w2cs = torch.as_tensor(w2cs, dtype=torch.float32)[:, :3, :4].reshape(-1, 12).to(dev).contiguous()
+            self.intrinsics = torch.as_tensor(intrinsics, dtype=torch.float32).reshape(-1, 9).to(dev).contiguous()
+            if self.w2cs.shape[0] != self.V or self.intrinsics.shape[0] != self.V:
+                raise RuntimeError("uc_nerf_amd: %d source images but %d poses / %d intrinsics"
+                                   % (self.V, self.w2cs.shape[0], self.intrinsics.shape[0]))
+            self.mask |= ((1 << self.V) - 1) << 4
+        if hw is None or self.mask == 0:
+            raise RuntimeError("uc_nerf_amd: the gather needs at least one source")
+        self.H, self.W = int(hw[0]), int(hw[1])
         self.F = 24 + 12 * self.V + 1
         self.device = dev
+        self.full = self.mask == (0b1111 | (((1 << self.V) - 1) << 4))
 
     def fill(self, p):
         p.V, p.H, p.W = self.V, self.H, self.W
+        p.unit_mask = 0 if self.full else self.mask
         for k, v in enumerate(self.vols):
-            p.vol_d[k], p.vol_h[k], p.vol_w[k] = v.shape[1], v.shape[2], v.shape[3]
+            if v is not None:
+                p.vol_d[k], p.vol_h[k], p.vol_w[k] = v.shape[1], v.shape[2], v.shape[3]
+            else:
+                p.vol_d[k] = p.vol_h[k] = p.vol_w[k] = 1
             p.vol[k] = _ptr(v)
         p.conf, p.imgs, p.img_feat = _ptr(self.conf), _ptr(self.imgs), _ptr(self.img_feat)
         p.w2cs, p.intrinsics = _ptr(self.w2cs), _ptr(self.intrinsics)
 
 
+def _opt(t):
+    return _f32(t) if t is not None else None
+
+
 def feat_gather_fwd(src, pts, ndc1, ndc2, ndc3, tiled=False):
-    pts, ndc1, ndc2, ndc3 = _f32(pts), _f32(ndc1), _f32(ndc2), _f32(ndc3)
-    m = pts.numel() // 3
+    pts, ndc1, ndc2, ndc3 = _opt(pts), _opt(ndc1), _opt(ndc2), _opt(ndc3)
+    lead = next(t for t in (pts, ndc1, ndc3) if t is not None)
+    m = lead.numel() // 3
     p = L.FeatGatherParams()
     src.fill(p)
     p.m, p.out_tiled = m, int(tiled)
-    feats = torch.empty(((m + 31) // 32) * 32 * src.F if tiled else m * src.F, device=pts.device)
+    n_out = ((m + 31) // 32) * 32 * src.F if tiled else m * src.F
+    feats = torch.empty(n_out, device=lead.device) if src.full else torch.zeros(n_out, device=lead.device)
     p.pts, p.ndc1, p.ndc2, p.ndc3, p.feats = _ptr(pts), _ptr(ndc1), _ptr(ndc2), _ptr(ndc3), _ptr(feats)
-    _launch("ucnerf_feat_gather_fwd", p, pts.device)
-    return feats if tiled else feats.view(*pts.shape[:-1], src.F)
+    _launch("ucnerf_feat_gather_fwd", p, lead.device)
+    return feats if tiled else feats.view(*lead.shape[:-1], src.F)
 
 
 def feat_gather_bwd(src, pts, ndc1, ndc2, ndc3, g_feats, need=(True, True, True, True, True)):
     """Returns grads (g_vol1, g_vol2, g_vol3, g_conf, g_img_feat); entries not needed are None."""
-    pts, ndc1, ndc2, ndc3, g_feats = _f32(pts), _f32(ndc1), _f32(ndc2), _f32(ndc3), _f32(g_feats)
+    pts, ndc1, ndc2, ndc3, g_feats = _opt(pts), _opt(ndc1), _opt(ndc2), _opt(ndc3), _f32(g_feats)
+    lead = next(t for t in (pts, ndc1, ndc3) if t is not None)
     bp = L.FeatGatherBwdParams()
     src.fill(bp.fwd)
-    bp.fwd.m = pts.numel() // 3
+    bp.fwd.m = lead.numel() // 3
     bp.fwd.pts, bp.fwd.ndc1, bp.fwd.ndc2, bp.fwd.ndc3 = _ptr(pts), _ptr(ndc1), _ptr(ndc2), _ptr(ndc3)
     bp.g_feats = _ptr(g_feats)
-    gv = [torch.zeros_like(v) if need[k] else None for k, v in enumerate(src.vols)]
-    gc = torch.zeros_like(src.conf) if need[3] else None
-    gi = torch.zeros_like(src.img_feat) if need[4] else None
+    gv = [torch.zeros_like(v) if (need[k] and v is not None) else None for k, v in enumerate(src.vols)]
+    gc = torch.zeros_like(src.conf) if (need[3] and src.conf is not None) else None
+    gi = torch.zeros_like(src.img_feat) if (need[4] and src.imgs is not None) else None
     for k in range(3):
         bp.g_vol[k] = _ptr(gv[k])
     bp.g_conf, bp.g_img_feat = _ptr(gc), _ptr(gi)
-    _launch("ucnerf_feat_gather_bwd", bp, pts.device)
+    _launch("ucnerf_feat_gather_bwd", bp, lead.device)
     return gv[0], gv[1], gv[2], gc, gi
 
 
 class _FeatGather(torch.autograd.Function):
-    """Differentiable w.r.t. the three volumes, confidence and img_feat (never positions: SURVEY 3.2)."""
+    """Differentiable w.r.t. the three volumes, confidence and img_feat (never positions: SURVEY 3.2).
+    Sources given as None are skipped (see GatherSources)."""
 
     @staticmethod
     def forward(ctx, vol1, vol2, vol3, conf, img_feat, imgs, w2cs, intrinsics, pts, ndc1, ndc2, ndc3):
-        src = GatherSources([vol1, vol2, vol3], conf, imgs, img_feat, w2cs, intrinsics)
-        ctx.src, ctx.shapes = src, (vol1.shape, vol2.shape, vol3.shape, conf.shape, img_feat.shape)
-        ctx.save_for_backward(pts, ndc1, ndc2, ndc3)
+        vols = None if vol1 is None else [vol1, vol2, vol3]
+        src = GatherSources(vols, conf, imgs, img_feat, w2cs, intrinsics)
+        ctx.src = src
+        ctx.shapes = tuple(None if t is None else t.shape for t in (vol1, vol2, vol3, conf, img_feat))
+        ctx.coords = (pts, ndc1, ndc2, ndc3)
         return feat_gather_fwd(src, pts, ndc1, ndc2, ndc3)
 
     @staticmethod
     def backward(ctx, g):
-        pts, ndc1, ndc2, ndc3 = ctx.saved_tensors
+        pts, ndc1, ndc2, ndc3 = ctx.coords
         need = ctx.needs_input_grad[:5]
         grads = feat_gather_bwd(ctx.src, pts, ndc1, ndc2, ndc3, g.reshape(-1, ctx.src.F), need)
-        out = [x.reshape(s) if x is not None else None for x, s in zip(grads, ctx.shapes)]
+        out = [x.reshape(s) if (x is not None and s is not None) else None for x, s in zip(grads, ctx.shapes)]
         return tuple(out) + (None,) * 7
 
 
@@ -396,6 +431,65 @@ class _MLP(torch.autograd.Function):
 
 def mlp(flat, feats, pts, dirs, pw, S):
     return _MLP.apply(flat, feats, pts, dirs, pw, S)
+
+
+def _encoded_params(p, pw, x):
+    """Points pts / feats / dirs of an MlpParams into the columns of x [m, 63 + F + 27]."""
+    F = 24 + 12 * pw.cfg.n_src + 1
+    X = 63 + F + 27
+    if x.shape[-1] != X:
+        raise RuntimeError("uc_nerf_amd: encoded MLP input must have %d columns (63 + %d + 27), got %d" % (X, F, x.shape[-1]))
+    p.cfg = pw.cfg
+    p.m, p.S, p.dirs_per_sample, p.encoded = x.shape[0], 1, 1, 1
+    p.pts_stride = p.dirs_stride = p.feat_stride = X
+    base = x.data_ptr()
+    p.pts, p.feats, p.dirs = base, base + 4 * 63, base + 4 * (63 + F)
+    return F, X
+
+
+def mlp_fwd_encoded(pw, wstream, x):
+    x = _f32(x, "x")
+    p = L.MlpParams()
+    _encoded_params(p, pw, x)
+    raw = torch.empty(x.shape[0], 4, device=x.device)
+    p.wstream, p.raw = _ptr(wstream), _ptr(raw)
+    _launch("ucnerf_mlp_fwd", p, x.device)
+    return raw
+
+
+class _MLPEncoded(torch.autograd.Function):
+    """UCNeRF.forward(x) on the reference's pre-encoded 187-wide rows.  Gradients: parameters and the feature
+    columns of x; the encoded pts/dir columns get zeros (positions are not differentiable on this path)."""
+
+    @staticmethod
+    def forward(ctx, flat, x, pw):
+        ws = pw.pack(flat)
+        x = _f32(x, "x")
+        ctx.pw = pw
+        ctx.save_for_backward(flat, x, ws)
+        return mlp_fwd_encoded(pw, ws, x)
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        flat, x, ws = ctx.saved_tensors
+        pw = ctx.pw
+        g_raw = _f32(g_raw)
+        bp = L.MlpBwdParams()
+        F, X = _encoded_params(bp.fwd, pw, x)
+        m = x.shape[0]
+        wsz = L.lib().ucnerf_mlp_bwd_workspace_floats(C.addressof(pw.cfg), m)
+        work = torch.empty(wsz, device=x.device)
+        g_x = torch.zeros(m, X, device=x.device)
+        g_flat = torch.zeros(pw.n_params, device=x.device)
+        bp.fwd.wstream, bp.fwd.raw = _ptr(ws), _ptr(g_raw)
+        bp.g_raw, bp.flat_params, bp.g_flat, bp.workspace = _ptr(g_raw), _ptr(flat), _ptr(g_flat), _ptr(work)
+        bp.g_feats, bp.g_feat_stride = g_x.data_ptr() + 4 * 63, X
+        _launch("ucnerf_mlp_bwd", bp, x.device)
+        return g_flat, g_x, None
+
+
+def mlp_encoded(flat, x, pw):
+    return _MLPEncoded.apply(flat, x, pw)
 
 
 # ------------------------------------------------------------------------------------------------ a9
