@@ -471,6 +471,7 @@ def sample_pdf(bins, weights, u, exact_f32=True):
     """data/ray_utils.py:98-141 with the uniform draws `u` [N,M] given.  Returns (samples, inds, cdf).
     `inds` = searchsorted(cdf, u, right=True) = number of cdf entries <= u (int64).
     With exact_f32 the float32 path reproduces torch-CPU's accumulation order bit for bit."""
+    weights = weights.detach()     # the hierarchy detaches the fine depths (data/ray_utils.py:217)
     if exact_f32 and weights.dtype == torch.float32:
         w = (weights + 1e-5).contiguous()
         tot = torch.from_numpy(torch_cpu_rowsum_f32(w.numpy())).unsqueeze(-1)

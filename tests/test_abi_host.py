@@ -1,0 +1,110 @@
+"""CPU-side checks of the C ABI and host logic (no GPU, no compute calls): the library loads, exports every symbol
+include/ucnerf_hip.h declares, the ctypes mirrors match, argument validation reports errors, and the host-built
+weight-pack index is a faithful rearrangement of the flat parameter vector."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from uc_nerf_amd.build import build
+    build()
+    from uc_nerf_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+def test_every_declared_symbol_is_exported_and_bound(L):
+    hdr = open(os.path.join(ROOT, "include", "ucnerf_hip.h")).read()
+    declared = set(re.findall(r"\b(ucnerf_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    raw = C.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), "library does not export " + name
+    assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
+    structs = set(re.findall(r"\}\s*(ucnerf_[a-z0-9_]+)\s*;", hdr))
+    assert structs == set(L.STRUCTS), structs ^ set(L.STRUCTS)
+    for cname, cls in L.STRUCTS.items():
+        assert L.lib().ucnerf_sizeof(cname.encode()) == C.sizeof(cls), cname
+    assert L.lib().ucnerf_sizeof(b"nope") == -1
+
+
+def test_argument_validation_reports_instead_of_launching(L):
+    lib = L.lib()
+    assert lib.ucnerf_ray_gen(None, None) == -1 and b"null params" in lib.ucnerf_last_error()
+    p = L.SamplePdfParams()
+    p.n, p.n_bins, p.n_samples = 4, 5000, 8
+    p.weights = p.u = p.bins = 8          # non-null dummies; never dereferenced because validation fails first
+    assert lib.ucnerf_sample_pdf(C.addressof(p), None) == -1 and b"n_bins" in lib.ucnerf_last_error()
+    q = L.CompositeParams()
+    q.n, q.S, q.raw, q.z, q.rgb_map, q.depth_map = 2, 5000, 16, 16, 16, 16
+    assert lib.ucnerf_composite_fwd(C.addressof(q), None) == -1 and b"outside 1..1024" in lib.ucnerf_last_error()
+    cfg = L.MlpConfig(12, 0)
+    assert lib.ucnerf_mlp_param_count(C.addressof(cfg)) < 0 and b"n_src" in lib.ucnerf_last_error()
+    e = L.RayGenParams()                   # empty batch: succeeds without touching any pointer or the device
+    assert lib.ucnerf_ray_gen(C.addressof(e), None) == 0
+    assert lib.ucnerf_render_workspace_floats(4096, 192, 6) > 4096 * 192 * 97
+    assert lib.ucnerf_render_workspace_floats(1, 0, 6) < 0
+
+
+@pytest.mark.parametrize("n_src,layout", [(6, 0), (3, 0), (6, 1), (1, 0), (8, 1)])
+def test_pack_index_is_a_rearrangement_of_the_parameters(L, n_src, layout):
+    from uc_nerf_amd.synthetic import ucnerf_param_shapes
+    lib = L.lib()
+    cfg = L.MlpConfig(n_src, layout)
+    n_params, n_stream = lib.ucnerf_mlp_param_count(C.addressof(cfg)), lib.ucnerf_mlp_stream_count(C.addressof(cfg))
+    shapes = ucnerf_param_shapes(n_src)
+    assert n_params == sum(int(np.prod(s)) for _, s in shapes)
+    idx = np.empty(n_stream, np.int32)
+    assert lib.ucnerf_mlp_pack_index(C.addressof(cfg), idx.ctypes.data) == 0
+    assert idx.min() == -1 and idx.max() < n_params
+    used = idx[idx >= 0]
+    counts = np.bincount(used, minlength=n_params)
+    off, unused = 0, {"nerf.pts_bias_confidence_1", "nerf.feature_linear_1", "nerf.confi_linear"}
+    for name, shp in shapes:
+        n = int(np.prod(shp))
+        c = counts[off:off + n]
+        if name.rsplit(".", 1)[0] in unused:
+            assert not c.any(), name                       # present for checkpoint compatibility, never read
+        else:
+            assert c.min() >= 1, name                      # every live weight reaches the kernel
+            assert c.max() <= 2, name                      # at most one extra copy (the ring's wrap-around k-steps)
+        off += n
+    # k-step region: 256 floats per k-step, all sections multiples of the 4-deep prefetch ring
+    ks = ((24 + 4 * n_src) // 2 + 3) // 4 * 4 + 4 * n_src + 32 + 4 * 64 + (32 + 64) + 64 + (64 + 16)
+    assert n_stream == (ks + 4) * 256 + 10 * 128 + 2 * 516
+    assert np.array_equal(idx[:4 * 256], idx[ks * 256:(ks + 4) * 256])      # wrap copy of the first ring
+    # the two encoding layouts permute the same columns of the first layer
+    if layout == 1:
+        cfg0 = L.MlpConfig(n_src, 0)
+        idx0 = np.empty(n_stream, np.int32)
+        lib.ucnerf_mlp_pack_index(C.addressof(cfg0), idx0.ctypes.data)
+        assert not np.array_equal(idx, idx0) and np.array_equal(np.sort(idx), np.sort(idx0))
+
+
+def test_product_package_never_imports_the_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import uc_nerf_amd, uc_nerf_amd.ops, uc_nerf_amd.pipeline, uc_nerf_amd.parallel;"
+            "uc_nerf_amd.install_dropin(); import network.renderer, network.models, utils.utils, utils.run_nerf_helpers, data.ray_utils;"
+            "assert not any(m.startswith('oracle') for m in sys.modules), 'oracle leaked into the product'") % ROOT
+    subprocess.run([sys.executable, "-c", code], check=True)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "uc_nerf_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read(), f
+
+
+def test_cpu_tensors_are_refused_loudly():
+    from uc_nerf_amd import ops
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        ops.embed(torch.zeros(4, 3), 10)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        ops.composite_fwd(torch.zeros(2, 8, 4), torch.zeros(2, 8))

@@ -1,0 +1,132 @@
+"""T4: the N>1 path on CPU -- world_size-2 `gloo` processes.  The compute function is injectable; here it is the
+CPU oracle (tests only), which exercises exactly the sharding / bucketing / gathering logic that runs over RCCL on
+the GPUs."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from uc_nerf_amd import parallel as P            # noqa: E402
+
+
+def test_shard_range_covers_everything_once():
+    for n in (0, 1, 7, 4096, 4097, 32768):
+        for world in (1, 2, 3, 8):
+            spans = [P.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert P.shard_range(4096, 3, 8) == (1536, 2048)          # the strong-scaling case: 512 rays per GPU
+    with pytest.raises(ValueError):
+        P.shard_range(10, 2, 2)
+
+
+def test_patch_aligned_ranges_keep_patches_whole():
+    # reference training batch: 50 patches of 6x6 first, then uniform + sparse-depth rays
+    ranges = P.patch_aligned_ranges(2217, 1800, 36, 8)
+    seen = torch.zeros(2217, dtype=torch.int32)
+    for rk in ranges:
+        for a, b in rk:
+            seen[a:b] += 1
+            if b <= 1800:
+                assert a % 36 == 0 and b % 36 == 0
+    assert torch.all(seen == 1)
+    with pytest.raises(ValueError):
+        P.patch_aligned_ranges(100, 50, 36, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def run_world(fn, world=2):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fn, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, "rank exited with %s" % p.exitcode
+    return [ret[r] for r in range(world)]
+
+
+# ---- module-level so that spawn can pickle them
+def _tiny_problem():
+    from oracle import ucnerf_oracle as O
+    from uc_nerf_amd.synthetic import init_ucnerf_state_dict, make_scene, random_pixels
+    scene = make_scene(seed=5, H=32, W=40, small_volumes=True)
+    sd = init_ucnerf_state_dict(seed=5, sigma_scale=0.05, sigma_bias=0.05)
+    xs, ys = random_pixels(37, 30, 40, seed=6)           # 37 rays: uneven split 19 / 18
+    return O, scene, sd, xs, ys + 1
+
+
+def _sharded_render(rank, world):
+    O, scene, sd, xs, ys = _tiny_problem()
+    fn = lambda x, y: {k: v for k, v in O.render_coarse_fine(sd, scene, x, y, 16, 24).items() if k in ("rgb", "depth")}
+    out = P.ShardedRenderer(fn).render(xs, ys)
+    return out["rgb"], out["depth"]
+
+
+def test_sharded_render_equals_single_rank_render():
+    O, scene, sd, xs, ys = _tiny_problem()
+    full = O.render_coarse_fine(sd, scene, xs, ys, 16, 24)
+    for rgb, depth in run_world(_sharded_render, 2):
+        assert rgb.shape == full["rgb"].shape
+        torch.testing.assert_close(rgb, full["rgb"], atol=1e-6, rtol=1e-5)
+        torch.testing.assert_close(depth, full["depth"], atol=1e-6, rtol=1e-5)
+
+
+def _sharded_grads(rank, world):
+    """Each rank: mean-squared-error loss over ITS rays -> backward -> one flat all-reduce with weight n_r/n."""
+    O, scene, sd, xs, ys = _tiny_problem()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    a, b = P.shard_range(xs.shape[0], rank, world)
+    target = torch.rand(xs.shape[0], 3, generator=torch.Generator().manual_seed(9))
+    out = O.render_coarse_fine(params, scene, xs[a:b], ys[a:b], 16, 24)
+    loss = torch.mean((out["rgb"] - target[a:b]) ** 2)
+    loss.backward()
+    bucket = P.FlatGradBucket(list(params.values()), n_scalars=1)
+    red = bucket.allreduce((b - a) / xs.shape[0], scalars=[loss.item()])
+    return {k: (None if v.grad is None else v.grad.clone()) for k, v in params.items()}, red[0].item(), bucket.numel
+
+
+def test_flat_bucket_allreduce_reproduces_the_single_rank_gradient():
+    O, scene, sd, xs, ys = _tiny_problem()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    target = torch.rand(xs.shape[0], 3, generator=torch.Generator().manual_seed(9))
+    loss = torch.mean((O.render_coarse_fine(params, scene, xs, ys, 16, 24)["rgb"] - target) ** 2)
+    loss.backward()
+    results = run_world(_sharded_grads, 2)
+    for grads, red_loss, numel in results:
+        assert numel == 181642 + 1                                       # ONE bucket: all MLP grads + the loss scalar
+        assert abs(red_loss - loss.item()) < 1e-6
+        for k, v in params.items():
+            if v.grad is None:
+                assert grads[k] is None                                   # untouched parameters stay grad=None
+            else:
+                torch.testing.assert_close(grads[k], v.grad, atol=1e-6 + 1e-4 * v.grad.abs().max().item(), rtol=1e-3)
+    for k in results[0][0]:                                               # both ranks hold identical reduced grads
+        if results[0][0][k] is not None:
+            assert torch.equal(results[0][0][k], results[1][0][k])
