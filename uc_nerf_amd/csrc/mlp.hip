@@ -6,13 +6,18 @@
 // A 256-thread block = 4 independent waves; the grid is persistent (waves stride over tiles).
 #include "common.h"
 #include "mlp_layout.h"
+#include "sincos_cw.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace ucnerf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MLP_WAVES = 8;          // waves per block: two per SIMD, waves w and w+4 share one
 
 // ------------------------------------------------------------------------------------------------
 // host: pack index
@@ -130,22 +135,32 @@ __global__ void unpack_grad_kernel(const float* __restrict__ g, const int32_t* _
 struct MlpGeom {      // MlpLayout subset the kernel needs (32-bit is plenty: the stream is < 1 MB)
     int F, kd, kc, f_img, off_const;
     int pts_stride, dirs_stride, feat_stride, pe_layout;
+    int stream_bytes;     // size of the packed weight stream
+    unsigned feat_bytes;  // size of the feature buffer
+    int stagger;          // start-up delay of waves 4..7 in units of s_sleep(127) (= 8128 cycles)
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// The weight stream is walked strictly in order by every wave: `A` points at this lane's float4 of the
-// current k-step, `ring` holds the next RING k-steps already in flight.  sched_barrier(0) after each
-// k-step keeps hipcc from hoisting the whole layer's loads (which spills) -- the ring IS the prefetch.
+// The weight stream is walked strictly in order by every wave.  It is addressed as a buffer: the descriptor and
+// the running k-step offset `soff` live in SGPRs, the per-lane part (lane*16 bytes) in one VGPR, so a load costs
+// no VALU address arithmetic.  `ring` holds the next RING k-steps already in flight; sched_barrier(0) after each
+// k-step keeps hipcc from hoisting a whole layer's loads (which spills) -- the ring IS the prefetch.
 struct Stream {
-    const f32x4* __restrict__ A;
+    __amdgpu_buffer_rsrc_t rs;
+    int voff;             // lane * 16
+    int soff;             // byte offset of the current k-step
     f32x4 ring[RING];
 };
+
+__device__ __forceinline__ f32x4 load_kstep(const Stream& S, int rel) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(S.rs, S.voff, S.soff + rel * (KSTEP_FLOATS * 4), 0));
+}
 
 #define KSTEP(S, T, BVAL, ACC)                                   \
     {                                                            \
         const f32x4 a_ = (S).ring[(T) & (RING - 1)];             \
-        (S).ring[(T) & (RING - 1)] = (S).A[((T) + RING) * 64];   \
+        (S).ring[(T) & (RING - 1)] = load_kstep((S), (T) + RING);\
         const float b_ = (BVAL);                                 \
         (ACC)[0] = MFMA(a_.x, b_, (ACC)[0]);                     \
         (ACC)[1] = MFMA(a_.y, b_, (ACC)[1]);                     \
@@ -153,6 +168,16 @@ struct Stream {
         (ACC)[3] = MFMA(a_.w, b_, (ACC)[3]);                     \
         __builtin_amdgcn_sched_barrier(0);                       \
     }
+
+// gathered features of this lane's sample, also through a buffer descriptor: element k at voff + k * step bytes
+struct FeatSrc {
+    __amdgpu_buffer_rsrc_t rs;
+    int voff;
+};
+
+__device__ __forceinline__ float load_feat(const FeatSrc& F, int soff_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(F.rs, F.voff, soff_bytes, 0));
+}
 
 // accumulators <- bias block of section `sec` (LDS copy of the constants)
 __device__ __forceinline__ void init_bias(const float* cst, int sec, int h, f32x16 (&acc)[4]) {
@@ -170,7 +195,7 @@ __device__ __forceinline__ void init_bias(const float* cst, int sec, int h, f32x
 __device__ __forceinline__ void gemm_hidden(Stream& S, const f32x16 (&x)[4], f32x16 (&acc)[4]) {
 #pragma unroll
     for (int t = 0; t < KS_HID; ++t) KSTEP(S, t, x[t >> 4][t & 15], acc)
-    S.A += KS_HID * 64;
+    S.soff += KS_HID * KSTEP_FLOATS * 4;
 }
 
 // KS k-steps whose B operands sit in a per-lane register array (encodings)
@@ -179,7 +204,7 @@ __device__ __forceinline__ void gemm_regs(Stream& S, const float (&x)[KS], f32x1
     static_assert(KS % RING == 0, "sections are multiples of the ring depth");
 #pragma unroll
     for (int t = 0; t < KS; ++t) KSTEP(S, t, x[t], acc)
-    S.A += KS * 64;
+    S.soff += KS * KSTEP_FLOATS * 4;
 }
 
 // KS k-steps whose B operands come from this wave's LDS stash (slot t at stash[t*64 + lane])
@@ -194,23 +219,27 @@ __device__ __forceinline__ void gemm_stash(Stream& S, const float* stash, int la
         if (t + RING < KS) b[t & (RING - 1)] = stash[(t + RING) * 64 + lane];
         KSTEP(S, t, bv, acc)
     }
-    S.A += KS * 64;
+    S.soff += KS * KSTEP_FLOATS * 4;
 }
 
-// ks (runtime, multiple of RING) k-steps whose B operands stream from global memory: element t at xb[t * xstride]
-__device__ __forceinline__ void gemm_mem(Stream& S, const float* __restrict__ xb, int xstride, int ks, f32x16 (&acc)[4]) {
-    float b[RING];
+// The gathered features of a section are fetched ALL AT ONCE (one HBM latency per section instead of one per ring
+// refill: they are streamed, never cached) and early, so the latency hides under VALU work issued in between.
+constexpr int KS_FEAT_MAX = 32;       // k-steps of a bias net at most: (24 + 4*8)/2 = 28, 8*8/2 = 32
+
+__device__ __forceinline__ void load_section_feats(const FeatSrc& F, int first, int step, int ks, float (&b)[KS_FEAT_MAX]) {
 #pragma unroll
-    for (int i = 0; i < RING; ++i) b[i] = xb[(size_t)i * xstride];
-    for (int t0 = 0; t0 < ks; t0 += RING) {
-        const bool more = t0 + RING < ks;
+    for (int t = 0; t < KS_FEAT_MAX; ++t) b[t] = t < ks ? load_feat(F, first + t * step) : 0.f;
+}
+
+// ks (runtime, multiple of RING, <= KS_FEAT_MAX) k-steps on prefetched feature operands
+__device__ __forceinline__ void gemm_feats(Stream& S, const float (&b)[KS_FEAT_MAX], int ks, f32x16 (&acc)[4]) {
 #pragma unroll
-        for (int i = 0; i < RING; ++i) {
-            const float bv = b[i];
-            if (more) b[i] = xb[(size_t)(t0 + RING + i) * xstride];
-            KSTEP(S, i, bv, acc)
+    for (int t0 = 0; t0 < KS_FEAT_MAX; t0 += RING) {
+        if (t0 < ks) {
+#pragma unroll
+            for (int i = 0; i < RING; ++i) KSTEP(S, i, b[t0 + i], acc)
+            S.soff += RING * KSTEP_FLOATS * 4;
         }
-        S.A += RING * 64;
     }
 }
 
@@ -234,7 +263,7 @@ __device__ __forceinline__ f32x4 head4(const float* hd, int h, const f32x16 (&x)
 
 // Positional encoding of a 3-vector in the k-step order of mlp_layout.h (this lane-half's slots).
 template <int NF, int KS>
-__device__ __forceinline__ void encode(const float (&x)[3], int h, float (&pe)[KS]) {
+__device__ __forceinline__ void encode(const float (&x)[3], int h, float (&pe)[KS]) {   // x: raw 3-vector
     constexpr int half = 3 * NF / 2;
 #pragma unroll
     for (int q = 0; q < half; ++q) {
@@ -242,7 +271,7 @@ __device__ __forceinline__ void encode(const float (&x)[3], int h, float (&pe)[K
         const int fr = a / 3, c = a - 3 * fr;
         const float xc = c == 0 ? x[0] : (c == 1 ? x[1] : x[2]);
         float s, co;
-        sincosf(xc * (float)(1 << fr), &s, &co);
+        sincos_pe(xc * (float)(1 << fr), &s, &co);
         pe[q] = s;
         pe[half + q] = co;
     }
@@ -285,58 +314,87 @@ __device__ __forceinline__ void save_rows(float* buf, int s, int h, bool valid, 
 }
 
 template <bool TILED, bool SAVE, bool ENC>
-__global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, MlpGeom g, int n_tiles, MlpSaved sv) {
+__global__ void __launch_bounds__(64 * MLP_WAVES, 2) mlp_fwd_kernel(ucnerf_mlp_params p, MlpGeom g, int n_tiles, MlpSaved sv) {
     __shared__ __attribute__((aligned(16))) float cst[CONST_FLOATS];
-    __shared__ __attribute__((aligned(16))) float pe_stash[4][KS_PE_PTS * 64];
+    __shared__ __attribute__((aligned(16))) float pe_stash[MLP_WAVES][KS_PE_PTS * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const float* __restrict__ ws = p.wstream;
-    const int n_waves = gridDim.x * 4;
+    const int n_waves = gridDim.x * MLP_WAVES;
     float* stash = pe_stash[wave];
 
-    for (int i = threadIdx.x; i < CONST_FLOATS; i += 256) cst[i] = ws[g.off_const + i];
+    for (int i = threadIdx.x; i < CONST_FLOATS; i += 64 * MLP_WAVES) cst[i] = ws[g.off_const + i];
     __syncthreads();
     const float* hb = cst + N_SEC * 128;
     const float* ha = hb + 516;
 
-    const f32x4* const A0 = reinterpret_cast<const f32x4*>(ws) + lane;
-    Stream S;
-#pragma unroll
-    for (int i = 0; i < RING; ++i) S.ring[i] = A0[i * 64];
+    // Waves w and w+4 share a SIMD and run the same program; started together they reach their VALU phases
+    // (encodings, epilogues, heads) together and the matrix pipe idles.  Delay the second half once, by about
+    // half a tile, so one wave's VALU work falls under its partner's MFMAs.
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256)
+        for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
-    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += n_waves) {
-        S.A = A0;
+    Stream S;
+    S.rs = __builtin_amdgcn_make_buffer_rsrc((void*)ws, 0, g.stream_bytes, 0x00020000);
+    S.voff = lane * 16;
+    S.soff = 0;
+#pragma unroll
+    for (int i = 0; i < RING; ++i) S.ring[i] = load_kstep(S, i);   // k-steps 0..RING-1
+    FeatSrc FS;
+    FS.rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.feats, 0, g.feat_bytes, 0x00020000);
+
+    // raw 3-vector of this lane's sample in the first tile; later tiles are prefetched one tile ahead
+    float px[3] = {0.f, 0.f, 0.f};
+    {
+        const int t0 = blockIdx.x * MLP_WAVES + wave;
+        if (!ENC && t0 < n_tiles) {
+            const int s0 = t0 * 32 + j < p.m ? t0 * 32 + j : p.m - 1;
+            const float* prow = p.pts + (size_t)s0 * g.pts_stride;
+            px[0] = prow[0]; px[1] = prow[1]; px[2] = prow[2];
+        }
+    }
+
+    for (int tile = blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += n_waves) {
+        S.soff = 0;
         const int s_raw = tile * 32 + j;
         const int s = s_raw < p.m ? s_raw : p.m - 1;
         const bool valid = s_raw < p.m;
-        // feature f of sample s lives at fb[f * fstride]
-        const float* fb;
+        // feature f of sample s lives fstride floats after feature f-1, starting at FS.voff bytes
         int fstride;
-        if (TILED) { fb = p.feats + (size_t)(s >> 5) * g.F * 32 + (s & 31); fstride = 32; }
-        else { fb = p.feats + (size_t)s * g.feat_stride; fstride = 1; }
+        if (TILED) { FS.voff = (int)((((size_t)(s >> 5) * g.F * 32) + (s & 31)) * 4); fstride = 32; }
+        else { FS.voff = (int)((size_t)s * g.feat_stride * 4); fstride = 1; }
 
         f32x16 bd[4], hin[4], acc[4];
+        float fsec[KS_FEAT_MAX];
+
+        // ---- (1) all operands of the depth-bias net + the confidence, in flight before any arithmetic
+        load_section_feats(FS, h * fstride * 4, 2 * fstride * 4, g.kd, fsec);
+        const float conf = load_feat(FS, (g.F - 1) * fstride * 4);
+
+        // ---- (2) point encoding (from registers), stashed in LDS for the skip connection
+        float pe[KS_PE_PTS];
+        if (ENC) {
+            load_encoded<10, KS_PE_PTS>(p.pts + (size_t)s * g.pts_stride, h, g.pe_layout, pe);
+        } else {
+            encode<10, KS_PE_PTS>(px, h, pe);
+            const int tn = tile + n_waves;              // (3) next tile's point: a whole tile of latency cover
+            if (tn < n_tiles) {
+                const int sn = tn * 32 + j < p.m ? tn * 32 + j : p.m - 1;
+                const float* prow = p.pts + (size_t)sn * g.pts_stride;
+                px[0] = prow[0]; px[1] = prow[1]; px[2] = prow[2];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < KS_PE_PTS; ++t) stash[t * 64 + lane] = pe[t];
 
         // ---- depth-bias net: bd = W_d [volume feats | colours+masks] + b      (models.py:150)
         init_bias(cst, SEC_BD, h, bd);
-        gemm_mem(S, fb + (size_t)h * fstride, 2 * fstride, g.kd, bd);
+        gemm_feats(S, fsec, g.kd, bd);
         if (SAVE) save_rows(sv.bd, s, h, valid, bd);
 
-        // ---- point encoding, stashed in LDS for the skip connection; layer 0
-        {
-            float pe[KS_PE_PTS];
-            const float* prow = p.pts + (size_t)s * g.pts_stride;
-            if (ENC) {
-                load_encoded<10, KS_PE_PTS>(prow, h, g.pe_layout, pe);
-            } else {
-                const float x[3] = {prow[0], prow[1], prow[2]};
-                encode<10, KS_PE_PTS>(x, h, pe);
-            }
-#pragma unroll
-            for (int t = 0; t < KS_PE_PTS; ++t) stash[t * 64 + lane] = pe[t];
-            init_bias(cst, SEC_L0, h, acc);
-            gemm_regs<KS_PE_PTS>(S, pe, acc);
-        }
+        // ---- layer 0
+        init_bias(cst, SEC_L0, h, acc);
+        gemm_regs<KS_PE_PTS>(S, pe, acc);
         EPILOGUE_RELU_MOD(hin, acc, bd)
         if (SAVE) save_rows(sv.h[0], s, h, valid, hin);
 
@@ -353,6 +411,8 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
         init_bias(cst, SEC_L0 + 5, h, acc);
         gemm_stash<KS_PE_PTS>(S, stash, lane, acc);
         gemm_hidden(S, hin, acc);
+        // operands of the confidence-bias net: issued now, they land during the epilogue and the base heads
+        load_section_feats(FS, (g.f_img + h) * fstride * 4, 2 * fstride * 4, g.kc, fsec);
         EPILOGUE_RELU_MOD(hin, acc, bd)
         if (SAVE) save_rows(sv.h[5], s, h, valid, hin);
 
@@ -361,12 +421,17 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
 
         // ---- confidence-bias net, feature_linear(h * b_c)                       (models.py:151,164)
         init_bias(cst, SEC_BC, h, bd);
-        gemm_mem(S, fb + (size_t)(g.f_img + h) * fstride, 2 * fstride, g.kc, bd);
+        gemm_feats(S, fsec, g.kc, bd);
         if (SAVE) save_rows(sv.bc, s, h, valid, bd);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) hin[nt][r] = hin[nt][r] * bd[nt][r];
+        // view direction of this sample's ray: needed after feature_linear's 64 k-steps
+        const size_t ray = p.dirs_per_sample ? (size_t)s : (size_t)(s / p.S);
+        const float* drow = p.dirs + ray * g.dirs_stride;
+        float dv[3] = {0.f, 0.f, 0.f};
+        if (!ENC) { dv[0] = drow[0]; dv[1] = drow[1]; dv[2] = drow[2]; }
         init_bias(cst, SEC_FT, h, acc);
         gemm_hidden(S, hin, acc);
         if (SAVE) save_rows(sv.ft, s, h, valid, acc);
@@ -375,15 +440,9 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
         init_bias(cst, SEC_VC, h, hin);
         gemm_hidden(S, acc, hin);
         {
-            const size_t ray = p.dirs_per_sample ? (size_t)s : (size_t)(s / p.S);
-            const float* drow = p.dirs + ray * g.dirs_stride;
             float pd[KS_PE_DIR];
-            if (ENC) {
-                load_encoded<4, KS_PE_DIR>(drow, h, g.pe_layout, pd);
-            } else {
-                const float d[3] = {drow[0], drow[1], drow[2]};
-                encode<4, KS_PE_DIR>(d, h, pd);
-            }
+            if (ENC) load_encoded<4, KS_PE_DIR>(drow, h, g.pe_layout, pd);
+            else encode<4, KS_PE_DIR>(dv, h, pd);
             gemm_regs<KS_PE_DIR>(S, pd, hin);
         }
 #pragma unroll
@@ -394,7 +453,6 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
 
         // ---- adapt heads (rgb_linear on rows 0..63, alpha_linear on rows 64..127), uncertainty blend
         const f32x4 adapt = head4(ha, h, hin);
-        const float conf = fb[(size_t)(g.F - 1) * fstride];
         const float u = 1.f - conf, omu = 1.f - u;          // models.py:149,177-178
         f32x4 out;
         out.x = 1.f / (1.f + expf(-(base.x * omu + adapt.x * u)));
@@ -408,7 +466,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(ucnerf_mlp_params p, Ml
 static MlpGeom geom_of(const MlpLayout& L) {
     MlpGeom g;
     g.F = L.F; g.kd = L.kd; g.kc = L.kc; g.f_img = 24 + 4 * L.v; g.off_const = (int)L.off_const;
-    g.pts_stride = g.dirs_stride = 3; g.feat_stride = L.F; g.pe_layout = 0;
+    g.pts_stride = g.dirs_stride = 3; g.feat_stride = L.F; g.pe_layout = 0; g.stream_bytes = 0; g.feat_bytes = 0; g.stagger = 0;
     return g;
 }
 
@@ -425,10 +483,22 @@ int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t
     const int n_tiles = cdiv(p->m, 32);
     int cus = device_cus();
     if (cus <= 0) return fail(UCNERF_EHIP, "mlp_fwd: no device");
-    int blocks = cdiv(n_tiles, 4);
-    int cap = p->max_blocks > 0 ? p->max_blocks : cus * 2;
+    int blocks = cdiv(n_tiles, MLP_WAVES);
+    int cap = p->max_blocks > 0 ? p->max_blocks : cus;          // one 8-wave block per CU (two waves per SIMD)
     if (blocks > cap) blocks = cap;
     MlpGeom g = geom_of(L);
+    g.stream_bytes = (int)(L.total * 4);
+    {
+        const size_t fstride = p->feat_stride ? (size_t)p->feat_stride : (size_t)L.F;
+        const size_t fbytes = p->feats_tiled ? (size_t)n_tiles * 32 * L.F * 4 : ((size_t)(p->m - 1) * fstride + L.F) * 4;
+        UCNERF_REQUIRE(fbytes < (1ull << 31), "mlp_fwd: feature buffer of %zu bytes exceeds the 2 GiB buffer-addressing range; split the batch", fbytes);
+        g.feat_bytes = (unsigned)fbytes;
+    }
+    {   // half a tile by default: 2304 MFMAs * 64 cycles shared by two waves ~ 295k cycles per tile
+        static int stagger = -1;
+        if (stagger < 0) { const char* e = getenv("UCNERF_MLP_STAGGER"); stagger = e ? atoi(e) : 0; }   // measured on MI355X: 0 is best (A/B in DESIGN.md)
+        g.stagger = n_tiles > blocks * 4 ? stagger : 0;          // nothing to hide when waves 4..7 have no partner work
+    }
     UCNERF_REQUIRE(p->cfg.pe_layout == 0 || p->cfg.pe_layout == 1, "mlp_fwd: pe_layout %d", p->cfg.pe_layout);
     UCNERF_REQUIRE(!p->encoded || (p->dirs_per_sample && !p->feats_tiled), "mlp_fwd: encoded inputs need per-sample dirs and row-major feats");
     UCNERF_REQUIRE(p->pts_stride >= 0 && p->dirs_stride >= 0 && p->feat_stride >= 0, "mlp_fwd: negative stride");
@@ -439,7 +509,7 @@ int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t
     MlpSaved sv;
     memset(&sv, 0, sizeof(sv));
     if (save) sv = *save;
-    dim3 grid(blocks), block(256);
+    dim3 grid(blocks), block(64 * MLP_WAVES);
 #define LAUNCH(T, SV, E) hipLaunchKernelGGL((mlp_fwd_kernel<T, SV, E>), grid, block, 0, st, *p, g, n_tiles, sv)
     if (p->encoded) { if (save) LAUNCH(false, true, true); else LAUNCH(false, false, true); }
     else if (save) { if (p->feats_tiled) LAUNCH(true, true, false); else LAUNCH(false, true, false); }

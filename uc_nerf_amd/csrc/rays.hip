@@ -1,5 +1,6 @@
 // K1/K2/K3 + a2/a5 small per-ray / per-sample kernels (HBM-bound, one thread per element).
 #include "common.h"
+#include "sincos_cw.h"
 
 namespace ucnerf {
 
@@ -233,7 +234,7 @@ __global__ void embed_kernel(ucnerf_embed_params p) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float s, co;
-        sincosf(x[c] * f, &s, &co);
+        sincos_pe(x[c] * f, &s, &co);
         if (p.layout == 0) {                 // [x | sin(f0..) | cos(f0..)], 3 per frequency
             o[3 + 3 * k + c] = s;
             o[3 + 3 * L + 3 * k + c] = co;
