@@ -81,9 +81,10 @@ int ucnerf_ndc_rays(const ucnerf_ndc_rays_params* p, void* stream);
 typedef struct {
     int32_t n;
     int32_t has_ref;
+    int32_t repeat;       /* 0/1: angle is [n,3]; S > 1: every ray's row is written S times -> [n*S,3] (per-sample form) */
     float w2c_ref[12];
     const float* rays_d;  /* [n,3] */
-    float* angle;         /* [n,3] out */
+    float* angle;         /* [n,3] (or [n*repeat,3]) out */
     float* cos_angle;     /* [n] out or NULL */
 } ucnerf_dir_feature_params;
 int ucnerf_dir_feature(const ucnerf_dir_feature_params* p, void* stream);
@@ -343,6 +344,9 @@ typedef struct {
     const float* w2cs;         /* [V,12] source views */
     const float* intrinsics;   /* [V,9] */
     const float* wstream;
+    const float* sources_cl;   /* optional: channel-last copies of the sources (ucnerf_gather_repack).  When given and
+                                  `feats` is NULL, the pass uses the fast gather that reads them and derives the
+                                  sample coordinates itself; vol/imgs/img_feat are then not touched */
     /* workspace: ucnerf_render_workspace_floats(n, S, V) floats */
     float* workspace;
     /* outputs */
@@ -359,6 +363,11 @@ typedef struct {
 } ucnerf_render_params;
 int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream);
+/* Channel-last repack of the gather sources named in `p` (vol[3] -> [D,h,w,8] each, imgs + img_feat ->
+ * [V,H,W,12] = (r,g,b,f0..f7,0)) into `dst` (ucnerf_gather_repack_floats(p) floats, 16-byte aligned).  Redo it
+ * whenever the sources change (once per image in evaluation, once per step in training): ~150 MB of traffic. */
+int64_t ucnerf_gather_repack_floats(const ucnerf_render_params* p);
+int ucnerf_gather_repack(const ucnerf_render_params* p, float* dst, void* stream);
 
 /* Backward of one render pass: d(rgb_map, depth_map) -> d(parameters), d(volumes, img_feat, confidence).
  * fwd.raw and fwd.feats must point at the buffers the forward call filled (keep them); all g_* outputs are

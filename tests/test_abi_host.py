@@ -78,9 +78,10 @@ def test_pack_index_is_a_rearrangement_of_the_parameters(L, n_src, layout):
             assert c.max() <= 2, name                      # at most one extra copy (the ring's wrap-around k-steps)
         off += n
     # k-step region: 256 floats per k-step, all sections multiples of the 4-deep prefetch ring
-    ks = ((24 + 4 * n_src) // 2 + 3) // 4 * 4 + 4 * n_src + 32 + 4 * 64 + (32 + 64) + 64 + (64 + 16)
-    assert n_stream == (ks + 4) * 256 + 10 * 128 + 2 * 516
-    assert np.array_equal(idx[:4 * 256], idx[ks * 256:(ks + 4) * 256])      # wrap copy of the first ring
+    ring = 4
+    ks = ((24 + 4 * n_src) // 2 + ring - 1) // ring * ring + (4 * n_src + ring - 1) // ring * ring + 32 + 4 * 64 + (32 + 64) + 64 + (64 + 16)
+    assert n_stream == (ks + ring) * 256 + 10 * 128 + 2 * 516
+    assert np.array_equal(idx[:ring * 256], idx[ks * 256:(ks + ring) * 256])      # wrap copy of the first ring
     # the two encoding layouts permute the same columns of the first layer
     if layout == 1:
         cfg0 = L.MlpConfig(n_src, 0)

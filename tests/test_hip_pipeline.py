@@ -73,6 +73,12 @@ def test_fused_render_pass_matches_oracle_stage_by_stage(N, S, per_ray_ranges):
     # the lean configuration (tiled features kept in the workspace, nothing stored) gives the same image
     lean = rp(rays_d.to(DEV), z.to(DEV), near_far=None if near_far is None else near_far.to(DEV), want=())
     assert torch.equal(lean["rgb"], out["rgb"]) and torch.equal(lean["depth"], out["depth"])
+    # the fast path: channel-last source copies + coordinates derived inside the gather
+    rp.repack_sources()
+    fast = rp(rays_d.to(DEV), z.to(DEV), near_far=None if near_far is None else near_far.to(DEV))
+    close(fast["rgb"], want["rgb"], 1e-4); close(fast["depth"], want["depth"], 1e-4, 1e-5)
+    close(fast["weights"], want["weights"], 2e-5, 1e-4)
+    close(fast["rgb"], out["rgb"], 2e-6); close(fast["depth"], out["depth"], 5e-6, 1e-6)
 
 
 def test_coarse_fine_pipeline_vs_reference_golden(sd_v7):

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libucnerf_hip.so")
+LIB_PATH = os.environ.get("UCNERF_LIB") or os.path.join(_HERE, "libucnerf_hip.so")   # override: A/B builds
 
 fp = C.POINTER(C.c_float)
 i32 = C.c_int32
@@ -26,7 +26,8 @@ class NdcRaysParams(C.Structure):
 
 
 class DirFeatureParams(C.Structure):
-    _fields_ = [("n", i32), ("has_ref", i32), ("w2c_ref", f32 * 12), ("rays_d", vp), ("angle", vp), ("cos_angle", vp)]
+    _fields_ = [("n", i32), ("has_ref", i32), ("repeat", i32), ("w2c_ref", f32 * 12), ("rays_d", vp), ("angle", vp),
+                ("cos_angle", vp)]
 
 
 class SampleStratifiedParams(C.Structure):
@@ -99,7 +100,7 @@ class RenderParams(C.Structure):
                 ("rays_d", vp), ("z", vp), ("w2c_ref", f32 * 12), ("K_ref", f32 * 9), ("w2c_dir", f32 * 12),
                 ("near", f32), ("far", f32), ("near_far", vp), ("H", i32), ("W", i32), ("vol_d", i32 * 3),
                 ("vol_h", i32 * 3), ("vol_w", i32 * 3), ("vol", vp * 3), ("conf", vp), ("imgs", vp), ("img_feat", vp),
-                ("w2cs", vp), ("intrinsics", vp), ("wstream", vp), ("workspace", vp), ("rgb_map", vp),
+                ("w2cs", vp), ("intrinsics", vp), ("wstream", vp), ("sources_cl", vp), ("workspace", vp), ("rgb_map", vp),
                 ("depth_map", vp), ("acc_map", vp), ("weights", vp), ("var", vp), ("raw", vp), ("feats", vp),
                 ("ev_mlp_start", vp), ("ev_mlp_stop", vp)]
 
@@ -153,6 +154,8 @@ SYMBOLS = {
     "ucnerf_sample_pdf": (C.c_int, [_P, _P]),
     "ucnerf_render_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "ucnerf_render_fused_fwd": (C.c_int, [_P, _P]),
+    "ucnerf_gather_repack_floats": (C.c_int64, [_P]),
+    "ucnerf_gather_repack": (C.c_int, [_P, _P, _P]),
     "ucnerf_render_bwd_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "ucnerf_render_fused_bwd": (C.c_int, [_P, _P]),
 }

@@ -1,0 +1,224 @@
+// K3+K4 fast path for the fused render pass: the gather reads CHANNEL-LAST copies of its sources and computes its
+// own sample coordinates from (ray, depth), so nothing per-sample is read except z.
+//
+//   volumes  [8,D,h,w]  -> [D,h,w,8]      one 32-byte voxel = two float4 loads (was 8 scattered dwords)
+//   images + image features [V,3,H,W] + [V,8,H,W] -> [V,H,W,12] = (r,g,b,f0..f7,0): one 48-byte pixel
+//   confidence stays [H,W]
+// A trilinear footprint is 8 voxels in 4 x-adjacent pairs: 4 x 64 contiguous bytes instead of 64 scattered
+// 4-byte reads.  Semantics are those of gather.hip (grid_sample restated; reference lines cited there).
+#include "common.h"
+
+namespace ucnerf {
+
+// ------------------------------------------------------------------------------------------------ repack
+__global__ void __launch_bounds__(256) repack_volume_kernel(const float* __restrict__ src, float4* __restrict__ dst, size_t n_vox) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_vox) return;
+    float c[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c[k] = src[(size_t)k * n_vox + i];
+    dst[2 * i] = make_float4(c[0], c[1], c[2], c[3]);
+    dst[2 * i + 1] = make_float4(c[4], c[5], c[6], c[7]);
+}
+
+__global__ void __launch_bounds__(256) repack_images_kernel(const float* __restrict__ imgs, const float* __restrict__ feat,
+                                                            float4* __restrict__ dst, int V, size_t hw) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)V * hw) return;
+    const size_t v = i / hw, px = i % hw;
+    const float* im = imgs + v * 3 * hw + px;
+    const float* ft = feat + v * 8 * hw + px;
+    dst[3 * i] = make_float4(im[0], im[hw], im[2 * hw], ft[0]);
+    dst[3 * i + 1] = make_float4(ft[hw], ft[2 * hw], ft[3 * hw], ft[4 * hw]);
+    dst[3 * i + 2] = make_float4(ft[5 * hw], ft[6 * hw], ft[7 * hw], 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------ gather
+struct GatherClArgs {
+    int n, S, V, H, W;
+    int vol_d[3], vol_h[3], vol_w[3];
+    const float4* vol[3];      // channel-last volumes
+    const float* conf;
+    const float4* img;         // [V,H,W,12]
+    const float* rays_o;       // [3]
+    const float* rays_d;       // [n,3]
+    const float* z;            // [n,S]
+    const float* near_far;     // [n,6] or NULL
+    float near, far;
+    float w2c_ref[12], K_ref[9];
+    const float* w2cs;         // [V,12] device (uniform per block -> scalar loads)
+    const float* Ks;           // [V,9]
+    float* feats;              // tiled [ceil(M/32)][F][32]
+    float* ndc;                // [M,3] (x, y, scene-normalised z) for the MLP's positional encoding, or NULL
+};
+
+__device__ __forceinline__ float unnorm_cl(float g, int size, bool align) {
+    float i = align ? (g + 1.f) / 2.f * (float)(size - 1) : ((g + 1.f) * (float)size - 1.f) / 2.f;
+    return fminf(fmaxf(i, 0.f), (float)(size - 1));
+}
+
+struct LerpCl { int i0, i1; float w0, w1; };
+
+__device__ __forceinline__ LerpCl axis_cl(float g, int size, bool align) {
+    const float x = unnorm_cl(g, size, align);
+    const float f = floorf(x);
+    LerpCl a;
+    a.i0 = (int)f;
+    a.w1 = x - f;
+    a.w0 = 1.f - a.w1;
+    a.i1 = a.i0 + 1;
+    if (a.i1 > size - 1) { a.i1 = size - 1; a.w1 = 0.f; }
+    return a;
+}
+
+__device__ __forceinline__ void project_cl(const float* M, const float* K, float x, float y, float z, float* qx, float* qy, float* qz) {
+    const float cx = x * M[0] + y * M[1] + z * M[2] + M[3];
+    const float cy = x * M[4] + y * M[5] + z * M[6] + M[7];
+    float cz = x * M[8] + y * M[9] + z * M[10] + M[11];
+    if (fabsf(cz) < 1e-4f) cz = 1e-4f;
+    *qx = cx * K[0] + cy * K[1] + cz * K[2];
+    *qy = cx * K[3] + cy * K[4] + cz * K[5];
+    *qz = cx * K[6] + cy * K[7] + cz * K[8];
+}
+
+#define ACC8(V0, V1, WT)                                                                         \
+    { const float4 a_ = (V0), b_ = (V1); const float w_ = (WT);                                 \
+      o[0] += a_.x * w_; o[1] += a_.y * w_; o[2] += a_.z * w_; o[3] += a_.w * w_;               \
+      o[4] += b_.x * w_; o[5] += b_.y * w_; o[6] += b_.z * w_; o[7] += b_.w * w_; }
+
+__global__ void __launch_bounds__(256) feat_gather_cl_kernel(GatherClArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long M = (long long)a.n * a.S;
+    if (idx >= M) return;
+    const int unit = blockIdx.y;
+    const int F = 24 + 12 * a.V + 1;
+    const int r = (int)(idx / a.S);
+    const float z = a.z[idx];
+    const float x = a.rays_o[0] + z * a.rays_d[3 * r], y = a.rays_o[1] + z * a.rays_d[3 * r + 1],
+                w = a.rays_o[2] + z * a.rays_d[3 * r + 2];
+    float* out = a.feats + ((size_t)(idx >> 5) * F) * 32 + (idx & 31);      // feature f at out[f * 32]
+    if (unit < 4) {
+        float qx, qy, qz;
+        project_cl(a.w2c_ref, a.K_ref, x, y, w, &qx, &qy, &qz);
+        const float u = (qx / qz + 0.0f) / (float)(a.W - 1), v = (qy / qz + 0.0f) / (float)(a.H - 1);
+        if (unit == 3) {
+            if (a.ndc) {
+                a.ndc[3 * idx] = u; a.ndc[3 * idx + 1] = v; a.ndc[3 * idx + 2] = (qz - a.near) / (a.far - a.near);
+            }
+            const LerpCl ax = axis_cl(u * 2.f - 1.0f, a.W, false), ay = axis_cl(v * 2.f - 1.0f, a.H, false);
+            const float* c = a.conf;
+            float acc = c[(size_t)ay.i0 * a.W + ax.i0] * (ay.w0 * ax.w0);
+            acc += c[(size_t)ay.i0 * a.W + ax.i1] * (ay.w0 * ax.w1);
+            acc += c[(size_t)ay.i1 * a.W + ax.i0] * (ay.w1 * ax.w0);
+            acc += c[(size_t)ay.i1 * a.W + ax.i1] * (ay.w1 * ax.w1);
+            out[(F - 1) * 32] = acc;
+            return;
+        }
+        float nk = a.near, fk = a.far;
+        if (a.near_far) { nk = a.near_far[6 * (size_t)r + 2 * unit]; fk = a.near_far[6 * (size_t)r + 2 * unit + 1]; }
+        const float zn = (qz - nk) / (fk - nk);
+        const int D = a.vol_d[unit], hh = a.vol_h[unit], ww = a.vol_w[unit];
+        const LerpCl ax = axis_cl(u * 2.f - 1.0f, ww, false), ay = axis_cl(v * 2.f - 1.0f, hh, false),
+                     az = axis_cl(zn * 2.f - 1.0f, D, false);
+        const float4* vol = a.vol[unit];
+        const size_t o00 = ((size_t)az.i0 * hh + ay.i0) * ww, o01 = ((size_t)az.i0 * hh + ay.i1) * ww,
+                     o10 = ((size_t)az.i1 * hh + ay.i0) * ww, o11 = ((size_t)az.i1 * hh + ay.i1) * ww;
+        const float w00 = az.w0 * ay.w0, w01 = az.w0 * ay.w1, w10 = az.w1 * ay.w0, w11 = az.w1 * ay.w1;
+        float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // same accumulation order as gather.hip: (z0,y0), (z0,y1), (z1,y0), (z1,y1), x0 before x1
+        ACC8(vol[2 * (o00 + ax.i0)], vol[2 * (o00 + ax.i0) + 1], w00 * ax.w0)
+        ACC8(vol[2 * (o00 + ax.i1)], vol[2 * (o00 + ax.i1) + 1], w00 * ax.w1)
+        ACC8(vol[2 * (o01 + ax.i0)], vol[2 * (o01 + ax.i0) + 1], w01 * ax.w0)
+        ACC8(vol[2 * (o01 + ax.i1)], vol[2 * (o01 + ax.i1) + 1], w01 * ax.w1)
+        ACC8(vol[2 * (o10 + ax.i0)], vol[2 * (o10 + ax.i0) + 1], w10 * ax.w0)
+        ACC8(vol[2 * (o10 + ax.i1)], vol[2 * (o10 + ax.i1) + 1], w10 * ax.w1)
+        ACC8(vol[2 * (o11 + ax.i0)], vol[2 * (o11 + ax.i0) + 1], w11 * ax.w0)
+        ACC8(vol[2 * (o11 + ax.i1)], vol[2 * (o11 + ax.i1) + 1], w11 * ax.w1)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) out[(8 * unit + c) * 32] = o[c];
+    } else {
+        const int vi = unit - 4;
+        float qx, qy, qz;
+        project_cl(a.w2cs + 12 * vi, a.Ks + 9 * vi, x, y, w, &qx, &qy, &qz);
+        const float gx = (qx / qz + 0.0f) / (float)(a.W - 1) * 2.0f - 1.0f, gy = (qy / qz + 0.0f) / (float)(a.H - 1) * 2.0f - 1.0f;
+        const LerpCl ax = axis_cl(gx, a.W, true), ay = axis_cl(gy, a.H, true);
+        const float4* img = a.img + (size_t)vi * a.H * a.W * 3;
+        const size_t p00 = ((size_t)ay.i0 * a.W + ax.i0) * 3, p01 = ((size_t)ay.i0 * a.W + ax.i1) * 3,
+                     p10 = ((size_t)ay.i1 * a.W + ax.i0) * 3, p11 = ((size_t)ay.i1 * a.W + ax.i1) * 3;
+        const float w00 = ay.w0 * ax.w0, w01 = ay.w0 * ax.w1, w10 = ay.w1 * ax.w0, w11 = ay.w1 * ax.w1;
+        float o[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define ACC12(P, WT)                                                                              \
+        { const float4 a_ = img[(P)], b_ = img[(P) + 1], c_ = img[(P) + 2]; const float w_ = (WT);  \
+          o[0] += a_.x * w_; o[1] += a_.y * w_; o[2] += a_.z * w_; o[3] += a_.w * w_;                \
+          o[4] += b_.x * w_; o[5] += b_.y * w_; o[6] += b_.z * w_; o[7] += b_.w * w_;                \
+          o[8] += c_.x * w_; o[9] += c_.y * w_; o[10] += c_.z * w_; }
+        ACC12(p00, w00) ACC12(p01, w01) ACC12(p10, w10) ACC12(p11, w11)
+#undef ACC12
+        out[(24 + 4 * vi) * 32] = o[0];
+        out[(24 + 4 * vi + 1) * 32] = o[1];
+        out[(24 + 4 * vi + 2) * 32] = o[2];
+        out[(24 + 4 * vi + 3) * 32] = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.f : 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) out[(24 + 4 * a.V + 8 * vi + c) * 32] = o[3 + c];
+    }
+}
+
+}  // namespace ucnerf
+
+using namespace ucnerf;
+
+extern "C" {
+
+int64_t ucnerf_gather_repack_floats(const ucnerf_render_params* p) {
+    if (!p) return fail(UCNERF_EINVAL, "gather_repack_floats: null params");
+    int64_t n = 0;
+    for (int k = 0; k < 3; ++k) n += 8ll * p->vol_d[k] * p->vol_h[k] * p->vol_w[k];
+    return n + 12ll * p->cfg.n_src * p->H * p->W;
+}
+
+int ucnerf_gather_repack(const ucnerf_render_params* p, float* dst, void* stream) {
+    UCNERF_REQUIRE(p && dst, "gather_repack: null pointer");
+    UCNERF_REQUIRE(p->vol[0] && p->vol[1] && p->vol[2] && p->imgs && p->img_feat, "gather_repack: null source");
+    UCNERF_REQUIRE(((uintptr_t)dst & 15) == 0, "gather_repack: destination must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    float* o = dst;
+    for (int k = 0; k < 3; ++k) {
+        const size_t nv = (size_t)p->vol_d[k] * p->vol_h[k] * p->vol_w[k];
+        hipLaunchKernelGGL(repack_volume_kernel, dim3(cdiv(nv, 256)), dim3(256), 0, st, p->vol[k], (float4*)o, nv);
+        o += 8 * nv;
+    }
+    const size_t hw = (size_t)p->H * p->W;
+    hipLaunchKernelGGL(repack_images_kernel, dim3(cdiv(hw * p->cfg.n_src, 256)), dim3(256), 0, st, p->imgs, p->img_feat,
+                       (float4*)o, p->cfg.n_src, hw);
+    return check_launch("gather_repack");
+}
+
+}  // extern "C"
+
+namespace ucnerf {
+
+// called by render.hip: gather (+ ndc) for one pass from the repacked sources
+int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float* feats_tiled, float* ndc, hipStream_t st) {
+    GatherClArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = p->n; a.S = p->S; a.V = p->cfg.n_src; a.H = p->H; a.W = p->W;
+    const float* o = repacked;
+    for (int k = 0; k < 3; ++k) {
+        a.vol_d[k] = p->vol_d[k]; a.vol_h[k] = p->vol_h[k]; a.vol_w[k] = p->vol_w[k];
+        a.vol[k] = (const float4*)o;
+        o += 8ull * p->vol_d[k] * p->vol_h[k] * p->vol_w[k];
+    }
+    a.img = (const float4*)o;
+    a.conf = p->conf; a.rays_o = p->rays_o; a.rays_d = p->rays_d; a.z = p->z; a.near_far = p->near_far;
+    a.near = p->near; a.far = p->far;
+    memcpy(a.w2c_ref, p->w2c_ref, sizeof(a.w2c_ref));
+    memcpy(a.K_ref, p->K_ref, sizeof(a.K_ref));
+    a.w2cs = p->w2cs; a.Ks = p->intrinsics;
+    a.feats = feats_tiled; a.ndc = ndc;
+    UCNERF_REQUIRE(a.V >= 1 && a.V <= 8, "gather_cl: V = %d outside 1..8", a.V);
+    const long long M = (long long)p->n * p->S;
+    hipLaunchKernelGGL(feat_gather_cl_kernel, dim3(cdiv(M, 256), 4 + a.V), dim3(256), 0, st, a);
+    return check_launch("feat_gather_cl");
+}
+
+}  // namespace ucnerf

@@ -16,8 +16,12 @@ namespace ucnerf {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int MLP_WAVES = 8;          // waves per block: two per SIMD, waves w and w+4 share one
+#ifndef UCNERF_MLP_WAVES
+#define UCNERF_MLP_WAVES 8
+#endif
+constexpr int MLP_WAVES = UCNERF_MLP_WAVES;   // waves per block: 8 = two per SIMD (waves w and w+4 share one)
 
 // ------------------------------------------------------------------------------------------------
 // host: pack index
@@ -138,6 +142,7 @@ struct MlpGeom {      // MlpLayout subset the kernel needs (32-bit is plenty: th
     int stream_bytes;     // size of the packed weight stream
     unsigned feat_bytes;  // size of the feature buffer
     int stagger;          // start-up delay of waves 4..7 in units of s_sleep(127) (= 8128 cycles)
+    unsigned long long* diag;   // diagnostic builds only (UCNERF_MLP_DIAG): per-wave tile start/end clocks
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -243,18 +248,21 @@ __device__ __forceinline__ void gemm_feats(Stream& S, const float (&b)[KS_FEAT_M
     }
 }
 
-// 4-wide heads on the VALU: out4 = sum_f x[f] * Wh[f][0..3] over this lane's 64 features, then both halves
+// 4-wide heads on the VALU: out4 = sum_f x[f] * Wh[f][0..3] over this lane's 64 features (two packed FMAs per
+// feature), then both lane halves
 __device__ __forceinline__ f32x4 head4(const float* hd, int h, const f32x16 (&x)[4]) {
     const f32x4* w = reinterpret_cast<const f32x4*>(hd) + h * 64;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const f32x4 wv = w[nt * 16 + r];
-            const float xv = x[nt][r];
-            s.x = fmaf(xv, wv.x, s.x); s.y = fmaf(xv, wv.y, s.y); s.z = fmaf(xv, wv.z, s.z); s.w = fmaf(xv, wv.w, s.w);
+            const f32x2 xv = {x[nt][r], x[nt][r]};
+            s01 = __builtin_elementwise_fma(xv, f32x2{wv.x, wv.y}, s01);
+            s23 = __builtin_elementwise_fma(xv, f32x2{wv.z, wv.w}, s23);
         }
+    f32x4 s = {s01.x, s01.y, s23.x, s23.y};
     s.x += __shfl_xor(s.x, 32); s.y += __shfl_xor(s.y, 32); s.z += __shfl_xor(s.z, 32); s.w += __shfl_xor(s.w, 32);
     const f32x4 b = *reinterpret_cast<const f32x4*>(hd + 512);
     s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
@@ -296,9 +304,24 @@ __device__ __forceinline__ void load_encoded(const float* __restrict__ row, int 
     }
 }
 
+// Wave priority: the short VALU phases (encodings, epilogues, heads) run at high priority so that the partner
+// wave's back-to-back MFMAs (which otherwise hold the SIMD's vector issue almost continuously: measured ~100
+// cycles per VALU instruction, 35-65k cycles per phase) cannot stretch them; GEMM sections run at priority 0.
+#ifndef UCNERF_MLP_PRIO
+#define UCNERF_MLP_PRIO 3
+#endif
+#define PRIO_VALU() __builtin_amdgcn_s_setprio(UCNERF_MLP_PRIO)
+#define PRIO_GEMM() __builtin_amdgcn_s_setprio(0)
+
+// On gfx950 the fp32 MFMA runs on the vector ALU itself (measured: VALU fillers cost their full issue time, a
+// partner wave's VALU starves while MFMAs stream), so every VALU instruction is paid in matrix throughput.
+// Packed fp32 math halves the instruction count of the element-wise stages.
 #define EPILOGUE_RELU_MOD(DST, ACC, MOD)                                               \
     _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                   \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) (DST)[nt][r] = fmaxf((ACC)[nt][r] * (MOD)[nt][r], 0.f);
+    _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                \
+        const f32x2 m_ = f32x2{(ACC)[nt][r], (ACC)[nt][r + 1]} * f32x2{(MOD)[nt][r], (MOD)[nt][r + 1]}; \
+        (DST)[nt][r] = fmaxf(m_.x, 0.f); (DST)[nt][r + 1] = fmaxf(m_.y, 0.f);          \
+    }
 
 // accumulator-layout activation set -> row-major [m,128] (lane = sample, 4 consecutive features per float4)
 __device__ __forceinline__ void save_rows(float* buf, int s, int h, bool valid, const f32x16 (&x)[4]) {
@@ -313,8 +336,13 @@ __device__ __forceinline__ void save_rows(float* buf, int s, int h, bool valid, 
         }
 }
 
-template <bool TILED, bool SAVE, bool ENC>
-__global__ void __launch_bounds__(64 * MLP_WAVES, 2) mlp_fwd_kernel(ucnerf_mlp_params p, MlpGeom g, int n_tiles, MlpSaved sv) {
+// NSRC > 0 fixes the number of source views at compile time: the two bias-net sections then have constant trip
+// counts and the whole tile body is straight-line code.  (With runtime counts hipcc wraps the k-steps in uniform
+// branches and drains the prefetch ring -- vmcnt(3),(2),(1),(0) -- at every join: ~12 full L2 latencies per tile.)
+template <bool TILED, bool SAVE, bool ENC, int NSRC>
+__global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(ucnerf_mlp_params p, MlpGeom g, int n_tiles, MlpSaved sv) {
+    constexpr int KD_STATIC = ((24 + 4 * NSRC) / 2 + RING - 1) / RING * RING, KC_STATIC = (4 * NSRC + RING - 1) / RING * RING;
+    const int kd = NSRC ? KD_STATIC : g.kd, kc = NSRC ? KC_STATIC : g.kc;
     __shared__ __attribute__((aligned(16))) float cst[CONST_FLOATS];
     __shared__ __attribute__((aligned(16))) float pe_stash[MLP_WAVES][KS_PE_PTS * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -354,7 +382,17 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, 2) mlp_fwd_kernel(ucnerf_mlp_p
         }
     }
 
+#ifdef UCNERF_MLP_DIAG
+    int diag_k = 0;
+#endif
     for (int tile = blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += n_waves) {
+#ifdef UCNERF_MLP_DIAG
+#define DIAG_STAMP(K) { __builtin_amdgcn_sched_barrier(0); if (g.diag && lane == 0 && diag_k == 5) g.diag[(size_t)(blockIdx.x * MLP_WAVES + wave) * 16 + (K)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define DIAG_STAMP(K)
+#endif
+        DIAG_STAMP(0)
+        PRIO_VALU();
         S.soff = 0;
         const int s_raw = tile * 32 + j;
         const int s = s_raw < p.m ? s_raw : p.m - 1;
@@ -366,10 +404,12 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, 2) mlp_fwd_kernel(ucnerf_mlp_p
 
         f32x16 bd[4], hin[4], acc[4];
         float fsec[KS_FEAT_MAX];
+        float pn[3] = {0.f, 0.f, 0.f};
 
         // ---- (1) all operands of the depth-bias net + the confidence, in flight before any arithmetic
-        load_section_feats(FS, h * fstride * 4, 2 * fstride * 4, g.kd, fsec);
+        load_section_feats(FS, h * fstride * 4, 2 * fstride * 4, kd, fsec);
         const float conf = load_feat(FS, (g.F - 1) * fstride * 4);
+        const size_t ray = p.dirs_per_sample ? (size_t)s : (size_t)(s / p.S);
 
         // ---- (2) point encoding (from registers), stashed in LDS for the skip connection
         float pe[KS_PE_PTS];
@@ -377,74 +417,87 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, 2) mlp_fwd_kernel(ucnerf_mlp_p
             load_encoded<10, KS_PE_PTS>(p.pts + (size_t)s * g.pts_stride, h, g.pe_layout, pe);
         } else {
             encode<10, KS_PE_PTS>(px, h, pe);
-            const int tn = tile + n_waves;              // (3) next tile's point: a whole tile of latency cover
-            if (tn < n_tiles) {
-                const int sn = tn * 32 + j < p.m ? tn * 32 + j : p.m - 1;
-                const float* prow = p.pts + (size_t)sn * g.pts_stride;
-                px[0] = prow[0]; px[1] = prow[1]; px[2] = prow[2];
-            }
+            // (3) next tile's point (clamped, so the load is unconditional): consumed only at the end of this tile
+            int sn = (tile + n_waves) * 32 + j;
+            sn = sn < p.m ? sn : p.m - 1;
+            const float* prow = p.pts + (size_t)sn * g.pts_stride;
+            pn[0] = prow[0]; pn[1] = prow[1]; pn[2] = prow[2];
         }
 #pragma unroll
         for (int t = 0; t < KS_PE_PTS; ++t) stash[t * 64 + lane] = pe[t];
 
         // ---- depth-bias net: bd = W_d [volume feats | colours+masks] + b      (models.py:150)
+        DIAG_STAMP(1)
         init_bias(cst, SEC_BD, h, bd);
-        gemm_feats(S, fsec, g.kd, bd);
+        PRIO_GEMM(); gemm_feats(S, fsec, kd, bd); PRIO_VALU();
+        DIAG_STAMP(2)
         if (SAVE) save_rows(sv.bd, s, h, valid, bd);
+        const float u = 1.f - conf, omu = 1.f - u;          // models.py:149,177-178 (consumed at the very end)
 
         // ---- layer 0
         init_bias(cst, SEC_L0, h, acc);
-        gemm_regs<KS_PE_PTS>(S, pe, acc);
+        PRIO_GEMM(); gemm_regs<KS_PE_PTS>(S, pe, acc); PRIO_VALU();
+        DIAG_STAMP(3)
         EPILOGUE_RELU_MOD(hin, acc, bd)
         if (SAVE) save_rows(sv.h[0], s, h, valid, hin);
+        DIAG_STAMP(4)
 
         // ---- layers 1..4                                                        (models.py:153-155)
 #pragma unroll 1
         for (int l = 1; l < 5; ++l) {
             init_bias(cst, SEC_L0 + l, h, acc);
-            gemm_hidden(S, hin, acc);
+            PRIO_GEMM(); gemm_hidden(S, hin, acc); PRIO_VALU();
             EPILOGUE_RELU_MOD(hin, acc, bd)
             if (SAVE) save_rows(sv.h[l], s, h, valid, hin);
         }
 
         // ---- layer 5 on [pe | h]                                                (models.py:156-157)
+        DIAG_STAMP(5)
         init_bias(cst, SEC_L0 + 5, h, acc);
-        gemm_stash<KS_PE_PTS>(S, stash, lane, acc);
-        gemm_hidden(S, hin, acc);
-        // operands of the confidence-bias net: issued now, they land during the epilogue and the base heads
-        load_section_feats(FS, (g.f_img + h) * fstride * 4, 2 * fstride * 4, g.kc, fsec);
+        PRIO_GEMM(); gemm_stash<KS_PE_PTS>(S, stash, lane, acc); PRIO_VALU();
+        PRIO_GEMM(); gemm_hidden(S, hin, acc); PRIO_VALU();
+        DIAG_STAMP(6)
         EPILOGUE_RELU_MOD(hin, acc, bd)
+        // operands of the confidence-bias net: issued now (b_d's registers are free), they land during the base heads
+        load_section_feats(FS, (g.f_img + h) * fstride * 4, 2 * fstride * 4, kc, fsec);
         if (SAVE) save_rows(sv.h[5], s, h, valid, hin);
 
         // ---- base heads: confi_rgb_linear, alpha_linear_1                       (models.py:161-162)
         const f32x4 base = head4(hb, h, hin);
+        DIAG_STAMP(7)
 
         // ---- confidence-bias net, feature_linear(h * b_c)                       (models.py:151,164)
         init_bias(cst, SEC_BC, h, bd);
-        gemm_feats(S, fsec, g.kc, bd);
+        PRIO_GEMM(); gemm_feats(S, fsec, kc, bd); PRIO_VALU();
+        DIAG_STAMP(8)
         if (SAVE) save_rows(sv.bc, s, h, valid, bd);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hin[nt][r] = hin[nt][r] * bd[nt][r];
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 m_ = f32x2{hin[nt][r], hin[nt][r + 1]} * f32x2{bd[nt][r], bd[nt][r + 1]};
+                hin[nt][r] = m_.x; hin[nt][r + 1] = m_.y;
+            }
         // view direction of this sample's ray: needed after feature_linear's 64 k-steps
-        const size_t ray = p.dirs_per_sample ? (size_t)s : (size_t)(s / p.S);
         const float* drow = p.dirs + ray * g.dirs_stride;
         float dv[3] = {0.f, 0.f, 0.f};
         if (!ENC) { dv[0] = drow[0]; dv[1] = drow[1]; dv[2] = drow[2]; }
+        DIAG_STAMP(9)
         init_bias(cst, SEC_FT, h, acc);
-        gemm_hidden(S, hin, acc);
+        PRIO_GEMM(); gemm_hidden(S, hin, acc); PRIO_VALU();
+        DIAG_STAMP(10)
         if (SAVE) save_rows(sv.ft, s, h, valid, acc);
 
         // ---- views_linears | view_confi_linears on [feature | dir encoding], relu   (models.py:166-173)
         init_bias(cst, SEC_VC, h, hin);
-        gemm_hidden(S, acc, hin);
+        PRIO_GEMM(); gemm_hidden(S, acc, hin); PRIO_VALU();
         {
             float pd[KS_PE_DIR];
             if (ENC) load_encoded<4, KS_PE_DIR>(drow, h, g.pe_layout, pd);
             else encode<4, KS_PE_DIR>(dv, h, pd);
-            gemm_regs<KS_PE_DIR>(S, pd, hin);
+            PRIO_GEMM(); gemm_regs<KS_PE_DIR>(S, pd, hin); PRIO_VALU();
         }
+        DIAG_STAMP(11)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -453,20 +506,25 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, 2) mlp_fwd_kernel(ucnerf_mlp_p
 
         // ---- adapt heads (rgb_linear on rows 0..63, alpha_linear on rows 64..127), uncertainty blend
         const f32x4 adapt = head4(ha, h, hin);
-        const float u = 1.f - conf, omu = 1.f - u;          // models.py:149,177-178
+        DIAG_STAMP(12)
         f32x4 out;
         out.x = 1.f / (1.f + expf(-(base.x * omu + adapt.x * u)));
         out.y = 1.f / (1.f + expf(-(base.y * omu + adapt.y * u)));
         out.z = 1.f / (1.f + expf(-(base.z * omu + adapt.z * u)));
         out.w = fmaxf(adapt.w * omu + base.w * u, 0.f);
         if (h == 0 && valid) reinterpret_cast<f32x4*>(p.raw)[s_raw] = out;
+        px[0] = pn[0]; px[1] = pn[1]; px[2] = pn[2];
+        DIAG_STAMP(13)
+#ifdef UCNERF_MLP_DIAG
+        ++diag_k;
+#endif
     }
 }
 
 static MlpGeom geom_of(const MlpLayout& L) {
     MlpGeom g;
     g.F = L.F; g.kd = L.kd; g.kc = L.kc; g.f_img = 24 + 4 * L.v; g.off_const = (int)L.off_const;
-    g.pts_stride = g.dirs_stride = 3; g.feat_stride = L.F; g.pe_layout = 0; g.stream_bytes = 0; g.feat_bytes = 0; g.stagger = 0;
+    g.pts_stride = g.dirs_stride = 3; g.feat_stride = L.F; g.pe_layout = 0; g.stream_bytes = 0; g.feat_bytes = 0; g.stagger = 0; g.diag = nullptr;
     return g;
 }
 
@@ -499,6 +557,9 @@ int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t
         if (stagger < 0) { const char* e = getenv("UCNERF_MLP_STAGGER"); stagger = e ? atoi(e) : 0; }   // measured on MI355X: 0 is best (A/B in DESIGN.md)
         g.stagger = n_tiles > blocks * 4 ? stagger : 0;          // nothing to hide when waves 4..7 have no partner work
     }
+#ifdef UCNERF_MLP_DIAG
+    { const char* e = getenv("UCNERF_MLP_DIAG_PTR"); g.diag = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
     UCNERF_REQUIRE(p->cfg.pe_layout == 0 || p->cfg.pe_layout == 1, "mlp_fwd: pe_layout %d", p->cfg.pe_layout);
     UCNERF_REQUIRE(!p->encoded || (p->dirs_per_sample && !p->feats_tiled), "mlp_fwd: encoded inputs need per-sample dirs and row-major feats");
     UCNERF_REQUIRE(p->pts_stride >= 0 && p->dirs_stride >= 0 && p->feat_stride >= 0, "mlp_fwd: negative stride");
@@ -510,10 +571,12 @@ int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t
     memset(&sv, 0, sizeof(sv));
     if (save) sv = *save;
     dim3 grid(blocks), block(64 * MLP_WAVES);
-#define LAUNCH(T, SV, E) hipLaunchKernelGGL((mlp_fwd_kernel<T, SV, E>), grid, block, 0, st, *p, g, n_tiles, sv)
-    if (p->encoded) { if (save) LAUNCH(false, true, true); else LAUNCH(false, false, true); }
-    else if (save) { if (p->feats_tiled) LAUNCH(true, true, false); else LAUNCH(false, true, false); }
-    else { if (p->feats_tiled) LAUNCH(true, false, false); else LAUNCH(false, false, false); }
+#define LAUNCH(T, SV, E, N) hipLaunchKernelGGL((mlp_fwd_kernel<T, SV, E, N>), grid, block, 0, st, *p, g, n_tiles, sv)
+#define LAUNCH_V(T, SV) { if (L.v == 6) LAUNCH(T, SV, false, 6); else if (L.v == 3) LAUNCH(T, SV, false, 3); else LAUNCH(T, SV, false, 0); }
+    if (p->encoded) { if (save) LAUNCH(false, true, true, 0); else LAUNCH(false, false, true, 0); }
+    else if (save) { if (p->feats_tiled) LAUNCH_V(true, true) else LAUNCH_V(false, true) }
+    else { if (p->feats_tiled) LAUNCH_V(true, false) else LAUNCH_V(false, false) }
+#undef LAUNCH_V
 #undef LAUNCH
     return check_launch("mlp_fwd");
 }

@@ -21,7 +21,10 @@ constexpr int KS_PE_PTS = 32;     // k-steps of the padded 64-wide point encodin
 constexpr int KS_PE_DIR = 16;     // k-steps of the direction encoding (28 wide, padded to 32: sections are multiples of 4 k-steps)
 constexpr int KS_HID = 64;        // k-steps of a 128-wide hidden input
 constexpr int KSTEP_FLOATS = 256; // 64 lanes x 4 row-tiles
-constexpr int RING = 4;           // k-steps of weight prefetch kept in flight per wave
+#ifndef UCNERF_MLP_RING
+#define UCNERF_MLP_RING 4
+#endif
+constexpr int RING = UCNERF_MLP_RING;   // k-steps of weight prefetch kept in flight per wave (sections are multiples of it)
 constexpr int N_SEC = 10;         // GEMM sections: bd, L0..L5, bc, ft, vc
 constexpr int CONST_FLOATS = N_SEC * 128 + 2 * 516;   // bias blocks + two head blocks (per-block LDS copy)
 
@@ -36,7 +39,7 @@ __host__ __device__ inline int acc_feature(int kt, int r, int h) { return 32 * k
 struct MlpLayout {
     int v;            // source views
     int F;            // feature row length 24 + 12 v + 1
-    int kd, kc;       // k-steps of the two bias nets, rounded up to a multiple of 4
+    int kd, kc;       // k-steps of the two bias nets, rounded up to a multiple of RING
     int64_t ks_total; // k-steps per tile
     int64_t off_sec[N_SEC];   // float offset of each section's first k-step
     int64_t off_wrap, off_const, total;
@@ -49,8 +52,8 @@ inline bool mlp_layout(int v, MlpLayout* L) {
     if (v < 1 || v > 8) return false;
     L->v = v;
     L->F = 24 + 12 * v + 1;
-    L->kd = ((24 + 4 * v) / 2 + 3) / 4 * 4;
-    L->kc = 4 * v;
+    L->kd = ((24 + 4 * v) / 2 + RING - 1) / RING * RING;
+    L->kc = (4 * v + RING - 1) / RING * RING;
     const int ks[N_SEC] = {L->kd, KS_PE_PTS, KS_HID, KS_HID, KS_HID, KS_HID, KS_PE_PTS + KS_HID, L->kc, KS_HID,
                            KS_HID + KS_PE_DIR};
     int64_t o = 0;

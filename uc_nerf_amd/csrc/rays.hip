@@ -78,19 +78,22 @@ __global__ void ndc_rays_kernel(ucnerf_ndc_rays_params p) {
 
 // ------------------------------------------------------------------------------- view-dir feature
 __global__ void dir_feature_kernel(ucnerf_dir_feature_params p) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
+    const int rep = p.repeat > 1 ? p.repeat : 1;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)p.n * rep) return;
+    const int i = (int)(idx / rep);
     float dx = p.rays_d[3 * i], dy = p.rays_d[3 * i + 1], dz = p.rays_d[3 * i + 2];
     float c = sqrtf(dx * dx + dy * dy + dz * dz);
     dx /= c; dy /= c; dz /= c;
-    if (p.cos_angle) p.cos_angle[i] = c;
+    if (p.cos_angle && idx % rep == 0) p.cos_angle[i] = c;
+    float* o = p.angle + 3 * idx;
     if (p.has_ref) {
         const float* R = p.w2c_ref;
-        p.angle[3 * i] = dx * R[0] + dy * R[1] + dz * R[2];
-        p.angle[3 * i + 1] = dx * R[4] + dy * R[5] + dz * R[6];
-        p.angle[3 * i + 2] = dx * R[8] + dy * R[9] + dz * R[10];
+        o[0] = dx * R[0] + dy * R[1] + dz * R[2];
+        o[1] = dx * R[4] + dy * R[5] + dz * R[6];
+        o[2] = dx * R[8] + dy * R[9] + dz * R[10];
     } else {
-        p.angle[3 * i] = dx; p.angle[3 * i + 1] = dy; p.angle[3 * i + 2] = dz;
+        o[0] = dx; o[1] = dy; o[2] = dz;
     }
 }
 
@@ -317,7 +320,8 @@ int ucnerf_dir_feature(const ucnerf_dir_feature_params* p, void* stream) {
     if (p->n <= 0) return UCNERF_OK;
     UCNERF_REQUIRE(p->rays_d && p->angle, "dir_feature: null pointer");
     if (p->n <= 0) return UCNERF_OK;
-    hipLaunchKernelGGL(dir_feature_kernel, dim3(cdiv(p->n, 256)), dim3(256), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(dir_feature_kernel, dim3(cdiv((long long)p->n * (p->repeat > 1 ? p->repeat : 1), 256)), dim3(256), 0,
+                       (hipStream_t)stream, *p);
     return check_launch("dir_feature");
 }
 

@@ -54,6 +54,8 @@ __global__ void __launch_bounds__(256) render_points_kernel(PointsArgs a) {
     a.ndc[o] = u; a.ndc[o + 1] = v; a.ndc[o + 2] = (qz - a.near) / (a.far - a.near);
 }
 
+int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float* feats_tiled, float* ndc, hipStream_t st);
+
 struct Workspace {
     float *pts, *ndc1, *ndc2, *ndc3, *ndc, *angle, *feats, *raw;
 };
@@ -66,7 +68,7 @@ static size_t carve(float* base, int n, int S, int V, Workspace* w) {
     size_t o = 0;
     auto take = [&](size_t k) { float* r = base ? base + o : nullptr; o += align4(k); return r; };
     w->pts = take(3 * M); w->ndc1 = take(3 * M); w->ndc2 = take(3 * M); w->ndc3 = take(3 * M); w->ndc = take(3 * M);
-    w->angle = take(3 * (size_t)n);
+    w->angle = take(3 * M);          // per-sample view directions
     w->raw = take(4 * M);
     w->feats = take(tiles * 32 * F);
     return o;
@@ -95,14 +97,14 @@ static void gather_geometry(const ucnerf_render_params* p, const Workspace* w, u
 
 static void mlp_args(const ucnerf_render_params* p, const Workspace* w, const float* feats, int tiled, float* raw, ucnerf_mlp_params* m) {
     memset(m, 0, sizeof(*m));
-    m->cfg = p->cfg; m->m = p->n * p->S; m->S = p->S; m->dirs_per_sample = 0; m->feats_tiled = tiled; m->max_blocks = p->max_blocks;
+    m->cfg = p->cfg; m->m = p->n * p->S; m->S = p->S; m->dirs_per_sample = 1; m->feats_tiled = tiled; m->max_blocks = p->max_blocks;
     m->pts = w->ndc; m->dirs = w->angle; m->feats = feats; m->wstream = p->wstream; m->raw = raw;
 }
 
 static int launch_dirs(const ucnerf_render_params* p, hipStream_t st, Workspace* w) {
     ucnerf_dir_feature_params d;
     memset(&d, 0, sizeof(d));
-    d.n = p->n; d.has_ref = 1; memcpy(d.w2c_ref, p->w2c_dir, sizeof(d.w2c_ref));
+    d.n = p->n; d.has_ref = 1; d.repeat = p->S; memcpy(d.w2c_ref, p->w2c_dir, sizeof(d.w2c_ref));
     d.rays_d = p->rays_d; d.angle = w->angle; d.cos_angle = nullptr;
     return ucnerf_dir_feature(&d, st);
 }
@@ -110,14 +112,20 @@ static int launch_dirs(const ucnerf_render_params* p, hipStream_t st, Workspace*
 static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace* w) {
     const int V = p->cfg.n_src;
     carve(p->workspace, p->n, p->S, V, w);
-    int rc = launch_points(p, st, w);
-    if (rc) return rc;
-    ucnerf_feat_gather_params g;
-    gather_geometry(p, w, &g);
+    int rc;
     const bool keep_feats = p->feats != nullptr;        // caller wants row-major features (for the backward)
-    g.out_tiled = keep_feats ? 0 : 1;
-    g.feats = keep_feats ? p->feats : w->feats;
-    if ((rc = ucnerf_feat_gather_fwd(&g, st))) return rc;
+    ucnerf_feat_gather_params g;
+    if (p->sources_cl && !keep_feats) {                 // fast path: channel-last sources, coordinates derived in-kernel
+        if ((rc = launch_gather_cl(p, p->sources_cl, w->feats, w->ndc, st))) return rc;
+        g.out_tiled = 1;
+        g.feats = w->feats;
+    } else {
+        if ((rc = launch_points(p, st, w))) return rc;
+        gather_geometry(p, w, &g);
+        g.out_tiled = keep_feats ? 0 : 1;
+        g.feats = keep_feats ? p->feats : w->feats;
+        if ((rc = ucnerf_feat_gather_fwd(&g, st))) return rc;
+    }
     if ((rc = launch_dirs(p, st, w))) return rc;
     ucnerf_mlp_params m;
     mlp_args(p, w, g.feats, g.out_tiled, p->raw ? p->raw : w->raw, &m);

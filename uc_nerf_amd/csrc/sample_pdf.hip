@@ -117,27 +117,32 @@ __global__ void __launch_bounds__(64) sample_pdf_kernel(ucnerf_sample_pdf_params
         if (p.z_sorted) srt[m] = smp;
     }
 
-    // ---- sort(cat(samples, z_merge)): bitonic network over the padded LDS buffer
+    // ---- sort(cat(samples, z_merge)) by counting: rank_i = #{x_j < x_i} + #{x_j == x_i, j < i} (a permutation even
+    // with ties; only values are returned, so any tie order is right).  n^2 = 36k compares per ray on LDS
+    // broadcast reads beats a 36-stage bitonic network with a barrier per stage.
     if (p.z_sorted) {
         const int tot_n = M + p.n_merge;
-        int P = 1;
-        while (P < tot_n) P <<= 1;
-        for (int i = lane; i < P - M; i += 64)
-            srt[M + i] = i < p.n_merge ? p.z_merge[(size_t)ray * p.n_merge + i] : __builtin_inff();
+        for (int i = lane; i < p.n_merge; i += 64) srt[M + i] = p.z_merge[(size_t)ray * p.n_merge + i];
         __syncthreads();
-        for (int k = 2; k <= P; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = lane; i < P; i += 64) {
-                    const int l = i ^ j;
-                    if (l > i) {
-                        const float a = srt[i], b = srt[l];
-                        const bool up = (i & k) == 0;
-                        if ((a > b) == up) { srt[i] = b; srt[l] = a; }
-                    }
-                }
-                __syncthreads();
+        float* dst = p.z_sorted + (size_t)ray * tot_n;
+        for (int i0 = 0; i0 < tot_n; i0 += 256) {            // 4 elements per lane per sweep
+            float x[4];
+            int rank[4], id[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                id[e] = i0 + e * 64 + lane;
+                x[e] = id[e] < tot_n ? srt[id[e]] : 0.f;
+                rank[e] = 0;
             }
-        for (int i = lane; i < tot_n; i += 64) p.z_sorted[(size_t)ray * tot_n + i] = srt[i];
+            for (int jj = 0; jj < tot_n; ++jj) {
+                const float v = srt[jj];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rank[e] += (v < x[e]) || (v == x[e] && jj < id[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (id[e] < tot_n) dst[rank[e]] = x[e];
+        }
     }
 }
 

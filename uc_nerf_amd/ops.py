@@ -605,6 +605,16 @@ class RenderPass:
         p.near, p.far = float(near), float(far)
         p.rays_o, p.wstream = _ptr(self.rays_o), _ptr(wstream)
         self._ws = None
+        self._cl = None
+
+    def repack_sources(self):
+        """(Re)builds the channel-last copies the fast gather reads; call whenever the sources changed."""
+        n = L.lib().ucnerf_gather_repack_floats(C.addressof(self.p))
+        if self._cl is None or self._cl.numel() != n:
+            self._cl = torch.empty(n, device=self.src.device)
+        with torch.cuda.device(self.src.device):
+            L.check(L.lib().ucnerf_gather_repack(C.addressof(self.p), _ptr(self._cl), _stream()), "ucnerf_gather_repack")
+        self.p.sources_cl = _ptr(self._cl)
 
     def __call__(self, rays_d, z, near_far=None, want=("acc", "weights", "var"), keep=(), events=None):
         rays_d, z = _f32(rays_d, "rays_d"), _f32(z, "z")

@@ -35,10 +35,13 @@ class CoarseFineRenderer:
     def set_params(self, flat_params):
         self.wstream.copy_(self.pw.pack(flat_params))
 
-    def render(self, xs, ys, perturb=0.0, noise=None, u=None, events=None):
+    def render(self, xs, ys, perturb=0.0, noise=None, u=None, events=None, repack=True):
         """xs, ys: pixel coordinates [n] (device, float32).  events: optional [(start, stop), (start, stop)]
-        Event pairs recorded around the coarse and the fine MLP launches."""
+        Event pairs recorded around the coarse and the fine MLP launches.  repack: rebuild the channel-last source
+        copies first (needed whenever volumes / images / features changed since the last call)."""
         sc = self.scene
+        if repack:
+            self.pass_.repack_sources()
         rays_d, _, _ = ops.ray_gen(sc["K"], sc["c2w"], xs=xs, ys=ys)
         n = rays_d.shape[0]
         z_c, _ = ops.sample_stratified(None, self.n_coarse, perturb=perturb, noise=noise, n=n, near=sc["near"],
