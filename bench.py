@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--fine", type=int, default=128)
     ap.add_argument("--cpu-rays", type=int, default=512, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--max-blocks", type=int, default=0)
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32",
+                    help="MLP arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product, fp32 accumulate)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -85,7 +87,8 @@ def main():
     scene_cpu = make_scene(seed=0)
     sd = init_ucnerf_state_dict(seed=0, n_src=6, sigma_scale=0.05, sigma_bias=0.05)
     scene = scene_to(scene_cpu, dev)
-    renderer = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, max_blocks=args.max_blocks)
+    renderer = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, max_blocks=args.max_blocks,
+                                  precision=args.precision)
     # this rank's shard of the global batch of rays*world pixels: contiguous block split
     xs_all, ys_all = random_pixels(args.rays * world, scene_cpu["H"], scene_cpu["W"], seed=0)
     xs = xs_all[rank * args.rays:(rank + 1) * args.rays].to(dev)

@@ -206,15 +206,22 @@ int ucnerf_feat_gather_bwd(const ucnerf_feat_gather_bwd_params* p, void* stream)
 typedef struct {
     int32_t n_src;        /* V = view_num - 1 */
     int32_t pe_layout;    /* 0 live (network/models.py), 1 interleaved (run_nerf_helpers.py) */
+    int32_t precision;    /* 0: f32 -- exact fp32 MFMA (v_mfma_f32_32x32x2_f32); forward, backward, every input mode.
+                             1: bf16x3 -- every product as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the bf16 matrix cores
+                                (v_mfma_f32_32x32x16_bf16, fp32 accumulate): inference forward only; rendered outputs
+                                stay within 1e-5 of fp64 (the parity bar is 1e-4), ~2.5x the f32 throughput. */
 } ucnerf_mlp_config;
 
-/* Sizes: number of floats in the flat parameter vector and in the packed stream (<0 on bad config). */
+/* Sizes: floats in the flat parameter vector, floats (4-byte units) of the packed stream, int32 entries of the pack
+ * index (<0 on bad config).  Stream and index depend on cfg.precision. */
 int64_t ucnerf_mlp_param_count(const ucnerf_mlp_config* cfg);
 int64_t ucnerf_mlp_stream_count(const ucnerf_mlp_config* cfg);
-/* Host-side: fills idx_host[stream_count] with the flat-parameter index feeding each stream slot (-1 = zero pad). */
+int64_t ucnerf_mlp_index_count(const ucnerf_mlp_config* cfg);
+/* Host-side: fills idx_host[index_count] with the flat-parameter index feeding each stream element (-1 = zero pad;
+ * bf16x3: bit 30 selects the low part of the split). */
 int ucnerf_mlp_pack_index(const ucnerf_mlp_config* cfg, int32_t* idx_host);
-/* Device-side: stream[i] = idx[i] >= 0 ? flat[idx[i]] : 0.  idx is the device copy of the table above. */
-int ucnerf_mlp_pack(const float* flat_params, const int32_t* idx, float* stream_out, int64_t n, void* stream);
+/* Device-side: builds the packed stream from the flat parameters; idx is the device copy of the table above. */
+int ucnerf_mlp_pack(const ucnerf_mlp_config* cfg, const float* flat_params, const int32_t* idx, float* stream_out, void* stream);
 /* Transpose of the pack for gradients: g_flat[idx[i]] += g_stream[i] (g_flat zeroed by the caller). */
 int ucnerf_mlp_unpack_grad(const float* g_stream, const int32_t* idx, float* g_flat, int64_t n, void* stream);
 

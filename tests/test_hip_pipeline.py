@@ -141,3 +141,33 @@ def test_full_size_properties_4096_rays():
     sel = interior[::64]
     ref = O.render_coarse_fine(sd, scene, xs[sel], ys[sel], 64, 128, z_fine_override=zf[sel].cpu())
     close(out["rgb"][sel], ref["rgb"], 1e-4); close(out["depth"][sel], ref["depth"], 1e-4, 1e-5)
+
+
+def test_bf16x3_pipeline_meets_the_1e4_parity_bar(sd_v7):
+    """The headline 64+128 pipeline in bf16x3 precision against the reference's G11 vectors (teacher-forced on the
+    reference's fine depths) and against the exact-f32 pipeline on 4096 rays."""
+    from uc_nerf_amd.pipeline import CoarseFineRenderer, flat_params_of
+    from uc_nerf_amd.synthetic import init_ucnerf_state_dict, make_scene, random_pixels
+    g = load_golden("g11_coarse_fine")
+    sd = scaled_sd(sd_v7, g["sigma_head_scale"], g["sigma_head_bias"])
+    r = CoarseFineRenderer(to_dev(scene_from_golden(g)), flat_params_of(sd).to(DEV), 64, 128, precision="bf16x3")
+    out = r.render(g["xs"].to(DEV), g["ys"].to(DEV))
+    ok = (g["ys"] > 0) & (g["ys"] < g["H"] - 1)
+    close(out["coarse"]["weights"][ok], g["c_weights"][ok], 5e-5, 1e-3)
+    fine = r.pass_(out["rays_d"], g["z_fine"].to(DEV))
+    close(fine["rgb"][ok], g["f_rgb"][ok], 1e-4); close(fine["depth"][ok], g["f_depth"][ok], 1e-4, 1e-4)
+    close(fine["acc"][ok], g["f_acc"][ok], 1e-4)
+    # full size, both precisions on the same fine depths
+    scene = make_scene(seed=0)
+    sd = init_ucnerf_state_dict(seed=0, sigma_scale=0.05, sigma_bias=0.05)
+    xs, ys = random_pixels(4096, 256, 320, seed=0)
+    r32 = CoarseFineRenderer(to_dev(scene), flat_params_of(sd).to(DEV), 64, 128)
+    r16 = CoarseFineRenderer(to_dev(scene), flat_params_of(sd).to(DEV), 64, 128, precision="bf16x3")
+    o32 = r32.render(xs.to(DEV), ys.to(DEV))
+    f16 = r16.pass_(o32["rays_d"], o32["z_fine"])
+    close(f16["rgb"], o32["rgb"], 1e-4); close(f16["depth"], o32["depth"], 1e-4, 1e-4)
+    o16 = r16.render(xs.to(DEV), ys.to(DEV))
+    err = (o16["rgb"] - o32["rgb"]).abs().max(-1)[0]
+    assert (err < 1e-4).float().mean() > 0.97      # free-running: a flipped searchsorted bin moves single samples
+    mse = torch.mean((o16["rgb"] - o32["rgb"]) ** 2).item()
+    assert mse < 1e-6                               # > 60 dB PSNR against the f32 render (flipped bins dominate)

@@ -63,7 +63,7 @@ class FeatGatherBwdParams(C.Structure):
 
 
 class MlpConfig(C.Structure):
-    _fields_ = [("n_src", i32), ("pe_layout", i32)]
+    _fields_ = [("n_src", i32), ("pe_layout", i32), ("precision", i32)]
 
 
 class MlpParams(C.Structure):
@@ -143,8 +143,9 @@ SYMBOLS = {
     "ucnerf_feat_gather_bwd": (C.c_int, [_P, _P]),
     "ucnerf_mlp_param_count": (C.c_int64, [_P]),
     "ucnerf_mlp_stream_count": (C.c_int64, [_P]),
+    "ucnerf_mlp_index_count": (C.c_int64, [_P]),
     "ucnerf_mlp_pack_index": (C.c_int, [_P, _P]),
-    "ucnerf_mlp_pack": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "ucnerf_mlp_pack": (C.c_int, [_P, _P, _P, _P, _P]),
     "ucnerf_mlp_unpack_grad": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "ucnerf_mlp_fwd": (C.c_int, [_P, _P]),
     "ucnerf_mlp_bwd_workspace_floats": (C.c_int64, [_P, C.c_int32]),

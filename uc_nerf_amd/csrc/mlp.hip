@@ -581,6 +581,13 @@ int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t
     return check_launch("mlp_fwd");
 }
 
+// mlp_bf16.hip
+int build_pack_index_bf16(const ucnerf_mlp_config* cfg, int32_t* idx);
+int64_t bf16_index_count(const ucnerf_mlp_config* cfg);
+int64_t bf16_stream_floats(const ucnerf_mlp_config* cfg);
+int launch_pack_bf16(const ucnerf_mlp_config* cfg, const float* flat, const int32_t* idx, float* out, hipStream_t st);
+int launch_mlp_fwd_bf16(const ucnerf_mlp_params* p, hipStream_t st);
+
 }  // namespace ucnerf
 
 using namespace ucnerf;
@@ -596,18 +603,41 @@ int64_t ucnerf_mlp_param_count(const ucnerf_mlp_config* cfg) {
 int64_t ucnerf_mlp_stream_count(const ucnerf_mlp_config* cfg) {
     MlpLayout L;
     if (!cfg || !mlp_layout(cfg->n_src, &L)) return fail(UCNERF_EINVAL, "mlp: n_src must be in 1..8");
+    if (cfg->precision == 1) return bf16_stream_floats(cfg);
+    if (cfg->precision != 0) return fail(UCNERF_EINVAL, "mlp: precision %d (0 = f32, 1 = bf16x3)", cfg->precision);
     return L.total;
+}
+
+int64_t ucnerf_mlp_index_count(const ucnerf_mlp_config* cfg) {
+    const int64_t n = ucnerf_mlp_stream_count(cfg);
+    if (n < 0) return n;
+    return cfg->precision == 1 ? bf16_index_count(cfg) : n;
 }
 
 int ucnerf_mlp_pack_index(const ucnerf_mlp_config* cfg, int32_t* idx_host) {
     UCNERF_REQUIRE(cfg && idx_host, "mlp_pack_index: null pointer");
     UCNERF_REQUIRE(cfg->pe_layout == 0 || cfg->pe_layout == 1, "mlp_pack_index: pe_layout %d", cfg->pe_layout);
-    UCNERF_REQUIRE(build_pack_index(cfg, idx_host) == 0, "mlp_pack_index: n_src %d outside 1..8", cfg->n_src);
+    UCNERF_REQUIRE(cfg->precision == 0 || cfg->precision == 1, "mlp_pack_index: precision %d", cfg->precision);
+    if (cfg->precision == 0) {
+        UCNERF_REQUIRE(build_pack_index(cfg, idx_host) == 0, "mlp_pack_index: n_src %d outside 1..8", cfg->n_src);
+        return UCNERF_OK;
+    }
+    UCNERF_REQUIRE(build_pack_index_bf16(cfg, idx_host) == 0, "mlp_pack_index: n_src %d outside 1..8", cfg->n_src);
+    // the fp32 constants block (biases, head weights) is shared with the f32 layout
+    MlpLayout L;
+    mlp_layout(cfg->n_src, &L);
+    std::vector<int32_t> tmp(L.total);
+    build_pack_index(cfg, tmp.data());
+    const int64_t n16 = bf16_index_count(cfg) - CONST_FLOATS;
+    for (int i = 0; i < CONST_FLOATS; ++i) idx_host[n16 + i] = tmp[L.off_const + i];
     return UCNERF_OK;
 }
 
-int ucnerf_mlp_pack(const float* flat, const int32_t* idx, float* out, int64_t n, void* stream) {
-    UCNERF_REQUIRE(flat && idx && out && n > 0, "mlp_pack: bad arguments");
+int ucnerf_mlp_pack(const ucnerf_mlp_config* cfg, const float* flat, const int32_t* idx, float* out, void* stream) {
+    UCNERF_REQUIRE(cfg && flat && idx && out, "mlp_pack: null pointer");
+    if (cfg->precision == 1) return launch_pack_bf16(cfg, flat, idx, out, (hipStream_t)stream);
+    const int64_t n = ucnerf_mlp_stream_count(cfg);
+    UCNERF_REQUIRE(n > 0, "mlp_pack: bad config");
     hipLaunchKernelGGL(pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, flat, idx, out, n);
     return check_launch("mlp_pack");
 }
@@ -618,6 +648,9 @@ int ucnerf_mlp_unpack_grad(const float* g, const int32_t* idx, float* gflat, int
     return check_launch("mlp_unpack_grad");
 }
 
-int ucnerf_mlp_fwd(const ucnerf_mlp_params* p, void* stream) { return launch_mlp_fwd(p, nullptr, (hipStream_t)stream); }
+int ucnerf_mlp_fwd(const ucnerf_mlp_params* p, void* stream) {
+    if (p && p->cfg.precision == 1) return launch_mlp_fwd_bf16(p, (hipStream_t)stream);
+    return launch_mlp_fwd(p, nullptr, (hipStream_t)stream);
+}
 
 }  // extern "C"

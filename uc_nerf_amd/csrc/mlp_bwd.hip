@@ -405,6 +405,7 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     const int ew_blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
 
     // 0. forward with the activations kept; encodings as explicit matrices for the weight-gradient GEMMs
+    UCNERF_REQUIRE(f.cfg.precision == 0, "mlp_bwd: the backward runs in f32 precision (pack the weights with precision 0)");
     ucnerf_mlp_params fw = f;
     fw.raw = w.raw;
     RUN(launch_mlp_fwd(&fw, &w.sv, st));

@@ -157,7 +157,7 @@ int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V) {
 static size_t carve_bwd_render(float* base, int n, int S, int V, Workspace* w, float** g_raw, float** g_feats, float** mlp_ws) {
     size_t o = carve(base, n, S, V, w);
     const size_t M = (size_t)n * S, F = 24 + 12 * V + 1;
-    ucnerf_mlp_config cfg{V, 0};
+    ucnerf_mlp_config cfg{V, 0, 0};
     const size_t mlp = (size_t)ucnerf_mlp_bwd_workspace_floats(&cfg, (int)M);
     auto take = [&](size_t k) { float* r = base ? base + o : nullptr; o += align4(k); return r; };
     *g_raw = take(4 * M); *g_feats = take(M * F); *mlp_ws = take(mlp);

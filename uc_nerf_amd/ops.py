@@ -320,25 +320,29 @@ class PackedWeights:
     """Pack index (host-built by the library, cached on device) + packing of a flat parameter vector."""
     _cache = {}
 
-    def __init__(self, n_src, pe_layout, device):
-        self.cfg = L.MlpConfig(n_src, pe_layout)
+    PRECISIONS = {"f32": 0, "bf16x3": 1}
+
+    def __init__(self, n_src, pe_layout, device, precision="f32"):
+        self.cfg = L.MlpConfig(n_src, pe_layout, self.PRECISIONS[precision])
+        self.precision = precision
         lib = L.lib()
         self.n_params = lib.ucnerf_mlp_param_count(C.addressof(self.cfg))
         self.n_stream = lib.ucnerf_mlp_stream_count(C.addressof(self.cfg))
-        if self.n_params < 0 or self.n_stream < 0:
-            raise RuntimeError("uc_nerf_amd: unsupported MLP config n_src=%d: %s"
-                               % (n_src, lib.ucnerf_last_error().decode()))
-        idx = torch.empty(self.n_stream, dtype=torch.int32)
+        n_idx = lib.ucnerf_mlp_index_count(C.addressof(self.cfg))
+        if self.n_params < 0 or self.n_stream < 0 or n_idx < 0:
+            raise RuntimeError("uc_nerf_amd: unsupported MLP config n_src=%d precision=%s: %s"
+                               % (n_src, precision, lib.ucnerf_last_error().decode()))
+        idx = torch.empty(n_idx, dtype=torch.int32)
         L.check(lib.ucnerf_mlp_pack_index(C.addressof(self.cfg), C.c_void_p(idx.data_ptr())), "ucnerf_mlp_pack_index")
         self.idx_host = idx
         self.idx = idx.to(device)
         self.device = device
 
     @classmethod
-    def get(cls, n_src, pe_layout, device):
-        key = (n_src, pe_layout, str(device))
+    def get(cls, n_src, pe_layout, device, precision="f32"):
+        key = (n_src, pe_layout, str(device), precision)
         if key not in cls._cache:
-            cls._cache[key] = cls(n_src, pe_layout, device)
+            cls._cache[key] = cls(n_src, pe_layout, device, precision)
         return cls._cache[key]
 
     def pack(self, flat):
@@ -348,7 +352,7 @@ class PackedWeights:
                                % (flat.numel(), self.n_params))
         out = torch.empty(self.n_stream, device=flat.device)
         with torch.cuda.device(flat.device):
-            L.check(L.lib().ucnerf_mlp_pack(_ptr(flat), _ptr(self.idx), _ptr(out), self.n_stream, _stream()), "ucnerf_mlp_pack")
+            L.check(L.lib().ucnerf_mlp_pack(C.addressof(self.cfg), _ptr(flat), _ptr(self.idx), _ptr(out), _stream()), "ucnerf_mlp_pack")
         return out
 
     def unpack_grad(self, g_stream):
@@ -593,6 +597,7 @@ class RenderPass:
     """Pre-bound arguments of ucnerf_render_fused_fwd for one scene; call it with (rays_d, z)."""
 
     def __init__(self, src, pw, wstream, rays_o, w2c_ref, K_ref, w2c_dir, near, far, white_bkgd=False, max_blocks=0):
+        # pw / wstream may be packed for either precision ("f32" or "bf16x3"); the backward needs "f32"
         self.src, self.pw, self.wstream = src, pw, wstream
         self.rays_o = _f32(rays_o.reshape(-1)[:3].clone(), "rays_o")
         self.p = p = L.RenderParams()

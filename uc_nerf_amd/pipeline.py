@@ -19,13 +19,15 @@ class CoarseFineRenderer:
     view, 1.. = source views), near, far, vols (3 x [1,8,D,h,w]), imgs [1,V-1,3,H,W], img_feat [V-1,1,8,H,W],
     confidence [H,W]; tensors already on the device.  flat_params: the MLP's flat parameter vector (device)."""
 
-    def __init__(self, scene, flat_params, n_coarse=64, n_fine=128, white_bkgd=False, pe_layout=0, max_blocks=0):
+    def __init__(self, scene, flat_params, n_coarse=64, n_fine=128, white_bkgd=False, pe_layout=0, max_blocks=0,
+                 precision="f32"):
         dev = scene["confidence"].device
         self.scene, self.dev = scene, dev
         self.n_coarse, self.n_fine = n_coarse, n_fine
         self.src = ops.GatherSources(scene["vols"], scene["confidence"], scene["imgs"], scene["img_feat"],
                                      scene["w2cs"][1:], scene["intrinsics"][1:])
-        self.pw = ops.PackedWeights.get(self.src.V, pe_layout, dev)
+        self.precision = precision          # "f32": exact fp32 MFMA; "bf16x3": split-bf16 matrix-core path (inference)
+        self.pw = ops.PackedWeights.get(self.src.V, pe_layout, dev, precision)
         self.wstream = self.pw.pack(flat_params)
         w2c_ref = scene["w2cs"][0]
         self.pass_ = ops.RenderPass(self.src, self.pw, self.wstream, scene["c2w"][:3, 3].to(dev), w2c_ref,
