@@ -1,20 +1,22 @@
 #!/bin/bash
 # PMC passes for the MLP kernel (run on the GPU box via gpurun).  Counters in separate runs, no tracing domains.
-# usage: bash scripts/pmc_mlp.sh <outdir-name> [quick]
+# usage: [PREC=bf16x3] bash scripts/pmc_mlp.sh <outdir-name> [quick|sq]
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${1:-pmc}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters
-  rocprofv3 --pmc $2 --kernel-include-regex "mlp_fwd" --output-format csv -d $OUT/$1 -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-rays 0 > $OUT/$1.log 2>&1
+  rocprofv3 --pmc $2 --kernel-include-regex "mlp_fwd" --output-format csv -d $OUT/$1 -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-rays 0 --precision ${PREC:-f32} > $OUT/$1.log 2>&1
   echo "$1 rc=$?"
 }
 run sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES"
 run grbm "GRBM_GUI_ACTIVE GRBM_COUNT"
 if [ "$2" != "quick" ]; then
 run sq2 "SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM"
+if [ "$2" != "sq" ]; then
 run fetch "FETCH_SIZE"
 run write "WRITE_SIZE"
 run tcc "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"
+fi
 fi

@@ -28,8 +28,9 @@ for kind, o in out.items():
         o["hbm_write_bytes"] = o["WRITE_SIZE"] * 1024
     if "TCC_HIT_sum" in o:
         o["l2_hit_rate"] = o["TCC_HIT_sum"] / (o["TCC_HIT_sum"] + o["TCC_MISS_sum"])
-    if "SQ_INSTS_VALU" in o:
-        o["valu_insts_per_tile"] = o["SQ_INSTS_VALU"] / (samples / 32)
+    for c in ("VALU", "SALU", "LDS", "MFMA", "VMEM_RD"):
+        if "SQ_INSTS_" + c in o:
+            o[c.lower() + "_insts_per_tile"] = o["SQ_INSTS_" + c] / (samples / 32)
     if "GRBM_GUI_ACTIVE" in o:
         o["clock_ghz"] = o["GRBM_GUI_ACTIVE"] / 8 / o["_duration_ns_grbm"]
         if "SQ_VALU_MFMA_BUSY_CYCLES" in o:
@@ -42,4 +43,4 @@ json.dump(res, open(sys.argv[2], "w"), indent=1)
 for k in ("coarse", "fine"):
     o = out[k]
     print(k, {kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in o.items() if kk in
-              ("valu_insts_per_tile", "clock_ghz", "mfma_busy_frac", "l2_hit_rate", "hbm_read_bytes_corrected", "hbm_write_bytes", "_duration_ns_sq1")})
+              ("valu_insts_per_tile", "salu_insts_per_tile", "lds_insts_per_tile", "mfma_insts_per_tile", "vmem_rd_insts_per_tile", "clock_ghz", "mfma_busy_frac", "l2_hit_rate", "hbm_read_bytes_corrected", "hbm_write_bytes", "_duration_ns_sq1")})

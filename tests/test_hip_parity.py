@@ -243,6 +243,27 @@ def test_sample_pdf_indices_bit_exact_and_merge():
     out = ops().sample_pdf(bins, w, dev(u_det), z_merge=dev(zc))
     want = torch.sort(torch.cat([g["samples_det"], zc], -1), -1)[0]
     assert torch.equal(out["z_sorted"].cpu(), want)
+    # unsorted draws take the counting merge, sorted ones the binary-search merge: same answer as torch.sort
+    out = ops().sample_pdf(bins, w, dev(g["u"]), z_merge=dev(zc))
+    assert torch.equal(out["z_sorted"].cpu(), torch.sort(torch.cat([g["samples_u"], zc], -1), -1)[0])
+    zt = zc.clone(); zt[:, 10] = zt[:, 11]; zt[:, 40] = g["samples_det"][:, 7]          # ties within and across the lists
+    out = ops().sample_pdf(bins, w, dev(u_det), z_merge=dev(zt))
+    assert torch.equal(out["z_sorted"].cpu(), torch.sort(torch.cat([g["samples_det"], zt], -1), -1)[0])
+
+
+def test_sample_pdf_cdf_outside_the_exact_scan_range_takes_the_sequential_sum():
+    """pdf values below 2^-28 (huge dynamic range) or negative weights: the float64 running sum is order dependent."""
+    gen = torch.Generator().manual_seed(5)
+    n, L, M = 64, 64, 40
+    z = torch.sort(torch.rand(n, L, generator=gen), -1)[0]
+    w = torch.rand(n, L - 1, generator=gen) * 1e-6
+    w[:, 5] = 3e5 * (1 + torch.rand(n, generator=gen))
+    w[::2, 9] = -0.25
+    u = torch.rand(n, M, generator=gen)
+    want_s, want_i, want_cdf = O.sample_pdf(z, w, u)
+    out = ops().sample_pdf(dev(z), dev(w), dev(u), want_cdf=True)
+    assert torch.equal(out["cdf"].cpu(), want_cdf)
+    assert torch.equal(out["inds"].cpu(), want_i) and torch.equal(out["samples"].cpu(), want_s)
 
 
 @pytest.mark.parametrize("L", [2, 5, 9, 16, 63, 64, 129, 600])

@@ -12,10 +12,14 @@
 //   * a k16-step = 16 input features: lane-half hh supplies 8 of them as one bf16x8 fragment.  For hidden layers
 //     the fragment of step (kt, s) is accumulator registers 8s..8s+7 of row-tile kt -- the accumulator layout is
 //     again directly the next layer's operand, only re-split into (hi, lo) after the epilogue;
-//   * weights are consumed 3x faster than in the fp32 kernel, too fast to stream per wave from L2 (48 TB/s chip-
-//     wide), so the 8 waves of a block share them: the packed stream ([step][row-tile][hi|lo][lane][8 bf16],
-//     8 KB per step) is copied into an LDS ring by global_load_lds (one 1-KB piece per wave per step, 6 steps
-//     ahead, counted vmcnt + one raw s_barrier per step), and every wave reads its A fragments with ds_read_b128.
+//   * weights are consumed 3x faster than in the fp32 kernel, too fast to stream per wave from L2, so the waves
+//     of a block share them: the packed stream ([step][row-tile][hi|lo][lane][8 bf16], 8 KB per step) is copied
+//     into a 4-slot LDS ring by global_load_lds (two 1-KB pieces per wave per step, issued 3.5 steps ahead,
+//     counted vmcnt + one raw s_barrier per step), and every wave reads its A fragments with ds_read_b128, one
+//     row-tile pair (6 MFMAs) ahead of the MFMAs that consume them;
+//   * a block is 4 waves = one per SIMD, and TWO blocks share a CU: the two waves of a SIMD belong to different
+//     blocks, are never coupled by a barrier and drift apart, so one wave's epilogue (bias-net product, relu,
+//     hi/lo split: ~45 % of its MFMA time, on the VALU) runs under the other wave's MFMAs.
 #include "common.h"
 #include "mlp_layout.h"
 #include "sincos_cw.h"
@@ -32,10 +36,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-constexpr int BW = 8;                 // waves per block
+constexpr int BW = 4;                 // waves per block (one per SIMD; two blocks per CU)
 constexpr int STEP_BYTES = 8192;      // [4 row-tiles][hi, lo][64 lanes][16 B]
-constexpr int NBUF = 8;               // LDS ring slots (k16-steps)
-constexpr int PF = 6;                 // DMA prefetch distance in steps (NBUF >= PF + 2 would allow issue-before-barrier)
+constexpr int NBUF = 4;               // LDS ring slots (k16-steps); the slot of step g is refilled with step g + NBUF
+constexpr int DMA_PER_STEP = STEP_BYTES / 1024 / BW;      // 1-KB global_load_lds pieces per wave per step
 constexpr int KS16_PE_PTS = 4, KS16_PE_DIR = 2, KS16_HID = 8;
 
 struct Bf16Layout {
@@ -142,47 +146,82 @@ struct BGeom {
     int F, kd16, kc16, f_img, steps, feat_stride;
     unsigned stream_bytes, feat_bytes;
     int const_off_bytes;
+    unsigned long long* diag;          // diagnostic builds only (UCNERF_MLP_DIAG): per-wave phase clocks of one tile
 };
+
+// A fragments of one row-tile pair of a step
+struct AF { bf16x8 h0, l0, h1, l1; };
 
 // block-wide weight pipeline state (all values wave-uniform)
 struct Pipe {
-    const char* __restrict__ gsrc;    // this lane's source byte within step 0: stream + wave*1024 + lane*16
+    const char* __restrict__ gsrc;    // this lane's source byte within step 0: stream + wave*2048 + lane*16
     char* ring;                        // LDS ring base
+    unsigned ring_lds;                 // ... as an LDS byte address
+    const char* buf;                   // slot of the step being multiplied
     int wave;
     int gstep;                         // running step counter (never reset: ring slot = gstep & (NBUF-1))
     int next_src;                      // step (mod steps) of the next DMA to issue
     int steps;
 };
 
+// The copy is issued from inline asm on purpose: the compiler models a global_load_lds as a FLAT access that may
+// touch both memories and from then on degrades every counted wait of the kernel to vmcnt(0) / lgkmcnt(0), which
+// serialises the fragment prefetch below.  All hazards of the ring are handled explicitly in advance().
 __device__ __forceinline__ void issue_dma(Pipe& P, int slot_step) {
-    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(P.gsrc + (size_t)P.next_src * STEP_BYTES),
-                                     (void __attribute__((address_space(3)))*)(P.ring + (slot_step & (NBUF - 1)) * STEP_BYTES + P.wave * 1024),
-                                     16, 0, 0);
+    const char* src = P.gsrc + (size_t)P.next_src * STEP_BYTES;
+    const unsigned dst = P.ring_lds + (slot_step & (NBUF - 1)) * STEP_BYTES + P.wave * (DMA_PER_STEP * 1024);
+#pragma unroll
+    for (int i = 0; i < DMA_PER_STEP; ++i)
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off offset:%2" ::"v"(src), "s"(dst), "n"(i * 1024) : "memory", "m0");   // the offset moves both addresses
     P.next_src = P.next_src + 1 == P.steps ? 0 : P.next_src + 1;
 }
 
-// Start of a k16-step: this wave's piece of the step has landed (counted vmcnt: PF-1 younger DMAs stay in flight),
-// everybody's has after the barrier; the slot read in the previous step is then free and is refilled.
-__device__ __forceinline__ const char* step_acquire(Pipe& P) {
-    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // PF - 1
-    __builtin_amdgcn_s_barrier();
-    issue_dma(P, P.gstep + PF);
-    const char* buf = P.ring + (P.gstep & (NBUF - 1)) * STEP_BYTES;
-    ++P.gstep;
-    return buf;
-}
-static_assert(PF == 6 && NBUF >= PF + 1, "step_acquire hard-codes vmcnt(PF-1)");
-
-// one k16-step: acc[nt] += A_hi*B_hi + A_hi*B_lo + A_lo*B_hi for the four row-tiles
-__device__ __forceinline__ void mfma_step(const char* buf, int lane, const Frag& b, f32x16 (&acc)[4]) {
+__device__ __forceinline__ AF read_pair(const char* buf, int lane, int pair) {
     const bf16x8* a = reinterpret_cast<const bf16x8*>(buf) + lane;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const bf16x8 ah = a[(nt * 2 + 0) * 64], al = a[(nt * 2 + 1) * 64];
-        acc[nt] = MFMA16(ah, b.hi, acc[nt]);
-        acc[nt] = MFMA16(ah, b.lo, acc[nt]);
-        acc[nt] = MFMA16(al, b.hi, acc[nt]);
-    }
+    AF f;
+    f.h0 = a[(pair * 4 + 0) * 64]; f.l0 = a[(pair * 4 + 1) * 64];
+    f.h1 = a[(pair * 4 + 2) * 64]; f.l1 = a[(pair * 4 + 3) * 64];
+    return f;
+}
+
+// acc += A_hi*B_hi + A_hi*B_lo + A_lo*B_hi for two row-tiles, interleaved so that dependent MFMAs are 2 apart
+__device__ __forceinline__ void mfma6(const AF& a, const Frag& b, f32x16& c0, f32x16& c1) {
+    c0 = MFMA16(a.h0, b.hi, c0); c1 = MFMA16(a.h1, b.hi, c1);
+    c0 = MFMA16(a.h0, b.lo, c0); c1 = MFMA16(a.h1, b.lo, c1);
+    c0 = MFMA16(a.l0, b.hi, c0); c1 = MFMA16(a.l1, b.hi, c1);
+}
+
+// Waits until the next step has landed for the whole block, refills the slot just read and moves on to it.
+// On entry every ds_read of the current slot has returned (lgkmcnt(0)), so after the barrier no wave still reads it.
+// vmcnt: the DMAs younger than the awaited step are those of the two steps after it.
+#ifndef UCNERF_BF16_EXP
+#define UCNERF_BF16_EXP 0      // timing experiments only (results are wrong): 1 no DMA wait, 2 no barrier, 4 no DMA
+#endif
+__device__ __forceinline__ void advance(Pipe& P) {
+#if !(UCNERF_BF16_EXP & 1)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * DMA_PER_STEP) : "memory");
+#endif
+#if !(UCNERF_BF16_EXP & 2)
+    __builtin_amdgcn_s_barrier();
+#endif
+#if !(UCNERF_BF16_EXP & 4)
+    issue_dma(P, P.gstep);                                  // step gstep + NBUF into the slot of step gstep
+#endif
+    ++P.gstep;
+    P.buf = P.ring + (P.gstep & (NBUF - 1)) * STEP_BYTES;
+}
+
+// One k16-step for the four row-tiles.  `cur` = fragments of (this step, pair 0) on entry, of (next step, pair 0) on exit.
+__device__ __forceinline__ void step16(Pipe& P, AF& cur, int lane, const Frag& b, f32x16 (&acc)[4]) {
+    const AF n1 = read_pair(P.buf, lane, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(cur, b, acc[0], acc[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    advance(P);
+    cur = read_pair(P.buf, lane, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(n1, b, acc[2], acc[3]);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 __device__ __forceinline__ void init_bias16(const float* cst, int sec, int h, f32x16 (&acc)[4]) {
@@ -196,17 +235,27 @@ __device__ __forceinline__ void init_bias16(const float* cst, int sec, int h, f3
         }
 }
 
+// Four head outputs from a 128-wide activation set (accumulator layout): VALU, two outputs per v_pk_fma_f32.  The
+// weight rows come from LDS in batches of 8 reads so that their latency is paid once per batch, not once per read.
 __device__ __forceinline__ f32x4 head4_16(const float* hd, int h, const f32x16 (&x)[4]) {
     const f32x4* w = reinterpret_cast<const f32x4*>(hd) + h * 64;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int b = 0; b < 8; ++b) {
+        f32x4 wv[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const f32x4 wv = w[nt * 16 + r];
-            const float xv = x[nt][r];
-            s.x = fmaf(xv, wv.x, s.x); s.y = fmaf(xv, wv.y, s.y); s.z = fmaf(xv, wv.z, s.z); s.w = fmaf(xv, wv.w, s.w);
+        for (int i = 0; i < 8; ++i) wv[i] = w[b * 8 + i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xv = x[b >> 1][(b & 1) * 8 + i];
+            const f32x2 xx = {xv, xv};
+            s01 = __builtin_elementwise_fma(xx, (f32x2){wv[i].x, wv[i].y}, s01);
+            s23 = __builtin_elementwise_fma(xx, (f32x2){wv[i].z, wv[i].w}, s23);
         }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x4 s = {s01.x, s01.y, s23.x, s23.y};
     s.x += __shfl_xor(s.x, 32); s.y += __shfl_xor(s.y, 32); s.z += __shfl_xor(s.z, 32); s.w += __shfl_xor(s.w, 32);
     const f32x4 b = *reinterpret_cast<const f32x4*>(hd + 512);
     s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
@@ -233,12 +282,9 @@ __device__ __forceinline__ void encode16(const float (&x)[3], int h, float (&pe)
 }
 
 // hidden layer: 8 k16-steps on the fragments of a 128-wide activation set
-__device__ __forceinline__ void gemm16_hidden(Pipe& P, int lane, const Frag (&x)[8], f32x16 (&acc)[4]) {
+__device__ __forceinline__ void gemm16_hidden(Pipe& P, AF& cur, int lane, const Frag (&x)[8], f32x16 (&acc)[4]) {
 #pragma unroll
-    for (int q = 0; q < KS16_HID; ++q) {
-        const char* buf = step_acquire(P);
-        mfma_step(buf, lane, x[q], acc);
-    }
+    for (int q = 0; q < KS16_HID; ++q) step16(P, cur, lane, x[q], acc);
 }
 
 // fragments of an accumulator-layout fp32 activation set (optionally with an element-wise map applied first)
@@ -265,6 +311,7 @@ __global__ void __launch_bounds__(64 * BW, 2) mlp_fwd_bf16_kernel(ucnerf_mlp_par
     const int j = lane & 31, h = lane >> 5;
     constexpr int KD_S = (24 + 4 * NSRC + 15) / 16, KC_S = (8 * NSRC + 15) / 16;
     const int kd16 = NSRC ? KD_S : g.kd16, kc16 = NSRC ? KC_S : g.kc16;
+    const int F = NSRC ? 24 + 12 * NSRC + 1 : g.F, f_img = NSRC ? 24 + 4 * NSRC : g.f_img;
     const char* __restrict__ ws = reinterpret_cast<const char*>(p.wstream);
 
     {   // constants (fp32 biases + head blocks) -> LDS, plain loads: they are waited for before any DMA is issued
@@ -277,38 +324,58 @@ __global__ void __launch_bounds__(64 * BW, 2) mlp_fwd_bf16_kernel(ucnerf_mlp_par
     Frag* stash = stash_all + (size_t)wave * (KS16_PE_PTS * 64) + lane;        // step q at stash[q * 64]
 
     Pipe P;
-    P.gsrc = ws + wave * 1024 + lane * 16;
-    P.ring = ring; P.wave = wave; P.gstep = 0; P.next_src = 0; P.steps = g.steps;
+    P.gsrc = ws + wave * (DMA_PER_STEP * 1024) + lane * 16;
+    P.ring = ring; P.ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring; P.buf = ring; P.wave = wave; P.gstep = 0; P.next_src = 0; P.steps = g.steps;
 #pragma unroll
-    for (int i = 0; i < PF; ++i) issue_dma(P, i);
+    for (int i = 0; i < NBUF; ++i) issue_dma(P, i);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * DMA_PER_STEP) : "memory");     // step 0 has landed ...
+    __builtin_amdgcn_s_barrier();                                                        // ... for every wave
+    AF cur = read_pair(P.buf, lane, 0);
 
     const int tiles_per_round = gridDim.x * BW;
     const int n_rounds = (n_tiles + tiles_per_round - 1) / tiles_per_round;
+#ifdef UCNERF_MLP_DIAG
+#define DIAG_STAMP(K) { __builtin_amdgcn_sched_barrier(0); if (g.diag && lane == 0 && round == 5) g.diag[(size_t)(blockIdx.x * BW + wave) * 16 + (K)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define DIAG_STAMP(K)
+#endif
+    // Inputs of a tile are fetched one tile ahead (under the previous tile's head / blend arithmetic, when few registers are live), so their latency never
+    // shows: operands of the depth-bias net (element e of step q = feature 16q + 8h + e; columns past a section's
+    // width meet zero weights, so their index is only clamped into the row -- no branch), confidence, point, direction.
+    float nfs[4][8], nconf, npx[3];
+    auto sample_of = [&](int tile) { const int s_raw = tile * 32 + j; return s_raw < p.m ? s_raw : p.m - 1; };
+    auto feat_base = [&](int s) { return TILED ? p.feats + ((size_t)(s >> 5) * F * 32 + (s & 31)) : p.feats + (size_t)s * g.feat_stride; };
+    constexpr int fstride = TILED ? 32 : 1;
+    auto fetch = [&](int tile) {
+        const int s = sample_of(tile);
+        const float* fb = feat_base(s);
+        const float* fh = fb + 8 * h * fstride;            // one per-lane base, constant offsets from it
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = 16 * q + e;                  // feature c + 8h
+                nfs[q][e] = q >= kd16 ? 0.f : (NSRC && c + 8 < F) ? fh[c * fstride] : fb[(size_t)min(c + 8 * h, F - 1) * fstride];
+            }
+        nconf = fb[(size_t)(F - 1) * fstride];
+        const float* prow = p.pts + (size_t)s * 3;
+        npx[0] = prow[0]; npx[1] = prow[1]; npx[2] = prow[2];
+    };
+    fetch(blockIdx.x * BW + wave);
+
     for (int round = 0; round < n_rounds; ++round) {                          // block-uniform trip count: every wave joins every barrier
         const int tile = round * tiles_per_round + blockIdx.x * BW + wave;
-        const int s_raw = tile * 32 + j;
-        const bool valid = s_raw < p.m;
-        const int s = valid ? s_raw : p.m - 1;
-        const float* fb;
-        int fstride;
-        if (TILED) { fb = p.feats + ((size_t)(s >> 5) * g.F * 32 + (s & 31)); fstride = 32; }
-        else { fb = p.feats + (size_t)s * g.feat_stride; fstride = 1; }
-
+        // (few scalars are carried through the trunk -- every VGPR there is spoken for: sample index, feature base
+        //  and view direction are re-derived / loaded where they are needed)
+        DIAG_STAMP(0)
         f32x16 bd[4], acc[4];
         Frag xin[8];
-
-        // ---- operands of the depth-bias net, confidence, point; element j of step q = feature 16q + 8h + j
         float fsec[4][8];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) fsec[q][e] = (q < kd16 && 16 * q + 8 * h + e < g.F) ? fb[(size_t)(16 * q + 8 * h + e) * fstride] : 0.f;
-        const float conf = fb[(size_t)(g.F - 1) * fstride];
-        const float* prow = p.pts + (size_t)s * 3;
-        const float px[3] = {prow[0], prow[1], prow[2]};
-        const size_t ray = p.dirs_per_sample ? (size_t)s : (size_t)(s / p.S);
-        const float* drow = p.dirs + ray * 3;
-        const float dv[3] = {drow[0], drow[1], drow[2]};
+            for (int e = 0; e < 8; ++e) fsec[q][e] = nfs[q][e];
+        const float px[3] = {npx[0], npx[1], npx[2]};
 
         // ---- point encoding -> fragments, kept in LDS for the skip connection
         Frag pef[KS16_PE_PTS];
@@ -325,62 +392,76 @@ __global__ void __launch_bounds__(64 * BW, 2) mlp_fwd_bf16_kernel(ucnerf_mlp_par
             }
         }
 
+        DIAG_STAMP(1)
         // ---- depth-bias net
         init_bias16(cst, SEC_BD, h, bd);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (q < kd16) { const char* buf = step_acquire(P); mfma_step(buf, lane, split8(fsec[q]), bd); }
-        const float u = 1.f - conf, omu = 1.f - u;
+            if (q < kd16) step16(P, cur, lane, split8(fsec[q]), bd);
+        const float u = 1.f - nconf;
+        DIAG_STAMP(2)
 
         // ---- layer 0
         init_bias16(cst, SEC_L0, h, acc);
 #pragma unroll
-        for (int q = 0; q < KS16_PE_PTS; ++q) { const char* buf = step_acquire(P); mfma_step(buf, lane, pef[q], acc); }
+        for (int q = 0; q < KS16_PE_PTS; ++q) step16(P, cur, lane, pef[q], acc);
+        DIAG_STAMP(3)
         to_frags(acc, xin, [&](int kt, int r, float y) { return fmaxf(y * bd[kt][r], 0.f); });
+        DIAG_STAMP(4)
 
         // ---- layers 1..4
 #pragma unroll 1
         for (int l = 1; l < 5; ++l) {
             init_bias16(cst, SEC_L0 + l, h, acc);
-            gemm16_hidden(P, lane, xin, acc);
+            gemm16_hidden(P, cur, lane, xin, acc);
             to_frags(acc, xin, [&](int kt, int r, float y) { return fmaxf(y * bd[kt][r], 0.f); });
         }
 
+        DIAG_STAMP(5)
         // ---- layer 5 on [pe | h]
         init_bias16(cst, SEC_L0 + 5, h, acc);
 #pragma unroll
-        for (int q = 0; q < KS16_PE_PTS; ++q) { const Frag f = stash[q * 64]; const char* buf = step_acquire(P); mfma_step(buf, lane, f, acc); }
-        gemm16_hidden(P, lane, xin, acc);
+        for (int q = 0; q < KS16_PE_PTS; ++q) { const Frag f = stash[q * 64]; step16(P, cur, lane, f, acc); }
+        gemm16_hidden(P, cur, lane, xin, acc);
+        DIAG_STAMP(6)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = fmaxf(acc[nt][r] * bd[nt][r], 0.f);      // h5 (fp32) stays in acc
 
         // ---- operands of the confidence-bias net; base heads meanwhile
+        const float* fb = feat_base(sample_of(tile));
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int f = 16 * q + 8 * h + e;
-                fsec[q][e] = (q < kc16 && g.f_img + f < g.F) ? fb[(size_t)(g.f_img + f) * fstride] : 0.f;
+                const int c = f_img + 16 * q + e;
+                fsec[q][e] = q >= kc16 ? 0.f : (NSRC && c + 8 < F) ? fb[(8 * h + c) * fstride] : fb[(size_t)min(c + 8 * h, F - 1) * fstride];
             }
         const f32x4 base = head4_16(hb, h, acc);
+        DIAG_STAMP(7)
 
         // ---- confidence-bias net -> bd; g = h5 * b_c -> fragments
         init_bias16(cst, SEC_BC, h, bd);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (q < kc16) { const char* buf = step_acquire(P); mfma_step(buf, lane, split8(fsec[q]), bd); }
+            if (q < kc16) step16(P, cur, lane, split8(fsec[q]), bd);
+        DIAG_STAMP(8)
         to_frags(acc, xin, [&](int kt, int r, float y) { return y * bd[kt][r]; });
+        DIAG_STAMP(9)
 
         // ---- feature_linear
         init_bias16(cst, SEC_FT, h, acc);
-        gemm16_hidden(P, lane, xin, acc);
+        gemm16_hidden(P, cur, lane, xin, acc);
         to_frags(acc, xin, [&](int, int, float y) { return y; });
+        DIAG_STAMP(10)
 
         // ---- views_linears | view_confi_linears on [feature | dir encoding], relu
         init_bias16(cst, SEC_VC, h, acc);
-        gemm16_hidden(P, lane, xin, acc);
+        const int sd = sample_of(tile);
+        const float* drow = p.dirs + (p.dirs_per_sample ? (size_t)sd : (size_t)(sd / p.S)) * 3;
+        const float dv[3] = {drow[0], drow[1], drow[2]};   // arrives under the 8 hidden steps
+        gemm16_hidden(P, cur, lane, xin, acc);
         {
             float pd[KS_PE_DIR];
             encode16<4, KS_PE_DIR>(dv, h, pd);
@@ -389,8 +470,7 @@ __global__ void __launch_bounds__(64 * BW, 2) mlp_fwd_bf16_kernel(ucnerf_mlp_par
                 float t[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t[e] = pd[8 * q + e];
-                const char* buf = step_acquire(P);
-                mfma_step(buf, lane, split8(t), acc);
+                step16(P, cur, lane, split8(t), acc);
             }
         }
 #pragma unroll
@@ -398,14 +478,20 @@ __global__ void __launch_bounds__(64 * BW, 2) mlp_fwd_bf16_kernel(ucnerf_mlp_par
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = fmaxf(acc[nt][r], 0.f);
 
+        DIAG_STAMP(11)
+        fetch(tile + tiles_per_round);                     // next tile's inputs (clamped past the end: harmless)
         // ---- adapt heads, uncertainty blend
         const f32x4 adapt = head4_16(ha, h, acc);
+        DIAG_STAMP(12)
+        const float omu = 1.f - u;
+        const int s_raw = tile * 32 + j;
         f32x4 out;
         out.x = 1.f / (1.f + expf(-(base.x * omu + adapt.x * u)));
         out.y = 1.f / (1.f + expf(-(base.y * omu + adapt.y * u)));
         out.z = 1.f / (1.f + expf(-(base.z * omu + adapt.z * u)));
         out.w = fmaxf(adapt.w * omu + base.w * u, 0.f);
-        if (h == 0 && valid) reinterpret_cast<f32x4*>(p.raw)[s_raw] = out;
+        if (h == 0 && s_raw < p.m) reinterpret_cast<f32x4*>(p.raw)[s_raw] = out;
+        DIAG_STAMP(13)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
 }
@@ -427,12 +513,16 @@ int launch_mlp_fwd_bf16(const ucnerf_mlp_params* p, hipStream_t st) {
     const int cus = device_cus();
     if (cus <= 0) return fail(UCNERF_EHIP, "mlp_fwd: no device");
     int blocks = cdiv(n_tiles, BW);
-    const int cap = p->max_blocks > 0 ? p->max_blocks : cus;
+    const int cap = p->max_blocks > 0 ? p->max_blocks : 2 * cus;
     if (blocks > cap) blocks = cap;
     BGeom g;
     g.F = B.F; g.kd16 = B.kd16; g.kc16 = B.kc16; g.f_img = 24 + 4 * B.v; g.steps = B.steps;
     g.feat_stride = p->feat_stride ? p->feat_stride : B.F;
     g.stream_bytes = (unsigned)B.total_bytes; g.feat_bytes = 0; g.const_off_bytes = (int)B.const_off_bytes;
+    g.diag = nullptr;
+#ifdef UCNERF_MLP_DIAG
+    { const char* e = getenv("UCNERF_MLP_DIAG_PTR"); g.diag = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
     static bool attr_set = false;
     const size_t smem = bf16_smem_bytes();
     if (!attr_set) {
