@@ -26,10 +26,14 @@ dbg.zero_()
 torch.cuda.synchronize()
 ops.mlp_fwd(pw, ws, pts, dirs, feats, S, feats_tiled=True)
 torch.cuda.synchronize()
+raw = dbg.cpu().view(NB * W, 16).double()
+raw = raw[raw[:, 13] > 0]
+print("tile start -> inputs arrived %.0f | sincos %.0f | split + stash %.0f" % ((raw[:, 4] - raw[:, 0]).mean(), (raw[:, 14] - raw[:, 4]).mean(), (raw[:, 1] - raw[:, 14]).mean()))
 t = dbg.cpu().view(NB * W, 16)[:, :14].double()
+t[:, 4] = t[:, 3]
 t = t[t[:, 13] > 0]
 d = t[:, 1:] - t[:, :-1]
-names = ["feat loads + PE + stash", "bd GEMM (3 st)", "L0 GEMM (4 st)", "L0 epilogue", "L1-4 (32 st + 4 epi)", "L5 GEMM (12 st)",
+names = ["feat loads + PE + stash", "bd GEMM (3 st)", "L0 GEMM (4 st)", "(unused)", "L1-4 (32 st + 4 epi)", "L5 GEMM (12 st)",
          "L5 epi + bc loads + base heads", "bc GEMM (3 st)", "h*bc -> frags", "FT GEMM (8 st) + frags", "VC GEMM (10 st) + dir PE", "relu + adapt heads",
          "blend + store"]
 st = [0, 3, 4, 0, 32, 12, 0, 3, 0, 8, 10, 0, 0]

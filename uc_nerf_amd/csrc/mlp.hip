@@ -273,16 +273,17 @@ __device__ __forceinline__ f32x4 head4(const float* hd, int h, const f32x16 (&x)
 template <int NF, int KS>
 __device__ __forceinline__ void encode(const float (&x)[3], int h, float (&pe)[KS]) {   // x: raw 3-vector
     constexpr int half = 3 * NF / 2;
+    float r[half], sn[half], cs[half];
 #pragma unroll
     for (int q = 0; q < half; ++q) {
         const int a = 2 * q + h;
         const int fr = a / 3, c = a - 3 * fr;
         const float xc = c == 0 ? x[0] : (c == 1 ? x[1] : x[2]);
-        float s, co;
-        sincos_pe(xc * (float)(1 << fr), &s, &co);
-        pe[q] = s;
-        pe[half + q] = co;
+        r[q] = xc * (float)(1 << fr);
     }
+    sincos_pe_batch(r, sn, cs);
+#pragma unroll
+    for (int q = 0; q < half; ++q) { pe[q] = sn[q]; pe[half + q] = cs[q]; }
     pe[2 * half] = h ? x[2] : x[0];
     pe[2 * half + 1] = h ? 0.f : x[1];
 #pragma unroll

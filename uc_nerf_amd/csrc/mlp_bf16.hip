@@ -6,20 +6,25 @@
 // Why: on gfx950 the fp32 MFMA executes on the vector ALU (VALU fillers cost their full issue time, a partner
 // wave's VALU starves while fp32 MFMAs stream -- scripts/micro/mfma_fillers.hip), so the fp32 kernel's ceiling is
 // the 157 TFLOP/s vector rate minus all element-wise work.  bf16 MFMAs run on the separate matrix cores at 16x
-// the rate: three of them per product are still > 5x faster, and the splitting / epilogue VALU overlaps them.
+// the rate: three of them per product are still > 5x faster, and the element-wise work can run underneath them.
 //
 // Structure (same transposed formulation as mlp.hip: lane = sample, activations live in accumulator registers):
 //   * a k16-step = 16 input features: lane-half hh supplies 8 of them as one bf16x8 fragment.  For hidden layers
 //     the fragment of step (kt, s) is accumulator registers 8s..8s+7 of row-tile kt -- the accumulator layout is
-//     again directly the next layer's operand, only re-split into (hi, lo) after the epilogue;
-//   * weights are consumed 3x faster than in the fp32 kernel, too fast to stream per wave from L2, so the waves
-//     of a block share them: the packed stream ([step][row-tile][hi|lo][lane][8 bf16], 8 KB per step) is copied
-//     into a 4-slot LDS ring by global_load_lds (two 1-KB pieces per wave per step, issued 3.5 steps ahead,
-//     counted vmcnt + one raw s_barrier per step), and every wave reads its A fragments with ds_read_b128, one
-//     row-tile pair (6 MFMAs) ahead of the MFMAs that consume them;
+//     again directly the next layer's operand, only re-split into (hi, lo) by the epilogue;
+//   * the unit of work is a HALF-STEP: one k16-step for one PAIR of 32-row output tiles = 6 MFMAs on a 4-KB block
+//     of weights [hi0 | lo0 | hi1 | lo1][lane][8 bf16].  The 128-wide layers run pair-split: all k-steps for row
+//     tiles 0,1 (phase A), then all k-steps for row tiles 2,3 (phase B).  Row tiles 0,1 are therefore final while
+//     phase B still multiplies, and their epilogue (bias-net product, relu, hi/lo split: ~45 % of a layer's MFMA
+//     time on the VALU) is issued BETWEEN phase B's MFMAs; the epilogue of tiles 2,3 runs under the next layer's
+//     phase A, whose first four k-steps only need the fragments of tiles 0,1.  Bias loads, head dot products and
+//     direction encodings are slotted into other phases the same way (sched_group_barrier pins the interleave);
+//   * weights are consumed too fast to stream per wave from L2, so the waves of a block share them: the packed
+//     stream (half-steps in consumption order) is copied into a 4-slot LDS ring (8 KB = two half-steps per slot) by
+//     global_load_lds (two 1-KB pieces per wave per slot, issued 3.5 slots ahead, counted vmcnt + one raw s_barrier
+//     per slot), and every wave reads its A fragments with ds_read_b128, one half-step ahead of the MFMAs;
 //   * a block is 4 waves = one per SIMD, and TWO blocks share a CU: the two waves of a SIMD belong to different
-//     blocks, are never coupled by a barrier and drift apart, so one wave's epilogue (bias-net product, relu,
-//     hi/lo split: ~45 % of its MFMA time, on the VALU) runs under the other wave's MFMAs.
+//     blocks, are never coupled by a barrier and drift apart, which hides what is left exposed.
 #include "common.h"
 #include "mlp_layout.h"
 #include "sincos_cw.h"
@@ -34,17 +39,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef UCNERF_BF16_EXP
+#define UCNERF_BF16_EXP 0      // timing experiments only (results are wrong): 1 no DMA wait, 2 no barrier, 4 no DMA, 64 no interleave hints
+#endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define SB0 __builtin_amdgcn_sched_barrier(0)
 
 constexpr int BW = 4;                 // waves per block (one per SIMD; two blocks per CU)
-constexpr int STEP_BYTES = 8192;      // [4 row-tiles][hi, lo][64 lanes][16 B]
-constexpr int NBUF = 4;               // LDS ring slots (k16-steps); the slot of step g is refilled with step g + NBUF
-constexpr int DMA_PER_STEP = STEP_BYTES / 1024 / BW;      // 1-KB global_load_lds pieces per wave per step
+constexpr int SLOT_BYTES = 8192;      // two half-steps: [2][hi0, lo0, hi1, lo1][64 lanes][16 B]
+constexpr int HALF_BYTES = 4096;
+constexpr int NBUF = 4;               // LDS ring slots; the slot of ring position g is refilled with position g + NBUF
+constexpr int DMA_PER_SLOT = SLOT_BYTES / 1024 / BW;      // 1-KB global_load_lds pieces per wave per slot
 constexpr int KS16_PE_PTS = 4, KS16_PE_DIR = 2, KS16_HID = 8;
 
 struct Bf16Layout {
-    int v, F, kd16, kc16, steps;
-    int sec_step[N_SEC];              // first step of each section (execution order = section order of mlp_layout.h)
+    int v, F, kd16, kc16, slots;      // slots = k16-steps per tile (two half-steps each)
     int64_t const_off_bytes, total_bytes;
 };
 
@@ -52,37 +61,38 @@ bool bf16_layout(int v, Bf16Layout* B) {
     if (v < 1 || v > 8) return false;
     B->v = v; B->F = 24 + 12 * v + 1;
     B->kd16 = (24 + 4 * v + 15) / 16; B->kc16 = (8 * v + 15) / 16;
-    const int ks[N_SEC] = {B->kd16, KS16_PE_PTS, KS16_HID, KS16_HID, KS16_HID, KS16_HID, KS16_PE_PTS + KS16_HID, B->kc16, KS16_HID,
-                           KS16_HID + KS16_PE_DIR};
-    int s = 0;
-    for (int i = 0; i < N_SEC; ++i) { B->sec_step[i] = s; s += ks[i]; }
-    B->steps = s;
-    B->const_off_bytes = (int64_t)s * STEP_BYTES;
+    B->slots = B->kd16 + KS16_PE_PTS + 4 * KS16_HID + (KS16_PE_PTS + KS16_HID) + B->kc16 + KS16_HID + (KS16_HID + KS16_PE_DIR);
+    B->const_off_bytes = (int64_t)B->slots * SLOT_BYTES;
     B->total_bytes = B->const_off_bytes + (int64_t)CONST_FLOATS * 4;
     return true;
 }
 
-// feature held by element j of lane-half hh in hidden k16-step (kt, s): accumulator register 8s + j of row-tile kt
+// feature held by element j of lane-half hh in hidden k16-step q = (kt, s): accumulator register 8s + j of row-tile kt
 __host__ __device__ inline int hid_feature16(int kt, int s, int j, int hh) { return 32 * kt + (j & 3) + 8 * (2 * s + (j >> 2)) + 4 * hh; }
 
 // ------------------------------------------------------------------------------------------------ host: pack index
 // idx16[e] for every bf16 element e of the stream: flat parameter index | (part << 30) (part 0 = hi, 1 = lo), -1 = zero.
+// Half-steps appear in the order the kernel consumes them (see the schedule in mlp_fwd_bf16_kernel):
+//   bd: step-major (q: pair 0, pair 1) | L0: pair-split | L1..L4: pair-split | L5: pair-split over [h 0..3 | pe 0..3 | h 4..7]
+//   bc: step-major | ft: pair-split | vc: pair-split over [h 0..7 | dir 0..1]
 int build_pack_index_bf16(const ucnerf_mlp_config* cfg, int32_t* idx) {
     Bf16Layout B;
     MlpLayout L;
     if (!bf16_layout(cfg->n_src, &B) || !mlp_layout(cfg->n_src, &L)) return -1;
     const int v = B.v, W = MLP_W;
-    const int64_t n16 = (int64_t)B.steps * (STEP_BYTES / 2);
+    const int64_t n16 = (int64_t)B.slots * (SLOT_BYTES / 2);
     for (int64_t i = 0; i < n16 + CONST_FLOATS; ++i) idx[i] = -1;
-    auto put_step = [&](int step, const std::vector<int64_t>& row_base, const int (&col)[2][8]) {
-        for (int nt = 0; nt < 4; ++nt)
+    int64_t hidx = 0;
+    auto put_half = [&](const std::vector<int64_t>& row_base, const int (&col)[2][8], int pair) {
+        for (int t = 0; t < 2; ++t)
             for (int part = 0; part < 2; ++part)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
                         const int c = col[lane >> 5][j];
-                        const int64_t e = ((((int64_t)step * 4 + nt) * 2 + part) * 64 + lane) * 8 + j;
-                        idx[e] = c < 0 ? -1 : (int32_t)((row_base[32 * nt + (lane & 31)] + c) | ((int64_t)part << 30));
+                        const int64_t e = (((hidx * 4 + t * 2 + part) * 64) + lane) * 8 + j;
+                        idx[e] = c < 0 ? -1 : (int32_t)((row_base[32 * (2 * pair + t) + (lane & 31)] + c) | ((int64_t)part << 30));
                     }
+        ++hidx;
     };
     auto rows = [&](int64_t base, int K) { std::vector<int64_t> rb(128); for (int n = 0; n < 128; ++n) rb[n] = base + (int64_t)n * K; return rb; };
     auto nat = [&](int q, int K, int (&col)[2][8]) { for (int hh = 0; hh < 2; ++hh) for (int j = 0; j < 8; ++j) { int f = 16 * q + 8 * hh + j; col[hh][j] = f < K ? f : -1; } };
@@ -97,21 +107,43 @@ int build_pack_index_bf16(const ucnerf_mlp_config* cfg, int32_t* idx) {
             }
     };
     int col[2][8];
-    for (int q = 0; q < B.kd16; ++q) { nat(q, 24 + 4 * v, col); put_step(B.sec_step[SEC_BD] + q, rows(L.p_bdw, 24 + 4 * v), col); }
-    for (int q = 0; q < B.kc16; ++q) { nat(q, 8 * v, col); put_step(B.sec_step[SEC_BC] + q, rows(L.p_bcw, 8 * v), col); }
-    for (int q = 0; q < KS16_PE_PTS; ++q) { pe(q, 10, 0, col); put_step(B.sec_step[SEC_L0] + q, rows(L.p_lw[0], MLP_PE_PTS), col); }
-    for (int l = 1; l < 5; ++l)
-        for (int q = 0; q < KS16_HID; ++q) { hid(q, 0, col); put_step(B.sec_step[SEC_L0 + l] + q, rows(L.p_lw[l], W), col); }
-    for (int q = 0; q < KS16_PE_PTS; ++q) { pe(q, 10, 0, col); put_step(B.sec_step[SEC_L0 + 5] + q, rows(L.p_lw[5], W + MLP_PE_PTS), col); }
-    for (int q = 0; q < KS16_HID; ++q) { hid(q, MLP_PE_PTS, col); put_step(B.sec_step[SEC_L0 + 5] + KS16_PE_PTS + q, rows(L.p_lw[5], W + MLP_PE_PTS), col); }
-    for (int q = 0; q < KS16_HID; ++q) { hid(q, 0, col); put_step(B.sec_step[SEC_FT] + q, rows(L.p_fw, W), col); }
-    {
+    {   // bd, step-major
+        const auto rb = rows(L.p_bdw, 24 + 4 * v);
+        for (int q = 0; q < B.kd16; ++q) { nat(q, 24 + 4 * v, col); put_half(rb, col, 0); put_half(rb, col, 1); }
+    }
+    {   // L0
+        const auto rb = rows(L.p_lw[0], MLP_PE_PTS);
+        for (int p = 0; p < 2; ++p) for (int q = 0; q < KS16_PE_PTS; ++q) { pe(q, 10, 0, col); put_half(rb, col, p); }
+    }
+    for (int l = 1; l < 5; ++l) {
+        const auto rb = rows(L.p_lw[l], W);
+        for (int p = 0; p < 2; ++p) for (int q = 0; q < KS16_HID; ++q) { hid(q, 0, col); put_half(rb, col, p); }
+    }
+    {   // L5 on [pe | h]: k order h 0..3, pe 0..3, h 4..7
+        const auto rb = rows(L.p_lw[5], W + MLP_PE_PTS);
+        for (int p = 0; p < 2; ++p) {
+            for (int q = 0; q < 4; ++q) { hid(q, MLP_PE_PTS, col); put_half(rb, col, p); }
+            for (int q = 0; q < KS16_PE_PTS; ++q) { pe(q, 10, 0, col); put_half(rb, col, p); }
+            for (int q = 4; q < 8; ++q) { hid(q, MLP_PE_PTS, col); put_half(rb, col, p); }
+        }
+    }
+    {   // bc, step-major
+        const auto rb = rows(L.p_bcw, 8 * v);
+        for (int q = 0; q < B.kc16; ++q) { nat(q, 8 * v, col); put_half(rb, col, 0); put_half(rb, col, 1); }
+    }
+    {   // feature_linear
+        const auto rb = rows(L.p_fw, W);
+        for (int p = 0; p < 2; ++p) for (int q = 0; q < KS16_HID; ++q) { hid(q, 0, col); put_half(rb, col, p); }
+    }
+    {   // views_linears | view_confi_linears on [feature | dir encoding]: k order h 0..7, dir 0..1
         std::vector<int64_t> rb(128);
         for (int n = 0; n < 64; ++n) { rb[n] = L.p_vw + (int64_t)n * (W + MLP_PE_DIR); rb[64 + n] = L.p_vcw + (int64_t)n * (W + MLP_PE_DIR); }
-        for (int q = 0; q < KS16_HID; ++q) { hid(q, 0, col); put_step(B.sec_step[SEC_VC] + q, rb, col); }
-        for (int q = 0; q < KS16_PE_DIR; ++q) { pe(q, 4, W, col); put_step(B.sec_step[SEC_VC] + KS16_HID + q, rb, col); }
+        for (int p = 0; p < 2; ++p) {
+            for (int q = 0; q < KS16_HID; ++q) { hid(q, 0, col); put_half(rb, col, p); }
+            for (int q = 0; q < KS16_PE_DIR; ++q) { pe(q, 4, W, col); put_half(rb, col, p); }
+        }
     }
-    return 0;
+    return hidx == 2 * (int64_t)B.slots ? 0 : -1;
 }
 
 __global__ void pack_bf16_kernel(const float* __restrict__ flat, const int32_t* __restrict__ idx, unsigned short* __restrict__ out, int64_t n) {
@@ -131,182 +163,214 @@ __global__ void pack_bf16_kernel(const float* __restrict__ flat, const int32_t* 
 // ------------------------------------------------------------------------------------------------ device helpers
 struct Frag { bf16x8 hi, lo; };
 
+// (hi, lo) split of eight activations.  hi is the TRUNCATED bf16 (top 16 bits: one v_and gives it as a float, one
+// v_perm_b32 packs two of them), lo = bf16_rne(x - hi), exact before its rounding: 5 VALU per pair of values against
+// 7 for a round-to-nearest hi.  |lo| < 2^-7 |x| (not 2^-8), so the dropped lo*lo term is 2^-16 relative.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ Frag split8(const float (&x)[8]) {
+    u32x4 hi;
     Frag f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)x[j];
-        f.hi[j] = h;
-        f.lo[j] = (__bf16)(x[j] - (float)h);
+    for (int j = 0; j < 8; j += 2) {
+        const unsigned b0 = __builtin_bit_cast(unsigned, x[j]), b1 = __builtin_bit_cast(unsigned, x[j + 1]);
+        hi[j >> 1] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+        const f32x2 h = {__builtin_bit_cast(float, b0 & 0xffff0000u), __builtin_bit_cast(float, b1 & 0xffff0000u)};
+        const f32x2 l = (f32x2){x[j], x[j + 1]} - h;
+        f.lo[j] = (__bf16)l.x;
+        f.lo[j + 1] = (__bf16)l.y;
     }
+    f.hi = __builtin_bit_cast(bf16x8, hi);
+    return f;
+}
+
+// (The constants never change, so the compiler would hoist these LDS loads out of the tile loop and then spill what it
+//  hoisted: the lane offset is laundered through an empty asm to keep every load where it is written.)
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// Results that are only needed much later would be sunk towards their use -- out of the MFMA shadow they were written
+// for, with their operands kept live meanwhile.  An empty volatile asm on the result pins the arithmetic in place.
+template <class T> __device__ __forceinline__ void pin(T& v) { asm volatile("" : "+v"(v)); }
+
+// fragment s (0/1) of an accumulator tile: MODE 0 plain, 1 times m, 2 relu(times m)   (two values per v_pk_mul_f32)
+template <int MODE>
+__device__ __forceinline__ Frag frag_of(const f32x16& a, const f32x16& m, int s) {
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        f32x2 v = {a[8 * s + j], a[8 * s + j + 1]};
+        if (MODE >= 1) v = v * (f32x2){m[8 * s + j], m[8 * s + j + 1]};
+        t[j] = MODE == 2 ? fmaxf(v.x, 0.f) : v.x;
+        t[j + 1] = MODE == 2 ? fmaxf(v.y, 0.f) : v.y;
+    }
+    Frag f = split8(t);
+    pin(f.hi); pin(f.lo);
     return f;
 }
 
 struct BGeom {
-    int F, kd16, kc16, f_img, steps, feat_stride;
-    unsigned stream_bytes, feat_bytes;
+    int F, kd16, kc16, f_img, slots, feat_stride;
     int const_off_bytes;
     unsigned long long* diag;          // diagnostic builds only (UCNERF_MLP_DIAG): per-wave phase clocks of one tile
 };
 
-// A fragments of one row-tile pair of a step
+// A fragments of one half-step (row-tile pair)
 struct AF { bf16x8 h0, l0, h1, l1; };
 
 // block-wide weight pipeline state (all values wave-uniform)
 struct Pipe {
-    const char* __restrict__ gsrc;    // this lane's source byte within step 0: stream + wave*2048 + lane*16
+    const char* __restrict__ gsrc;    // this lane's source byte within slot 0: stream + wave*2048 + lane*16
     char* ring;                        // LDS ring base
     unsigned ring_lds;                 // ... as an LDS byte address
-    const char* buf;                   // slot of the step being multiplied
+    const char* buf;                   // slot being multiplied
     int wave;
-    int gstep;                         // running step counter (never reset: ring slot = gstep & (NBUF-1))
-    int next_src;                      // step (mod steps) of the next DMA to issue
-    int steps;
+    int gpos;                          // running ring position (never reset: ring slot = gpos & (NBUF-1))
+    int next_src;                      // stream slot (mod slots) of the next DMA to issue
+    int slots;
 };
 
 // The copy is issued from inline asm on purpose: the compiler models a global_load_lds as a FLAT access that may
 // touch both memories and from then on degrades every counted wait of the kernel to vmcnt(0) / lgkmcnt(0), which
 // serialises the fragment prefetch below.  All hazards of the ring are handled explicitly in advance().
-__device__ __forceinline__ void issue_dma(Pipe& P, int slot_step) {
-    const char* src = P.gsrc + (size_t)P.next_src * STEP_BYTES;
-    const unsigned dst = P.ring_lds + (slot_step & (NBUF - 1)) * STEP_BYTES + P.wave * (DMA_PER_STEP * 1024);
+__device__ __forceinline__ void issue_dma(Pipe& P, int pos) {
+    const char* src = P.gsrc + (size_t)P.next_src * SLOT_BYTES;
+    const unsigned dst = P.ring_lds + (pos & (NBUF - 1)) * SLOT_BYTES + P.wave * (DMA_PER_SLOT * 1024);
 #pragma unroll
-    for (int i = 0; i < DMA_PER_STEP; ++i)
+    for (int i = 0; i < DMA_PER_SLOT; ++i)
         asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off offset:%2" ::"v"(src), "s"(dst), "n"(i * 1024) : "memory", "m0");   // the offset moves both addresses
-    P.next_src = P.next_src + 1 == P.steps ? 0 : P.next_src + 1;
+    P.next_src = P.next_src + 1 == P.slots ? 0 : P.next_src + 1;
 }
 
-__device__ __forceinline__ AF read_pair(const char* buf, int lane, int pair) {
-    const bf16x8* a = reinterpret_cast<const bf16x8*>(buf) + lane;
+__device__ __forceinline__ AF read_half(const char* buf, int lane, int half) {
+    const bf16x8* a = reinterpret_cast<const bf16x8*>(buf + half * HALF_BYTES) + lane;
     AF f;
-    f.h0 = a[(pair * 4 + 0) * 64]; f.l0 = a[(pair * 4 + 1) * 64];
-    f.h1 = a[(pair * 4 + 2) * 64]; f.l1 = a[(pair * 4 + 3) * 64];
+    f.h0 = a[0]; f.l0 = a[64]; f.h1 = a[128]; f.l1 = a[192];
     return f;
 }
 
-// acc += A_hi*B_hi + A_hi*B_lo + A_lo*B_hi for two row-tiles, interleaved so that dependent MFMAs are 2 apart
-__device__ __forceinline__ void mfma6(const AF& a, const Frag& b, f32x16& c0, f32x16& c1) {
-    c0 = MFMA16(a.h0, b.hi, c0); c1 = MFMA16(a.h1, b.hi, c1);
-    c0 = MFMA16(a.h0, b.lo, c0); c1 = MFMA16(a.h1, b.lo, c1);
-    c0 = MFMA16(a.l0, b.hi, c0); c1 = MFMA16(a.l1, b.hi, c1);
-}
-
-// Waits until the next step has landed for the whole block, refills the slot just read and moves on to it.
-// On entry every ds_read of the current slot has returned (lgkmcnt(0)), so after the barrier no wave still reads it.
-// vmcnt: the DMAs younger than the awaited step are those of the two steps after it.
-#ifndef UCNERF_BF16_EXP
-#define UCNERF_BF16_EXP 0      // timing experiments only (results are wrong): 1 no DMA wait, 2 no barrier, 4 no DMA
-#endif
+// Waits until the next slot has landed for the whole block, refills the slot just read and moves on to it.
+// The lgkmcnt(0) retires every ds_read of the current slot, so after the barrier no wave still reads it.
+// vmcnt: the DMAs younger than the awaited slot are those of the two slots after it.
 __device__ __forceinline__ void advance(Pipe& P) {
 #if !(UCNERF_BF16_EXP & 1)
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * DMA_PER_STEP) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * DMA_PER_SLOT) : "memory");
 #endif
 #if !(UCNERF_BF16_EXP & 2)
     __builtin_amdgcn_s_barrier();
 #endif
 #if !(UCNERF_BF16_EXP & 4)
-    issue_dma(P, P.gstep);                                  // step gstep + NBUF into the slot of step gstep
+    issue_dma(P, P.gpos);                                   // position gpos + NBUF into the slot of position gpos
 #endif
-    ++P.gstep;
-    P.buf = P.ring + (P.gstep & (NBUF - 1)) * STEP_BYTES;
+    ++P.gpos;
+    P.buf = P.ring + (P.gpos & (NBUF - 1)) * SLOT_BYTES;
 }
 
-// One k16-step for the four row-tiles.  `cur` = fragments of (this step, pair 0) on entry, of (next step, pair 0) on exit.
-__device__ __forceinline__ void step16(Pipe& P, AF& cur, int lane, const Frag& b, f32x16 (&acc)[4]) {
-    const AF n1 = read_pair(P.buf, lane, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma6(cur, b, acc[0], acc[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    advance(P);
-    cur = read_pair(P.buf, lane, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma6(n1, b, acc[2], acc[3]);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-__device__ __forceinline__ void init_bias16(const float* cst, int sec, int h, f32x16 (&acc)[4]) {
-    const f32x4* b = reinterpret_cast<const f32x4*>(cst + sec * 128 + h * 64);
+// scheduling hint for a half-step region: one MFMA, then up to `V` VALU, six times (LDS reads stay with their users)
+template <int V>
+__device__ __forceinline__ void interleave_hint() {
+#if !(UCNERF_BF16_EXP & 64)
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int i = 0; i < 6; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
+    }
+#endif
+}
+
+// One half-step: (c0, c1) += A_hi*B_hi + A_hi*B_lo + A_lo*B_hi for one row-tile pair, with `fill()` -- element-wise work
+// that does not depend on these MFMAs -- issued between them.  ODD = second half-step of its ring slot (the next
+// fragments then come from the next slot).  `cur` holds this half-step's A fragments on entry, the next one's on exit.
+template <class F>
+__device__ __forceinline__ void half_step(const int ODD, Pipe& P, AF& cur, int lane, const Frag& b, f32x16& c0, f32x16& c1, F&& fill) {
+    if (ODD) advance(P);                                   // (a constant once the caller's loop is unrolled)
+    const AF nxt = read_half(P.buf, lane, ODD ? 0 : 1);
+    SB0;
+    c0 = MFMA16(cur.h0, b.hi, c0); c0 = MFMA16(cur.h0, b.lo, c0); c0 = MFMA16(cur.l0, b.hi, c0);   // (one accumulation chain
+    c1 = MFMA16(cur.h1, b.hi, c1); c1 = MFMA16(cur.h1, b.lo, c1); c1 = MFMA16(cur.l1, b.hi, c1);   //  runs at full rate)
+    fill();
+    interleave_hint<7>();
+    SB0;
+    cur = nxt;
+}
+#define HS(ODD, B, C0, C1, ...) half_step((ODD), P, cur, lane, (B), (C0), (C1), [&]() { __VA_ARGS__; })
+
+// bias block of section `sec` -> accumulators of one row-tile pair
+__device__ __forceinline__ void init_bias_pair(const float* cst, int sec, int h, int pair, f32x16 (&acc)[4]) {
+    const f32x4* b = reinterpret_cast<const f32x4*>(cst + sec * 128 + opaque(h * 64)) + pair * 8;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 v = b[nt * 4 + q];
-            acc[nt][4 * q] = v.x; acc[nt][4 * q + 1] = v.y; acc[nt][4 * q + 2] = v.z; acc[nt][4 * q + 3] = v.w;
+            const f32x4 v = b[t * 4 + q];
+            acc[2 * pair + t][4 * q] = v.x; acc[2 * pair + t][4 * q + 1] = v.y; acc[2 * pair + t][4 * q + 2] = v.z; acc[2 * pair + t][4 * q + 3] = v.w;
         }
 }
 
-// Four head outputs from a 128-wide activation set (accumulator layout): VALU, two outputs per v_pk_fma_f32.  The
-// weight rows come from LDS in batches of 8 reads so that their latency is paid once per batch, not once per read.
-__device__ __forceinline__ f32x4 head4_16(const float* hd, int h, const f32x16 (&x)[4]) {
-    const f32x4* w = reinterpret_cast<const f32x4*>(hd) + h * 64;
-    f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+// head partial sums over registers [r0, r0 + n) of row-tile nt (two outputs per v_pk_fma_f32); weights [h][nt][r][4] in LDS
+struct HeadAcc { f32x2 s01, s23; };
+template <class Map>
+__device__ __forceinline__ void head_part(HeadAcc& a, const float* hd, int h, const f32x16& x, int nt, int r0, int n, Map map) {
+    const f32x4* w = reinterpret_cast<const f32x4*>(hd) + opaque(h * 64) + nt * 16;
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        f32x4 wv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) wv[i] = w[b * 8 + i];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float xv = x[b >> 1][(b & 1) * 8 + i];
+    for (int i = 0; i < 16; ++i)
+        if (i >= r0 && i < r0 + n) {
+            const f32x4 wv = w[i];
+            const float xv = map(x[i]);
             const f32x2 xx = {xv, xv};
-            s01 = __builtin_elementwise_fma(xx, (f32x2){wv[i].x, wv[i].y}, s01);
-            s23 = __builtin_elementwise_fma(xx, (f32x2){wv[i].z, wv[i].w}, s23);
+            a.s01 = __builtin_elementwise_fma(xx, (f32x2){wv.x, wv.y}, a.s01);
+            a.s23 = __builtin_elementwise_fma(xx, (f32x2){wv.z, wv.w}, a.s23);
         }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    f32x4 s = {s01.x, s01.y, s23.x, s23.y};
+    pin(a.s01); pin(a.s23);
+}
+__device__ __forceinline__ f32x4 head_finish(const HeadAcc& a, const float* hd) {
+    // x + x[lane ^ 32] with v_permlane32_swap: swapping the upper half of one copy with the lower half of another
+    // leaves both addends of every lane in the two results (no lane id, no LDS)
+    // (inline asm: the builtin's second result is dropped by the compiler when both operands are one value; the
+    //  s_nop covers the VALU-write -> permlane-read hazard the compiler would otherwise pad itself)
+    auto fold = [](float v) {
+        float a = v, b = v;
+        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        return a + b;
+    };
+#ifdef UCNERF_BF16_SHFL
+    f32x4 s = {a.s01.x, a.s01.y, a.s23.x, a.s23.y};
     s.x += __shfl_xor(s.x, 32); s.y += __shfl_xor(s.y, 32); s.z += __shfl_xor(s.z, 32); s.w += __shfl_xor(s.w, 32);
+#else
+    f32x4 s = {fold(a.s01.x), fold(a.s01.y), fold(a.s23.x), fold(a.s23.y)};
+#endif
     const f32x4 b = *reinterpret_cast<const f32x4*>(hd + 512);
     s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
     return s;
 }
 
+// encoding argument q of this lane-half: a = 2q + h, frequency a / 3, coordinate a % 3.  Both candidates are formed
+// with compile-time (frequency, coordinate) and selected by h: written with a / 3 and a % 3 of the lane-dependent a,
+// the compiler keeps ~40 per-lane multipliers and selectors alive across the whole tile loop (and spills them).
+__device__ __forceinline__ float encode_arg(const float (&x)[3], int h, int q) {
+    const int a0 = 2 * q, a1 = 2 * q + 1;
+    const float r0 = x[a0 % 3] * (float)(1 << (a0 / 3)), r1 = x[a1 % 3] * (float)(1 << (a1 / 3));
+    return h ? r1 : r0;
+}
+
 template <int NF, int KS>
 __device__ __forceinline__ void encode16(const float (&x)[3], int h, float (&pe)[KS]) {
     constexpr int half = 3 * NF / 2;
+    float r[half], sn[half], cs[half];
 #pragma unroll
-    for (int q = 0; q < half; ++q) {
-        const int a = 2 * q + h;
-        const int fr = a / 3, c = a - 3 * fr;
-        const float xc = c == 0 ? x[0] : (c == 1 ? x[1] : x[2]);
-        float s, co;
-        sincos_pe(xc * (float)(1 << fr), &s, &co);
-        pe[q] = s;
-        pe[half + q] = co;
-    }
+    for (int q = 0; q < half; ++q) r[q] = encode_arg(x, h, q);
+    sincos_pe_batch(r, sn, cs);
+#pragma unroll
+    for (int q = 0; q < half; ++q) { pe[q] = sn[q]; pe[half + q] = cs[q]; }
     pe[2 * half] = h ? x[2] : x[0];
     pe[2 * half + 1] = h ? 0.f : x[1];
 #pragma unroll
     for (int q = 2 * half + 2; q < KS; ++q) pe[q] = 0.f;
 }
 
-// hidden layer: 8 k16-steps on the fragments of a 128-wide activation set
-__device__ __forceinline__ void gemm16_hidden(Pipe& P, AF& cur, int lane, const Frag (&x)[8], f32x16 (&acc)[4]) {
-#pragma unroll
-    for (int q = 0; q < KS16_HID; ++q) step16(P, cur, lane, x[q], acc);
-}
-
-// fragments of an accumulator-layout fp32 activation set (optionally with an element-wise map applied first)
-template <class Map>
-__device__ __forceinline__ void to_frags(const f32x16 (&v)[4], Frag (&x)[8], Map map) {
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = map(kt, 8 * s + j, v[kt][8 * s + j]);
-            x[2 * kt + s] = split8(t);
-        }
-}
-
 template <bool TILED, int NSRC>
 __global__ void __launch_bounds__(64 * BW, 2) mlp_fwd_bf16_kernel(ucnerf_mlp_params p, BGeom g, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // ONE shared object: [ring][constants][pe stash]
     char* ring = smem;
-    float* cst = reinterpret_cast<float*>(smem + NBUF * STEP_BYTES);
-    Frag* stash_all = reinterpret_cast<Frag*>(smem + NBUF * STEP_BYTES + ((CONST_FLOATS * 4 + 15) & ~15));
+    float* cst = reinterpret_cast<float*>(smem + NBUF * SLOT_BYTES);
+    Frag* stash_all = reinterpret_cast<Frag*>(smem + NBUF * SLOT_BYTES + ((CONST_FLOATS * 4 + 15) & ~15));
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     constexpr int KD_S = (24 + 4 * NSRC + 15) / 16, KC_S = (8 * NSRC + 15) / 16;
@@ -322,26 +386,24 @@ __global__ void __launch_bounds__(64 * BW, 2) mlp_fwd_bf16_kernel(ucnerf_mlp_par
     const float* hb = cst + N_SEC * 128;
     const float* ha = hb + 516;
     Frag* stash = stash_all + (size_t)wave * (KS16_PE_PTS * 64) + lane;        // step q at stash[q * 64]
+    float* ustash = reinterpret_cast<float*>(stash_all + (size_t)BW * KS16_PE_PTS * 64) + wave * 64 + lane;   // per-sample scalar parked across the tile
 
     Pipe P;
-    P.gsrc = ws + wave * (DMA_PER_STEP * 1024) + lane * 16;
-    P.ring = ring; P.ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring; P.buf = ring; P.wave = wave; P.gstep = 0; P.next_src = 0; P.steps = g.steps;
+    P.gsrc = ws + wave * (DMA_PER_SLOT * 1024) + lane * 16;
+    P.ring = ring; P.ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring; P.buf = ring;
+    P.wave = wave; P.gpos = 0; P.next_src = 0; P.slots = g.slots;
 #pragma unroll
     for (int i = 0; i < NBUF; ++i) issue_dma(P, i);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * DMA_PER_STEP) : "memory");     // step 0 has landed ...
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * DMA_PER_SLOT) : "memory");     // slot 0 has landed ...
     __builtin_amdgcn_s_barrier();                                                        // ... for every wave
-    AF cur = read_pair(P.buf, lane, 0);
+    AF cur = read_half(P.buf, lane, 0);
 
     const int tiles_per_round = gridDim.x * BW;
     const int n_rounds = (n_tiles + tiles_per_round - 1) / tiles_per_round;
-#ifdef UCNERF_MLP_DIAG
-#define DIAG_STAMP(K) { __builtin_amdgcn_sched_barrier(0); if (g.diag && lane == 0 && round == 5) g.diag[(size_t)(blockIdx.x * BW + wave) * 16 + (K)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
-#else
-#define DIAG_STAMP(K)
-#endif
-    // Inputs of a tile are fetched one tile ahead (under the previous tile's head / blend arithmetic, when few registers are live), so their latency never
-    // shows: operands of the depth-bias net (element e of step q = feature 16q + 8h + e; columns past a section's
-    // width meet zero weights, so their index is only clamped into the row -- no branch), confidence, point, direction.
+
+    // Inputs of a tile are fetched one tile ahead (under the previous tile's head / blend arithmetic, when few registers
+    // are live): operands of the depth-bias net (element e of step q = feature 16q + 8h + e; columns past a section's
+    // width meet zero weights, so their index is only clamped into the row -- no branch), confidence, point.
     float nfs[4][8], nconf, npx[3];
     auto sample_of = [&](int tile) { const int s_raw = tile * 32 + j; return s_raw < p.m ? s_raw : p.m - 1; };
     auto feat_base = [&](int s) { return TILED ? p.feats + ((size_t)(s >> 5) * F * 32 + (s & 31)) : p.feats + (size_t)s * g.feat_stride; };
@@ -363,127 +425,243 @@ __global__ void __launch_bounds__(64 * BW, 2) mlp_fwd_bf16_kernel(ucnerf_mlp_par
     };
     fetch(blockIdx.x * BW + wave);
 
+#ifdef UCNERF_MLP_DIAG
+#define DIAG_STAMP(K) { SB0; if (g.diag && lane == 0 && round == 5) g.diag[(size_t)(blockIdx.x * BW + wave) * 16 + (K)] = __builtin_readcyclecounter(); SB0; }
+#else
+#define DIAG_STAMP(K)
+#endif
     for (int round = 0; round < n_rounds; ++round) {                          // block-uniform trip count: every wave joins every barrier
         const int tile = round * tiles_per_round + blockIdx.x * BW + wave;
         // (few scalars are carried through the trunk -- every VGPR there is spoken for: sample index, feature base
         //  and view direction are re-derived / loaded where they are needed)
         DIAG_STAMP(0)
         f32x16 bd[4], acc[4];
-        Frag xin[8];
+        Frag X[8], Y[8];
         float fsec[4][8];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int e = 0; e < 8; ++e) fsec[q][e] = nfs[q][e];
-        const float px[3] = {npx[0], npx[1], npx[2]};
+        *ustash = 1.f - nconf;                             // u: only needed again at the very end of the tile
+#ifdef UCNERF_MLP_DIAG
+        pin(npx[2]);
+        DIAG_STAMP(4)
+#endif
 
-        // ---- point encoding -> fragments, kept in LDS for the skip connection
-        Frag pef[KS16_PE_PTS];
+        // ---- point encoding -> fragments in LDS (layer 0 and the skip connection read them from there)
         {
+            const float px[3] = {npx[0], npx[1], npx[2]};
             float pe[KS_PE_PTS];
             encode16<10, KS_PE_PTS>(px, h, pe);
+#ifdef UCNERF_MLP_DIAG
+            pin(pe[0]); pin(pe[14]); pin(pe[29]);
+            DIAG_STAMP(14)
+#endif
 #pragma unroll
             for (int q = 0; q < KS16_PE_PTS; ++q) {
                 float t[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t[e] = pe[8 * q + e];
-                pef[q] = split8(t);
-                stash[q * 64] = pef[q];
+                stash[q * 64] = split8(t);
             }
         }
-
         DIAG_STAMP(1)
-        // ---- depth-bias net
-        init_bias16(cst, SEC_BD, h, bd);
+
+        // ---- depth-bias net (step-major): bd = W_bd feats + b
+        init_bias_pair(cst, SEC_BD, h, 0, bd);
+        init_bias_pair(cst, SEC_BD, h, 1, bd);
+        {
+            Frag fc = split8(fsec[0]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (q < kd16) step16(P, cur, lane, split8(fsec[q]), bd);
-        const float u = 1.f - nconf;
+            for (int q = 0; q < 4; ++q)
+                if (q < kd16) {
+                    Frag fn;
+                    HS(0, fc, bd[0], bd[1], if (q + 1 < 4 && q + 1 < kd16) { fn = split8(fsec[q + 1]); pin(fn.hi); pin(fn.lo); });
+                    HS(1, fc, bd[2], bd[3], if (q + 1 >= kd16) init_bias_pair(cst, SEC_L0, h, 0, acc));
+                    if (q + 1 < 4 && q + 1 < kd16) fc = fn;
+                }
+        }
         DIAG_STAMP(2)
 
-        // ---- layer 0
-        init_bias16(cst, SEC_L0, h, acc);
+        // ---- layer 0 (pair-split) on the point encoding
+        {
+            Frag pf = stash[0];
 #pragma unroll
-        for (int q = 0; q < KS16_PE_PTS; ++q) step16(P, cur, lane, pef[q], acc);
-        DIAG_STAMP(3)
-        to_frags(acc, xin, [&](int kt, int r, float y) { return fmaxf(y * bd[kt][r], 0.f); });
-        DIAG_STAMP(4)
-
-        // ---- layers 1..4
-#pragma unroll 1
-        for (int l = 1; l < 5; ++l) {
-            init_bias16(cst, SEC_L0 + l, h, acc);
-            gemm16_hidden(P, cur, lane, xin, acc);
-            to_frags(acc, xin, [&](int kt, int r, float y) { return fmaxf(y * bd[kt][r], 0.f); });
+            for (int q = 0; q < 4; ++q) {                                     // phase A -> acc[0], acc[1]
+                const Frag b = pf;
+                HS(q & 1, b, acc[0], acc[1], pf = stash[((q + 1) & 3) * 64]; if (q == 2) init_bias_pair(cst, SEC_L0, h, 1, acc));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                                     // phase B -> acc[2], acc[3]; epilogue of tiles 0,1 underneath
+                const Frag b = pf;
+                HS(q & 1, b, acc[2], acc[3],
+                   if (q < 3) pf = stash[(q + 1) * 64];
+                   X[q] = frag_of<2>(acc[q >> 1], bd[q >> 1], q & 1);
+                   if (q == 3) init_bias_pair(cst, SEC_L0 + 1, h, 0, acc));
+            }
         }
+        DIAG_STAMP(3)
 
-        DIAG_STAMP(5)
-        // ---- layer 5 on [pe | h]
-        init_bias16(cst, SEC_L0 + 5, h, acc);
+        // ---- layers 1..4 (pair-split, fragments ping-pong between X and Y).  In: in[0..3] + acc[2], acc[3] of the
+        // previous layer (their epilogue -> in[4..7] runs under phase A); out: out[0..3] + acc[2], acc[3].
+        auto layer128 = [&](Frag (&in)[8], Frag (&out)[8], int sec) {
 #pragma unroll
-        for (int q = 0; q < KS16_PE_PTS; ++q) { const Frag f = stash[q * 64]; step16(P, cur, lane, f, acc); }
-        gemm16_hidden(P, cur, lane, xin, acc);
+            for (int q = 0; q < 8; ++q)
+                HS(q & 1, in[q], acc[0], acc[1],
+                   if (q < 4) in[4 + q] = frag_of<2>(acc[2 + (q >> 1)], bd[2 + (q >> 1)], q & 1);
+                   if (q == 4) init_bias_pair(cst, sec, h, 1, acc));
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                HS(q & 1, in[q], acc[2], acc[3],
+                   if (!(q & 1)) out[q >> 1] = frag_of<2>(acc[q >> 2], bd[q >> 2], (q >> 1) & 1);
+                   if (q == 7) init_bias_pair(cst, sec + 1, h, 0, acc));
+        };
+#pragma unroll 1
+        for (int l = 1; l < 5; l += 2) {
+            layer128(X, Y, SEC_L0 + l);
+            layer128(Y, X, SEC_L0 + l + 1);
+        }
+        DIAG_STAMP(5)
+
+        // ---- layer 5 on [h | pe] in k order h 0..3, pe 0..3, h 4..7; its output h5 = relu(. * bd) stays fp32 in acc
+        const float* fb = feat_base(sample_of(tile));
+        {
+            Frag pf;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {                                    // phase A
+                const Frag b = q < 4 ? X[q] : (q < 8 ? pf : X[q - 4]);
+                HS(q & 1, b, acc[0], acc[1],
+                   if (q < 4) X[4 + q] = frag_of<2>(acc[2 + (q >> 1)], bd[2 + (q >> 1)], q & 1);
+                   if (q >= 3 && q < 7) pf = stash[(q - 3) * 64];
+                   if (q == 4) init_bias_pair(cst, SEC_L0 + 5, h, 1, acc));
+            }
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {                                    // phase B; h5 of tiles 0,1 underneath
+                const Frag b = q < 4 ? X[q] : (q < 8 ? pf : X[q - 4]);
+                HS(q & 1, b, acc[2], acc[3],
+                   if (q >= 3 && q < 7) pf = stash[(q - 3) * 64];
+                   if (q < 2) {
+                       _Pragma("unroll")
+                       for (int r = 0; r < 16; ++r) acc[q][r] = fmaxf(acc[q][r] * bd[q][r], 0.f);
+                       pin(acc[q]);
+                   }
+                   if (q == 8) {                                              // operands of the confidence-bias net
+                       _Pragma("unroll")
+                       for (int qq = 0; qq < 4; ++qq)
+                           _Pragma("unroll")
+                           for (int e = 0; e < 8; ++e) {
+                               const int c = f_img + 16 * qq + e;
+                               fsec[qq][e] = qq >= kc16 ? 0.f : (NSRC && c + 8 < F) ? fb[(8 * h + c) * fstride] : fb[(size_t)min(c + 8 * h, F - 1) * fstride];
+                           }
+                   });
+            }
+        }
         DIAG_STAMP(6)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 2; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = fmaxf(acc[nt][r] * bd[nt][r], 0.f);      // h5 (fp32) stays in acc
-
-        // ---- operands of the confidence-bias net; base heads meanwhile
-        const float* fb = feat_base(sample_of(tile));
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = f_img + 16 * q + e;
-                fsec[q][e] = q >= kc16 ? 0.f : (NSRC && c + 8 < F) ? fb[(8 * h + c) * fstride] : fb[(size_t)min(c + 8 * h, F - 1) * fstride];
-            }
-        const f32x4 base = head4_16(hb, h, acc);
+            for (int r = 0; r < 16; ++r) acc[nt][r] = fmaxf(acc[nt][r] * bd[nt][r], 0.f);
         DIAG_STAMP(7)
 
-        // ---- confidence-bias net -> bd; g = h5 * b_c -> fragments
-        init_bias16(cst, SEC_BC, h, bd);
+        // ---- confidence-bias net (step-major) -> bd; base heads of row tiles 0,1 underneath
+        HeadAcc hbase = {{0.f, 0.f}, {0.f, 0.f}};
+        auto ident = [](float v) { return v; };
+        init_bias_pair(cst, SEC_BC, h, 0, bd);
+        init_bias_pair(cst, SEC_BC, h, 1, bd);
+        {
+            Frag fc = split8(fsec[0]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (q < kc16) step16(P, cur, lane, split8(fsec[q]), bd);
+            for (int q = 0; q < 4; ++q)
+                if (q < kc16) {
+                    Frag fn;
+                    HS(0, fc, bd[0], bd[1],
+                       if (q + 1 < 4 && q + 1 < kc16) { fn = split8(fsec[q + 1]); pin(fn.hi); pin(fn.lo); }
+                       if (q < 2) head_part(hbase, hb, h, acc[q], q, 0, 8, ident));
+                    HS(1, fc, bd[2], bd[3],
+                       if (q < 2) head_part(hbase, hb, h, acc[q], q, 8, 8, ident));
+                    if (q + 1 < 4 && q + 1 < kc16) fc = fn;
+                }
+        }
+        if (kc16 < 2) head_part(hbase, hb, h, acc[1], 1, 0, 16, ident);        // (one-step bias net: the rest is exposed)
         DIAG_STAMP(8)
-        to_frags(acc, xin, [&](int kt, int r, float y) { return y * bd[kt][r]; });
+        // g = h5 * b_c: fragments of row tiles 0,1 now, of 2,3 under feature_linear's phase A
+#pragma unroll
+        for (int q = 0; q < 4; ++q) X[q] = frag_of<1>(acc[q >> 1], bd[q >> 1], q & 1);
+        init_bias_pair(cst, SEC_FT, h, 0, acc);
         DIAG_STAMP(9)
 
-        // ---- feature_linear
-        init_bias16(cst, SEC_FT, h, acc);
-        gemm16_hidden(P, cur, lane, xin, acc);
-        to_frags(acc, xin, [&](int, int, float y) { return y; });
+        // ---- feature_linear (pair-split); base heads of row tiles 2,3 and the view direction underneath
+        float dv[3];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            HS(q & 1, X[q], acc[0], acc[1],
+               if (q < 4) X[4 + q] = frag_of<1>(acc[2 + (q >> 1)], bd[2 + (q >> 1)], q & 1);
+               if (q >= 4) head_part(hbase, hb, h, acc[2 + ((q - 4) >> 1)], 2 + ((q - 4) >> 1), (q & 1) * 8, 8, ident);
+               if (q == 7) init_bias_pair(cst, SEC_FT, h, 1, acc);
+               if (q == 3) {
+                   const int sd = sample_of(tile);
+                   int ray = sd;
+                   if (!p.dirs_per_sample) { int S = p.S; asm volatile("" : "+s"(S)); ray = sd / S; }   // (opaque: no reciprocal hoisted into a loop-long VGPR)
+                   const float* drow = p.dirs + (size_t)ray * 3;
+                   dv[0] = drow[0]; dv[1] = drow[1]; dv[2] = drow[2];
+               });
+        const f32x4 base = head_finish(hbase, hb);
+        float pd[KS_PE_DIR];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            HS(q & 1, X[q], acc[2], acc[3],
+               if (!(q & 1)) Y[q >> 1] = frag_of<0>(acc[q >> 2], acc[q >> 2], (q >> 1) & 1);
+               if (q & 1) {                                                    // direction encoding: 6 arguments, two per odd half-step
+                   if (q < 7) {                                                // (branch-free here; out-of-range arguments are redone below)
+                       sincos_pe_fast(encode_arg(dv, h, q - 1), &pd[q - 1], &pd[6 + q - 1]);
+                       sincos_pe_fast(encode_arg(dv, h, q), &pd[q], &pd[6 + q]);
+                       pin(pd[q - 1]); pin(pd[q]); pin(pd[5 + q]); pin(pd[6 + q]);
+                   } else init_bias_pair(cst, SEC_VC, h, 0, acc);
+               });
+        if (__any(fabsf(encode_arg(dv, h, 5)) > SINCOS_FAST_MAX || fabsf(encode_arg(dv, h, 4)) > SINCOS_FAST_MAX)) {   // the two largest multiples
+            float r[6], sn[6], cs[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) r[q] = encode_arg(dv, h, q);
+            sincos_pe_batch(r, sn, cs);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { pd[q] = sn[q]; pd[6 + q] = cs[q]; }
+        }
+        pd[12] = h ? dv[2] : dv[0];
+        pd[13] = h ? 0.f : dv[1];
+        pd[14] = 0.f; pd[15] = 0.f;
         DIAG_STAMP(10)
 
-        // ---- views_linears | view_confi_linears on [feature | dir encoding], relu
-        init_bias16(cst, SEC_VC, h, acc);
-        const int sd = sample_of(tile);
-        const float* drow = p.dirs + (p.dirs_per_sample ? (size_t)sd : (size_t)(sd / p.S)) * 3;
-        const float dv[3] = {drow[0], drow[1], drow[2]};   // arrives under the 8 hidden steps
-        gemm16_hidden(P, cur, lane, xin, acc);
-        {
-            float pd[KS_PE_DIR];
-            encode16<4, KS_PE_DIR>(dv, h, pd);
+        // ---- views_linears | view_confi_linears on [feature | dir encoding] (pair-split), relu
+        Frag D[2];
 #pragma unroll
-            for (int q = 0; q < KS16_PE_DIR; ++q) {
-                float t[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t[e] = pd[8 * q + e];
-                step16(P, cur, lane, split8(t), acc);
-            }
+        for (int q = 0; q < 10; ++q) {
+            const Frag b = q < 8 ? Y[q] : D[q - 8];
+            HS(q & 1, b, acc[0], acc[1],
+               if (q < 4) Y[4 + q] = frag_of<0>(acc[2 + (q >> 1)], acc[2 + (q >> 1)], q & 1);
+               if (q == 4) init_bias_pair(cst, SEC_VC, h, 1, acc);
+               if (q == 5 || q == 6) {
+                   float t[8];
+                   _Pragma("unroll")
+                   for (int e = 0; e < 8; ++e) t[e] = pd[8 * (q - 5) + e];
+                   D[q - 5] = split8(t); pin(D[q - 5].hi); pin(D[q - 5].lo);
+               });
         }
+        HeadAcc hadapt = {{0.f, 0.f}, {0.f, 0.f}};
+        auto relu = [](float v) { return fmaxf(v, 0.f); };
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = fmaxf(acc[nt][r], 0.f);
-
+        for (int q = 0; q < 10; ++q) {
+            const Frag b = q < 8 ? Y[q] : D[q - 8];
+            HS(q & 1, b, acc[2], acc[3],
+               if (q < 4) head_part(hadapt, ha, h, acc[q >> 1], q >> 1, (q & 1) * 8, 8, relu));
+        }
         DIAG_STAMP(11)
         fetch(tile + tiles_per_round);                     // next tile's inputs (clamped past the end: harmless)
-        // ---- adapt heads, uncertainty blend
-        const f32x4 adapt = head4_16(ha, h, acc);
+        // ---- adapt heads of row tiles 2,3, uncertainty blend
+        head_part(hadapt, ha, h, acc[2], 2, 0, 16, relu);
+        head_part(hadapt, ha, h, acc[3], 3, 0, 16, relu);
+        const f32x4 adapt = head_finish(hadapt, ha);
         DIAG_STAMP(12)
-        const float omu = 1.f - u;
+        const float u = *ustash, omu = 1.f - u;
         const int s_raw = tile * 32 + j;
         f32x4 out;
         out.x = 1.f / (1.f + expf(-(base.x * omu + adapt.x * u)));
@@ -497,7 +675,7 @@ __global__ void __launch_bounds__(64 * BW, 2) mlp_fwd_bf16_kernel(ucnerf_mlp_par
 }
 
 constexpr size_t bf16_smem_bytes() {
-    return (size_t)NBUF * STEP_BYTES + ((CONST_FLOATS * 4 + 15) & ~15) + (size_t)BW * KS16_PE_PTS * 64 * sizeof(Frag);
+    return (size_t)NBUF * SLOT_BYTES + ((CONST_FLOATS * 4 + 15) & ~15) + (size_t)BW * KS16_PE_PTS * 64 * sizeof(Frag) + (size_t)BW * 64 * sizeof(float);
 }
 
 int launch_mlp_fwd_bf16(const ucnerf_mlp_params* p, hipStream_t st) {
@@ -516,9 +694,9 @@ int launch_mlp_fwd_bf16(const ucnerf_mlp_params* p, hipStream_t st) {
     const int cap = p->max_blocks > 0 ? p->max_blocks : 2 * cus;
     if (blocks > cap) blocks = cap;
     BGeom g;
-    g.F = B.F; g.kd16 = B.kd16; g.kc16 = B.kc16; g.f_img = 24 + 4 * B.v; g.steps = B.steps;
+    g.F = B.F; g.kd16 = B.kd16; g.kc16 = B.kc16; g.f_img = 24 + 4 * B.v; g.slots = B.slots;
     g.feat_stride = p->feat_stride ? p->feat_stride : B.F;
-    g.stream_bytes = (unsigned)B.total_bytes; g.feat_bytes = 0; g.const_off_bytes = (int)B.const_off_bytes;
+    g.const_off_bytes = (int)B.const_off_bytes;
     g.diag = nullptr;
 #ifdef UCNERF_MLP_DIAG
     { const char* e = getenv("UCNERF_MLP_DIAG_PTR"); g.diag = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
@@ -546,7 +724,7 @@ int launch_mlp_fwd_bf16(const ucnerf_mlp_params* p, hipStream_t st) {
 int64_t bf16_index_count(const ucnerf_mlp_config* cfg) {
     Bf16Layout B;
     if (!bf16_layout(cfg->n_src, &B)) return -1;
-    return (int64_t)B.steps * (STEP_BYTES / 2) + CONST_FLOATS;
+    return (int64_t)B.slots * (SLOT_BYTES / 2) + CONST_FLOATS;
 }
 
 int64_t bf16_stream_floats(const ucnerf_mlp_config* cfg) {
@@ -563,7 +741,7 @@ __global__ void pack_f32_kernel(const float* __restrict__ flat, const int32_t* _
 int launch_pack_bf16(const ucnerf_mlp_config* cfg, const float* flat, const int32_t* idx, float* out, hipStream_t st) {
     Bf16Layout B;
     UCNERF_REQUIRE(bf16_layout(cfg->n_src, &B), "mlp_pack: n_src %d outside 1..8", cfg->n_src);
-    const int64_t n16 = (int64_t)B.steps * (STEP_BYTES / 2);
+    const int64_t n16 = (int64_t)B.slots * (SLOT_BYTES / 2);
     hipLaunchKernelGGL(pack_bf16_kernel, dim3(cdiv(n16, 256)), dim3(256), 0, st, flat, idx, reinterpret_cast<unsigned short*>(out), n16);
     hipLaunchKernelGGL(pack_f32_kernel, dim3(cdiv(CONST_FLOATS, 256)), dim3(256), 0, st, flat, idx + n16,
                        reinterpret_cast<float*>(reinterpret_cast<char*>(out) + B.const_off_bytes), CONST_FLOATS);

@@ -10,11 +10,10 @@
 
 namespace ucnerf {
 
-__device__ __forceinline__ void sincos_pe(float r, float* s_out, float* c_out) {
-    if (fabsf(r) > 65536.0f) {          // rare: wave-divergent slow path
-        sincosf(r, s_out, c_out);
-        return;
-    }
+constexpr float SINCOS_FAST_MAX = 65536.0f;
+
+// branch-free part: valid for |r| <= SINCOS_FAST_MAX
+__device__ __forceinline__ void sincos_pe_fast(float r, float* s_out, float* c_out) {
     const float qf = rintf(r * 0.63661977236758134f);            // r * 2/pi
     float y = fmaf(qf, -1.57079637050628662109375f, r);          // pi/2 split in three floats
     y = fmaf(qf, 4.37113900018624283e-8f, y);
@@ -33,6 +32,42 @@ __device__ __forceinline__ void sincos_pe(float r, float* s_out, float* c_out) {
     c = ((q + 1) & 2) ? -c : c;
     *s_out = s;
     *c_out = c;
+}
+
+__device__ __forceinline__ void sincos_pe(float r, float* s_out, float* c_out) {
+    if (fabsf(r) > SINCOS_FAST_MAX) {          // rare: wave-divergent slow path
+        sincosf(r, s_out, c_out);
+        return;
+    }
+    sincos_pe_fast(r, s_out, c_out);
+}
+
+// N arguments at once: all of them branch-free (so that the N dependent chains interleave), then ONE wave-uniform
+// check; only if some lane holds an argument outside the fast range are those redone with OCML.
+template <int N>
+__device__ __forceinline__ void sincos_pe_batch(const float (&r)[N], float (&s)[N], float (&c)[N]) {
+    bool big = false;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        sincos_pe_fast(r[i], &s[i], &c[i]);
+        big = big || fabsf(r[i]) > SINCOS_FAST_MAX;
+    }
+    if (__any(big)) {
+        // cold: ONE instance of OCML's sincosf in a rolled loop (the arrays live in registers, so element i is
+        // picked and put back with selects) -- the kernels using this are instruction-cache bound otherwise
+#pragma unroll 1
+        for (int i = 0; i < N; ++i) {
+            float ri = r[0];
+#pragma unroll
+            for (int k = 1; k < N; ++k) ri = k == i ? r[k] : ri;
+            if (fabsf(ri) > SINCOS_FAST_MAX) {
+                float ss, cc;
+                sincosf(ri, &ss, &cc);
+#pragma unroll
+                for (int k = 0; k < N; ++k) { s[k] = k == i ? ss : s[k]; c[k] = k == i ? cc : c[k]; }
+            }
+        }
+    }
 }
 
 }  // namespace ucnerf
