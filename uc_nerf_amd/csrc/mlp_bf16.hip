@@ -366,7 +366,10 @@ __device__ __forceinline__ void encode16(const float (&x)[3], int h, float (&pe)
 }
 
 template <bool TILED, int NSRC>
-__global__ void __launch_bounds__(64 * BW, 2) mlp_fwd_bf16_kernel(ucnerf_mlp_params p, BGeom g, int n_tiles) {
+#ifndef UCNERF_BF16_WPS
+#define UCNERF_BF16_WPS 2      // waves per SIMD (= blocks per CU): 2 -> 256 VGPRs per wave, 1 -> 512
+#endif
+__global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(ucnerf_mlp_params p, BGeom g, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // ONE shared object: [ring][constants][pe stash]
     char* ring = smem;
     float* cst = reinterpret_cast<float*>(smem + NBUF * SLOT_BYTES);
@@ -691,7 +694,7 @@ int launch_mlp_fwd_bf16(const ucnerf_mlp_params* p, hipStream_t st) {
     const int cus = device_cus();
     if (cus <= 0) return fail(UCNERF_EHIP, "mlp_fwd: no device");
     int blocks = cdiv(n_tiles, BW);
-    const int cap = p->max_blocks > 0 ? p->max_blocks : 2 * cus;
+    const int cap = p->max_blocks > 0 ? p->max_blocks : UCNERF_BF16_WPS * cus;
     if (blocks > cap) blocks = cap;
     BGeom g;
     g.F = B.F; g.kd16 = B.kd16; g.kc16 = B.kc16; g.f_img = 24 + 4 * B.v; g.slots = B.slots;

@@ -33,6 +33,10 @@ class CoarseFineRenderer:
         self.pass_ = ops.RenderPass(self.src, self.pw, self.wstream, scene["c2w"][:3, 3].to(dev), w2c_ref,
                                     scene["intrinsics"][0], w2c_ref, scene["near"], scene["far"], white_bkgd, max_blocks)
         self.u_det = torch.linspace(0., 1., n_fine, device=dev)
+        # camera matrices and depth range travel BY VALUE in the ABI structs: keep host copies so that a render call
+        # never reads device memory back (a read-back would drain the stream once per batch)
+        self.K_host, self.c2w_host = scene["K"].detach().cpu(), scene["c2w"].detach().cpu()
+        self.near_host, self.far_host = float(scene["near"]), float(scene["far"])
 
     def set_params(self, flat_params):
         self.wstream.copy_(self.pw.pack(flat_params))
@@ -44,10 +48,10 @@ class CoarseFineRenderer:
         sc = self.scene
         if repack:
             self.pass_.repack_sources()
-        rays_d, _, _ = ops.ray_gen(sc["K"], sc["c2w"], xs=xs, ys=ys)
+        rays_d, _, _ = ops.ray_gen(self.K_host, self.c2w_host, xs=xs, ys=ys)
         n = rays_d.shape[0]
-        z_c, _ = ops.sample_stratified(None, self.n_coarse, perturb=perturb, noise=noise, n=n, near=sc["near"],
-                                       far=sc["far"], device=self.dev)
+        z_c, _ = ops.sample_stratified(None, self.n_coarse, perturb=perturb, noise=noise, n=n, near=self.near_host,
+                                       far=self.far_host, device=self.dev)
         ev = [(a.h, b.h) for a, b in events] if events else (None, None)
         coarse = self.pass_(rays_d, z_c, want=("weights",), events=ev[0])
         hs = ops.sample_pdf(None, coarse["weights"], self.u_det if u is None else u, z_merge=z_c, want_inds=False,
