@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     const float* hb = cst + N_SEC * 128;
     const float* ha = hb + 516;
     Frag* stash = stash_all + (size_t)wave * (KS16_PE_PTS * 64) + lane;        // step q at stash[q * 64]
-    float* ustash = reinterpret_cast<float*>(stash_all + (size_t)BW * KS16_PE_PTS * 64) + wave * 64 + lane;   // per-sample scalar parked across the tile
+    float* ustash_w = reinterpret_cast<float*>(stash_all + (size_t)BW * KS16_PE_PTS * 64) + wave * 64;          // per-sample scalar parked across the tile
 
     Pipe P;
     P.gsrc = ws + wave * (DMA_PER_SLOT * 1024) + lane * 16;
@@ -408,13 +408,14 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     // are live): operands of the depth-bias net (element e of step q = feature 16q + 8h + e; columns past a section's
     // width meet zero weights, so their index is only clamped into the row -- no branch), confidence, point.
     float nfs[4][8], nconf, npx[3];
-    auto sample_of = [&](int tile) { const int s_raw = tile * 32 + j; return s_raw < p.m ? s_raw : p.m - 1; };
+    // (j and the parked-scalar address are re-derived from `lane` at each use: as loop-long values they get spilled)
+    auto sample_of = [&](int tile) { const int s_raw = tile * 32 + (opaque(lane) & 31); return s_raw < p.m ? s_raw : p.m - 1; };
     auto feat_base = [&](int s) { return TILED ? p.feats + ((size_t)(s >> 5) * F * 32 + (s & 31)) : p.feats + (size_t)s * g.feat_stride; };
     constexpr int fstride = TILED ? 32 : 1;
     auto fetch = [&](int tile) {
         const int s = sample_of(tile);
         const float* fb = feat_base(s);
-        const float* fh = fb + 8 * h * fstride;            // one per-lane base, constant offsets from it
+        const float* fh = fb + 8 * opaque(h) * fstride;    // one per-lane base, constant offsets from it (re-derived: not a loop-long value)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -445,7 +446,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int e = 0; e < 8; ++e) fsec[q][e] = nfs[q][e];
-        *ustash = 1.f - nconf;                             // u: only needed again at the very end of the tile
+        ustash_w[opaque(lane)] = 1.f - nconf;                             // u: only needed again at the very end of the tile
 #ifdef UCNERF_MLP_DIAG
         pin(npx[2]);
         DIAG_STAMP(4)
@@ -527,7 +528,13 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         DIAG_STAMP(5)
 
         // ---- layer 5 on [h | pe] in k order h 0..3, pe 0..3, h 4..7; its output h5 = relu(. * bd) stays fp32 in acc
-        const float* fb = feat_base(sample_of(tile));
+        // One batch of plain loads per tile (confidence-net operands + view direction, issued under phase B below):
+        // a compiler-counted wait cannot see the weight DMAs and so drains them -- once here instead of per load site.
+        int s_here = sample_of(tile);
+        asm volatile("" : "+v"(s_here));                    // (re-derive the row pointer instead of carrying 64 bits through the trunk)
+        const float* fb = feat_base(s_here);
+        const float* fhb = fb + 8 * opaque(h) * fstride;
+        float dv[3];
         {
             Frag pf;
 #pragma unroll
@@ -554,8 +561,12 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                            _Pragma("unroll")
                            for (int e = 0; e < 8; ++e) {
                                const int c = f_img + 16 * qq + e;
-                               fsec[qq][e] = qq >= kc16 ? 0.f : (NSRC && c + 8 < F) ? fb[(8 * h + c) * fstride] : fb[(size_t)min(c + 8 * h, F - 1) * fstride];
+                               fsec[qq][e] = qq >= kc16 ? 0.f : (NSRC && c + 8 < F) ? fhb[c * fstride] : fb[(size_t)min(c + 8 * h, F - 1) * fstride];
                            }
+                       int ray = s_here;
+                       if (!p.dirs_per_sample) { int S = p.S; asm volatile("" : "+s"(S)); ray = s_here / S; }   // (opaque: no reciprocal hoisted into a loop-long VGPR)
+                       const float* drow = p.dirs + (size_t)ray * 3;
+                       dv[0] = drow[0]; dv[1] = drow[1]; dv[2] = drow[2];
                    });
             }
         }
@@ -593,21 +604,14 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         init_bias_pair(cst, SEC_FT, h, 0, acc);
         DIAG_STAMP(9)
 
-        // ---- feature_linear (pair-split); base heads of row tiles 2,3 and the view direction underneath
-        float dv[3];
+        // ---- feature_linear (pair-split); base heads of row tiles 2,3 underneath
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             HS(q & 1, X[q], acc[0], acc[1],
                if (q < 4) X[4 + q] = frag_of<1>(acc[2 + (q >> 1)], bd[2 + (q >> 1)], q & 1);
                if (q >= 4) head_part(hbase, hb, h, acc[2 + ((q - 4) >> 1)], 2 + ((q - 4) >> 1), (q & 1) * 8, 8, ident);
                if (q == 7) init_bias_pair(cst, SEC_FT, h, 1, acc);
-               if (q == 3) {
-                   const int sd = sample_of(tile);
-                   int ray = sd;
-                   if (!p.dirs_per_sample) { int S = p.S; asm volatile("" : "+s"(S)); ray = sd / S; }   // (opaque: no reciprocal hoisted into a loop-long VGPR)
-                   const float* drow = p.dirs + (size_t)ray * 3;
-                   dv[0] = drow[0]; dv[1] = drow[1]; dv[2] = drow[2];
-               });
+               );
         const f32x4 base = head_finish(hbase, hb);
         float pd[KS_PE_DIR];
 #pragma unroll
@@ -664,8 +668,8 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         head_part(hadapt, ha, h, acc[3], 3, 0, 16, relu);
         const f32x4 adapt = head_finish(hadapt, ha);
         DIAG_STAMP(12)
-        const float u = *ustash, omu = 1.f - u;
-        const int s_raw = tile * 32 + j;
+        const float u = ustash_w[opaque(lane)], omu = 1.f - u;
+        const int s_raw = tile * 32 + (opaque(lane) & 31);
         f32x4 out;
         out.x = 1.f / (1.f + expf(-(base.x * omu + adapt.x * u)));
         out.y = 1.f / (1.f + expf(-(base.y * omu + adapt.y * u)));
