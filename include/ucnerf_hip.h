@@ -318,8 +318,23 @@ typedef struct {
     int64_t* inds;         /* [n,M] out or NULL */
     float* cdf;            /* [n,L] out or NULL */
     float* z_sorted;       /* [n,n_merge+M] out: sort(cat(samples, z_merge)), or NULL */
+    int32_t* merge_rank;   /* [n,M+n_merge] out or NULL (needs z_sorted): position in z_sorted of element i of
+                              cat(samples, z_merge) -- the permutation of that sort, for ucnerf_merge_rows */
 } ucnerf_sample_pdf_params;
 int ucnerf_sample_pdf(const ucnerf_sample_pdf_params* p, void* stream);
+
+/* Applies the permutation of a sorted merge to per-sample rows: out[r][rank[r][i]] = cat(a[r], b[r])[i].
+ * Lets the fine pass of the hierarchical renderer (data/ray_utils.py:199-224) evaluate the network on the NEW depths
+ * only and take the coarse depths' outputs from the coarse pass: the merged rows are bit-identical to re-evaluating
+ * all of them, because a sample's network output depends on nothing but that sample. */
+typedef struct {
+    int32_t n, na, nb, width;  /* rows per ray in a / b, floats per row (1..8) */
+    const float* a;            /* [n,na,width] rows of the first na elements of the concatenation */
+    const float* b;            /* [n,nb,width] */
+    const int32_t* rank;       /* [n,na+nb] */
+    float* out;                /* [n,na+nb,width] */
+} ucnerf_merge_rows_params;
+int ucnerf_merge_rows(const ucnerf_merge_rows_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a10  one fused render pass -- network/renderer.py:215-255 (rendering) with the projection of

@@ -7,6 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 dev = torch.device("cuda:0")
 W, NB = 4, 512
+MB = int(os.environ.get("DIAG_MAX_BLOCKS", "0"))     # 256 = one wave per SIMD (solo phase times)
 dbg = torch.zeros(NB * W * 16, dtype=torch.int64, device=dev)
 os.environ["UCNERF_MLP_DIAG_PTR"] = str(dbg.data_ptr())
 from uc_nerf_amd import ops  # noqa: E402
@@ -20,11 +21,11 @@ g = torch.Generator().manual_seed(0)
 pts = torch.rand(m, 3, generator=g).to(dev)
 dirs = torch.randn(m, 3, generator=g).to(dev)
 feats = torch.randn(((m + 31) // 32) * 32 * F, generator=g).to(dev)
-ops.mlp_fwd(pw, ws, pts, dirs, feats, S, feats_tiled=True)
+ops.mlp_fwd(pw, ws, pts, dirs, feats, S, feats_tiled=True, max_blocks=MB)
 torch.cuda.synchronize()
 dbg.zero_()
 torch.cuda.synchronize()
-ops.mlp_fwd(pw, ws, pts, dirs, feats, S, feats_tiled=True)
+ops.mlp_fwd(pw, ws, pts, dirs, feats, S, feats_tiled=True, max_blocks=MB)
 torch.cuda.synchronize()
 raw = dbg.cpu().view(NB * W, 16).double()
 raw = raw[raw[:, 13] > 0]

@@ -171,3 +171,22 @@ def test_bf16x3_pipeline_meets_the_1e4_parity_bar(sd_v7):
     assert (err < 1e-4).float().mean() > 0.97      # free-running: a flipped searchsorted bin moves single samples
     mse = torch.mean((o16["rgb"] - o32["rgb"]) ** 2).item()
     assert mse < 1e-6                               # > 60 dB PSNR against the f32 render (flipped bins dominate)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_reusing_the_coarse_evaluations_in_the_fine_pass_is_bit_identical(precision):
+    """reuse_coarse: network on the 128 new depths only + permutation of the merge == re-evaluating all 192."""
+    from uc_nerf_amd.pipeline import CoarseFineRenderer, flat_params_of
+    from uc_nerf_amd.synthetic import init_ucnerf_state_dict, make_scene, random_pixels
+    scene = make_scene(seed=2, H=64, W=80, small_volumes=True)
+    sd = init_ucnerf_state_dict(seed=2, sigma_scale=0.05, sigma_bias=0.05)
+    xs, ys = random_pixels(777, 64, 80, seed=5)
+    r = CoarseFineRenderer(to_dev(scene), flat_params_of(sd).to(DEV), 64, 128, precision=precision)
+    noise = torch.rand(777, 64, generator=torch.Generator().manual_seed(1)).to(DEV)
+    for kw in (dict(), dict(perturb=1.0, noise=noise, u=torch.rand(777, 128, generator=torch.Generator().manual_seed(2)).to(DEV))):
+        full = r.render(xs.to(DEV), ys.to(DEV), **kw)
+        fast = r.render(xs.to(DEV), ys.to(DEV), reuse_coarse=True, **kw)
+        assert torch.equal(full["z_fine"], fast["z_fine"])
+        for k in ("rgb", "depth", "acc", "weights", "var"):
+            assert torch.equal(full[k], fast[k]), k

@@ -92,7 +92,11 @@ class SamplePdfParams(C.Structure):
     _fields_ = [("n", i32), ("n_bins", i32), ("n_samples", i32), ("u_stride", i32), ("n_merge", i32), ("from_coarse", i32),
                 ("bins", vp),
                 ("weights", vp), ("u", vp), ("z_merge", vp), ("samples", vp), ("inds", vp), ("cdf", vp),
-                ("z_sorted", vp)]
+                ("z_sorted", vp), ("merge_rank", vp)]
+
+
+class MergeRowsParams(C.Structure):
+    _fields_ = [("n", i32), ("na", i32), ("nb", i32), ("width", i32), ("a", vp), ("b", vp), ("rank", vp), ("out", vp)]
 
 
 class RenderParams(C.Structure):
@@ -119,6 +123,7 @@ STRUCTS = {
     "ucnerf_mlp_params": MlpParams, "ucnerf_mlp_bwd_params": MlpBwdParams, "ucnerf_composite_params": CompositeParams,
     "ucnerf_composite_bwd_params": CompositeBwdParams, "ucnerf_sample_pdf_params": SamplePdfParams,
     "ucnerf_render_params": RenderParams, "ucnerf_render_bwd_params": RenderBwdParams,
+    "ucnerf_merge_rows_params": MergeRowsParams,
 }
 
 # every symbol include/ucnerf_hip.h declares: name -> (restype, argtypes)
@@ -153,6 +158,7 @@ SYMBOLS = {
     "ucnerf_composite_fwd": (C.c_int, [_P, _P]),
     "ucnerf_composite_bwd": (C.c_int, [_P, _P]),
     "ucnerf_sample_pdf": (C.c_int, [_P, _P]),
+    "ucnerf_merge_rows": (C.c_int, [_P, _P]),
     "ucnerf_render_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "ucnerf_render_fused_fwd": (C.c_int, [_P, _P]),
     "ucnerf_gather_repack_floats": (C.c_int64, [_P]),

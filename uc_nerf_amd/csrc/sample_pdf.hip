@@ -164,6 +164,7 @@ __global__ void __launch_bounds__(64) sample_pdf_kernel(ucnerf_sample_pdf_params
                     r = (i - M) + lo;
                 }
                 dst[r] = x;
+                if (p.merge_rank) p.merge_rank[(size_t)ray * tot_n + i] = r;
             }
         } else {
             for (int i0 = 0; i0 < tot_n; i0 += 256) {            // 4 elements per lane per sweep
@@ -182,10 +183,24 @@ __global__ void __launch_bounds__(64) sample_pdf_kernel(ucnerf_sample_pdf_params
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (id[e] < tot_n) dst[rank[e]] = x[e];
+                    if (id[e] < tot_n) {
+                        dst[rank[e]] = x[e];
+                        if (p.merge_rank) p.merge_rank[(size_t)ray * tot_n + id[e]] = rank[e];
+                    }
             }
         }
     }
+}
+
+__global__ void merge_rows_kernel(ucnerf_merge_rows_params p) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int tot = p.na + p.nb;
+    if (i >= (long long)p.n * tot) return;
+    const int ray = (int)(i / tot), e = (int)(i - (long long)ray * tot);
+    const float* src = e < p.na ? p.a + ((size_t)ray * p.na + e) * p.width : p.b + ((size_t)ray * p.nb + (e - p.na)) * p.width;
+    float* dst = p.out + ((size_t)ray * tot + p.rank[i]) * p.width;
+    if (p.width == 4) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+    else for (int k = 0; k < p.width; ++k) dst[k] = src[k];
 }
 
 }  // namespace ucnerf
@@ -206,7 +221,19 @@ extern "C" int ucnerf_sample_pdf(const ucnerf_sample_pdf_params* p, void* stream
     UCNERF_REQUIRE(p->n_merge >= 0 && p->n_merge + p->n_samples <= PDF_MAX_SORT, "sample_pdf: n_merge + n_samples > %d", PDF_MAX_SORT);
     UCNERF_REQUIRE(!p->z_sorted || p->n_merge == 0 || p->z_merge, "sample_pdf: z_sorted with n_merge > 0 needs z_merge");
     UCNERF_REQUIRE(p->samples || p->inds || p->cdf || p->z_sorted, "sample_pdf: no outputs requested");
+    UCNERF_REQUIRE(!p->merge_rank || p->z_sorted, "sample_pdf: merge_rank needs z_sorted");
     if (p->n <= 0) return UCNERF_OK;
     hipLaunchKernelGGL(sample_pdf_kernel, dim3(p->n), dim3(64), 0, (hipStream_t)stream, *p);
     return check_launch("sample_pdf");
+}
+
+extern "C" int ucnerf_merge_rows(const ucnerf_merge_rows_params* p, void* stream) {
+    UCNERF_REQUIRE(p, "merge_rows: null params");
+    if (p->n <= 0 || p->na + p->nb <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->rank && p->out && (p->a || p->na == 0) && (p->b || p->nb == 0), "merge_rows: null pointer");
+    UCNERF_REQUIRE(p->width >= 1 && p->width <= 8, "merge_rows: width = %d outside 1..8", p->width);
+    UCNERF_REQUIRE(p->width != 4 || ((((uintptr_t)p->a | (uintptr_t)p->b | (uintptr_t)p->out) & 15) == 0), "merge_rows: 4-float rows must be 16-byte aligned");
+    const long long tot = (long long)p->n * (p->na + p->nb);
+    hipLaunchKernelGGL(merge_rows_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, *p);
+    return check_launch("merge_rows");
 }

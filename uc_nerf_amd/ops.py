@@ -554,9 +554,11 @@ def composite(raw, z, white_bkgd=False):
 
 
 # ------------------------------------------------------------------------------------------------ a8
-def sample_pdf(bins, weights, u, z_merge=None, want_inds=True, want_cdf=False, from_coarse=False):
+def sample_pdf(bins, weights, u, z_merge=None, want_inds=True, want_cdf=False, from_coarse=False, want_rank=False):
     """Returns dict(samples[n,M], inds[n,M] int64, cdf[n,L] (opt), z_sorted[n,M+n_merge] (when z_merge given)).
-    from_coarse: bins=None, weights = coarse weights [n,S], z_merge = coarse depths [n,S] (mid-point bins, w[1:-1])."""
+    from_coarse: bins=None, weights = coarse weights [n,S], z_merge = coarse depths [n,S] (mid-point bins, w[1:-1]).
+    want_rank (with z_merge): merge_rank[n,M+n_merge] int32, the position in z_sorted of each element of
+    cat(samples, z_merge) -- feed it to merge_rows."""
     weights, u = _f32(weights, "weights"), _f32(u, "u")
     if from_coarse:
         n, Lb = weights.shape[0], weights.shape[1] - 1
@@ -586,9 +588,28 @@ def sample_pdf(bins, weights, u, z_merge=None, want_inds=True, want_cdf=False, f
         z_merge = _f32(z_merge, "z_merge")
         p.n_merge = z_merge.shape[1]
         out["z_sorted"] = torch.empty(n, M + p.n_merge, device=dev)
+        if want_rank:
+            out["merge_rank"] = torch.empty(n, M + p.n_merge, dtype=torch.int32, device=dev)
+            p.merge_rank = _ptr(out["merge_rank"])
     p.bins, p.weights, p.u, p.z_merge = _ptr(None if from_coarse else bins), _ptr(weights), _ptr(u), _ptr(z_merge)
     p.samples, p.inds, p.cdf, p.z_sorted = _ptr(out["samples"]), _ptr(out.get("inds")), _ptr(out.get("cdf")), _ptr(out.get("z_sorted"))
     _launch("ucnerf_sample_pdf", p, dev)
+    return out
+
+
+def merge_rows(a, b, rank):
+    """out[r, rank[r, i]] = cat(a[r], b[r])[i] for rows a [n,na,w], b [n,nb,w] and rank [n,na+nb] (int32)."""
+    a, b = _f32(a, "a"), _f32(b, "b")
+    n, na, w = a.shape
+    nb = b.shape[1]
+    if rank.dtype != torch.int32 or tuple(rank.shape) != (n, na + nb) or b.shape[0] != n or b.shape[2] != w:
+        raise RuntimeError("uc_nerf_amd.merge_rows: shape / dtype mismatch")
+    rank = rank.contiguous()
+    out = torch.empty(n, na + nb, w, device=a.device)
+    p = L.MergeRowsParams()
+    p.n, p.na, p.nb, p.width = n, na, nb, w
+    p.a, p.b, p.rank, p.out = _ptr(a), _ptr(b), _ptr(rank), _ptr(out)
+    _launch("ucnerf_merge_rows", p, a.device)
     return out
 
 

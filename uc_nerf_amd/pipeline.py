@@ -23,7 +23,7 @@ class CoarseFineRenderer:
                  precision="f32"):
         dev = scene["confidence"].device
         self.scene, self.dev = scene, dev
-        self.n_coarse, self.n_fine = n_coarse, n_fine
+        self.n_coarse, self.n_fine, self.white_bkgd = n_coarse, n_fine, white_bkgd
         self.src = ops.GatherSources(scene["vols"], scene["confidence"], scene["imgs"], scene["img_feat"],
                                      scene["w2cs"][1:], scene["intrinsics"][1:])
         self.precision = precision          # "f32": exact fp32 MFMA; "bf16x3": split-bf16 matrix-core path (inference)
@@ -41,10 +41,14 @@ class CoarseFineRenderer:
     def set_params(self, flat_params):
         self.wstream.copy_(self.pw.pack(flat_params))
 
-    def render(self, xs, ys, perturb=0.0, noise=None, u=None, events=None, repack=True):
+    def render(self, xs, ys, perturb=0.0, noise=None, u=None, events=None, repack=True, reuse_coarse=False):
         """xs, ys: pixel coordinates [n] (device, float32).  events: optional [(start, stop), (start, stop)]
         Event pairs recorded around the coarse and the fine MLP launches.  repack: rebuild the channel-last source
-        copies first (needed whenever volumes / images / features changed since the last call)."""
+        copies first (needed whenever volumes / images / features changed since the last call).
+        reuse_coarse: the fine pass evaluates the network on the n_fine NEW depths only and takes the n_coarse coarse
+        depths' outputs from the coarse pass (a sample's output depends on nothing but that sample, so the merged
+        rows -- and everything composited from them -- are bit-identical to re-evaluating all n_coarse + n_fine, which is
+        what the reference and the default do): one third less network and gather work in the fine pass."""
         sc = self.scene
         if repack:
             self.pass_.repack_sources()
@@ -53,9 +57,14 @@ class CoarseFineRenderer:
         z_c, _ = ops.sample_stratified(None, self.n_coarse, perturb=perturb, noise=noise, n=n, near=self.near_host,
                                        far=self.far_host, device=self.dev)
         ev = [(a.h, b.h) for a, b in events] if events else (None, None)
-        coarse = self.pass_(rays_d, z_c, want=("weights",), events=ev[0])
+        coarse = self.pass_(rays_d, z_c, want=("weights",), events=ev[0], keep=("raw",) if reuse_coarse else ())
         hs = ops.sample_pdf(None, coarse["weights"], self.u_det if u is None else u, z_merge=z_c, want_inds=False,
-                            from_coarse=True)
-        out = self.pass_(rays_d, hs["z_sorted"], want=("acc", "weights", "var"), events=ev[1])
+                            from_coarse=True, want_rank=reuse_coarse)
+        if reuse_coarse:
+            new = self.pass_(rays_d, hs["samples"], want=(), events=ev[1], keep=("raw",))
+            raw = ops.merge_rows(new["raw"], coarse["raw"], hs["merge_rank"])      # cat(samples, z_coarse) order
+            out = ops.composite_fwd(raw, hs["z_sorted"], 0, self.white_bkgd)
+        else:
+            out = self.pass_(rays_d, hs["z_sorted"], want=("acc", "weights", "var"), events=ev[1])
         out.update(z_coarse=z_c, z_fine=hs["z_sorted"], z_samples=hs["samples"], coarse=coarse, rays_d=rays_d)
         return out
