@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--fine", type=int, default=128)
     ap.add_argument("--cpu-rays", type=int, default=512, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--max-blocks", type=int, default=0)
+    ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (no per-kernel HIP events)")
     ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3",
                     help="MLP arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product, fp32 accumulate)")
     args = ap.parse_args()
@@ -107,6 +108,19 @@ def main():
     for _ in range(args.warmup):
         out = renderer.render(xs, ys, perturb=1.0, noise=noise)
     events = [[(ops.Event(), ops.Event()), (ops.Event(), ops.Event())] for _ in range(args.steps)]
+    graph_ms = None
+    if args.graph:                       # extra measurement: the same K steps as replays of one captured HIP graph
+        g = renderer.capture(args.rays, perturb=1.0)
+        for _ in range(args.warmup):
+            og = g(xs, ys, noise)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            og = g(xs, ys, noise)
+        barrier()
+        graph_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        ref = renderer.render(xs, ys, perturb=1.0, noise=noise)
+        assert torch.equal(og["rgb"], ref["rgb"]) and torch.equal(og["depth"], ref["depth"])
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -172,6 +186,7 @@ def main():
                        "precision": args.precision},
             "roofline": roof,
             "mlp_share_of_step": mlp_ms / (dt * 1e3),
+            **({"hip_graph_ms_per_step": graph_ms} if graph_ms is not None else {}),
             "reuse_coarse": {"value": args.rays * world * args.steps / dt2, "unit": "rays/s", "ms_per_step": dt2 / args.steps * 1e3,
                              "note": "NOT the headline: fine pass evaluates only the 128 new depths and re-uses the coarse pass's "
                                      "outputs for the 64 coarse ones; renders verified bit-identical in this run"},

@@ -429,3 +429,21 @@ def test_mlp_bf16x3_matches_fp64_within_split_precision(n_src, m, S, sd_v7):
     tiled = ft.view(mt // 32, 32, F).permute(0, 2, 1).contiguous().reshape(-1)
     raw_t = ops().mlp_fwd(pw, ws, dev(pts), dev(dirs), dev(tiled), S=S, feats_tiled=True, max_blocks=2)
     assert torch.equal(raw_t.cpu().double(), raw)
+
+
+def test_merge_rows_applies_the_sort_permutation_and_handles_empty_input():
+    gen = torch.Generator().manual_seed(11)
+    n, na, nb = 5, 7, 4
+    za, zb = torch.rand(n, na, generator=gen), torch.rand(n, nb, generator=gen)
+    z = torch.cat([za, zb], -1)
+    order = torch.argsort(z, -1)
+    rank = torch.empty_like(order)
+    rank.scatter_(1, order, torch.arange(na + nb).expand(n, -1))
+    a, b = torch.rand(n, na, 4, generator=gen), torch.rand(n, nb, 4, generator=gen)
+    out = ops().merge_rows(dev(a), dev(b), dev(rank.int()))
+    want = torch.gather(torch.cat([a, b], 1), 1, order[..., None].expand(-1, -1, 4))
+    assert torch.equal(out.cpu(), want)
+    out3 = ops().merge_rows(dev(a[..., :3].contiguous()), dev(b[..., :3].contiguous()), dev(rank.int()))
+    assert torch.equal(out3.cpu(), want[..., :3])
+    empty = ops().merge_rows(dev(a[:0]), dev(b[:0]), dev(rank[:0].int()))
+    assert empty.shape == (0, na + nb, 4)

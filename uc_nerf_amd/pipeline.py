@@ -68,3 +68,34 @@ class CoarseFineRenderer:
             out = self.pass_(rays_d, hs["z_sorted"], want=("acc", "weights", "var"), events=ev[1])
         out.update(z_coarse=z_c, z_fine=hs["z_sorted"], z_samples=hs["samples"], coarse=coarse, rays_d=rays_d)
         return out
+
+    # ------------------------------------------------------------------------------------------------ HIP graph
+    def capture(self, n_rays, perturb=0.0, repack=True, reuse_coarse=False):
+        """Captures one render of `n_rays` rays into a HIP graph (the launch-bound regime of small
+        per-GPU batches).  Returns a callable g(xs, ys, noise=None) -> the same dict as render(); its tensors are owned
+        by the graph and overwritten by the next replay.  Every launch of the step goes to the capturing stream and
+        the step allocates only through torch's caching allocator, so the capture is a plain stream capture."""
+        dev = self.dev
+        xs_s, ys_s = torch.zeros(n_rays, device=dev), torch.zeros(n_rays, device=dev)
+        noise_s = torch.rand(n_rays, self.n_coarse, device=dev) if perturb > 0 else None
+        kw = dict(perturb=perturb, noise=noise_s, repack=repack, reuse_coarse=reuse_coarse)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                       # warm-up: one-time attribute calls, workspace allocation
+            for _ in range(2):
+                self.render(xs_s, ys_s, **kw)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.render(xs_s, ys_s, **kw)
+
+        def replay(xs, ys, noise=None):
+            xs_s.copy_(xs, non_blocking=True)
+            ys_s.copy_(ys, non_blocking=True)
+            if noise_s is not None and noise is not None:
+                noise_s.copy_(noise, non_blocking=True)
+            graph.replay()
+            return out
+
+        replay.graph = graph
+        return replay
