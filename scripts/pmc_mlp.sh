@@ -1,13 +1,13 @@
 #!/bin/bash
 # PMC passes for the MLP kernel (run on the GPU box via gpurun).  Counters in separate runs, no tracing domains.
-# usage: [PREC=bf16x3] bash scripts/pmc_mlp.sh <outdir-name> [quick|sq]
+# usage: [PREC=bf16x3] [KERNEL=regex] bash scripts/pmc_mlp.sh <outdir-name> [quick|sq]
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${1:-pmc}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters
-  rocprofv3 --pmc $2 --kernel-include-regex "mlp_fwd" --output-format csv -d $OUT/$1 -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-rays 0 --precision ${PREC:-f32} > $OUT/$1.log 2>&1
+  rocprofv3 --pmc $2 --kernel-include-regex "${KERNEL:-mlp_fwd}" --output-format csv -d $OUT/$1 -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-rays 0 --precision ${PREC:-f32} > $OUT/$1.log 2>&1
   echo "$1 rc=$?"
 }
 run sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES"

@@ -708,11 +708,15 @@ int launch_mlp_fwd_bf16(const ucnerf_mlp_params* p, hipStream_t st) {
 #ifdef UCNERF_MLP_DIAG
     { const char* e = getenv("UCNERF_MLP_DIAG_PTR"); g.diag = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
+    // compile-time view counts for the reference's two configurations (7 views: SCARED, 4 views: Hamlyn); others run
+    // the generic instantiation (runtime section lengths: correct, but the compiler spills there)
     static bool attr_set = false;
     const size_t smem = bf16_smem_bytes();
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<true, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
@@ -721,6 +725,9 @@ int launch_mlp_fwd_bf16(const ucnerf_mlp_params* p, hipStream_t st) {
     if (B.v == 6) {
         if (p->feats_tiled) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, 6>), grid, block, smem, st, *p, g, n_tiles);
         else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, 6>), grid, block, smem, st, *p, g, n_tiles);
+    } else if (B.v == 3) {
+        if (p->feats_tiled) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, 3>), grid, block, smem, st, *p, g, n_tiles);
+        else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, 3>), grid, block, smem, st, *p, g, n_tiles);
     } else {
         if (p->feats_tiled) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, 0>), grid, block, smem, st, *p, g, n_tiles);
         else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, 0>), grid, block, smem, st, *p, g, n_tiles);
