@@ -42,6 +42,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef UCNERF_BF16_EXP
 #define UCNERF_BF16_EXP 0      // timing experiments only (results are wrong): 1 no DMA wait, 2 no barrier, 4 no DMA, 64 no interleave hints
 #endif
+#ifndef UCNERF_BF16_HINT_V
+#define UCNERF_BF16_HINT_V 7   // VALU instructions the scheduler may place after each MFMA of a half-step
+#endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define SB0 __builtin_amdgcn_sched_barrier(0)
 
@@ -193,6 +196,12 @@ template <class T> __device__ __forceinline__ void pin(T& v) { asm volatile("" :
 // fragment s (0/1) of an accumulator tile: MODE 0 plain, 1 times m, 2 relu(times m)   (two values per v_pk_mul_f32)
 template <int MODE>
 __device__ __forceinline__ Frag frag_of(const f32x16& a, const f32x16& m, int s) {
+#if UCNERF_BF16_EXP & 128      // timing experiment: no epilogue arithmetic at all (wrong results)
+    Frag e;
+    e.hi = __builtin_bit_cast(bf16x8, (f32x4){a[8 * s], a[8 * s + 1], a[8 * s + 2], a[8 * s + 3]});
+    e.lo = __builtin_bit_cast(bf16x8, (f32x4){a[8 * s + 4], a[8 * s + 5], a[8 * s + 6], a[8 * s + 7]});
+    return e;
+#endif
     float t[8];
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
@@ -286,7 +295,7 @@ __device__ __forceinline__ void half_step(const int ODD, Pipe& P, AF& cur, int l
     c0 = MFMA16(cur.h0, b.hi, c0); c0 = MFMA16(cur.h0, b.lo, c0); c0 = MFMA16(cur.l0, b.hi, c0);   // (one accumulation chain
     c1 = MFMA16(cur.h1, b.hi, c1); c1 = MFMA16(cur.h1, b.lo, c1); c1 = MFMA16(cur.l1, b.hi, c1);   //  runs at full rate)
     fill();
-    interleave_hint<7>();
+    interleave_hint<UCNERF_BF16_HINT_V>();
     SB0;
     cur = nxt;
 }
@@ -309,6 +318,9 @@ struct HeadAcc { f32x2 s01, s23; };
 template <class Map>
 __device__ __forceinline__ void head_part(HeadAcc& a, const float* hd, int h, const f32x16& x, int nt, int r0, int n, Map map) {
     const f32x4* w = reinterpret_cast<const f32x4*>(hd) + opaque(h * 64) + nt * 16;
+#if UCNERF_BF16_EXP & 128
+    a.s01.x += x[r0]; return;
+#endif
 #pragma unroll
     for (int i = 0; i < 16; ++i)
         if (i >= r0 && i < r0 + n) {
@@ -356,7 +368,12 @@ __device__ __forceinline__ void encode16(const float (&x)[3], int h, float (&pe)
     float r[half], sn[half], cs[half];
 #pragma unroll
     for (int q = 0; q < half; ++q) r[q] = encode_arg(x, h, q);
+#if UCNERF_BF16_EXP & 128
+#pragma unroll
+    for (int q = 0; q < half; ++q) { sn[q] = r[q]; cs[q] = r[q] * 0.5f; }
+#else
     sincos_pe_batch(r, sn, cs);
+#endif
 #pragma unroll
     for (int q = 0; q < half; ++q) { pe[q] = sn[q]; pe[half + q] = cs[q]; }
     pe[2 * half] = h ? x[2] : x[0];
