@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--fine", type=int, default=128)
     ap.add_argument("--cpu-rays", type=int, default=512, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--max-blocks", type=int, default=0)
+    ap.add_argument("--no-reuse", action="store_true", help="skip the secondary reuse_coarse measurement (profiling runs)")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (no per-kernel HIP events)")
     ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3",
                     help="MLP arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product, fp32 accumulate)")
@@ -135,19 +136,21 @@ def main():
 
     # secondary number (not `value`): the same steps with the fine pass re-using the coarse pass's network outputs for the
     # 64 coarse depths (bit-identical renders, tests/test_hip_pipeline.py) -- 192 instead of 256 evaluations per ray
-    for _ in range(args.warmup):
-        out2 = renderer.render(xs, ys, perturb=1.0, noise=noise, reuse_coarse=True)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        out2 = renderer.render(xs, ys, perturb=1.0, noise=noise, reuse_coarse=True)
-    barrier()
-    dt2 = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt2], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt2 = t.item()
-    assert torch.equal(out2["rgb"], out["rgb"]) and torch.equal(out2["depth"], out["depth"])
+    dt2 = None
+    if not args.no_reuse:
+        for _ in range(args.warmup):
+            out2 = renderer.render(xs, ys, perturb=1.0, noise=noise, reuse_coarse=True)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            out2 = renderer.render(xs, ys, perturb=1.0, noise=noise, reuse_coarse=True)
+        barrier()
+        dt2 = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = t.item()
+        assert torch.equal(out2["rgb"], out["rgb"]) and torch.equal(out2["depth"], out["depth"])
 
     # dominant kernel (mlp_fwd): HIP events recorded around its two launches per step, on the launch stream
     mlp_ms = sum(a.elapsed_ms(b) for step in events for a, b in step)
@@ -187,10 +190,11 @@ def main():
             "roofline": roof,
             "mlp_share_of_step": mlp_ms / (dt * 1e3),
             **({"hip_graph_ms_per_step": graph_ms} if graph_ms is not None else {}),
-            "reuse_coarse": {"value": args.rays * world * args.steps / dt2, "unit": "rays/s", "ms_per_step": dt2 / args.steps * 1e3,
-                             "note": "NOT the headline: fine pass evaluates only the 128 new depths and re-uses the coarse pass's "
-                                     "outputs for the 64 coarse ones; renders verified bit-identical in this run"},
         }
+        if dt2 is not None:
+            line["reuse_coarse"] = {"value": args.rays * world * args.steps / dt2, "unit": "rays/s", "ms_per_step": dt2 / args.steps * 1e3,
+                                    "note": "NOT the headline: fine pass evaluates only the 128 new depths and re-uses the coarse "
+                                            "pass's outputs for the 64 coarse ones; renders verified bit-identical in this run"}
         if world == 1 and args.cpu_rays > 0:
             line["cpu_baseline"] = cpu_baseline(scene_cpu, sd, args.cpu_rays, args.coarse, args.fine)
         print(json.dumps(line), flush=True)

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/${1:-pmc}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters
-  rocprofv3 --pmc $2 --kernel-include-regex "${KERNEL:-mlp_fwd}" --output-format csv -d $OUT/$1 -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-rays 0 --precision ${PREC:-f32} > $OUT/$1.log 2>&1
+  rocprofv3 --pmc $2 --kernel-include-regex "${KERNEL:-mlp_fwd}" --output-format csv -d $OUT/$1 -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-rays 0 --no-reuse --precision ${PREC:-f32} > $OUT/$1.log 2>&1
   echo "$1 rc=$?"
 }
 run sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES"
