@@ -77,13 +77,23 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # one rank per GPU; UCNERF_BENCH_BACKEND=gloo is a rehearsal mode for a box with fewer GPUs than ranks (ranks then
+    # share devices round-robin and the barrier / MAX go through gloo) -- the driver's runs use RCCL ("nccl")
+    backend = os.environ.get("UCNERF_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if local >= n_dev and backend == "nccl":
+        raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPUs visible" % (local, n_dev))
+    local_dev = local % n_dev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from uc_nerf_amd import ops
     from uc_nerf_amd.pipeline import CoarseFineRenderer, flat_params_of
