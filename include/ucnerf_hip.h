@@ -193,8 +193,14 @@ typedef struct {
     float* g_vol[3];                 /* [8,D,h,w] or NULL to skip */
     float* g_conf;                   /* [H,W] or NULL */
     float* g_img_feat;               /* [V,8,H,W] or NULL */
+    float* scratch;                  /* optional, ucnerf_feat_gather_bwd_scratch_floats() floats, 16-byte aligned: the
+                                        volume / image-feature gradients are then accumulated channel-LAST in it (eight
+                                        lanes add the 32 contiguous bytes of one corner instead of eight scattered
+                                        cache lines) and added to g_vol / g_img_feat by a transposing pass.  Contents
+                                        are overwritten.  NULL: atomics go straight to the channel-major outputs. */
 } ucnerf_feat_gather_bwd_params;
 int ucnerf_feat_gather_bwd(const ucnerf_feat_gather_bwd_params* p, void* stream);
+int64_t ucnerf_feat_gather_bwd_scratch_floats(const ucnerf_feat_gather_params* p);
 
 /* ------------------------------------------------------------------------------------------------
  * a6 (+a5 fused)  the uncertainty-conditioned MLP -- network/models.py:138-184 driven by
@@ -404,6 +410,7 @@ typedef struct {
     float* g_conf;
     float* g_img_feat;
     float* workspace;              /* ucnerf_render_bwd_workspace_floats(n, S, V) floats, 16-byte aligned */
+    float* gather_scratch;         /* optional: ucnerf_feat_gather_bwd_params.scratch for the gather backward */
 } ucnerf_render_bwd_params;
 int64_t ucnerf_render_bwd_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* p, void* stream);

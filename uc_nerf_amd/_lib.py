@@ -59,7 +59,8 @@ class FeatGatherParams(C.Structure):
 
 
 class FeatGatherBwdParams(C.Structure):
-    _fields_ = [("fwd", FeatGatherParams), ("g_feats", vp), ("g_vol", vp * 3), ("g_conf", vp), ("g_img_feat", vp)]
+    _fields_ = [("fwd", FeatGatherParams), ("g_feats", vp), ("g_vol", vp * 3), ("g_conf", vp), ("g_img_feat", vp),
+                ("scratch", vp)]
 
 
 class MlpConfig(C.Structure):
@@ -111,7 +112,7 @@ class RenderParams(C.Structure):
 
 class RenderBwdParams(C.Structure):
     _fields_ = [("fwd", RenderParams), ("g_rgb", vp), ("g_depth", vp), ("flat_params", vp), ("g_flat", vp),
-                ("g_vol", vp * 3), ("g_conf", vp), ("g_img_feat", vp), ("workspace", vp)]
+                ("g_vol", vp * 3), ("g_conf", vp), ("g_img_feat", vp), ("workspace", vp), ("gather_scratch", vp)]
 
 
 STRUCTS = {
@@ -146,6 +147,7 @@ SYMBOLS = {
     "ucnerf_embed": (C.c_int, [_P, _P]),
     "ucnerf_feat_gather_fwd": (C.c_int, [_P, _P]),
     "ucnerf_feat_gather_bwd": (C.c_int, [_P, _P]),
+    "ucnerf_feat_gather_bwd_scratch_floats": (C.c_int64, [_P]),
     "ucnerf_mlp_param_count": (C.c_int64, [_P]),
     "ucnerf_mlp_stream_count": (C.c_int64, [_P]),
     "ucnerf_mlp_index_count": (C.c_int64, [_P]),

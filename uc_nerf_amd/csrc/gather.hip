@@ -190,6 +190,80 @@ __global__ void __launch_bounds__(256) feat_gather_bwd_kernel(ucnerf_feat_gather
     }
 }
 
+// ---- channel-last accumulation (scratch given): thread = (sample, channel); the eight lanes of a sample add the 32
+// contiguous bytes of one corner, so an atomic wave-instruction touches 8 cache lines instead of 64.
+struct ScratchLayout { size_t vol[3], img, total; };
+__host__ __device__ inline ScratchLayout scratch_layout(const ucnerf_feat_gather_params& p) {
+    ScratchLayout L;
+    size_t o = 0;
+    for (int k = 0; k < 3; ++k) { L.vol[k] = o; o += 8 * (size_t)p.vol_d[k] * p.vol_h[k] * p.vol_w[k]; }
+    L.img = o; o += 8 * (size_t)p.V * p.H * p.W;
+    L.total = o;
+    return L;
+}
+
+__global__ void __launch_bounds__(256) feat_gather_bwd_cl_kernel(ucnerf_feat_gather_bwd_params bp) {
+    const ucnerf_feat_gather_params& p = bp.fwd;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int s = (int)(t >> 3), c = (int)(t & 7);
+    if (s >= p.m) return;
+    const int unit = blockIdx.y < 3 ? blockIdx.y : blockIdx.y + 1;      // units 0..2 volumes, 4.. views (conf stays on the direct path)
+    const int F = 24 + 12 * p.V + 1;
+    if (p.unit_mask && !((p.unit_mask >> unit) & 1)) return;
+    const float* gf = bp.g_feats + (size_t)s * F;
+    const ScratchLayout L = scratch_layout(p);
+    if (unit < 3) {
+        if (!bp.g_vol[unit]) return;
+        float* gv = bp.scratch + L.vol[unit] + c;
+        const float* g = (unit == 0 ? p.ndc1 : unit == 1 ? p.ndc2 : p.ndc3) + 3 * (size_t)s;
+        const int D = p.vol_d[unit], h = p.vol_h[unit], w = p.vol_w[unit];
+        const Lerp ax = axis(g[0] * 2.f - 1.0f, w, false), ay = axis(g[1] * 2.f - 1.0f, h, false),
+                   az = axis(g[2] * 2.f - 1.0f, D, false);
+        const size_t o00 = ((size_t)az.i0 * h + ay.i0) * w, o01 = ((size_t)az.i0 * h + ay.i1) * w,
+                     o10 = ((size_t)az.i1 * h + ay.i0) * w, o11 = ((size_t)az.i1 * h + ay.i1) * w;
+        const float w00 = az.w0 * ay.w0, w01 = az.w0 * ay.w1, w10 = az.w1 * ay.w0, w11 = az.w1 * ay.w1;
+        const float gc = gf[8 * unit + c];
+        // same products as the direct path (weights folded in the same order); zero-weight corners are skipped there
+        // only to save atomics -- adding 0 here is the same sum
+        atomicAdd(gv + 8 * (o00 + ax.i0), gc * (w00 * ax.w0));
+        if (ax.w1 != 0.f) atomicAdd(gv + 8 * (o00 + ax.i1), gc * (w00 * ax.w1));
+        if (w01 != 0.f) {
+            atomicAdd(gv + 8 * (o01 + ax.i0), gc * (w01 * ax.w0));
+            if (ax.w1 != 0.f) atomicAdd(gv + 8 * (o01 + ax.i1), gc * (w01 * ax.w1));
+        }
+        if (w10 != 0.f) {
+            atomicAdd(gv + 8 * (o10 + ax.i0), gc * (w10 * ax.w0));
+            if (ax.w1 != 0.f) atomicAdd(gv + 8 * (o10 + ax.i1), gc * (w10 * ax.w1));
+        }
+        if (w11 != 0.f) {
+            atomicAdd(gv + 8 * (o11 + ax.i0), gc * (w11 * ax.w0));
+            if (ax.w1 != 0.f) atomicAdd(gv + 8 * (o11 + ax.i1), gc * (w11 * ax.w1));
+        }
+    } else {
+        if (!bp.g_img_feat) return;
+        const int v = unit - 4;
+        float gx, gy;
+        project_view(p, v, s, &gx, &gy);
+        const Lerp ax = axis(gx, p.W, true), ay = axis(gy, p.H, true);
+        const size_t hw = (size_t)p.H * p.W;
+        const size_t o00 = (size_t)ay.i0 * p.W + ax.i0, o01 = (size_t)ay.i0 * p.W + ax.i1,
+                     o10 = (size_t)ay.i1 * p.W + ax.i0, o11 = (size_t)ay.i1 * p.W + ax.i1;
+        float* ft = bp.scratch + L.img + 8 * (size_t)v * hw + c;
+        const float gc = gf[24 + 4 * p.V + 8 * v + c];
+        atomicAdd(ft + 8 * o00, gc * (ay.w0 * ax.w0)); atomicAdd(ft + 8 * o01, gc * (ay.w0 * ax.w1));
+        atomicAdd(ft + 8 * o10, gc * (ay.w1 * ax.w0)); atomicAdd(ft + 8 * o11, gc * (ay.w1 * ax.w1));
+    }
+}
+
+// g[c][i] += scratch[i][c] for one source of `n` positions (single writer per element)
+__global__ void __launch_bounds__(256) add_transposed_kernel(const float4* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = src[2 * i], b = src[2 * i + 1];
+    dst[i] += a.x; dst[n + i] += a.y; dst[2 * n + i] += a.z; dst[3 * n + i] += a.w;
+    dst[4 * n + i] += b.x; dst[5 * n + i] += b.y; dst[6 * n + i] += b.z; dst[7 * n + i] += b.w;
+}
+
 static int check_geometry(const ucnerf_feat_gather_params* p, const char* who) {
     const int mask = p->unit_mask ? p->unit_mask : ~0;
     UCNERF_REQUIRE(p->V >= 1 && p->V <= 8, "%s: V = %d outside 1..8", who, p->V);
@@ -233,9 +307,40 @@ int ucnerf_feat_gather_bwd(const ucnerf_feat_gather_bwd_params* bp, void* stream
     int rc = check_geometry(&bp->fwd, "feat_gather_bwd");
     if (rc) return rc;
     if (bp->fwd.m <= 0) return UCNERF_OK;
-    hipLaunchKernelGGL(feat_gather_bwd_kernel, dim3(cdiv(bp->fwd.m, 256), 4 + bp->fwd.V), dim3(256), 0,
-                       (hipStream_t)stream, *bp);
+    hipStream_t st = (hipStream_t)stream;
+    const ucnerf_feat_gather_params& f = bp->fwd;
+    if (!bp->scratch) {
+        hipLaunchKernelGGL(feat_gather_bwd_kernel, dim3(cdiv(f.m, 256), 4 + f.V), dim3(256), 0, st, *bp);
+        return check_launch("feat_gather_bwd");
+    }
+    UCNERF_REQUIRE(((uintptr_t)bp->scratch & 15) == 0, "feat_gather_bwd: scratch must be 16-byte aligned");
+    const ScratchLayout L = scratch_layout(f);
+    if (hipMemsetAsync(bp->scratch, 0, L.total * sizeof(float), st) != hipSuccess) return fail(UCNERF_EHIP, "feat_gather_bwd: memset failed");
+    hipLaunchKernelGGL(feat_gather_bwd_cl_kernel, dim3(cdiv((long long)f.m * 8, 256), 3 + f.V), dim3(256), 0, st, *bp);
+    if (bp->g_conf) {                                   // confidence: 4 atomics per sample, direct
+        ucnerf_feat_gather_bwd_params c = *bp;
+        c.fwd.unit_mask = 8 & (f.unit_mask ? f.unit_mask : ~0);
+        if (c.fwd.unit_mask) hipLaunchKernelGGL(feat_gather_bwd_kernel, dim3(cdiv(f.m, 256), 4), dim3(256), 0, st, c);
+    }
+    const int mask = f.unit_mask ? f.unit_mask : ~0;
+    for (int k = 0; k < 3; ++k)
+        if (bp->g_vol[k] && (mask & (1 << k))) {
+            const size_t n = (size_t)f.vol_d[k] * f.vol_h[k] * f.vol_w[k];
+            hipLaunchKernelGGL(add_transposed_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float4*)(bp->scratch + L.vol[k]), bp->g_vol[k], n);
+        }
+    if (bp->g_img_feat) {
+        const size_t hw = (size_t)f.H * f.W;
+        for (int v = 0; v < f.V; ++v)
+            if (mask & (1 << (4 + v)))
+                hipLaunchKernelGGL(add_transposed_kernel, dim3(cdiv(hw, 256)), dim3(256), 0, st,
+                                   (const float4*)(bp->scratch + L.img + 8 * (size_t)v * hw), bp->g_img_feat + 8 * (size_t)v * hw, hw);
+    }
     return check_launch("feat_gather_bwd");
+}
+
+int64_t ucnerf_feat_gather_bwd_scratch_floats(const ucnerf_feat_gather_params* p) {
+    if (!p) return fail(UCNERF_EINVAL, "feat_gather_bwd_scratch_floats: null params");
+    return (int64_t)scratch_layout(*p).total;
 }
 
 }  // extern "C"

@@ -208,7 +208,7 @@ int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* bp, void* stream) {
         gather_geometry(&q, &w, &gb.fwd);
         gb.g_feats = g_feats;
         for (int k = 0; k < 3; ++k) gb.g_vol[k] = bp->g_vol[k];
-        gb.g_conf = bp->g_conf; gb.g_img_feat = bp->g_img_feat;
+        gb.g_conf = bp->g_conf; gb.g_img_feat = bp->g_img_feat; gb.scratch = bp->gather_scratch;
         if ((rc = ucnerf_feat_gather_bwd(&gb, st))) return rc;
     }
     return UCNERF_OK;

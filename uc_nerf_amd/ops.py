@@ -285,8 +285,19 @@ def feat_gather_bwd(src, pts, ndc1, ndc2, ndc3, g_feats, need=(True, True, True,
     for k in range(3):
         bp.g_vol[k] = _ptr(gv[k])
     bp.g_conf, bp.g_img_feat = _ptr(gc), _ptr(gi)
+    bp.scratch = _ptr(_gather_scratch(src, bp.fwd, lead.device))
     _launch("ucnerf_feat_gather_bwd", bp, lead.device)
     return gv[0], gv[1], gv[2], gc, gi
+
+
+def _gather_scratch(src, fwd_params, device):
+    """Channel-last accumulation buffer of the gather backward, cached on the sources object."""
+    n = L.lib().ucnerf_feat_gather_bwd_scratch_floats(C.addressof(fwd_params))
+    buf = getattr(src, "_bwd_scratch", None)
+    if buf is None or buf.numel() < n or buf.device != device:
+        buf = torch.empty(max(int(n), 4), device=device)
+        src._bwd_scratch = buf
+    return buf
 
 
 class _FeatGather(torch.autograd.Function):
@@ -694,6 +705,9 @@ class RenderPass:
         for k in range(3):
             bp.g_vol[k] = _ptr(gv[k])
         bp.g_conf, bp.g_img_feat = _ptr(gc), _ptr(gi)
+        gfwd = L.FeatGatherParams()
+        self.src.fill(gfwd)
+        bp.gather_scratch = _ptr(_gather_scratch(self.src, gfwd, dev))
         _launch("ucnerf_render_fused_bwd", bp, dev)
         return g_flat, gv[0], gv[1], gv[2], gc, gi
 
