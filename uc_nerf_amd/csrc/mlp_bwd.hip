@@ -107,7 +107,9 @@ struct TnArgs {
     int m, Nout, Kin;
 };
 
-constexpr int TN_CHUNK = 1024;
+// samples per block: small enough that a training batch (~1e5 samples) fills the chip several times over (the
+// partial tiles are merged with well-shaped float atomics, 128-byte row segments)
+constexpr int TN_CHUNK = 256;
 
 template <int KT>
 __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
