@@ -45,6 +45,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef UCNERF_BF16_HINT_V
 #define UCNERF_BF16_HINT_V 7   // VALU instructions the scheduler may place after each MFMA of a half-step
 #endif
+#ifndef UCNERF_BF16_PRIO_VALU
+#define UCNERF_BF16_PRIO_VALU 0     // wave priority during the phases without MFMAs (point encoding, tail)
+#endif
+#ifndef UCNERF_BF16_PRIO_GEMM
+#define UCNERF_BF16_PRIO_GEMM 0     // ... and during the GEMM phases
+#endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define SB0 __builtin_amdgcn_sched_barrier(0)
 
@@ -456,6 +462,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         // (few scalars are carried through the trunk -- every VGPR there is spoken for: sample index, feature base
         //  and view direction are re-derived / loaded where they are needed)
         DIAG_STAMP(0)
+        __builtin_amdgcn_s_setprio(UCNERF_BF16_PRIO_VALU);
         f32x16 bd[4], acc[4];
         Frag X[8], Y[8];
         float fsec[4][8];
@@ -487,6 +494,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             }
         }
         DIAG_STAMP(1)
+        __builtin_amdgcn_s_setprio(UCNERF_BF16_PRIO_GEMM);
 
         // ---- depth-bias net (step-major): bd = W_bd feats + b
         init_bias_pair(cst, SEC_BD, h, 0, bd);
@@ -679,6 +687,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                if (q < 4) head_part(hadapt, ha, h, acc[q >> 1], q >> 1, (q & 1) * 8, 8, relu));
         }
         DIAG_STAMP(11)
+        __builtin_amdgcn_s_setprio(UCNERF_BF16_PRIO_VALU);
         fetch(tile + tiles_per_round);                     // next tile's inputs (clamped past the end: harmless)
         // ---- adapt heads of row tiles 2,3, uncertainty blend
         head_part(hadapt, ha, h, acc[2], 2, 0, 16, relu);
