@@ -1,0 +1,77 @@
+// Micro-benchmark: sustained rate of the split-bf16 inner loop with the two bf16 MFMA shapes, A fragments re-read from
+// LDS every step, all CUs busy, two waves per SIMD -- is the 16x16x32 shape faster under the chip's power limit?
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_shapes scripts/micro/mfma_shapes.hip && /tmp/mfma_shapes
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// one "half-step" = 4 KB of A fragments (h0, l0, h1, l1) from LDS, 12 MFMA16 or 6 MFMA32, same FLOPs
+template <int SHAPE>
+__global__ void __launch_bounds__(256, 2) loop_kernel(const bf16x8* __restrict__ w, float* out, int iters) {
+    __shared__ bf16x8 lds[4 * 64 * 8];           // 8 half-steps of A fragments
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 4 * 64 * 8; i += 256) lds[i] = w[i];
+    __syncthreads();
+    bf16x8 bh0 = w[lane], bl0 = w[64 + lane], bh1 = w[128 + lane], bl1 = w[192 + lane];
+    f32x16 c32[2] = {};
+    f32x4 c16[4] = {};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int hs = 0; hs < 8; ++hs) {
+            const bf16x8* a = lds + hs * 256 + lane;
+            const bf16x8 h0 = a[0], l0 = a[64], h1 = a[128], l1 = a[192];
+            if (SHAPE == 32) {
+                c32[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bh0, c32[0], 0, 0, 0);
+                c32[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bl0, c32[0], 0, 0, 0);
+                c32[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, bh0, c32[0], 0, 0, 0);
+                c32[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bh0, c32[1], 0, 0, 0);
+                c32[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bl0, c32[1], 0, 0, 0);
+                c32[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, bh0, c32[1], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const bf16x8 bh = c ? bh1 : bh0, bl = c ? bl1 : bl0;
+                    c16[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, bh, c16[c], 0, 0, 0);
+                    c16[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, bl, c16[c], 0, 0, 0);
+                    c16[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0, bh, c16[c], 0, 0, 0);
+                    c16[2 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, bh, c16[2 + c], 0, 0, 0);
+                    c16[2 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, bl, c16[2 + c], 0, 0, 0);
+                    c16[2 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1, bh, c16[2 + c], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += c32[0][r] + c32[1][r];
+    for (int r = 0; r < 4; ++r) s += c16[0][r] + c16[1][r] + c16[2][r] + c16[3][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+int main() {
+    const int n = 4 * 64 * 8;
+    std::vector<unsigned short> h(n * 8);
+    srand(1);
+    for (auto& v : h) v = (unsigned short)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));    // random mantissas, |x| ~ 0.01..0.03
+    bf16x8* w; float* out;
+    hipMalloc(&w, n * 16); hipMalloc(&out, 1024 * 256 * 4);
+    hipMemcpy(w, h.data(), n * 16, hipMemcpyHostToDevice);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    const int iters = 4000, blocks = 512;
+    for (int rep = 0; rep < 2; ++rep)
+        for (int shape : {32, 16}) {
+            if (shape == 32) loop_kernel<32><<<blocks, 256>>>(w, out, 100); else loop_kernel<16><<<blocks, 256>>>(w, out, 100);
+            hipDeviceSynchronize();
+            hipEventRecord(a);
+            if (shape == 32) loop_kernel<32><<<blocks, 256>>>(w, out, iters); else loop_kernel<16><<<blocks, 256>>>(w, out, iters);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            const double flop = (double)blocks * 4 * iters * 8 * 6 * 32768.0;
+            printf("shape %dx: %.3f ms, %.1f TFLOP/s executed\n", shape, ms, flop / ms / 1e9);
+        }
+    return 0;
+}

@@ -15,9 +15,14 @@ m, S, F = 4096 * 192, 192, 97
 pw = ops.PackedWeights.get(6, 0, dev, precision=prec)
 ws = pw.pack(flat_params_of(init_ucnerf_state_dict(0)).to(dev))
 g = torch.Generator().manual_seed(0)
+mode = os.environ.get("DATA", "random")        # random | zeros | small : operand toggling (the kernel is power-bound)
 pts = torch.rand(m, 3, generator=g).to(dev)
 dirs = torch.randn(m, 3, generator=g).to(dev)
 feats = torch.randn(((m + 31) // 32) * 32 * F, generator=g).to(dev)
+if mode == "zeros":
+    pts, dirs, feats = torch.zeros_like(pts), torch.zeros_like(dirs), torch.zeros_like(feats)
+elif mode == "small":
+    feats = feats * 0.05
 for _ in range(3):
     ops.mlp_fwd(pw, ws, pts, dirs, feats, S, feats_tiled=True)
 a, b = ops.Event(), ops.Event()
@@ -28,4 +33,4 @@ for _ in range(K):
     ops.mlp_fwd(pw, ws, pts, dirs, feats, S, feats_tiled=True)
 b.record()
 torch.cuda.synchronize()
-print("%s %s: %.4f ms per fine-pass launch (786432 samples)" % (os.environ.get("UCNERF_LIB", "default").split("_")[-1], prec, a.elapsed_ms(b) / K))
+print("%s %s data=%s: %.4f ms per fine-pass launch (786432 samples)" % (os.environ.get("UCNERF_LIB", "default").split("_")[-1], prec, mode, a.elapsed_ms(b) / K))
