@@ -273,17 +273,16 @@ __device__ __forceinline__ f32x4 head4(const float* hd, int h, const f32x16 (&x)
 template <int NF, int KS>
 __device__ __forceinline__ void encode(const float (&x)[3], int h, float (&pe)[KS]) {   // x: raw 3-vector
     constexpr int half = 3 * NF / 2;
-    float r[half], sn[half], cs[half];
+    const Rev2 t[3] = {to_revolutions(x[0]), to_revolutions(x[1]), to_revolutions(x[2])};
 #pragma unroll
-    for (int q = 0; q < half; ++q) {
-        const int a = 2 * q + h;
-        const int fr = a / 3, c = a - 3 * fr;
-        const float xc = c == 0 ? x[0] : (c == 1 ? x[1] : x[2]);
-        r[q] = xc * (float)(1 << fr);
+    for (int q = 0; q < half; ++q) {                       // argument a = 2q + h: frequency a / 3, coordinate a % 3 (selected by h)
+        const int a0 = 2 * q, a1 = 2 * q + 1, c0 = a0 % 3, c1 = a1 % 3;
+        const float h0 = c0 == 0 ? t[0].hi : c0 == 1 ? t[1].hi : t[2].hi, l0 = c0 == 0 ? t[0].lo : c0 == 1 ? t[1].lo : t[2].lo;
+        const float h1 = c1 == 0 ? t[0].hi : c1 == 1 ? t[1].hi : t[2].hi, l1 = c1 == 0 ? t[0].lo : c1 == 1 ? t[1].lo : t[2].lo;
+        const float hi = h ? h1 : h0, lo = h ? l1 : l0;
+        const float scale = h ? (float)(1 << (a1 / 3)) : (float)(1 << (a0 / 3));
+        sincos_rev(hi, lo, scale, &pe[q], &pe[half + q]);
     }
-    sincos_pe_batch(r, sn, cs);
-#pragma unroll
-    for (int q = 0; q < half; ++q) { pe[q] = sn[q]; pe[half + q] = cs[q]; }
     pe[2 * half] = h ? x[2] : x[0];
     pe[2 * half + 1] = h ? 0.f : x[1];
 #pragma unroll

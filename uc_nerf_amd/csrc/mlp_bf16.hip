@@ -359,29 +359,27 @@ __device__ __forceinline__ f32x4 head_finish(const HeadAcc& a, const float* hd) 
     return s;
 }
 
-// encoding argument q of this lane-half: a = 2q + h, frequency a / 3, coordinate a % 3.  Both candidates are formed
-// with compile-time (frequency, coordinate) and selected by h: written with a / 3 and a % 3 of the lane-dependent a,
-// the compiler keeps ~40 per-lane multipliers and selectors alive across the whole tile loop (and spills them).
-__device__ __forceinline__ float encode_arg(const float (&x)[3], int h, int q) {
+// sin / cos of encoding argument q of this lane-half: a = 2q + h, frequency a / 3, coordinate a % 3.  Both candidates
+// have compile-time (frequency, coordinate) and are selected by h (written with a / 3 and a % 3 of the lane-dependent a,
+// the compiler keeps ~40 per-lane multipliers and selectors alive across the whole tile loop).  t = coordinates in
+// revolutions (to_revolutions), so one pair costs 3 selects + mul, fract, fma, sin, cos.
+__device__ __forceinline__ void encode_sincos(const Rev2 (&t)[3], int h, int q, float* s, float* c) {
     const int a0 = 2 * q, a1 = 2 * q + 1;
-    const float r0 = x[a0 % 3] * (float)(1 << (a0 / 3)), r1 = x[a1 % 3] * (float)(1 << (a1 / 3));
-    return h ? r1 : r0;
+    const int c0 = a0 % 3, c1 = a1 % 3;
+    // (values first, select second: a select between array ELEMENTS becomes an indexed load from a stack copy)
+    const float h0 = c0 == 0 ? t[0].hi : c0 == 1 ? t[1].hi : t[2].hi, l0 = c0 == 0 ? t[0].lo : c0 == 1 ? t[1].lo : t[2].lo;
+    const float h1 = c1 == 0 ? t[0].hi : c1 == 1 ? t[1].hi : t[2].hi, l1 = c1 == 0 ? t[0].lo : c1 == 1 ? t[1].lo : t[2].lo;
+    const float hi = h ? h1 : h0, lo = h ? l1 : l0;
+    const float scale = h ? (float)(1 << (a1 / 3)) : (float)(1 << (a0 / 3));
+    sincos_rev(hi, lo, scale, s, c);
 }
 
 template <int NF, int KS>
 __device__ __forceinline__ void encode16(const float (&x)[3], int h, float (&pe)[KS]) {
     constexpr int half = 3 * NF / 2;
-    float r[half], sn[half], cs[half];
+    const Rev2 t[3] = {to_revolutions(x[0]), to_revolutions(x[1]), to_revolutions(x[2])};
 #pragma unroll
-    for (int q = 0; q < half; ++q) r[q] = encode_arg(x, h, q);
-#if UCNERF_BF16_EXP & 128
-#pragma unroll
-    for (int q = 0; q < half; ++q) { sn[q] = r[q]; cs[q] = r[q] * 0.5f; }
-#else
-    sincos_pe_batch(r, sn, cs);
-#endif
-#pragma unroll
-    for (int q = 0; q < half; ++q) { pe[q] = sn[q]; pe[half + q] = cs[q]; }
+    for (int q = 0; q < half; ++q) encode_sincos(t, h, q, &pe[q], &pe[half + q]);
     pe[2 * half] = h ? x[2] : x[0];
     pe[2 * half + 1] = h ? 0.f : x[1];
 #pragma unroll
@@ -639,25 +637,18 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                );
         const f32x4 base = head_finish(hbase, hb);
         float pd[KS_PE_DIR];
+        const Rev2 dt[3] = {to_revolutions(dv[0]), to_revolutions(dv[1]), to_revolutions(dv[2])};
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             HS(q & 1, X[q], acc[2], acc[3],
                if (!(q & 1)) Y[q >> 1] = frag_of<0>(acc[q >> 2], acc[q >> 2], (q >> 1) & 1);
                if (q & 1) {                                                    // direction encoding: 6 arguments, two per odd half-step
-                   if (q < 7) {                                                // (branch-free here; out-of-range arguments are redone below)
-                       sincos_pe_fast(encode_arg(dv, h, q - 1), &pd[q - 1], &pd[6 + q - 1]);
-                       sincos_pe_fast(encode_arg(dv, h, q), &pd[q], &pd[6 + q]);
+                   if (q < 7) {
+                       encode_sincos(dt, h, q - 1, &pd[q - 1], &pd[6 + q - 1]);
+                       encode_sincos(dt, h, q, &pd[q], &pd[6 + q]);
                        pin(pd[q - 1]); pin(pd[q]); pin(pd[5 + q]); pin(pd[6 + q]);
                    } else init_bias_pair(cst, SEC_VC, h, 0, acc);
                });
-        if (__any(fabsf(encode_arg(dv, h, 5)) > SINCOS_FAST_MAX || fabsf(encode_arg(dv, h, 4)) > SINCOS_FAST_MAX)) {   // the two largest multiples
-            float r[6], sn[6], cs[6];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) r[q] = encode_arg(dv, h, q);
-            sincos_pe_batch(r, sn, cs);
-#pragma unroll
-            for (int q = 0; q < 6; ++q) { pd[q] = sn[q]; pd[6 + q] = cs[q]; }
-        }
         pd[12] = h ? dv[2] : dv[0];
         pd[13] = h ? 0.f : dv[1];
         pd[14] = 0.f; pd[15] = 0.f;

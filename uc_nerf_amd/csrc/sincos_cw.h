@@ -70,4 +70,27 @@ __device__ __forceinline__ void sincos_pe_batch(const float (&r)[N], float (&s)[
     }
 }
 
+// ---- hardware path used by the MLP kernels: v_sin_f32 / v_cos_f32 take their argument in REVOLUTIONS, so the range
+// reduction is one v_fract_f32 -- exact -- provided x / (2 pi) is carried as an unevaluated two-float sum (the residual of
+// the product and the low part of 1 / (2 pi) ride in `lo`).  2^k * hi is exact, fract() of it is exact, and the low part is
+// added after the reduction: measured max error against float64 over |x| <= 1.3, k = 0..9: 4.2e-7 (scripts/micro/
+// hw_sincos.hip) -- the accuracy of the 25-instruction Cody-Waite path above for 5 instructions per (sin, cos) pair, with
+// no argument-size limit to branch on.
+struct Rev2 { float hi, lo; };
+
+__device__ __forceinline__ Rev2 to_revolutions(float x) {
+    const float chi = 0.15915494309189535f;                                   // fl(1 / (2 pi))
+    const float clo = 6.4206383e-09f;                                         // 1 / (2 pi) - chi
+    Rev2 t;
+    t.hi = x * chi;
+    t.lo = fmaf(x, clo, fmaf(x, chi, -t.hi));
+    return t;
+}
+
+__device__ __forceinline__ void sincos_rev(float hi, float lo, float scale, float* s_out, float* c_out) {
+    const float f = fmaf(lo, scale, __builtin_amdgcn_fractf(hi * scale));
+    *s_out = __builtin_amdgcn_sinf(f);
+    *c_out = __builtin_amdgcn_cosf(f);
+}
+
 }  // namespace ucnerf
