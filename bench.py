@@ -2,7 +2,7 @@
 """Headline benchmark: rendered rays/sec, 64 coarse + 128 fine samples (the fine pass evaluates the merged
 192), 4096 synthetic rays per GPU (BASELINE.json configs[1]).
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -57,8 +57,8 @@ def cpu_baseline(scene_cpu, sd, n_rays, n_coarse, n_fine, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)      # ~0.2 s of GPU time: the clocks need ~100 steps to settle
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
     ap.add_argument("--coarse", type=int, default=64)
     ap.add_argument("--fine", type=int, default=128)
