@@ -264,9 +264,14 @@ typedef struct {
     int32_t g_feat_stride;     /* 0 = F */
     float* g_flat;             /* [param_count] accumulated */
     float* workspace;          /* scratch, ucnerf_mlp_bwd_workspace_floats() floats, 16-byte aligned */
+    int32_t saved_valid;       /* 1: `workspace` already holds the activations of THIS forward, written by
+                                  ucnerf_mlp_fwd_train with the same arguments -- the backward then skips its own forward */
 } ucnerf_mlp_bwd_params;
 int64_t ucnerf_mlp_bwd_workspace_floats(const ucnerf_mlp_config* cfg, int32_t m);
 int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* p, void* stream);
+/* Training forward: ucnerf_mlp_fwd (f32 precision) that also keeps the per-layer activations in `bwd_workspace`
+ * (ucnerf_mlp_bwd_workspace_floats floats), for a following ucnerf_mlp_bwd with saved_valid = 1. */
+int ucnerf_mlp_fwd_train(const ucnerf_mlp_params* p, float* bwd_workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a9  alpha compositing -- network/renderer.py:25-36,109-140 (variant 0 "live": alpha = 1-exp(-sigma),
@@ -388,6 +393,9 @@ typedef struct {
     /* optional timing hooks: events (ucnerf_event_create) recorded on `stream` right before / after the MLP kernel */
     void* ev_mlp_start;
     void* ev_mlp_stop;
+    float* train_workspace;    /* optional (training forward; needs raw and feats): the workspace of the coming
+                                  ucnerf_render_fused_bwd call -- the MLP activations are kept there, see
+                                  ucnerf_render_bwd_params.saved_valid */
 } ucnerf_render_params;
 int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream);
@@ -411,6 +419,8 @@ typedef struct {
     float* g_img_feat;
     float* workspace;              /* ucnerf_render_bwd_workspace_floats(n, S, V) floats, 16-byte aligned */
     float* gather_scratch;         /* optional: ucnerf_feat_gather_bwd_params.scratch for the gather backward */
+    int32_t saved_valid;           /* 1: the forward call was given this `workspace` as fwd.train_workspace (it kept the
+                                      MLP activations there), so the backward does not repeat the network forward */
 } ucnerf_render_bwd_params;
 int64_t ucnerf_render_bwd_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* p, void* stream);

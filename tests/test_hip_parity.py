@@ -396,6 +396,11 @@ def test_render_pass_backward_reaches_volumes_features_confidence_and_parameters
         if p[k].grad is not None:
             w = p[k].grad
             torch.testing.assert_close(got, w, atol=3e-4 * w.abs().max().item() + 1e-7, rtol=3e-3, msg=lambda s_: k + ": " + s_)
+    # the call above consumed the activations the training forward kept; a second backward re-runs the network forward
+    # itself -- same gradients either way (float atomics: not bit-identical)
+    again = rp.backward(dev(rays_d), dev(z), kept, dev(r3), dev(r1), flat)
+    for a, b in zip(again, (g_flat, gv1, gv2, gv3, gc, gi)):
+        torch.testing.assert_close(a, b, atol=1e-5 * b.abs().max().item() + 1e-9, rtol=1e-4)
 
 
 # ---------------------------------------------------------------------------------------------- a6, bf16x3 precision

@@ -75,7 +75,7 @@ class MlpParams(C.Structure):
 
 class MlpBwdParams(C.Structure):
     _fields_ = [("fwd", MlpParams), ("g_raw", vp), ("flat_params", vp), ("g_feats", vp), ("g_feat_stride", i32),
-                ("g_flat", vp), ("workspace", vp)]
+                ("g_flat", vp), ("workspace", vp), ("saved_valid", i32)]
 
 
 class CompositeParams(C.Structure):
@@ -107,12 +107,13 @@ class RenderParams(C.Structure):
                 ("vol_h", i32 * 3), ("vol_w", i32 * 3), ("vol", vp * 3), ("conf", vp), ("imgs", vp), ("img_feat", vp),
                 ("w2cs", vp), ("intrinsics", vp), ("wstream", vp), ("sources_cl", vp), ("workspace", vp), ("rgb_map", vp),
                 ("depth_map", vp), ("acc_map", vp), ("weights", vp), ("var", vp), ("raw", vp), ("feats", vp),
-                ("ev_mlp_start", vp), ("ev_mlp_stop", vp)]
+                ("ev_mlp_start", vp), ("ev_mlp_stop", vp), ("train_workspace", vp)]
 
 
 class RenderBwdParams(C.Structure):
     _fields_ = [("fwd", RenderParams), ("g_rgb", vp), ("g_depth", vp), ("flat_params", vp), ("g_flat", vp),
-                ("g_vol", vp * 3), ("g_conf", vp), ("g_img_feat", vp), ("workspace", vp), ("gather_scratch", vp)]
+                ("g_vol", vp * 3), ("g_conf", vp), ("g_img_feat", vp), ("workspace", vp), ("gather_scratch", vp),
+                ("saved_valid", i32)]
 
 
 STRUCTS = {
@@ -157,6 +158,7 @@ SYMBOLS = {
     "ucnerf_mlp_fwd": (C.c_int, [_P, _P]),
     "ucnerf_mlp_bwd_workspace_floats": (C.c_int64, [_P, C.c_int32]),
     "ucnerf_mlp_bwd": (C.c_int, [_P, _P]),
+    "ucnerf_mlp_fwd_train": (C.c_int, [_P, _P, _P]),
     "ucnerf_composite_fwd": (C.c_int, [_P, _P]),
     "ucnerf_composite_bwd": (C.c_int, [_P, _P]),
     "ucnerf_sample_pdf": (C.c_int, [_P, _P]),

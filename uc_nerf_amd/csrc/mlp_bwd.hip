@@ -382,6 +382,22 @@ int64_t ucnerf_mlp_bwd_workspace_floats(const ucnerf_mlp_config* cfg, int32_t m)
     return (int64_t)carve_bwd(nullptr, m, m, &w);      // upper bound (direction rows <= m)
 }
 
+int ucnerf_mlp_fwd_train(const ucnerf_mlp_params* p, float* bwd_workspace, void* stream) {
+    UCNERF_REQUIRE(p && bwd_workspace, "mlp_fwd_train: null pointer");
+    if (p->m <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->cfg.precision == 0, "mlp_fwd_train: the training forward runs in f32 precision");
+    UCNERF_REQUIRE(!p->feats_tiled, "mlp_fwd_train: features must be row-major [m,F]");
+    UCNERF_REQUIRE(((uintptr_t)bwd_workspace & 15) == 0, "mlp_fwd_train: workspace must be 16-byte aligned");
+    BwdWork w;
+    carve_bwd(bwd_workspace, p->m, p->dirs_per_sample ? p->m : p->m / (p->S > 0 ? p->S : 1), &w);
+    hipStream_t st = (hipStream_t)stream;
+    RUN(launch_mlp_fwd(p, &w.sv, st));
+    // the backward reads the forward's output from its own slot
+    if (hipMemcpyAsync(w.raw, p->raw, (size_t)p->m * 4 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(UCNERF_EHIP, "mlp_fwd_train: copy failed");
+    return UCNERF_OK;
+}
+
 int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     UCNERF_REQUIRE(bp, "mlp_bwd: null params");
     const ucnerf_mlp_params& f = bp->fwd;
@@ -408,9 +424,11 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
 
     // 0. forward with the activations kept; encodings as explicit matrices for the weight-gradient GEMMs
     UCNERF_REQUIRE(f.cfg.precision == 0, "mlp_bwd: the backward runs in f32 precision (pack the weights with precision 0)");
-    ucnerf_mlp_params fw = f;
-    fw.raw = w.raw;
-    RUN(launch_mlp_fwd(&fw, &w.sv, st));
+    if (!bp->saved_valid) {
+        ucnerf_mlp_params fw = f;
+        fw.raw = w.raw;
+        RUN(launch_mlp_fwd(&fw, &w.sv, st));
+    }
     const float *pep = w.pep, *ped = w.ped;      // encodings as matrices: [m,63] and [n_dirs,27]
     int ld_pep = 63, ld_ped = 27;
     if (f.encoded) {                              // already in memory (UCNeRF.forward(x) of the reference)

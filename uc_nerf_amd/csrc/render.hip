@@ -109,6 +109,16 @@ static int launch_dirs(const ucnerf_render_params* p, hipStream_t st, Workspace*
     return ucnerf_dir_feature(&d, st);
 }
 
+static size_t carve_bwd_render(float* base, int n, int S, int V, Workspace* w, float** g_raw, float** g_feats, float** mlp_ws) {
+    size_t o = carve(base, n, S, V, w);
+    const size_t M = (size_t)n * S, F = 24 + 12 * V + 1;
+    ucnerf_mlp_config cfg{V, 0, 0};
+    const size_t mlp = (size_t)ucnerf_mlp_bwd_workspace_floats(&cfg, (int)M);
+    auto take = [&](size_t k) { float* r = base ? base + o : nullptr; o += align4(k); return r; };
+    *g_raw = take(4 * M); *g_feats = take(M * F); *mlp_ws = take(mlp);
+    return o;
+}
+
 static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace* w) {
     const int V = p->cfg.n_src;
     carve(p->workspace, p->n, p->S, V, w);
@@ -130,7 +140,12 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
     ucnerf_mlp_params m;
     mlp_args(p, w, g.feats, g.out_tiled, p->raw ? p->raw : w->raw, &m);
     if (p->ev_mlp_start && (rc = ucnerf_event_record(p->ev_mlp_start, st))) return rc;
-    if ((rc = ucnerf_mlp_fwd(&m, st))) return rc;
+    if (p->train_workspace && keep_feats && p->raw) {    // training forward: activations go straight into the backward's workspace
+        Workspace wb;
+        float *g_raw, *g_feats, *mlp_ws;
+        carve_bwd_render(p->train_workspace, p->n, p->S, V, &wb, &g_raw, &g_feats, &mlp_ws);
+        if ((rc = ucnerf_mlp_fwd_train(&m, mlp_ws, st))) return rc;
+    } else if ((rc = ucnerf_mlp_fwd(&m, st))) return rc;
     if (p->ev_mlp_stop && (rc = ucnerf_event_record(p->ev_mlp_stop, st))) return rc;
 
     ucnerf_composite_params c;
@@ -154,15 +169,6 @@ int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V) {
 }
 
 // backward workspace = [forward-style carve (points, coordinates, directions)] [g_raw 4M] [g_feats M*F] [mlp_bwd scratch]
-static size_t carve_bwd_render(float* base, int n, int S, int V, Workspace* w, float** g_raw, float** g_feats, float** mlp_ws) {
-    size_t o = carve(base, n, S, V, w);
-    const size_t M = (size_t)n * S, F = 24 + 12 * V + 1;
-    ucnerf_mlp_config cfg{V, 0, 0};
-    const size_t mlp = (size_t)ucnerf_mlp_bwd_workspace_floats(&cfg, (int)M);
-    auto take = [&](size_t k) { float* r = base ? base + o : nullptr; o += align4(k); return r; };
-    *g_raw = take(4 * M); *g_feats = take(M * F); *mlp_ws = take(mlp);
-    return o;
-}
 
 int64_t ucnerf_render_bwd_workspace_floats(int32_t n, int32_t S, int32_t V) {
     if (n < 0 || S < 1 || V < 1 || V > 8) return fail(UCNERF_EINVAL, "render_bwd_workspace: bad sizes n=%d S=%d V=%d", n, S, V);
@@ -200,6 +206,7 @@ int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* bp, void* stream) {
     mlp_args(&q, &w, p->feats, 0, nullptr, &mb.fwd);
     mb.fwd.raw = g_raw;                      // placeholder (not written by the backward)
     mb.g_raw = g_raw; mb.flat_params = bp->flat_params; mb.g_feats = g_feats; mb.g_flat = bp->g_flat; mb.workspace = mlp_ws;
+    mb.saved_valid = bp->saved_valid;
     if ((rc = ucnerf_mlp_bwd(&mb, st))) return rc;
 
     if (bp->g_vol[0] || bp->g_vol[1] || bp->g_vol[2] || bp->g_conf || bp->g_img_feat) {

@@ -678,6 +678,16 @@ class RenderPass:
         p.rgb_map, p.depth_map, p.acc_map = _ptr(out["rgb"]), _ptr(out["depth"]), _ptr(out.get("acc"))
         p.weights, p.var, p.raw, p.feats = _ptr(out.get("weights")), _ptr(out.get("var")), _ptr(out.get("raw")), _ptr(out.get("feats"))
         p.ev_mlp_start, p.ev_mlp_stop = events if events is not None else (None, None)
+        p.train_workspace = None
+        self._saved_for = None
+        if "raw" in keep and "feats" in keep and self.pw.cfg.precision == 0:
+            # training forward: keep the MLP activations in the backward's workspace so that backward() need not
+            # repeat the network forward
+            need_b = L.lib().ucnerf_render_bwd_workspace_floats(n, S, self.src.V)
+            if getattr(self, "_bwd_ws", None) is None or self._bwd_ws.numel() < need_b:
+                self._bwd_ws = torch.empty(need_b, device=dev)
+            p.train_workspace = _ptr(self._bwd_ws)
+            self._saved_for = (n, S, out["raw"].data_ptr())
         _launch("ucnerf_render_fused_fwd", p, dev)
         return out
 
@@ -695,7 +705,10 @@ class RenderPass:
         p.rays_d, p.z, p.near_far = _ptr(rays_d), _ptr(z), _ptr(near_far)
         p.raw, p.feats = _ptr(kept["raw"]), _ptr(kept["feats"])
         p.ev_mlp_start = p.ev_mlp_stop = None
-        ws = torch.empty(L.lib().ucnerf_render_bwd_workspace_floats(n, S, self.src.V), device=dev)
+        saved = getattr(self, "_saved_for", None) == (n, S, kept["raw"].data_ptr())
+        ws = self._bwd_ws if saved else torch.empty(L.lib().ucnerf_render_bwd_workspace_floats(n, S, self.src.V), device=dev)
+        bp.saved_valid = int(saved)
+        self._saved_for = None
         g_flat = torch.zeros(self.pw.n_params, device=dev)
         gv = [torch.zeros_like(v) if need[k] else None for k, v in enumerate(self.src.vols)]
         gc = torch.zeros_like(self.src.conf) if need[3] else None
