@@ -215,7 +215,10 @@ typedef struct {
     int32_t precision;    /* 0: f32 -- exact fp32 MFMA (v_mfma_f32_32x32x2_f32); forward, backward, every input mode.
                              1: bf16x3 -- every product as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the bf16 matrix cores
                                 (v_mfma_f32_32x32x16_bf16, fp32 accumulate): inference forward only; rendered outputs
-                                stay within 1e-5 of fp64 (the parity bar is 1e-4), ~2.5x the f32 throughput. */
+                                stay within 1e-5 of fp64 (the parity bar is 1e-4), ~2.9x the f32 throughput.
+                             2: bf16 -- the hi*hi term only (plain bf16 operands, fp32 accumulate; same packed stream as 1):
+                                inference forward only, NOT within the 1e-4 parity bar (rendered error ~3e-3, > 50 dB PSNR
+                                against the f32 render); offered because the reference configuration names bf16. */
 } ucnerf_mlp_config;
 
 /* Sizes: floats in the flat parameter vector, floats (4-byte units) of the packed stream, int32 entries of the pack

@@ -293,19 +293,26 @@ __device__ __forceinline__ void interleave_hint() {
 // One half-step: (c0, c1) += A_hi*B_hi + A_hi*B_lo + A_lo*B_hi for one row-tile pair, with `fill()` -- element-wise work
 // that does not depend on these MFMAs -- issued between them.  ODD = second half-step of its ring slot (the next
 // fragments then come from the next slot).  `cur` holds this half-step's A fragments on entry, the next one's on exit.
-template <class F>
+template <int TERMS, class F>
 __device__ __forceinline__ void half_step(const int ODD, Pipe& P, AF& cur, int lane, const Frag& b, f32x16& c0, f32x16& c1, F&& fill) {
     if (ODD) advance(P);                                   // (a constant once the caller's loop is unrolled)
-    const AF nxt = read_half(P.buf, lane, ODD ? 0 : 1);
+    AF nxt;
+    if (TERMS == 3) nxt = read_half(P.buf, lane, ODD ? 0 : 1);
+    else {                                                 // plain bf16: the lo halves are never read
+        const bf16x8* a = reinterpret_cast<const bf16x8*>(P.buf + (ODD ? 0 : 1) * HALF_BYTES) + lane;
+        nxt.h0 = a[0]; nxt.h1 = a[128]; nxt.l0 = nxt.h0; nxt.l1 = nxt.h1;
+    }
     SB0;
-    c0 = MFMA16(cur.h0, b.hi, c0); c0 = MFMA16(cur.h0, b.lo, c0); c0 = MFMA16(cur.l0, b.hi, c0);   // (one accumulation chain
-    c1 = MFMA16(cur.h1, b.hi, c1); c1 = MFMA16(cur.h1, b.lo, c1); c1 = MFMA16(cur.l1, b.hi, c1);   //  runs at full rate)
+    c0 = MFMA16(cur.h0, b.hi, c0);
+    if (TERMS == 3) { c0 = MFMA16(cur.h0, b.lo, c0); c0 = MFMA16(cur.l0, b.hi, c0); }   // (one accumulation chain runs at full rate)
+    c1 = MFMA16(cur.h1, b.hi, c1);
+    if (TERMS == 3) { c1 = MFMA16(cur.h1, b.lo, c1); c1 = MFMA16(cur.l1, b.hi, c1); }
     fill();
-    interleave_hint<UCNERF_BF16_HINT_V>();
+    if (TERMS == 3) interleave_hint<UCNERF_BF16_HINT_V>();
     SB0;
     cur = nxt;
 }
-#define HS(ODD, B, C0, C1, ...) half_step((ODD), P, cur, lane, (B), (C0), (C1), [&]() { __VA_ARGS__; })
+#define HS(ODD, B, C0, C1, ...) half_step<TERMS>((ODD), P, cur, lane, (B), (C0), (C1), [&]() { __VA_ARGS__; })
 
 // bias block of section `sec` -> accumulators of one row-tile pair
 __device__ __forceinline__ void init_bias_pair(const float* cst, int sec, int h, int pair, f32x16 (&acc)[4]) {
@@ -386,7 +393,7 @@ __device__ __forceinline__ void encode16(const float (&x)[3], int h, float (&pe)
     for (int q = 2 * half + 2; q < KS; ++q) pe[q] = 0.f;
 }
 
-template <bool TILED, int NSRC>
+template <bool TILED, int NSRC, int TERMS>       // TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only)
 #ifndef UCNERF_BF16_WPS
 #define UCNERF_BF16_WPS 2      // waves per SIMD (= blocks per CU): 2 -> 256 VGPRs per wave, 1 -> 512
 #endif
@@ -420,7 +427,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     for (int i = 0; i < NBUF; ++i) issue_dma(P, i);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * DMA_PER_SLOT) : "memory");     // slot 0 has landed ...
     __builtin_amdgcn_s_barrier();                                                        // ... for every wave
-    AF cur = read_half(P.buf, lane, 0);
+    AF cur = read_half(P.buf, lane, 0);                     // (TERMS 1 reads the unused lo halves once here)
 
     const int tiles_per_round = gridDim.x * BW;
     const int n_rounds = (n_tiles + tiles_per_round - 1) / tiles_per_round;
@@ -729,26 +736,21 @@ int launch_mlp_fwd_bf16(const ucnerf_mlp_params* p, hipStream_t st) {
     // the generic instantiation (runtime section lengths: correct, but the compiler spills there)
     static bool attr_set = false;
     const size_t smem = bf16_smem_bytes();
+#define UCNERF_BF16_FOR_ALL(X) X(true, 6, 3) X(false, 6, 3) X(true, 3, 3) X(false, 3, 3) X(true, 0, 3) X(false, 0, 3) X(true, 6, 1) X(false, 6, 1) X(true, 0, 1) X(false, 0, 1)
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<true, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#define X(T, N, K) (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<T, N, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        UCNERF_BF16_FOR_ALL(X)
+#undef X
         attr_set = true;
     }
     dim3 grid(blocks), block(64 * BW);
-    if (B.v == 6) {
-        if (p->feats_tiled) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, 6>), grid, block, smem, st, *p, g, n_tiles);
-        else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, 6>), grid, block, smem, st, *p, g, n_tiles);
-    } else if (B.v == 3) {
-        if (p->feats_tiled) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, 3>), grid, block, smem, st, *p, g, n_tiles);
-        else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, 3>), grid, block, smem, st, *p, g, n_tiles);
-    } else {
-        if (p->feats_tiled) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, 0>), grid, block, smem, st, *p, g, n_tiles);
-        else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, 0>), grid, block, smem, st, *p, g, n_tiles);
-    }
+    const bool tiled = p->feats_tiled != 0;
+    const int terms = p->cfg.precision == 2 ? 1 : 3;
+    const int nsrc = B.v == 6 ? 6 : (B.v == 3 && terms == 3 ? 3 : 0);
+#define X(T, N, K) if (tiled == T && nsrc == N && terms == K) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<T, N, K>), grid, block, smem, st, *p, g, n_tiles);
+    UCNERF_BF16_FOR_ALL(X)
+#undef X
+#undef UCNERF_BF16_FOR_ALL
     return check_launch("mlp_fwd_bf16");
 }
 

@@ -26,7 +26,8 @@ class CoarseFineRenderer:
         self.n_coarse, self.n_fine, self.white_bkgd = n_coarse, n_fine, white_bkgd
         self.src = ops.GatherSources(scene["vols"], scene["confidence"], scene["imgs"], scene["img_feat"],
                                      scene["w2cs"][1:], scene["intrinsics"][1:])
-        self.precision = precision          # "f32": exact fp32 MFMA; "bf16x3": split-bf16 matrix-core path (inference)
+        self.precision = precision          # "f32": exact fp32 MFMA; "bf16x3": split-bf16 matrix cores (inference, within the
+                                            # parity bar); "bf16": plain bf16 operands (inference, ~3e-3 render error)
         self.pw = ops.PackedWeights.get(self.src.V, pe_layout, dev, precision)
         self.wstream = self.pw.pack(flat_params)
         w2c_ref = scene["w2cs"][0]
