@@ -587,12 +587,6 @@ int64_t bf16_index_count(const ucnerf_mlp_config* cfg);
 int64_t bf16_stream_floats(const ucnerf_mlp_config* cfg);
 int launch_pack_bf16(const ucnerf_mlp_config* cfg, const float* flat, const int32_t* idx, float* out, hipStream_t st);
 int launch_mlp_fwd_bf16(const ucnerf_mlp_params* p, hipStream_t st);
-int launch_pack_bf16_stream(const float* flat, const int32_t* idx, float* out, int64_t n16, int64_t const_off_bytes, hipStream_t st);
-// mlp_bf16_s16.hip (precision 3: the bf16x3 evaluation on the 16x16x32 MFMA shape)
-int build_pack_index_bf16_s16(const ucnerf_mlp_config* cfg, int32_t* idx);
-int64_t bf16_s16_index_count(const ucnerf_mlp_config* cfg);
-int64_t bf16_s16_stream_floats(const ucnerf_mlp_config* cfg);
-int launch_mlp_fwd_bf16_s16(const ucnerf_mlp_params* p, hipStream_t st);
 
 }  // namespace ucnerf
 
@@ -610,25 +604,20 @@ int64_t ucnerf_mlp_stream_count(const ucnerf_mlp_config* cfg) {
     MlpLayout L;
     if (!cfg || !mlp_layout(cfg->n_src, &L)) return fail(UCNERF_EINVAL, "mlp: n_src must be in 1..8");
     if (cfg->precision == 1 || cfg->precision == 2) return bf16_stream_floats(cfg);
-    if (cfg->precision == 3) return bf16_s16_stream_floats(cfg);
-    if (cfg->precision != 0) return fail(UCNERF_EINVAL, "mlp: precision %d (0 = f32, 1 = bf16x3, 2 = bf16, 3 = bf16x3 on 16x16x32)", cfg->precision);
+    if (cfg->precision != 0) return fail(UCNERF_EINVAL, "mlp: precision %d (0 = f32, 1 = bf16x3, 2 = bf16)", cfg->precision);
     return L.total;
 }
 
 int64_t ucnerf_mlp_index_count(const ucnerf_mlp_config* cfg) {
     const int64_t n = ucnerf_mlp_stream_count(cfg);
     if (n < 0) return n;
-    return cfg->precision == 3 ? bf16_s16_index_count(cfg) : (cfg->precision != 0 ? bf16_index_count(cfg) : n);
+    return cfg->precision != 0 ? bf16_index_count(cfg) : n;
 }
 
 int ucnerf_mlp_pack_index(const ucnerf_mlp_config* cfg, int32_t* idx_host) {
     UCNERF_REQUIRE(cfg && idx_host, "mlp_pack_index: null pointer");
     UCNERF_REQUIRE(cfg->pe_layout == 0 || cfg->pe_layout == 1, "mlp_pack_index: pe_layout %d", cfg->pe_layout);
-    UCNERF_REQUIRE(cfg->precision >= 0 && cfg->precision <= 3, "mlp_pack_index: precision %d", cfg->precision);
-    if (cfg->precision == 3) {
-        UCNERF_REQUIRE(build_pack_index_bf16_s16(cfg, idx_host) == 0, "mlp_pack_index: n_src %d outside 1..8", cfg->n_src);
-        return UCNERF_OK;
-    }
+    UCNERF_REQUIRE(cfg->precision >= 0 && cfg->precision <= 2, "mlp_pack_index: precision %d", cfg->precision);
     if (cfg->precision == 0) {
         UCNERF_REQUIRE(build_pack_index(cfg, idx_host) == 0, "mlp_pack_index: n_src %d outside 1..8", cfg->n_src);
         return UCNERF_OK;
@@ -646,11 +635,6 @@ int ucnerf_mlp_pack_index(const ucnerf_mlp_config* cfg, int32_t* idx_host) {
 
 int ucnerf_mlp_pack(const ucnerf_mlp_config* cfg, const float* flat, const int32_t* idx, float* out, void* stream) {
     UCNERF_REQUIRE(cfg && flat && idx && out, "mlp_pack: null pointer");
-    if (cfg->precision == 3) {
-        const int64_t n16 = bf16_s16_index_count(cfg) - CONST_FLOATS;
-        UCNERF_REQUIRE(n16 > 0, "mlp_pack: bad config");
-        return launch_pack_bf16_stream(flat, idx, out, n16, n16 * 2, (hipStream_t)stream);
-    }
     if (cfg->precision != 0) return launch_pack_bf16(cfg, flat, idx, out, (hipStream_t)stream);
     const int64_t n = ucnerf_mlp_stream_count(cfg);
     UCNERF_REQUIRE(n > 0, "mlp_pack: bad config");
@@ -665,7 +649,6 @@ int ucnerf_mlp_unpack_grad(const float* g, const int32_t* idx, float* gflat, int
 }
 
 int ucnerf_mlp_fwd(const ucnerf_mlp_params* p, void* stream) {
-    if (p && p->cfg.precision == 3) return launch_mlp_fwd_bf16_s16(p, (hipStream_t)stream);
     if (p && p->cfg.precision != 0) return launch_mlp_fwd_bf16(p, (hipStream_t)stream);
     return launch_mlp_fwd(p, nullptr, (hipStream_t)stream);
 }

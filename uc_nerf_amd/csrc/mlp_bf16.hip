@@ -771,18 +771,14 @@ __global__ void pack_f32_kernel(const float* __restrict__ flat, const int32_t* _
     if (i < n) { const int32_t k = idx[i]; out[i] = k >= 0 ? flat[k] : 0.f; }
 }
 
-// bf16 (hi | lo) part of a stream from its index (n16 elements), then the fp32 constants block behind it
-int launch_pack_bf16_stream(const float* flat, const int32_t* idx, float* out, int64_t n16, int64_t const_off_bytes, hipStream_t st) {
-    hipLaunchKernelGGL(pack_bf16_kernel, dim3(cdiv(n16, 256)), dim3(256), 0, st, flat, idx, reinterpret_cast<unsigned short*>(out), n16);
-    hipLaunchKernelGGL(pack_f32_kernel, dim3(cdiv(CONST_FLOATS, 256)), dim3(256), 0, st, flat, idx + n16,
-                       reinterpret_cast<float*>(reinterpret_cast<char*>(out) + const_off_bytes), CONST_FLOATS);
-    return check_launch("mlp_pack (bf16)");
-}
-
 int launch_pack_bf16(const ucnerf_mlp_config* cfg, const float* flat, const int32_t* idx, float* out, hipStream_t st) {
     Bf16Layout B;
     UCNERF_REQUIRE(bf16_layout(cfg->n_src, &B), "mlp_pack: n_src %d outside 1..8", cfg->n_src);
-    return launch_pack_bf16_stream(flat, idx, out, (int64_t)B.slots * (SLOT_BYTES / 2), B.const_off_bytes, st);
+    const int64_t n16 = (int64_t)B.slots * (SLOT_BYTES / 2);
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(cdiv(n16, 256)), dim3(256), 0, st, flat, idx, reinterpret_cast<unsigned short*>(out), n16);
+    hipLaunchKernelGGL(pack_f32_kernel, dim3(cdiv(CONST_FLOATS, 256)), dim3(256), 0, st, flat, idx + n16,
+                       reinterpret_cast<float*>(reinterpret_cast<char*>(out) + B.const_off_bytes), CONST_FLOATS);
+    return check_launch("mlp_pack (bf16x3)");
 }
 
 }  // namespace ucnerf

@@ -4,7 +4,6 @@ PyTorch is plumbing here (device memory, streams, autograd bookkeeping); every c
 libucnerf_hip.so.  All functions require float32 tensors on a ROCm device and raise otherwise.
 """
 import ctypes as C
-import os
 
 import torch
 
@@ -332,13 +331,10 @@ class PackedWeights:
     """Pack index (host-built by the library, cached on device) + packing of a flat parameter vector."""
     _cache = {}
 
-    PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2, "bf16x3_s16": 3}
+    PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}
 
     def __init__(self, n_src, pe_layout, device, precision="f32"):
-        code = self.PRECISIONS[precision]
-        if precision == "bf16x3" and os.environ.get("UCNERF_BF16_SHAPE", "") == "16":
-            code = self.PRECISIONS["bf16x3_s16"]        # A/B switch: same arithmetic on the 16x16x32 MFMA shape
-        self.cfg = L.MlpConfig(n_src, pe_layout, code)
+        self.cfg = L.MlpConfig(n_src, pe_layout, self.PRECISIONS[precision])
         self.precision = precision
         lib = L.lib()
         self.n_params = lib.ucnerf_mlp_param_count(C.addressof(self.cfg))
