@@ -68,7 +68,7 @@ static size_t carve(float* base, int n, int S, int V, Workspace* w) {
     size_t o = 0;
     auto take = [&](size_t k) { float* r = base ? base + o : nullptr; o += align4(k); return r; };
     w->pts = take(3 * M); w->ndc1 = take(3 * M); w->ndc2 = take(3 * M); w->ndc3 = take(3 * M); w->ndc = take(3 * M);
-    w->angle = take(3 * M);          // per-sample view directions
+    w->angle = take(3 * M);          // view directions in the reference camera frame, one per RAY (the MLP kernels index them by sample / S)
     w->raw = take(4 * M);
     w->feats = take(tiles * 32 * F);
     return o;
@@ -97,14 +97,14 @@ static void gather_geometry(const ucnerf_render_params* p, const Workspace* w, u
 
 static void mlp_args(const ucnerf_render_params* p, const Workspace* w, const float* feats, int tiled, float* raw, ucnerf_mlp_params* m) {
     memset(m, 0, sizeof(*m));
-    m->cfg = p->cfg; m->m = p->n * p->S; m->S = p->S; m->dirs_per_sample = 1; m->feats_tiled = tiled; m->max_blocks = p->max_blocks;
+    m->cfg = p->cfg; m->m = p->n * p->S; m->S = p->S; m->dirs_per_sample = 0; m->feats_tiled = tiled; m->max_blocks = p->max_blocks;
     m->pts = w->ndc; m->dirs = w->angle; m->feats = feats; m->wstream = p->wstream; m->raw = raw;
 }
 
 static int launch_dirs(const ucnerf_render_params* p, hipStream_t st, Workspace* w) {
     ucnerf_dir_feature_params d;
     memset(&d, 0, sizeof(d));
-    d.n = p->n; d.has_ref = 1; d.repeat = p->S; memcpy(d.w2c_ref, p->w2c_dir, sizeof(d.w2c_ref));
+    d.n = p->n; d.has_ref = 1; d.repeat = 1; memcpy(d.w2c_ref, p->w2c_dir, sizeof(d.w2c_ref));
     d.rays_d = p->rays_d; d.angle = w->angle; d.cos_angle = nullptr;
     return ucnerf_dir_feature(&d, st);
 }
