@@ -29,6 +29,9 @@
 #include "mlp_layout.h"
 #include "sincos_cw.h"
 
+// the LDS-DMA asm below names m0 as a clobber on purpose (it loads the LDS base into it)
+#pragma clang diagnostic ignored "-Winline-asm"
+
 #include <cstdlib>
 #include <vector>
 
@@ -403,7 +406,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     float* cst = reinterpret_cast<float*>(smem + NBUF * SLOT_BYTES);
     Frag* stash_all = reinterpret_cast<Frag*>(smem + NBUF * SLOT_BYTES + ((CONST_FLOATS * 4 + 15) & ~15));
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 31, h = lane >> 5;
+    const int h = lane >> 5;
     constexpr int KD_S = (24 + 4 * NSRC + 15) / 16, KC_S = (8 * NSRC + 15) / 16;
     const int kd16 = NSRC ? KD_S : g.kd16, kc16 = NSRC ? KC_S : g.kc16;
     const int F = NSRC ? 24 + 12 * NSRC + 1 : g.F, f_img = NSRC ? 24 + 4 * NSRC : g.f_img;

@@ -42,34 +42,6 @@ __device__ __forceinline__ void sincos_pe(float r, float* s_out, float* c_out) {
     sincos_pe_fast(r, s_out, c_out);
 }
 
-// N arguments at once: all of them branch-free (so that the N dependent chains interleave), then ONE wave-uniform
-// check; only if some lane holds an argument outside the fast range are those redone with OCML.
-template <int N>
-__device__ __forceinline__ void sincos_pe_batch(const float (&r)[N], float (&s)[N], float (&c)[N]) {
-    bool big = false;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        sincos_pe_fast(r[i], &s[i], &c[i]);
-        big = big || fabsf(r[i]) > SINCOS_FAST_MAX;
-    }
-    if (__any(big)) {
-        // cold: ONE instance of OCML's sincosf in a rolled loop (the arrays live in registers, so element i is
-        // picked and put back with selects) -- the kernels using this are instruction-cache bound otherwise
-#pragma unroll 1
-        for (int i = 0; i < N; ++i) {
-            float ri = r[0];
-#pragma unroll
-            for (int k = 1; k < N; ++k) ri = k == i ? r[k] : ri;
-            if (fabsf(ri) > SINCOS_FAST_MAX) {
-                float ss, cc;
-                sincosf(ri, &ss, &cc);
-#pragma unroll
-                for (int k = 0; k < N; ++k) { s[k] = k == i ? ss : s[k]; c[k] = k == i ? cc : c[k]; }
-            }
-        }
-    }
-}
-
 // ---- hardware path used by the MLP kernels: v_sin_f32 / v_cos_f32 take their argument in REVOLUTIONS, so the range
 // reduction is one v_fract_f32 -- exact -- provided x / (2 pi) is carried as an unevaluated two-float sum (the residual of
 // the product and the low part of 1 / (2 pi) ride in `lo`).  2^k * hi is exact, fract() of it is exact, and the low part is
