@@ -66,7 +66,9 @@ int main() {
     hipMalloc(&w, n * 16); hipMalloc(&out, 1024 * 256 * 4);
     hipMemcpy(w, h.data(), n * 16, hipMemcpyHostToDevice);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    const int iters = 4000, blocks = 512;
+    const int iters = 4000;
+    for (int blocks : {512, 256}) {          // two waves per SIMD, then one
+    printf("--- %d blocks of 4 waves (%d wave(s) per SIMD)\n", blocks, blocks / 256);
     auto run = [&](int shape, int fill, int it) {
         if (shape == 16) { loop_kernel<16, 0><<<blocks, 256>>>(w, out, it); return; }
         switch (fill) {
@@ -89,5 +91,6 @@ int main() {
             const double flop = (double)blocks * 4 * iters * 8 * 6 * 32768.0;
             printf("shape %dx fillers/MFMA %d: %.3f ms, %.1f TFLOP/s executed\n", shape, fill, ms, flop / ms / 1e9);
         }
+    }
     return 0;
 }

@@ -60,7 +60,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BW = 4;                 // waves per block (one per SIMD; two blocks per CU)
 constexpr int SLOT_BYTES = 8192;      // two half-steps: [2][hi0, lo0, hi1, lo1][64 lanes][16 B]
 constexpr int HALF_BYTES = 4096;
-constexpr int NBUF = 4;               // LDS ring slots; the slot of ring position g is refilled with position g + NBUF
+#ifndef UCNERF_BF16_NBUF
+#define UCNERF_BF16_NBUF 4
+#endif
+constexpr int NBUF = UCNERF_BF16_NBUF;   // LDS ring slots (power of two); the slot of ring position g is refilled with position g + NBUF
 constexpr int DMA_PER_SLOT = SLOT_BYTES / 1024 / BW;      // 1-KB global_load_lds pieces per wave per slot
 constexpr int KS16_PE_PTS = 4, KS16_PE_DIR = 2, KS16_HID = 8;
 
@@ -266,10 +269,10 @@ __device__ __forceinline__ AF read_half(const char* buf, int lane, int half) {
 
 // Waits until the next slot has landed for the whole block, refills the slot just read and moves on to it.
 // The lgkmcnt(0) retires every ds_read of the current slot, so after the barrier no wave still reads it.
-// vmcnt: the DMAs younger than the awaited slot are those of the two slots after it.
+// vmcnt: the DMAs younger than the awaited slot are those of the NBUF - 2 slots after it.
 __device__ __forceinline__ void advance(Pipe& P) {
 #if !(UCNERF_BF16_EXP & 1)
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * DMA_PER_SLOT) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NBUF - 2) * DMA_PER_SLOT) : "memory");
 #endif
 #if !(UCNERF_BF16_EXP & 2)
     __builtin_amdgcn_s_barrier();
