@@ -452,3 +452,25 @@ def test_merge_rows_applies_the_sort_permutation_and_handles_empty_input():
     assert torch.equal(out3.cpu(), want[..., :3])
     empty = ops().merge_rows(dev(a[:0]), dev(b[:0]), dev(rank[:0].int()))
     assert empty.shape == (0, na + nb, 4)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_bf16_mlp_is_deterministic_across_many_launches(precision):
+    """Race screen for the LDS weight ring (LDS-DMA + counted vmcnt + one barrier per slot): a read that overtakes its DMA,
+    or a refill that overtakes a read, shows as run-to-run differences.  Several sizes (1, 2, 3 and 12 tiles per wave; ragged
+    last tile), a few hundred launches each, every output compared bit for bit with the first."""
+    from uc_nerf_amd.synthetic import init_ucnerf_state_dict
+    sd = init_ucnerf_state_dict(seed=4, n_src=6)
+    pw = ops().PackedWeights.get(6, 0, torch.device(DEV), precision)
+    ws = pw.pack(dev(flat_params(sd)))
+    gen = torch.Generator().manual_seed(123)
+    for m, S, reps in ((2048 * 32, 64, 150), (2048 * 64 - 17, 1, 100), (4096 * 192, 192, 40)):
+        n_dirs = m // S if S > 1 else m
+        pts, feats = torch.rand(m, 3, generator=gen), torch.randn(m, 97, generator=gen)
+        feats[:, -1] = torch.rand(m, generator=gen)
+        dirs = torch.nn.functional.normalize(torch.randn(n_dirs, 3, generator=gen), dim=-1)
+        pts, feats, dirs = dev(pts), dev(feats), dev(dirs)
+        first = ops().mlp_fwd(pw, ws, pts, dirs, feats, S=S).clone()
+        assert torch.isfinite(first).all()
+        for _ in range(reps):
+            assert torch.equal(ops().mlp_fwd(pw, ws, pts, dirs, feats, S=S), first)
