@@ -43,7 +43,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef UCNERF_BF16_EXP
-#define UCNERF_BF16_EXP 0      // timing experiments only (results are wrong): 1 no DMA wait, 2 no barrier, 4 no DMA, 64 no interleave hints
+#define UCNERF_BF16_EXP 0      // timing experiments only (results are wrong): 1 no DMA wait, 2 no barrier, 4 no DMA, 64 no interleave hints, 128 no epilogue arithmetic, 256 half the LDS fragment reads
 #endif
 #ifndef UCNERF_BF16_HINT_V
 #define UCNERF_BF16_HINT_V 7   // VALU instructions the scheduler may place after each MFMA of a half-step
@@ -303,7 +303,11 @@ template <int TERMS, class F>
 __device__ __forceinline__ void half_step(const int ODD, Pipe& P, AF& cur, int lane, const Frag& b, f32x16& c0, f32x16& c1, F&& fill) {
     if (ODD) advance(P);                                   // (a constant once the caller's loop is unrolled)
     AF nxt;
+#if UCNERF_BF16_EXP & 256       // timing experiment: half the fragment reads (lo := hi, wrong results)
+    if (false) {}
+#else
     if (TERMS == 3) nxt = read_half(P.buf, lane, ODD ? 0 : 1);
+#endif
     else {                                                 // plain bf16: the lo halves are never read
         const bf16x8* a = reinterpret_cast<const bf16x8*>(P.buf + (ODD ? 0 : 1) * HALF_BYTES) + lane;
         nxt.h0 = a[0]; nxt.h1 = a[128]; nxt.l0 = nxt.h0; nxt.l1 = nxt.h1;

@@ -24,80 +24,153 @@ int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t
 __device__ __forceinline__ f32x4 ld4(const float* p) { return f32x4{p[0], p[1], p[2], p[3]}; }
 
 // ------------------------------------------------------------------------------------------------
-// gemm_nn: C[s][n] (=|+=) sum_k A[s][k] W[k][n],  K = 8*KQ, n < N <= 32*NT
+// gemm_nn: C[s][n] (=|+=) sum_k A[s][k] W[k][n],  K = 64*KH, n < N <= 32*NT, optionally followed by the trunk
+// layer's element-wise backward (EPI 1):  g_pre = C * [h > 0];  out = g_pre * bd;  g_bd (+)= g_pre * (h / bd).
+//
+// D rows = samples, D columns = output features, so that everything the epilogue touches (h, bd, g_bd, the output)
+// is a coalesced 128-byte row segment per accumulator register.  The activations reach the A operand (lane = sample)
+// through a wave-private LDS tile filled with coalesced 16-byte loads, one 64-wide half of K at a time with the next
+// half's loads in flight under the MFMAs; the weight matrix sits in LDS once per (persistent) block, padded so that
+// the two k-halves of a wave read disjoint banks.
 // ------------------------------------------------------------------------------------------------
 struct NnArgs {
     const float* A; int lda;
     const float* W; int ldw;
     float* C; int ldc;
     int m, N, accumulate;
+    const float* hh; const float* bd; float* gbd;                // EPI 1 only (all [m,128]; g_bd accumulates)
 };
 
-template <int KQ, int NT>
-__global__ void __launch_bounds__(256) gemm_nn_kernel(NnArgs a, int n_tiles) {
+constexpr int NN_WAVES = 8;
+constexpr int NN_TP = 68;                                          // tile pitch (floats): 64 + 4 -> conflict-free b128 rows
+struct NnEpi { float hv[8], b[8], g[8]; };            // operands of half a column tile (8 accumulator registers)
+template <int KH, int NT> constexpr int nn_lds_bytes() { return (64 * KH * (32 * NT + 8) + NN_WAVES * 32 * NN_TP) * 4; }
+
+template <int KH, int NT, int EPI>
+__global__ void __launch_bounds__(64 * NN_WAVES) gemm_nn_kernel(NnArgs a, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float nn_lds[];
+    constexpr int NP = 32 * NT + 8, K = 64 * KH;
+    float* Wl = nn_lds;
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int n_waves = gridDim.x * 4;
-    for (int tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += n_waves) {
-        const int s_raw = tile * 32 + j;
-        const int s = s_raw < a.m ? s_raw : a.m - 1;
-        const f32x4* arow = reinterpret_cast<const f32x4*>(a.A + (size_t)s * a.lda) + h;     // float4 #(2q + h)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* tile = nn_lds + K * NP + wave * (32 * NN_TP);
+    {                                                                        // weights -> LDS (columns >= N as zeros)
+        constexpr int KS = 64 * NN_WAVES / (32 * NT);                        // rows covered per pass: thread = (row, column)
+        const int n = threadIdx.x % (32 * NT), k0 = threadIdx.x / (32 * NT);
+        const int nc = n < a.N ? n : a.N - 1;
+        float wv[K / KS];
+#pragma unroll
+        for (int i = 0; i < K / KS; ++i) wv[i] = a.W[(size_t)(k0 + i * KS) * a.ldw + nc];   // all loads in flight at once
+#pragma unroll
+        for (int i = 0; i < K / KS; ++i) Wl[(k0 + i * KS) * NP + n] = n < a.N ? wv[i] : 0.f;
+    }
+    __syncthreads();
+
+    // staging: 32 rows x 16 float4 per half = 8 float4 per lane; 16 consecutive lanes cover one row
+    const int srow = lane >> 4, sc4 = lane & 15;
+    auto fetch = [&](int t, int kh, f32x4 (&v)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int s = t * 32 + 4 * u + srow;
+            s = s < a.m ? s : a.m - 1;
+            v[u] = *reinterpret_cast<const f32x4*>(a.A + (size_t)s * a.lda + 64 * kh + 4 * sc4);
+        }
+    };
+    auto stage = [&](const f32x4 (&v)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4*>(tile + (4 * u + srow) * NN_TP + 4 * sc4) = v[u];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");              // (wave-private tile: no barrier needed,
+        __builtin_amdgcn_wave_barrier();                                     //  LDS operations of one wave stay in order)
+    };
+
+    NnEpi e0, e1;
+    // (32-bit element offsets from uniform bases: one address register per access instead of a 64-bit pair)
+    auto epi_off = [&](int t, int nt, int r) {
+        int s = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        s = s < a.m ? s : a.m - 1;
+        return (unsigned)s * 128u + (unsigned)(32 * nt + j);
+    };
+    auto epi_load = [&](int t, int unit, NnEpi& e) {                          // unit = 2 nt + register half (EPI 1: N = ldc = 128)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const unsigned o = epi_off(t, unit >> 1, 8 * (unit & 1) + r);
+            e.hv[r] = a.hh[o]; e.b[r] = a.bd[o]; e.g[r] = a.gbd[o];
+        }
+    };
+    const int stride = gridDim.x * NN_WAVES;
+    int t = blockIdx.x * NN_WAVES + wave;
+    f32x4 v[8];
+    if (t < n_tiles) fetch(t, 0, v);
+    for (; t < n_tiles; t += stride) {
         f32x16 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-        // stage = one group of 8 k: this lane-half's 4 activations + the 4 weight rows it pairs with
-        f32x4 xa = arow[0];
-        float w[4][NT];
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int kh = 0; kh < KH; ++kh) {
+            stage(v);
+            if (kh + 1 < KH) fetch(t, kh + 1, v);                             // lands under this half's MFMAs
+            else if (t + stride < n_tiles) fetch(t + stride, 0, v);
+            if (EPI == 1 && kh == KH - 1) epi_load(t, 0, e0);                 // first column tile's h / bd / g_bd land under the MFMAs
+            const float* wk = Wl + (64 * kh + 4 * h) * NP + j;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(tile + j * NN_TP + 8 * q + 4 * h);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = MFMA(av[c], wk[(8 * q + c) * NP + 32 * nt], acc[nt]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the tile is rewritten next
+            __builtin_amdgcn_wave_barrier();
+        }
+        // D[row][col]: row = (r&3) + 8(r>>2) + 4h (sample), col = lane&31 (feature)
+        if (EPI == 1) {
+#pragma unroll
+            for (int unit = 0; unit < 2 * NT; ++unit) {
+                NnEpi& cur = (unit & 1) ? e1 : e0;
+                asm volatile("" ::: "memory");                                   // (keeps later units' loads from being hoisted -> spills)
+                if (unit + 1 < 2 * NT) epi_load(t, unit + 1, (unit & 1) ? e0 : e1);   // next unit's operands under this one's arithmetic
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int nt = unit >> 1, rr = 8 * (unit & 1) + r;
+                    const int s = t * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+                    const bool on = cur.hv[r] > 0.f;
+                    const float gp = on ? acc[nt][rr] : 0.f;
+                    const float add = on ? gp * (cur.hv[r] / cur.b[r]) : 0.f;
+                    if (s < a.m) {
+                        const unsigned o = epi_off(t, nt, rr);
+                        a.gbd[o] = cur.g[r] + add;
+                        a.C[o] = gp * cur.b[r];
+                    }
+                }
+            }
+        } else {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int col = 32 * nt + j;
-                w[c][nt] = col < a.N ? a.W[(size_t)(4 * h + c) * a.ldw + col] : 0.f;
-            }
-#pragma unroll 2
-        for (int q = 0; q < KQ; ++q) {
-            f32x4 xn = xa;
-            float wn[4][NT];
-            if (q + 1 < KQ) {
-                xn = arow[2 * (q + 1)];
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const int col = 32 * nt + j;
-                        wn[c][nt] = col < a.N ? a.W[(size_t)(8 * (q + 1) + 4 * h + c) * a.ldw + col] : 0.f;
-                    }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = MFMA(w[c][nt], xa[c], acc[nt]);
-            if (q + 1 < KQ) {
-                xa = xn;
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) w[c][nt] = wn[c][nt];
-            }
-        }
-        if (s_raw < a.m) {
-            float* crow = a.C + (size_t)s * a.ldc;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int col = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (col < a.N) crow[col] = a.accumulate ? crow[col] + acc[nt][r] : acc[nt][r];
+                    const int s = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (s < a.m && col < a.N) {
+                        float* c = a.C + (size_t)s * a.ldc + col;
+                        *c = a.accumulate ? *c + acc[nt][r] : acc[nt][r];
+                    }
                 }
+            }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // gemm_tn: gW[n][k] += sum_s G[s][n] X[s / xdiv][k];  gb[n] += sum_s G[s][n]
-// block = 4 waves, wave w owns output rows 32w..32w+31; grid.x = sample chunks of CH
+// block = 16 waves = 4 sample groups x 4 row tiles: wave (g, nt) contracts its quarter of the block's sample chunk
+// into rows 32nt..32nt+31 (all KT column tiles), the four groups are summed through LDS and group 0 merges the
+// block's tile into the gradient with float atomics on 128-byte row segments (one flush per `chunk` samples).
+// The loop is branch-free: out-of-range rows / columns read a clamped (valid) column and are simply never
+// stored -- a D element only depends on its own A row and B column -- and loads run one stage (8 samples) ahead of the MFMAs,
+// four waves per SIMD.
 // ------------------------------------------------------------------------------------------------
 struct TnArgs {
     const float* G; int ldg;
@@ -105,70 +178,136 @@ struct TnArgs {
     float* gW; int ldw;
     float* gb;
     int m, Nout, Kin;
+    int chunk;            // samples per block, a multiple of 32
 };
 
-// samples per block: small enough that a training batch (~1e5 samples) fills the chip several times over (the
-// partial tiles are merged with well-shaped float atomics, 128-byte row segments)
-constexpr int TN_CHUNK = 256;
+constexpr int TN_GROUPS = 4;
+#ifndef UCNERF_TN_EXP
+#define UCNERF_TN_EXP 0
+#endif
 
 template <int KT>
-__global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
+struct TnStage { float g[4], x[4][KT]; };
+
+template <int KT, bool DIV>
+__global__ void __launch_bounds__(1024) gemm_tn_kernel(TnArgs a) {
+    __shared__ f32x4 red[(TN_GROUPS - 1) * 4 * 4 * 64];          // [writer wave][q][lane], 48 KB
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
-    const int nt = threadIdx.x >> 6;
-    if (32 * nt >= a.Nout) return;
-    const int s0 = blockIdx.x * TN_CHUNK;
-    const int s1 = s0 + TN_CHUNK < a.m ? s0 + TN_CHUNK : a.m;
-    const bool row_ok = 32 * nt + i < a.Nout;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nt = wave & 3, g = wave >> 2;   // (scalar: uniform branches)
+    const int per = a.chunk / TN_GROUPS;                          // multiple of 8
+    const int ws0 = blockIdx.x * a.chunk + g * per;
+    const int ws1 = ws0 + per < a.m ? ws0 + per : a.m;
+    const bool rows = 32 * nt < a.Nout;                           // (wave-uniform) this row tile exists
+    const int gcol = 32 * nt + i < a.Nout ? 32 * nt + i : a.Nout - 1;
+    int xcol[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) xcol[kt] = 32 * kt + i < a.Kin ? 32 * kt + i : a.Kin - 1;
     f32x16 acc[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[kt][r] = 0.f;
     float colsum = 0.f;
-    auto load = [&](int s, float& ga, float (&xb)[KT]) {
-        const bool ok = s < s1;
-        const int sc = ok ? s : s1 - 1;
-        ga = ok && row_ok ? a.G[(size_t)sc * a.ldg + 32 * nt + i] : 0.f;
-        const float* xr = a.X + (size_t)(sc / a.xdiv) * a.ldx;
+
+    if (rows && ws0 < ws1) {
+        // addresses = wave-uniform base + 32-bit byte offset (lane constant + uniform row term): one v_add per load
+        const char* Gw = reinterpret_cast<const char*>(a.G + (size_t)ws0 * a.ldg);
+        const char* Xw = reinterpret_cast<const char*>(a.X + (DIV ? (size_t)0 : (size_t)ws0 * a.ldx));
+        const unsigned g_lane = 4u * (unsigned)(h * a.ldg + gcol), g_row = 4u * (unsigned)a.ldg;
+        const unsigned x_row = 4u * (unsigned)a.ldx;
+        unsigned x_lane[KT];
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) xb[kt] = ok && 32 * kt + i < a.Kin ? xr[32 * kt + i] : 0.f;
-    };
-    float ga[4], xb[4][KT];
+        for (int kt = 0; kt < KT; ++kt) x_lane[kt] = 4u * (unsigned)((DIV ? 0 : h * a.ldx) + xcol[kt]);
+        auto ldf = [](const char* base, unsigned off) { return *reinterpret_cast<const float*>(base + off); };
+        // stage `it` = samples ws0 + 8 it .. + 7: k-step u contracts samples 8 it + 2u + h
+        // (the k-step term rides in four uniform base pointers, so the per-lane offsets are 1 + KT registers)
+        const char *Gu[4], *Xu[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) load(s0 + 2 * u + h, ga[u], xb[u]);
-    for (int s = s0; s < s1; s += 8) {           // 4 k-steps (8 samples) per iteration, next 4 prefetched
-        float gn[4], xn[4][KT];
-        const bool more = s + 8 < s1;
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) load(s + 8 + 2 * u + h, gn[u], xn[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            colsum += ga[u];
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) acc[kt] = MFMA(ga[u], xb[u][kt], acc[kt]);
-        }
-        if (more) {
+        for (int u = 0; u < 4; ++u) { Gu[u] = Gw + (size_t)(2 * u) * g_row; Xu[u] = Xw + (DIV ? (size_t)0 : (size_t)(2 * u) * x_row); }
+        auto load = [&](int it, TnStage<KT>& st) {
+            const unsigned go = g_lane + (unsigned)(8 * it) * g_row;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                ga[u] = gn[u];
+                st.g[u] = ldf(Gu[u], go);
+                const unsigned xo = DIV ? (unsigned)((ws0 + 8 * it + 2 * u + h) / a.xdiv) * x_row : (unsigned)(8 * it) * x_row;
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) xb[u][kt] = xn[u][kt];
+                for (int kt = 0; kt < KT; ++kt) st.x[u][kt] = ldf(Xu[u], x_lane[kt] + xo);
+            }
+        };
+        auto load_tail = [&](int it, TnStage<KT>& st) {          // ragged last stage: clamped row, zeroed G
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sl = 8 * it + 2 * u + h;
+                const bool ok = ws0 + sl < ws1;
+                const int sc = ok ? sl : ws1 - 1 - ws0;
+                const float gv = ldf(Gw, 4u * (unsigned)gcol + (unsigned)sc * g_row);
+                st.g[u] = ok ? gv : 0.f;
+                const unsigned xo = (DIV ? (unsigned)((ws0 + sc) / a.xdiv) : (unsigned)sc) * x_row;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) { const float xv = ldf(Xw, 4u * (unsigned)xcol[kt] + xo); st.x[u][kt] = ok ? xv : 0.f; }
+            }
+        };
+        auto mma = [&](const TnStage<KT>& st) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                colsum += st.g[u];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+#if UCNERF_TN_EXP == 1          // timing experiment: loads only
+                    acc[kt][u] += st.g[u] * st.x[u][kt];
+#else
+                    acc[kt] = MFMA(st.g[u], st.x[u][kt], acc[kt]);
+#endif
+                }
+            }
+        };
+        const int n_full = (ws1 - ws0) >> 3;
+        TnStage<KT> s0, s1;
+        if (n_full > 0) load(0, s0);
+        for (int it = 0; it < n_full; it += 2) {                 // two register stages; with 4 waves per SIMD the next
+#if UCNERF_TN_EXP == 2              // timing experiment: MFMAs only
+            mma(s0); asm volatile("" : "+v"(s0.g[0])); mma(s0); asm volatile("" : "+v"(s0.g[1]));
+            continue;
+#endif
+            if (it + 1 < n_full) load(it + 1, s1);               // stage's loads have ~4 stages of MFMA time to land
+            mma(s0);
+            if (it + 1 < n_full) {
+                if (it + 2 < n_full) load(it + 2, s0);
+                mma(s1);
             }
         }
+        if ((ws1 - ws0) & 7) { load_tail(n_full, s0); mma(s0); }
     }
-    // D[row][col]: row = (r&3) + 8(r>>2) + 4h (output feature), col = lane&31 (input feature)
+
+    // sum the sample groups: one column tile at a time through LDS, group 0 keeps the total
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int kt = 0; kt < KT; ++kt) {
+        if (g > 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h, k = 32 * kt + i;
-            if (n < a.Nout && k < a.Kin) atomicAdd(a.gW + (size_t)n * a.ldw + k, acc[kt][r]);
+            for (int q = 0; q < 4; ++q)
+                red[(((g - 1) * 4 + nt) * 4 + q) * 64 + lane] = f32x4{acc[kt][4 * q], acc[kt][4 * q + 1], acc[kt][4 * q + 2], acc[kt][4 * q + 3]};
         }
-    if (a.gb) {
+        __syncthreads();
+        if (g == 0 && rows) {
+#pragma unroll
+            for (int gg = 0; gg < TN_GROUPS - 1; ++gg)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = red[((gg * 4 + nt) * 4 + q) * 64 + lane];
+                    acc[kt][4 * q] += v.x; acc[kt][4 * q + 1] += v.y; acc[kt][4 * q + 2] += v.z; acc[kt][4 * q + 3] += v.w;
+                }
+            // D[row][col]: row = (r&3) + 8(r>>2) + 4h (output feature), col = lane&31 (input feature)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h, k = 32 * kt + i;
+                if (n < a.Nout && k < a.Kin) atomicAdd(a.gW + (size_t)n * a.ldw + k, acc[kt][r]);
+            }
+        }
+        __syncthreads();
+    }
+    if (a.gb && rows) {
         colsum += __shfl_xor(colsum, 32);
-        if (h == 0 && row_ok) atomicAdd(a.gb + 32 * nt + i, colsum);
+        if (h == 0 && 32 * nt + i < a.Nout) atomicAdd(a.gb + 32 * nt + i, colsum);
     }
 }
 
@@ -330,37 +469,57 @@ static size_t carve_bwd(float* base, int m, int n_dirs, BwdWork* w) {
     return o;
 }
 
-static int run_nn(hipStream_t st, int m, const float* A, int lda, int K, const float* W, int ldw, int N, float* C, int ldc,
-                  bool accumulate) {
-    NnArgs a{A, lda, W, ldw, C, ldc, m, N, accumulate ? 1 : 0};
-    const int n_tiles = cdiv(m, 32);
-    int blocks = cdiv(n_tiles, 4);
-    const int cap = device_cus() * 4;
-    if (blocks > cap) blocks = cap;
-    const bool wide = N > 64;
-    if (K == 128) {
-        if (wide) hipLaunchKernelGGL((gemm_nn_kernel<16, 4>), dim3(blocks), dim3(256), 0, st, a, n_tiles);
-        else hipLaunchKernelGGL((gemm_nn_kernel<16, 2>), dim3(blocks), dim3(256), 0, st, a, n_tiles);
-    } else if (K == 64) {
-        if (wide) hipLaunchKernelGGL((gemm_nn_kernel<8, 4>), dim3(blocks), dim3(256), 0, st, a, n_tiles);
-        else hipLaunchKernelGGL((gemm_nn_kernel<8, 2>), dim3(blocks), dim3(256), 0, st, a, n_tiles);
-    } else {
-        return fail(UCNERF_EINVAL, "mlp_bwd: gemm_nn K = %d", K);
+template <int KH, int NT, int EPI>
+static int launch_nn(hipStream_t st, const NnArgs& a) {
+    static bool attr_set = false;                                         // > 64 KB of dynamic LDS needs the opt-in
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nn_kernel<KH, NT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                nn_lds_bytes<KH, NT>()) != hipSuccess)
+            return fail(UCNERF_EHIP, "mlp_bwd: cannot reserve %d bytes of LDS for gemm_nn", nn_lds_bytes<KH, NT>());
+        attr_set = true;
     }
+    const int n_tiles = cdiv(a.m, 32);
+    int blocks = cdiv(n_tiles, NN_WAVES);
+    if (blocks > device_cus()) blocks = device_cus();                     // persistent: the weights are staged once per block
+    const int lds = nn_lds_bytes<KH, NT>();
+    hipLaunchKernelGGL((gemm_nn_kernel<KH, NT, EPI>), dim3(blocks), dim3(64 * NN_WAVES), lds, st, a, n_tiles);
     return check_launch("mlp_bwd gemm_nn");
+}
+
+// {h, bd, g_bd}: fuse the trunk layer's element-wise backward into the epilogue (N = K = 128 only)
+static int run_nn(hipStream_t st, int m, const float* A, int lda, int K, const float* W, int ldw, int N, float* C, int ldc,
+                  bool accumulate, const float* hh = nullptr, const float* bd = nullptr, float* gbd = nullptr) {
+    NnArgs a{A, lda, W, ldw, C, ldc, m, N, accumulate ? 1 : 0, hh, bd, gbd};
+    if (((uintptr_t)A & 15) || (lda & 3)) return fail(UCNERF_EINVAL, "mlp_bwd: gemm_nn operand must be 16-byte aligned rows");
+    const bool wide = N > 64;
+    if (hh) {
+        if (K != 128 || N != 128 || ldc != 128 || accumulate || m > (1 << 24)) return fail(UCNERF_EINVAL, "mlp_bwd: fused trunk epilogue is 128 x 128 only");
+        return launch_nn<2, 4, 1>(st, a);
+    }
+    if (K == 128) return wide ? launch_nn<2, 4, 0>(st, a) : launch_nn<2, 2, 0>(st, a);
+    if (K == 64) return wide ? launch_nn<1, 4, 0>(st, a) : launch_nn<1, 2, 0>(st, a);
+    return fail(UCNERF_EINVAL, "mlp_bwd: gemm_nn K = %d", K);
 }
 
 static int run_tn(hipStream_t st, int m, const float* G, int ldg, int Nout, const float* X, int ldx, int xdiv, int Kin, float* gW,
                   int ldw, float* gb) {
+    // samples per block: about one block per CU for a training batch (~1e5 samples), so that the float atomics of the
+    // merge stay a small part of the launch; larger batches get proportionally larger chunks
+    int chunk = 32 * cdiv(cdiv(m, device_cus()), 32);
+    if (chunk < 512) chunk = 512;
+    if (chunk > 8192) chunk = 8192;
     for (int k0 = 0; k0 < Kin; k0 += 128) {               // at most 4 accumulator tiles per launch
         const int kin = Kin - k0 < 128 ? Kin - k0 : 128;
-        TnArgs a{G, ldg, X + k0, ldx, xdiv, gW + k0, ldw, k0 == 0 ? gb : nullptr, m, Nout, kin};
-        dim3 grid(cdiv(m, TN_CHUNK)), block(256);
+        TnArgs a{G, ldg, X + k0, ldx, xdiv, gW + k0, ldw, k0 == 0 ? gb : nullptr, m, Nout, kin, chunk};
+        dim3 grid(cdiv(m, chunk)), block(1024);
         const int kt = cdiv(kin, 32);
-        if (kt == 1) hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, block, 0, st, a);
-        else if (kt == 2) hipLaunchKernelGGL(gemm_tn_kernel<2>, grid, block, 0, st, a);
-        else if (kt == 3) hipLaunchKernelGGL(gemm_tn_kernel<3>, grid, block, 0, st, a);
-        else hipLaunchKernelGGL(gemm_tn_kernel<4>, grid, block, 0, st, a);
+        if (xdiv != 1) {
+            if (kt != 1) return fail(UCNERF_EINVAL, "mlp_bwd: gemm_tn with shared rows is built for <= 32 columns");
+            hipLaunchKernelGGL((gemm_tn_kernel<1, true>), grid, block, 0, st, a);
+        } else if (kt == 1) hipLaunchKernelGGL((gemm_tn_kernel<1, false>), grid, block, 0, st, a);
+        else if (kt == 2) hipLaunchKernelGGL((gemm_tn_kernel<2, false>), grid, block, 0, st, a);
+        else if (kt == 3) hipLaunchKernelGGL((gemm_tn_kernel<3, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gemm_tn_kernel<4, false>), grid, block, 0, st, a);
         int rc = check_launch("mlp_bwd gemm_tn");
         if (rc) return rc;
     }
@@ -482,21 +641,24 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     RUN(run_tn(st, m, w.g3, 128, 128, f.feats + n_mvs, ldf, 1, n_img, G + L.p_bcw, n_img, G + L.p_bcb));
     RUN(run_nn(st, m, w.g3, 128, 128, P + L.p_bcw, n_img, n_img, bp->g_feats + n_mvs, ldgf, false));
 
-    // 5. trunk, layers 5..0:  g_h (g2) -> g_y (g1), g_bd accumulates; weights; g_h of the layer below -> g2
+    // 5. trunk, layers 5..0.  g_h5 (g2) -> g_y of layer 5 (g1) by the element-wise kernel; below that the data-gradient
+    //    GEMM of layer l applies layer l-1's element-wise backward in its epilogue (g_y ping-pongs between g1 and g2,
+    //    g_bd accumulates in place)
+    hipLaunchKernelGGL(relu_mod_bwd_kernel, dim3(ew_blocks), dim3(256), 0, st, (const f32x4*)w.g2, (const f32x4*)w.sv.h[5],
+                       (const f32x4*)w.sv.bd, (f32x4*)w.g1, (f32x4*)w.gbd, 1, n4);
+    RUN(check_launch("mlp_bwd relu_mod"));
+    float *gy = w.g1, *gnext = w.g2;
     for (int l = 5; l >= 0; --l) {
-        hipLaunchKernelGGL(relu_mod_bwd_kernel, dim3(ew_blocks), dim3(256), 0, st, (const f32x4*)w.g2, (const f32x4*)w.sv.h[l],
-                           (const f32x4*)w.sv.bd, (f32x4*)w.g1, (f32x4*)w.gbd, l == 5 ? 1 : 0, n4);
-        RUN(check_launch("mlp_bwd relu_mod"));
         if (l == 0) {
-            RUN(run_tn(st, m, w.g1, 128, 128, pep, ld_pep, 1, 63, G + L.p_lw[0], 63, G + L.p_lb[0]));
-        } else if (l == 5) {
-            RUN(run_tn(st, m, w.g1, 128, 128, pep, ld_pep, 1, 63, G + L.p_lw[5], 191, G + L.p_lb[5]));
-            RUN(run_tn(st, m, w.g1, 128, 128, w.sv.h[4], 128, 1, 128, G + L.p_lw[5] + 63, 191, nullptr));
-            RUN(run_nn(st, m, w.g1, 128, 128, P + L.p_lw[5] + 63, 191, 128, w.g2, 128, false));
-        } else {
-            RUN(run_tn(st, m, w.g1, 128, 128, w.sv.h[l - 1], 128, 1, 128, G + L.p_lw[l], 128, G + L.p_lb[l]));
-            RUN(run_nn(st, m, w.g1, 128, 128, P + L.p_lw[l], 128, 128, w.g2, 128, false));
+            RUN(run_tn(st, m, gy, 128, 128, pep, ld_pep, 1, 63, G + L.p_lw[0], 63, G + L.p_lb[0]));
+            break;
         }
+        const float* Wl = l == 5 ? P + L.p_lw[5] + 63 : P + L.p_lw[l];
+        const int ldw = l == 5 ? 191 : 128;
+        if (l == 5) RUN(run_tn(st, m, gy, 128, 128, pep, ld_pep, 1, 63, G + L.p_lw[5], 191, G + L.p_lb[5]));
+        RUN(run_tn(st, m, gy, 128, 128, w.sv.h[l - 1], 128, 1, 128, G + (Wl - P), ldw, l == 5 ? nullptr : G + L.p_lb[l]));
+        RUN(run_nn(st, m, gy, 128, 128, Wl, ldw, 128, gnext, 128, false, w.sv.h[l - 1], w.sv.bd, w.gbd));
+        float* t = gy; gy = gnext; gnext = t;
     }
 
     // 6. depth-bias net
