@@ -165,12 +165,14 @@ __global__ void __launch_bounds__(64 * NN_WAVES) gemm_nn_kernel(NnArgs a, int n_
 
 // ------------------------------------------------------------------------------------------------
 // gemm_tn: gW[n][k] += sum_s G[s][n] X[s / xdiv][k];  gb[n] += sum_s G[s][n]
-// block = 16 waves = 4 sample groups x 4 row tiles: wave (g, nt) contracts its quarter of the block's sample chunk
-// into rows 32nt..32nt+31 (all KT column tiles), the four groups are summed through LDS and group 0 merges the
-// block's tile into the gradient with float atomics on 128-byte row segments (one flush per `chunk` samples).
+// block = 16 waves = sample groups x 4 row tiles x KSPLIT: a wave contracts its group's share of the block's sample
+// chunk into rows 32nt..32nt+31 of its KT column tiles (up to 64 columns: four groups; wider: two waves split the
+// columns of a row tile, two groups), the groups are summed through LDS and group 0 merges the block's tile into the
+// gradient with float atomics on 128-byte row segments (one flush per `chunk` samples).
 // The loop is branch-free: out-of-range rows / columns read a clamped (valid) column and are simply never
-// stored -- a D element only depends on its own A row and B column -- and loads run one stage (8 samples) ahead of the MFMAs,
-// four waves per SIMD.
+// stored -- a D element only depends on its own A row and B column -- with loads a few stages (8 samples each) ahead of
+// the MFMAs in a register ring, four waves per SIMD.  Measured on 131 072 samples x 128 x 128: 58.7 us, of which the
+// MFMAs need ~35 at the sustained clock and the merge (LDS sums + 4.2 M float atomics) ~15.
 // ------------------------------------------------------------------------------------------------
 struct TnArgs {
     const float* G; int ldg;
@@ -181,7 +183,9 @@ struct TnArgs {
     int chunk;            // samples per block, a multiple of 32
 };
 
-constexpr int TN_GROUPS = 4;
+#ifndef UCNERF_TN_DEPTH2
+#define UCNERF_TN_DEPTH2 2      // stages (8 samples each) of loads in flight (measured: 1, 2 and 3 time the same -- the loop is not latency-bound)
+#endif
 #ifndef UCNERF_TN_EXP
 #define UCNERF_TN_EXP 0
 #endif
@@ -189,19 +193,23 @@ constexpr int TN_GROUPS = 4;
 template <int KT>
 struct TnStage { float g[4], x[4][KT]; };
 
-template <int KT, bool DIV>
+// KT column tiles per wave, KSPLIT waves share a row tile (each with its own KT column tiles), DEPTH stages of loads in
+// flight ahead of the MFMAs.  16 waves = (4 / KSPLIT sample groups) x 4 row tiles x KSPLIT.
+template <int KT, int KSPLIT, int DEPTH, bool DIV>
 __global__ void __launch_bounds__(1024) gemm_tn_kernel(TnArgs a) {
-    __shared__ f32x4 red[(TN_GROUPS - 1) * 4 * 4 * 64];          // [writer wave][q][lane], 48 KB
+    constexpr int GROUPS = 4 / KSPLIT, NB = DEPTH + 1;
+    __shared__ f32x4 red[(GROUPS - 1) * 4 * KSPLIT * 4 * 64];     // [writer wave][q][lane], <= 48 KB
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nt = wave & 3, g = wave >> 2;   // (scalar: uniform branches)
-    const int per = a.chunk / TN_GROUPS;                          // multiple of 8
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: uniform branches)
+    const int nt = wave & 3, ks = (wave >> 2) % KSPLIT, g = wave / (4 * KSPLIT);
+    const int per = a.chunk / GROUPS;                             // multiple of 8
     const int ws0 = blockIdx.x * a.chunk + g * per;
     const int ws1 = ws0 + per < a.m ? ws0 + per : a.m;
-    const bool rows = 32 * nt < a.Nout;                           // (wave-uniform) this row tile exists
+    const bool rows = 32 * nt < a.Nout && 32 * ks * KT < a.Kin;   // (wave-uniform) this wave's tiles exist
     const int gcol = 32 * nt + i < a.Nout ? 32 * nt + i : a.Nout - 1;
     int xcol[KT];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) xcol[kt] = 32 * kt + i < a.Kin ? 32 * kt + i : a.Kin - 1;
+    for (int kt = 0; kt < KT; ++kt) xcol[kt] = 32 * (ks * KT + kt) + i < a.Kin ? 32 * (ks * KT + kt) + i : a.Kin - 1;
     f32x16 acc[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
@@ -252,31 +260,23 @@ __global__ void __launch_bounds__(1024) gemm_tn_kernel(TnArgs a) {
             for (int u = 0; u < 4; ++u) {
                 colsum += st.g[u];
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-#if UCNERF_TN_EXP == 1          // timing experiment: loads only
-                    acc[kt][u] += st.g[u] * st.x[u][kt];
-#else
-                    acc[kt] = MFMA(st.g[u], st.x[u][kt], acc[kt]);
-#endif
-                }
+                for (int kt = 0; kt < KT; ++kt) acc[kt] = MFMA(st.g[u], st.x[u][kt], acc[kt]);
             }
         };
         const int n_full = (ws1 - ws0) >> 3;
-        TnStage<KT> s0, s1;
-        if (n_full > 0) load(0, s0);
-        for (int it = 0; it < n_full; it += 2) {                 // two register stages; with 4 waves per SIMD the next
-#if UCNERF_TN_EXP == 2              // timing experiment: MFMAs only
-            mma(s0); asm volatile("" : "+v"(s0.g[0])); mma(s0); asm volatile("" : "+v"(s0.g[1]));
-            continue;
-#endif
-            if (it + 1 < n_full) load(it + 1, s1);               // stage's loads have ~4 stages of MFMA time to land
-            mma(s0);
-            if (it + 1 < n_full) {
-                if (it + 2 < n_full) load(it + 2, s0);
-                mma(s1);
-            }
+        TnStage<KT> sb[NB];                                      // register ring (indices are compile-time after unrolling)
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (d < n_full) load(d, sb[d]);
+        for (int it = 0; it < n_full; it += NB) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                if (it + b < n_full) {
+                    if (it + b + DEPTH < n_full) load(it + b + DEPTH, sb[(b + DEPTH) % NB]);
+                    mma(sb[b]);
+                }
         }
-        if ((ws1 - ws0) & 7) { load_tail(n_full, s0); mma(s0); }
+        if ((ws1 - ws0) & 7) { load_tail(n_full, sb[0]); mma(sb[0]); }
     }
 
     // sum the sample groups: one column tile at a time through LDS, group 0 keeps the total
@@ -285,27 +285,28 @@ __global__ void __launch_bounds__(1024) gemm_tn_kernel(TnArgs a) {
         if (g > 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                red[(((g - 1) * 4 + nt) * 4 + q) * 64 + lane] = f32x4{acc[kt][4 * q], acc[kt][4 * q + 1], acc[kt][4 * q + 2], acc[kt][4 * q + 3]};
+                red[(((g - 1) * 4 * KSPLIT + (wave & (4 * KSPLIT - 1))) * 4 + q) * 64 + lane] =
+                    f32x4{acc[kt][4 * q], acc[kt][4 * q + 1], acc[kt][4 * q + 2], acc[kt][4 * q + 3]};
         }
         __syncthreads();
         if (g == 0 && rows) {
 #pragma unroll
-            for (int gg = 0; gg < TN_GROUPS - 1; ++gg)
+            for (int gg = 0; gg < GROUPS - 1; ++gg)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = red[((gg * 4 + nt) * 4 + q) * 64 + lane];
+                    const f32x4 v = red[((gg * 4 * KSPLIT + wave) * 4 + q) * 64 + lane];
                     acc[kt][4 * q] += v.x; acc[kt][4 * q + 1] += v.y; acc[kt][4 * q + 2] += v.z; acc[kt][4 * q + 3] += v.w;
                 }
             // D[row][col]: row = (r&3) + 8(r>>2) + 4h (output feature), col = lane&31 (input feature)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h, k = 32 * kt + i;
+                const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h, k = 32 * (ks * KT + kt) + i;
                 if (n < a.Nout && k < a.Kin) atomicAdd(a.gW + (size_t)n * a.ldw + k, acc[kt][r]);
             }
         }
         __syncthreads();
     }
-    if (a.gb && rows) {
+    if (a.gb && rows && ks == 0) {
         colsum += __shfl_xor(colsum, 32);
         if (h == 0 && 32 * nt + i < a.Nout) atomicAdd(a.gb + 32 * nt + i, colsum);
     }
@@ -515,11 +516,10 @@ static int run_tn(hipStream_t st, int m, const float* G, int ldg, int Nout, cons
         const int kt = cdiv(kin, 32);
         if (xdiv != 1) {
             if (kt != 1) return fail(UCNERF_EINVAL, "mlp_bwd: gemm_tn with shared rows is built for <= 32 columns");
-            hipLaunchKernelGGL((gemm_tn_kernel<1, true>), grid, block, 0, st, a);
-        } else if (kt == 1) hipLaunchKernelGGL((gemm_tn_kernel<1, false>), grid, block, 0, st, a);
-        else if (kt == 2) hipLaunchKernelGGL((gemm_tn_kernel<2, false>), grid, block, 0, st, a);
-        else if (kt == 3) hipLaunchKernelGGL((gemm_tn_kernel<3, false>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((gemm_tn_kernel<4, false>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((gemm_tn_kernel<1, 1, 2, true>), grid, block, 0, st, a);
+        } else if (kt == 1) hipLaunchKernelGGL((gemm_tn_kernel<1, 1, UCNERF_TN_DEPTH2, false>), grid, block, 0, st, a);
+        else if (kt == 2) hipLaunchKernelGGL((gemm_tn_kernel<2, 1, UCNERF_TN_DEPTH2, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, UCNERF_TN_DEPTH2, false>), grid, block, 0, st, a);     // 3 or 4 column tiles: two waves per row tile
         int rc = check_launch("mlp_bwd gemm_tn");
         if (rc) return rc;
     }
