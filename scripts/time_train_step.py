@@ -21,10 +21,10 @@ xs, ys = random_pixels(n, scene["H"], scene["W"], seed=0)
 rays_d, _, _ = ops.ray_gen(r.K_host, r.c2w_host, xs=xs.to(dev), ys=ys.to(dev))
 z, _ = ops.sample_stratified(None, S, n=n, near=r.near_host, far=r.far_host, device=dev)
 g_rgb, g_depth = torch.randn(n, 3, device=dev), torch.randn(n, device=dev)
-r.pass_.repack_sources()
 
 
 def step():
+    r.pass_.repack_sources()                  # the MVS net produces new volumes / feature maps every training step
     out = r.pass_(rays_d, z, keep=("raw", "feats"))
     return r.pass_.backward(rays_d, z, out, g_rgb, g_depth, flat)
 

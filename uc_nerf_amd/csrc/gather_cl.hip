@@ -48,7 +48,8 @@ struct GatherClArgs {
     float w2c_ref[12], K_ref[9];
     const float* w2cs;         // [V,12] device (uniform per block -> scalar loads)
     const float* Ks;           // [V,9]
-    float* feats;              // tiled [ceil(M/32)][F][32]
+    float* feats;              // tiled [ceil(M/32)][F][32], or row-major [M][F] (tiled = 0: the training forward keeps them)
+    int tiled;
     float* ndc;                // [M,3] (x, y, scene-normalised z) for the MLP's positional encoding, or NULL
 };
 
@@ -96,7 +97,8 @@ __global__ void __launch_bounds__(256) feat_gather_cl_kernel(GatherClArgs a) {
     const float z = a.z[idx];
     const float x = a.rays_o[0] + z * a.rays_d[3 * r], y = a.rays_o[1] + z * a.rays_d[3 * r + 1],
                 w = a.rays_o[2] + z * a.rays_d[3 * r + 2];
-    float* out = a.feats + ((size_t)(idx >> 5) * F) * 32 + (idx & 31);      // feature f at out[f * 32]
+    const int fs = a.tiled ? 32 : 1;                                        // feature f at out[f * fs]
+    float* out = a.tiled ? a.feats + ((size_t)(idx >> 5) * F) * 32 + (idx & 31) : a.feats + (size_t)idx * F;
     if (unit < 4) {
         float qx, qy, qz;
         project_cl(a.w2c_ref, a.K_ref, x, y, w, &qx, &qy, &qz);
@@ -111,7 +113,7 @@ __global__ void __launch_bounds__(256) feat_gather_cl_kernel(GatherClArgs a) {
             acc += c[(size_t)ay.i0 * a.W + ax.i1] * (ay.w0 * ax.w1);
             acc += c[(size_t)ay.i1 * a.W + ax.i0] * (ay.w1 * ax.w0);
             acc += c[(size_t)ay.i1 * a.W + ax.i1] * (ay.w1 * ax.w1);
-            out[(F - 1) * 32] = acc;
+            out[(F - 1) * fs] = acc;
             return;
         }
         float nk = a.near, fk = a.far;
@@ -135,7 +137,7 @@ __global__ void __launch_bounds__(256) feat_gather_cl_kernel(GatherClArgs a) {
         ACC8(vol[2 * (o11 + ax.i0)], vol[2 * (o11 + ax.i0) + 1], w11 * ax.w0)
         ACC8(vol[2 * (o11 + ax.i1)], vol[2 * (o11 + ax.i1) + 1], w11 * ax.w1)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) out[(8 * unit + c) * 32] = o[c];
+        for (int c = 0; c < 8; ++c) out[(8 * unit + c) * fs] = o[c];
     } else {
         const int vi = unit - 4;
         float qx, qy, qz;
@@ -154,12 +156,12 @@ __global__ void __launch_bounds__(256) feat_gather_cl_kernel(GatherClArgs a) {
           o[8] += c_.x * w_; o[9] += c_.y * w_; o[10] += c_.z * w_; }
         ACC12(p00, w00) ACC12(p01, w01) ACC12(p10, w10) ACC12(p11, w11)
 #undef ACC12
-        out[(24 + 4 * vi) * 32] = o[0];
-        out[(24 + 4 * vi + 1) * 32] = o[1];
-        out[(24 + 4 * vi + 2) * 32] = o[2];
-        out[(24 + 4 * vi + 3) * 32] = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.f : 0.f;
+        out[(24 + 4 * vi) * fs] = o[0];
+        out[(24 + 4 * vi + 1) * fs] = o[1];
+        out[(24 + 4 * vi + 2) * fs] = o[2];
+        out[(24 + 4 * vi + 3) * fs] = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.f : 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) out[(24 + 4 * a.V + 8 * vi + c) * 32] = o[3 + c];
+        for (int c = 0; c < 8; ++c) out[(24 + 4 * a.V + 8 * vi + c) * fs] = o[3 + c];
     }
 }
 
@@ -198,7 +200,7 @@ int ucnerf_gather_repack(const ucnerf_render_params* p, float* dst, void* stream
 namespace ucnerf {
 
 // called by render.hip: gather (+ ndc) for one pass from the repacked sources
-int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float* feats_tiled, float* ndc, hipStream_t st) {
+int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float* feats, int tiled, float* ndc, hipStream_t st) {
     GatherClArgs a;
     memset(&a, 0, sizeof(a));
     a.n = p->n; a.S = p->S; a.V = p->cfg.n_src; a.H = p->H; a.W = p->W;
@@ -214,7 +216,7 @@ int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float
     memcpy(a.w2c_ref, p->w2c_ref, sizeof(a.w2c_ref));
     memcpy(a.K_ref, p->K_ref, sizeof(a.K_ref));
     a.w2cs = p->w2cs; a.Ks = p->intrinsics;
-    a.feats = feats_tiled; a.ndc = ndc;
+    a.feats = feats; a.tiled = tiled; a.ndc = ndc;
     UCNERF_REQUIRE(a.V >= 1 && a.V <= 8, "gather_cl: V = %d outside 1..8", a.V);
     const long long M = (long long)p->n * p->S;
     hipLaunchKernelGGL(feat_gather_cl_kernel, dim3(cdiv(M, 256), 4 + a.V), dim3(256), 0, st, a);

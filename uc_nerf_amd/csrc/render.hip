@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) render_points_kernel(PointsArgs a) {
     a.ndc[o] = u; a.ndc[o + 1] = v; a.ndc[o + 2] = (qz - a.near) / (a.far - a.near);
 }
 
-int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float* feats_tiled, float* ndc, hipStream_t st);
+int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float* feats, int tiled, float* ndc, hipStream_t st);
 
 struct Workspace {
     float *pts, *ndc1, *ndc2, *ndc3, *ndc, *angle, *feats, *raw;
@@ -125,10 +125,10 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
     int rc;
     const bool keep_feats = p->feats != nullptr;        // caller wants row-major features (for the backward)
     ucnerf_feat_gather_params g;
-    if (p->sources_cl && !keep_feats) {                 // fast path: channel-last sources, coordinates derived in-kernel
-        if ((rc = launch_gather_cl(p, p->sources_cl, w->feats, w->ndc, st))) return rc;
-        g.out_tiled = 1;
-        g.feats = w->feats;
+    if (p->sources_cl) {                                // fast path: channel-last sources, coordinates derived in-kernel
+        g.out_tiled = keep_feats ? 0 : 1;
+        g.feats = keep_feats ? p->feats : w->feats;
+        if ((rc = launch_gather_cl(p, p->sources_cl, g.feats, g.out_tiled, w->ndc, st))) return rc;
     } else {
         if ((rc = launch_points(p, st, w))) return rc;
         gather_geometry(p, w, &g);
