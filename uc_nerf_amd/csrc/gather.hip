@@ -202,14 +202,54 @@ __host__ __device__ inline ScratchLayout scratch_layout(const ucnerf_feat_gather
     return L;
 }
 
+// Neighbouring samples of a ray fall into the same cell again and again (a ray crosses a source view along a short
+// epipolar segment and the reference frustum along one column), so most atomics of a wave would hit addresses another
+// lane of the same wave also hits.  The eight samples of a wave are therefore combined first: a segmented suffix sum
+// over runs of equal cell offsets along the sample dimension (lane stride 8), log2(run window) shuffle steps, and only the first
+// lane of a run issues the atomic.  key < 0 = nothing to add.  Must be called by all 64 lanes.
+template <int STRIDE>                                                  // lanes STRIDE apart are consecutive samples; pos = lane / STRIDE
+__device__ __forceinline__ void run_atomic_add(float* base, int key, float v, int pos) {
+    constexpr int N = 64 / STRIDE;
+    const int kp = __shfl_up(key, STRIDE), kn = __shfl_down(key, STRIDE);   // (unconditionally: a shuffle inside `a || b` would run
+    const bool head = pos == 0 || kp != key;                                 //  with the short-circuited lanes masked off and read 0 from them)
+    int end = pos == N - 1 || kn != key;
+    float s = v;
+#pragma unroll
+    for (int d = 1; d < N; d <<= 1) {
+        const float sn = __shfl_down(s, STRIDE * d);
+        const int en = __shfl_down(end, STRIDE * d);
+        if (!end) { s += sn; end = en; }          // (no run end within the covered span -> lane pos + d exists)
+    }
+    if (head && key >= 0 && s != 0.f) atomicAdd(base + key, s);
+}
+
+// confidence map: thread = sample; the samples of a ray share their four pixels in the reference view
+__global__ void __launch_bounds__(256) conf_bwd_kernel(ucnerf_feat_gather_bwd_params bp) {
+    const ucnerf_feat_gather_params& p = bp.fwd;
+    const int s_raw = blockIdx.x * 256 + threadIdx.x;
+    const bool live = s_raw < p.m;
+    const int s = live ? s_raw : p.m - 1;
+    const int F = 24 + 12 * p.V + 1, pos = threadIdx.x & 63;
+    const float* g = p.ndc3 + 3 * (size_t)s;
+    const Lerp ax = axis(g[0] * 2.f - 1.0f, p.W, false), ay = axis(g[1] * 2.f - 1.0f, p.H, false);
+    const float gc = live ? bp.g_feats[(size_t)s * F + F - 1] : 0.f;
+    const int dead = live ? 0 : -1;
+    run_atomic_add<1>(bp.g_conf, dead | (ay.i0 * p.W + ax.i0), gc * (ay.w0 * ax.w0), pos);
+    run_atomic_add<1>(bp.g_conf, dead | (ay.i0 * p.W + ax.i1), gc * (ay.w0 * ax.w1), pos);
+    run_atomic_add<1>(bp.g_conf, dead | (ay.i1 * p.W + ax.i0), gc * (ay.w1 * ax.w0), pos);
+    run_atomic_add<1>(bp.g_conf, dead | (ay.i1 * p.W + ax.i1), gc * (ay.w1 * ax.w1), pos);
+}
+
 __global__ void __launch_bounds__(256) feat_gather_bwd_cl_kernel(ucnerf_feat_gather_bwd_params bp) {
     const ucnerf_feat_gather_params& p = bp.fwd;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int s = (int)(t >> 3), c = (int)(t & 7);
-    if (s >= p.m) return;
+    const int s_raw = (int)(t >> 3), c = (int)(t & 7);
+    const int sl = (threadIdx.x >> 3) & 7;                              // sample within the wave
+    const bool live = s_raw < p.m;
+    const int s = live ? s_raw : p.m - 1;
     const int unit = blockIdx.y < 3 ? blockIdx.y : blockIdx.y + 1;      // units 0..2 volumes, 4.. views (conf stays on the direct path)
     const int F = 24 + 12 * p.V + 1;
-    if (p.unit_mask && !((p.unit_mask >> unit) & 1)) return;
+    if (p.unit_mask && !((p.unit_mask >> unit) & 1)) return;            // (uniform per block)
     const float* gf = bp.g_feats + (size_t)s * F;
     const ScratchLayout L = scratch_layout(p);
     if (unit < 3) {
@@ -219,26 +259,20 @@ __global__ void __launch_bounds__(256) feat_gather_bwd_cl_kernel(ucnerf_feat_gat
         const int D = p.vol_d[unit], h = p.vol_h[unit], w = p.vol_w[unit];
         const Lerp ax = axis(g[0] * 2.f - 1.0f, w, false), ay = axis(g[1] * 2.f - 1.0f, h, false),
                    az = axis(g[2] * 2.f - 1.0f, D, false);
-        const size_t o00 = ((size_t)az.i0 * h + ay.i0) * w, o01 = ((size_t)az.i0 * h + ay.i1) * w,
-                     o10 = ((size_t)az.i1 * h + ay.i0) * w, o11 = ((size_t)az.i1 * h + ay.i1) * w;
+        const int o00 = (az.i0 * h + ay.i0) * w, o01 = (az.i0 * h + ay.i1) * w,
+                  o10 = (az.i1 * h + ay.i0) * w, o11 = (az.i1 * h + ay.i1) * w;
         const float w00 = az.w0 * ay.w0, w01 = az.w0 * ay.w1, w10 = az.w1 * ay.w0, w11 = az.w1 * ay.w1;
-        const float gc = gf[8 * unit + c];
-        // same products as the direct path (weights folded in the same order); zero-weight corners are skipped there
-        // only to save atomics -- adding 0 here is the same sum
-        atomicAdd(gv + 8 * (o00 + ax.i0), gc * (w00 * ax.w0));
-        if (ax.w1 != 0.f) atomicAdd(gv + 8 * (o00 + ax.i1), gc * (w00 * ax.w1));
-        if (w01 != 0.f) {
-            atomicAdd(gv + 8 * (o01 + ax.i0), gc * (w01 * ax.w0));
-            if (ax.w1 != 0.f) atomicAdd(gv + 8 * (o01 + ax.i1), gc * (w01 * ax.w1));
-        }
-        if (w10 != 0.f) {
-            atomicAdd(gv + 8 * (o10 + ax.i0), gc * (w10 * ax.w0));
-            if (ax.w1 != 0.f) atomicAdd(gv + 8 * (o10 + ax.i1), gc * (w10 * ax.w1));
-        }
-        if (w11 != 0.f) {
-            atomicAdd(gv + 8 * (o11 + ax.i0), gc * (w11 * ax.w0));
-            if (ax.w1 != 0.f) atomicAdd(gv + 8 * (o11 + ax.i1), gc * (w11 * ax.w1));
-        }
+        const float gc = live ? gf[8 * unit + c] : 0.f;
+        const int dead = live ? 0 : -1;                                 // keys of lanes past the end
+        // same products as the direct path (weights folded in the same order); zero-weight corners add nothing
+        run_atomic_add<8>(gv, dead | (8 * (o00 + ax.i0)), gc * (w00 * ax.w0), sl);
+        run_atomic_add<8>(gv, dead | (8 * (o00 + ax.i1)), gc * (w00 * ax.w1), sl);
+        run_atomic_add<8>(gv, dead | (8 * (o01 + ax.i0)), gc * (w01 * ax.w0), sl);
+        run_atomic_add<8>(gv, dead | (8 * (o01 + ax.i1)), gc * (w01 * ax.w1), sl);
+        run_atomic_add<8>(gv, dead | (8 * (o10 + ax.i0)), gc * (w10 * ax.w0), sl);
+        run_atomic_add<8>(gv, dead | (8 * (o10 + ax.i1)), gc * (w10 * ax.w1), sl);
+        run_atomic_add<8>(gv, dead | (8 * (o11 + ax.i0)), gc * (w11 * ax.w0), sl);
+        run_atomic_add<8>(gv, dead | (8 * (o11 + ax.i1)), gc * (w11 * ax.w1), sl);
     } else {
         if (!bp.g_img_feat) return;
         const int v = unit - 4;
@@ -246,12 +280,12 @@ __global__ void __launch_bounds__(256) feat_gather_bwd_cl_kernel(ucnerf_feat_gat
         project_view(p, v, s, &gx, &gy);
         const Lerp ax = axis(gx, p.W, true), ay = axis(gy, p.H, true);
         const size_t hw = (size_t)p.H * p.W;
-        const size_t o00 = (size_t)ay.i0 * p.W + ax.i0, o01 = (size_t)ay.i0 * p.W + ax.i1,
-                     o10 = (size_t)ay.i1 * p.W + ax.i0, o11 = (size_t)ay.i1 * p.W + ax.i1;
+        const int o00 = ay.i0 * p.W + ax.i0, o01 = ay.i0 * p.W + ax.i1, o10 = ay.i1 * p.W + ax.i0, o11 = ay.i1 * p.W + ax.i1;
         float* ft = bp.scratch + L.img + 8 * (size_t)v * hw + c;
-        const float gc = gf[24 + 4 * p.V + 8 * v + c];
-        atomicAdd(ft + 8 * o00, gc * (ay.w0 * ax.w0)); atomicAdd(ft + 8 * o01, gc * (ay.w0 * ax.w1));
-        atomicAdd(ft + 8 * o10, gc * (ay.w1 * ax.w0)); atomicAdd(ft + 8 * o11, gc * (ay.w1 * ax.w1));
+        const float gc = live ? gf[24 + 4 * p.V + 8 * v + c] : 0.f;
+        const int dead = live ? 0 : -1;
+        run_atomic_add<8>(ft, dead | (8 * o00), gc * (ay.w0 * ax.w0), sl); run_atomic_add<8>(ft, dead | (8 * o01), gc * (ay.w0 * ax.w1), sl);
+        run_atomic_add<8>(ft, dead | (8 * o10), gc * (ay.w1 * ax.w0), sl); run_atomic_add<8>(ft, dead | (8 * o11), gc * (ay.w1 * ax.w1), sl);
     }
 }
 
@@ -317,11 +351,8 @@ int ucnerf_feat_gather_bwd(const ucnerf_feat_gather_bwd_params* bp, void* stream
     const ScratchLayout L = scratch_layout(f);
     if (hipMemsetAsync(bp->scratch, 0, L.total * sizeof(float), st) != hipSuccess) return fail(UCNERF_EHIP, "feat_gather_bwd: memset failed");
     hipLaunchKernelGGL(feat_gather_bwd_cl_kernel, dim3(cdiv((long long)f.m * 8, 256), 3 + f.V), dim3(256), 0, st, *bp);
-    if (bp->g_conf) {                                   // confidence: 4 atomics per sample, direct
-        ucnerf_feat_gather_bwd_params c = *bp;
-        c.fwd.unit_mask = 8 & (f.unit_mask ? f.unit_mask : ~0);
-        if (c.fwd.unit_mask) hipLaunchKernelGGL(feat_gather_bwd_kernel, dim3(cdiv(f.m, 256), 4), dim3(256), 0, st, c);
-    }
+    if (bp->g_conf && (8 & (f.unit_mask ? f.unit_mask : ~0)))      // confidence: straight into the map (one channel), runs combined per wave
+        hipLaunchKernelGGL(conf_bwd_kernel, dim3(cdiv(f.m, 256)), dim3(256), 0, st, *bp);
     const int mask = f.unit_mask ? f.unit_mask : ~0;
     for (int k = 0; k < 3; ++k)
         if (bp->g_vol[k] && (mask & (1 << k))) {
