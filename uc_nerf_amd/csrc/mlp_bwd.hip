@@ -315,7 +315,11 @@ __global__ void __launch_bounds__(1024) gemm_tn_kernel(TnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // element-wise stages
 // ------------------------------------------------------------------------------------------------
-// Output stage (models.py:177-178 backwards) + both 4-wide heads.  32 lanes per sample (4 features each).
+// Output stage (models.py:177-178 backwards) + both 4-wide heads, data AND weight gradients.  32 lanes per sample
+// (4 features each), eight samples per block pass, persistent blocks: every lane keeps the 4 x 4 products of its
+// features with the head gradients in registers across its samples, the eight sample slots of a block are summed
+// through LDS at the end and go to the flat gradient with one atomic per weight and block.  (As separate
+// weight-gradient GEMMs these four 1-to-3-row products cost a full pass over the activations each.)
 struct HeadArgs {
     int m, F;
     const float* raw;     // [m,4] forward output
@@ -332,65 +336,115 @@ struct HeadArgs {
     float* g_adapt;       // [m,4]
     float* g_vc;          // [m,128] gradient at the pre-relu output of views/view_confi linears
     float* g_feats; int ldgf;       // writes column F-1 (confidence)
+    float *gw_crgb, *gw_a1, *gw_rgb, *gw_a, *gb_crgb, *gb_a1, *gb_rgb, *gb_a;     // parameter gradients (accumulated)
 };
 
 __global__ void __launch_bounds__(256) head_bwd_kernel(HeadArgs a) {
-    const int s = blockIdx.x * 8 + (threadIdx.x >> 5);
+    __shared__ float red[8][32][33];                     // [sample slot][lane][value] (+1: conflict-free column sums)
+    __shared__ float redb[8][8];
+    const int slot = threadIdx.x >> 5;
     const int c = threadIdx.x & 31;                      // features 4c..4c+3
-    if (s >= a.m) return;
-    const f32x4 hv = reinterpret_cast<const f32x4*>(a.h5 + (size_t)s * 128)[c];
-    const f32x4 vv = reinterpret_cast<const f32x4*>(a.vc + (size_t)s * 128)[c];
-    float base[4], adapt[4];
+    // weights of this lane's features (constant over samples)
+    f32x4 wc[3], w1, wr[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, wa = {0, 0, 0, 0};
 #pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        const f32x4 w = ld4(a.w_crgb + o * 128 + 4 * c);
-        base[o] = hv.x * w.x + hv.y * w.y + hv.z * w.z + hv.w * w.w;
-    }
-    {
-        const f32x4 w = ld4(a.w_a1 + 4 * c);
-        base[3] = hv.x * w.x + hv.y * w.y + hv.z * w.z + hv.w * w.w;
-    }
-    f32x4 wr[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, wa = {0, 0, 0, 0};
+    for (int o = 0; o < 3; ++o) wc[o] = ld4(a.w_crgb + o * 128 + 4 * c);
+    w1 = ld4(a.w_a1 + 4 * c);
     if (c < 16) {
 #pragma unroll
         for (int o = 0; o < 3; ++o) wr[o] = ld4(a.w_rgb + o * 64 + 4 * c);
     } else {
         wa = ld4(a.w_a + 4 * (c - 16));
     }
+    float accb[4][4], acca[4][4], bsum[8];               // [output][feature]: base heads x h5, adapt heads x vc; bias sums
 #pragma unroll
-    for (int o = 0; o < 3; ++o) adapt[o] = vv.x * wr[o].x + vv.y * wr[o].y + vv.z * wr[o].z + vv.w * wr[o].w;
-    adapt[3] = vv.x * wa.x + vv.y * wa.y + vv.z * wa.z + vv.w * wa.w;
+    for (int o = 0; o < 4; ++o)
 #pragma unroll
-    for (int d = 16; d > 0; d >>= 1)
+        for (int k = 0; k < 4; ++k) accb[o][k] = acca[o][k] = 0.f;
 #pragma unroll
-        for (int o = 0; o < 4; ++o) { base[o] += __shfl_xor(base[o], d); adapt[o] += __shfl_xor(adapt[o], d); }
-#pragma unroll
-    for (int o = 0; o < 3; ++o) { base[o] += a.b_crgb[o]; adapt[o] += a.b_rgb[o]; }
-    base[3] += a.b_a1[0]; adapt[3] += a.b_a[0];
+    for (int o = 0; o < 8; ++o) bsum[o] = 0.f;
 
-    const f32x4 raw = reinterpret_cast<const f32x4*>(a.raw)[s];
-    const f32x4 gr = reinterpret_cast<const f32x4*>(a.g_raw)[s];
-    const float conf = a.feats[(size_t)s * a.ldf + a.F - 1];
-    const float u = 1.f - conf, omu = 1.f - u;
-    const float gp[4] = {gr.x * raw.x * (1.f - raw.x), gr.y * raw.y * (1.f - raw.y), gr.z * raw.z * (1.f - raw.z),
-                         raw.w > 0.f ? gr.w : 0.f};
-    const float gb4[4] = {gp[0] * omu, gp[1] * omu, gp[2] * omu, gp[3] * u};
-    const float ga4[4] = {gp[0] * u, gp[1] * u, gp[2] * u, gp[3] * omu};
-    if (c == 0) {
-        reinterpret_cast<f32x4*>(a.g_base)[s] = f32x4{gb4[0], gb4[1], gb4[2], gb4[3]};
-        reinterpret_cast<f32x4*>(a.g_adapt)[s] = f32x4{ga4[0], ga4[1], ga4[2], ga4[3]};
-        const float gu = gp[0] * (adapt[0] - base[0]) + gp[1] * (adapt[1] - base[1]) + gp[2] * (adapt[2] - base[2]) +
-                         gp[3] * (base[3] - adapt[3]);
-        a.g_feats[(size_t)s * a.ldgf + a.F - 1] = -gu;          // u = 1 - confidence
+    for (int s = blockIdx.x * 8 + slot; s < a.m; s += gridDim.x * 8) {
+        const f32x4 hv = reinterpret_cast<const f32x4*>(a.h5 + (size_t)s * 128)[c];
+        const f32x4 vv = reinterpret_cast<const f32x4*>(a.vc + (size_t)s * 128)[c];
+        float base[4], adapt[4];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) base[o] = hv.x * wc[o].x + hv.y * wc[o].y + hv.z * wc[o].z + hv.w * wc[o].w;
+        base[3] = hv.x * w1.x + hv.y * w1.y + hv.z * w1.z + hv.w * w1.w;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) adapt[o] = vv.x * wr[o].x + vv.y * wr[o].y + vv.z * wr[o].z + vv.w * wr[o].w;
+        adapt[3] = vv.x * wa.x + vv.y * wa.y + vv.z * wa.z + vv.w * wa.w;
+#pragma unroll
+        for (int d = 16; d > 0; d >>= 1)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) { base[o] += __shfl_xor(base[o], d); adapt[o] += __shfl_xor(adapt[o], d); }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) { base[o] += a.b_crgb[o]; adapt[o] += a.b_rgb[o]; }
+        base[3] += a.b_a1[0]; adapt[3] += a.b_a[0];
+
+        const f32x4 raw = reinterpret_cast<const f32x4*>(a.raw)[s];
+        const f32x4 gr = reinterpret_cast<const f32x4*>(a.g_raw)[s];
+        const float conf = a.feats[(size_t)s * a.ldf + a.F - 1];
+        const float u = 1.f - conf, omu = 1.f - u;
+        const float gp[4] = {gr.x * raw.x * (1.f - raw.x), gr.y * raw.y * (1.f - raw.y), gr.z * raw.z * (1.f - raw.z),
+                             raw.w > 0.f ? gr.w : 0.f};
+        const float gb4[4] = {gp[0] * omu, gp[1] * omu, gp[2] * omu, gp[3] * u};
+        const float ga4[4] = {gp[0] * u, gp[1] * u, gp[2] * u, gp[3] * omu};
+        if (c == 0) {
+            reinterpret_cast<f32x4*>(a.g_base)[s] = f32x4{gb4[0], gb4[1], gb4[2], gb4[3]};
+            reinterpret_cast<f32x4*>(a.g_adapt)[s] = f32x4{ga4[0], ga4[1], ga4[2], ga4[3]};
+            const float gu = gp[0] * (adapt[0] - base[0]) + gp[1] * (adapt[1] - base[1]) + gp[2] * (adapt[2] - base[2]) +
+                             gp[3] * (base[3] - adapt[3]);
+            a.g_feats[(size_t)s * a.ldgf + a.F - 1] = -gu;          // u = 1 - confidence
+#pragma unroll
+            for (int o = 0; o < 4; ++o) { bsum[o] += gb4[o]; bsum[4 + o] += ga4[o]; }
+        }
+        // head weight gradients: (head gradient) x (this lane's features)
+        const float hvv[4] = {hv.x, hv.y, hv.z, hv.w}, vvv[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { accb[o][k] += gb4[o] * hvv[k]; acca[o][k] += ga4[o] * vvv[k]; }
+        // g_vc = relu'(vc) * (W_head^T g_adapt)
+        f32x4 g;
+        g.x = ga4[0] * wr[0].x + ga4[1] * wr[1].x + ga4[2] * wr[2].x + ga4[3] * wa.x;
+        g.y = ga4[0] * wr[0].y + ga4[1] * wr[1].y + ga4[2] * wr[2].y + ga4[3] * wa.y;
+        g.z = ga4[0] * wr[0].z + ga4[1] * wr[1].z + ga4[2] * wr[2].z + ga4[3] * wa.z;
+        g.w = ga4[0] * wr[0].w + ga4[1] * wr[1].w + ga4[2] * wr[2].w + ga4[3] * wa.w;
+        g.x = vv.x > 0.f ? g.x : 0.f; g.y = vv.y > 0.f ? g.y : 0.f; g.z = vv.z > 0.f ? g.z : 0.f; g.w = vv.w > 0.f ? g.w : 0.f;
+        reinterpret_cast<f32x4*>(a.g_vc + (size_t)s * 128)[c] = g;
     }
-    // g_vc = relu'(vc) * (W_head^T g_adapt)
-    f32x4 g;
-    g.x = ga4[0] * wr[0].x + ga4[1] * wr[1].x + ga4[2] * wr[2].x + ga4[3] * wa.x;
-    g.y = ga4[0] * wr[0].y + ga4[1] * wr[1].y + ga4[2] * wr[2].y + ga4[3] * wa.y;
-    g.z = ga4[0] * wr[0].z + ga4[1] * wr[1].z + ga4[2] * wr[2].z + ga4[3] * wa.z;
-    g.w = ga4[0] * wr[0].w + ga4[1] * wr[1].w + ga4[2] * wr[2].w + ga4[3] * wa.w;
-    g.x = vv.x > 0.f ? g.x : 0.f; g.y = vv.y > 0.f ? g.y : 0.f; g.z = vv.z > 0.f ? g.z : 0.f; g.w = vv.w > 0.f ? g.w : 0.f;
-    reinterpret_cast<f32x4*>(a.g_vc + (size_t)s * 128)[c] = g;
+
+    // block sums over the eight sample slots, then one atomic per weight
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[slot][c][4 * o + k] = accb[o][k]; red[slot][c][16 + 4 * o + k] = acca[o][k]; }
+    if (c == 0) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) redb[slot][o] = bsum[o];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = threadIdx.x + 256 * q;                        // 1024 = 32 lanes x 32 values
+        const int cc = e >> 5, i = e & 31, o = (i & 15) >> 2, k = i & 3;
+        float v = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) v += red[sl][cc][i];
+        float* dst = nullptr;
+        if (i < 16) dst = o < 3 ? a.gw_crgb + o * 128 + 4 * cc + k : a.gw_a1 + 4 * cc + k;
+        else if (cc < 16) { if (o < 3) dst = a.gw_rgb + o * 64 + 4 * cc + k; }
+        else if (o == 3) dst = a.gw_a + 4 * (cc - 16) + k;
+        if (dst) atomicAdd(dst, v);
+    }
+    if (threadIdx.x < 8) {
+        float v = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) v += redb[sl][threadIdx.x];
+        const int o = threadIdx.x & 3;
+        float* dst = threadIdx.x < 4 ? (o < 3 ? a.gb_crgb + o : a.gb_a1) : (o < 3 ? a.gb_rgb + o : a.gb_a);
+        atomicAdd(dst, v);
+    }
 }
 
 // gx = h5 * bc  (input of feature_linear)
@@ -603,19 +657,20 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
         RUN(ucnerf_embed(&e, st));
     }
 
-    // 1. output stage + heads: g_base, g_adapt, d/d(confidence), g_vc -> g1
+    // 1. output stage + heads: g_base, g_adapt, d/d(confidence), g_vc -> g1, and the four head layers' parameter gradients
     HeadArgs ha;
     ha.m = m; ha.F = F; ha.raw = w.raw; ha.g_raw = bp->g_raw; ha.feats = f.feats; ha.ldf = ldf; ha.h5 = w.sv.h[5]; ha.vc = w.sv.vc;
     ha.w_crgb = P + L.p_crw; ha.w_a1 = P + L.p_a1w; ha.w_rgb = P + L.p_rw; ha.w_a = P + L.p_aw;
     ha.b_crgb = P + L.p_crb; ha.b_a1 = P + L.p_a1b; ha.b_rgb = P + L.p_rb; ha.b_a = P + L.p_ab;
     ha.g_base = w.g_base; ha.g_adapt = w.g_adapt; ha.g_vc = w.g1; ha.g_feats = bp->g_feats; ha.ldgf = ldgf;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(cdiv(m, 8)), dim3(256), 0, st, ha);
+    ha.gw_crgb = G + L.p_crw; ha.gw_a1 = G + L.p_a1w; ha.gw_rgb = G + L.p_rw; ha.gw_a = G + L.p_aw;
+    ha.gb_crgb = G + L.p_crb; ha.gb_a1 = G + L.p_a1b; ha.gb_rgb = G + L.p_rb; ha.gb_a = G + L.p_ab;
+    {
+        int blocks = cdiv(m, 8);
+        if (blocks > 4 * device_cus()) blocks = 4 * device_cus();
+        hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks), dim3(256), 0, st, ha);
+    }
     RUN(check_launch("mlp_bwd head"));
-    // head weights: rgb_linear [3,64] <- g_adapt[:, :3]^T vc[:, :64]; alpha_linear [1,64] <- g_adapt[:, 3]^T vc[:, 64:]
-    RUN(run_tn(st, m, w.g_adapt, 4, 3, w.sv.vc, 128, 1, 64, G + L.p_rw, 64, G + L.p_rb));
-    RUN(run_tn(st, m, w.g_adapt + 3, 4, 1, w.sv.vc + 64, 128, 1, 64, G + L.p_aw, 64, G + L.p_ab));
-    RUN(run_tn(st, m, w.g_base, 4, 3, w.sv.h[5], 128, 1, 128, G + L.p_crw, 128, G + L.p_crb));
-    RUN(run_tn(st, m, w.g_base + 3, 4, 1, w.sv.h[5], 128, 1, 128, G + L.p_a1w, 128, G + L.p_a1b));
 
     // 2. views_linears / view_confi_linears: weights [64,155] on [f | dir encoding]; g_f -> g2
     const int KV = MLP_W + MLP_PE_DIR;
