@@ -39,6 +39,7 @@ struct NnArgs {
     float* C; int ldc;
     int m, N, accumulate;
     const float* hh; const float* bd; float* gbd;                // EPI 1 only (all [m,128]; g_bd accumulates)
+    const float* W_hi;                                            // optional: rows k >= 64 come from this matrix (row k - 64)
 };
 
 constexpr int NN_WAVES = 8;
@@ -60,7 +61,10 @@ __global__ void __launch_bounds__(64 * NN_WAVES) gemm_nn_kernel(NnArgs a, int n_
         const int nc = n < a.N ? n : a.N - 1;
         float wv[K / KS];
 #pragma unroll
-        for (int i = 0; i < K / KS; ++i) wv[i] = a.W[(size_t)(k0 + i * KS) * a.ldw + nc];   // all loads in flight at once
+        for (int i = 0; i < K / KS; ++i) {                                    // all loads in flight at once
+            const int k = k0 + i * KS;
+            wv[i] = a.W_hi && k >= 64 ? a.W_hi[(size_t)(k - 64) * a.ldw + nc] : a.W[(size_t)k * a.ldw + nc];
+        }
 #pragma unroll
         for (int i = 0; i < K / KS; ++i) Wl[(k0 + i * KS) * NP + n] = n < a.N ? wv[i] : 0.f;
     }
@@ -181,6 +185,7 @@ struct TnArgs {
     float* gb;
     int m, Nout, Kin;
     int chunk;            // samples per block, a multiple of 32
+    float* gW_hi; float* gb_hi;   // optional: rows n >= 64 belong to a second layer (row n - 64 of these)
 };
 
 #ifndef UCNERF_TN_DEPTH2
@@ -301,14 +306,16 @@ __global__ void __launch_bounds__(1024) gemm_tn_kernel(TnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h, k = 32 * (ks * KT + kt) + i;
-                if (n < a.Nout && k < a.Kin) atomicAdd(a.gW + (size_t)n * a.ldw + k, acc[kt][r]);
+                float* drow = a.gW_hi && n >= 64 ? a.gW_hi + (size_t)(n - 64) * a.ldw : a.gW + (size_t)n * a.ldw;
+                if (n < a.Nout && k < a.Kin) atomicAdd(drow + k, acc[kt][r]);
             }
         }
         __syncthreads();
     }
     if (a.gb && rows && ks == 0) {
         colsum += __shfl_xor(colsum, 32);
-        if (h == 0 && 32 * nt + i < a.Nout) atomicAdd(a.gb + 32 * nt + i, colsum);
+        const int n = 32 * nt + i;
+        if (h == 0 && n < a.Nout) atomicAdd(a.gb_hi && n >= 64 ? a.gb_hi + n - 64 : a.gb + n, colsum);
     }
 }
 
@@ -543,8 +550,8 @@ static int launch_nn(hipStream_t st, const NnArgs& a) {
 
 // {h, bd, g_bd}: fuse the trunk layer's element-wise backward into the epilogue (N = K = 128 only)
 static int run_nn(hipStream_t st, int m, const float* A, int lda, int K, const float* W, int ldw, int N, float* C, int ldc,
-                  bool accumulate, const float* hh = nullptr, const float* bd = nullptr, float* gbd = nullptr) {
-    NnArgs a{A, lda, W, ldw, C, ldc, m, N, accumulate ? 1 : 0, hh, bd, gbd};
+                  bool accumulate, const float* hh = nullptr, const float* bd = nullptr, float* gbd = nullptr, const float* W_hi = nullptr) {
+    NnArgs a{A, lda, W, ldw, C, ldc, m, N, accumulate ? 1 : 0, hh, bd, gbd, W_hi};
     if (((uintptr_t)A & 15) || (lda & 3)) return fail(UCNERF_EINVAL, "mlp_bwd: gemm_nn operand must be 16-byte aligned rows");
     const bool wide = N > 64;
     if (hh) {
@@ -557,7 +564,7 @@ static int run_nn(hipStream_t st, int m, const float* A, int lda, int K, const f
 }
 
 static int run_tn(hipStream_t st, int m, const float* G, int ldg, int Nout, const float* X, int ldx, int xdiv, int Kin, float* gW,
-                  int ldw, float* gb) {
+                  int ldw, float* gb, float* gW_hi = nullptr, float* gb_hi = nullptr) {
     // samples per block: about one block per CU for a training batch (~1e5 samples), so that the float atomics of the
     // merge stay a small part of the launch; larger batches get proportionally larger chunks
     int chunk = 32 * cdiv(cdiv(m, device_cus()), 32);
@@ -565,7 +572,8 @@ static int run_tn(hipStream_t st, int m, const float* G, int ldg, int Nout, cons
     if (chunk > 8192) chunk = 8192;
     for (int k0 = 0; k0 < Kin; k0 += 128) {               // at most 4 accumulator tiles per launch
         const int kin = Kin - k0 < 128 ? Kin - k0 : 128;
-        TnArgs a{G, ldg, X + k0, ldx, xdiv, gW + k0, ldw, k0 == 0 ? gb : nullptr, m, Nout, kin, chunk};
+        TnArgs a{G, ldg, X + k0, ldx, xdiv, gW + k0, ldw, k0 == 0 ? gb : nullptr, m, Nout, kin, chunk,
+                 gW_hi ? gW_hi + k0 : nullptr, k0 == 0 ? gb_hi : nullptr};
         dim3 grid(cdiv(m, chunk)), block(1024);
         const int kt = cdiv(kin, 32);
         if (xdiv != 1) {
@@ -674,12 +682,10 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
 
     // 2. views_linears / view_confi_linears: weights [64,155] on [f | dir encoding]; g_f -> g2
     const int KV = MLP_W + MLP_PE_DIR;
-    RUN(run_tn(st, m, w.g1, 128, 64, w.sv.ft, 128, 1, 128, G + L.p_vw, KV, G + L.p_vb));
-    RUN(run_tn(st, m, w.g1, 128, 64, ped, ld_ped, xdiv_dir, 27, G + L.p_vw + 128, KV, nullptr));
-    RUN(run_tn(st, m, w.g1 + 64, 128, 64, w.sv.ft, 128, 1, 128, G + L.p_vcw, KV, G + L.p_vcb));
-    RUN(run_tn(st, m, w.g1 + 64, 128, 64, ped, ld_ped, xdiv_dir, 27, G + L.p_vcw + 128, KV, nullptr));
-    RUN(run_nn(st, m, w.g1, 128, 64, P + L.p_vw, KV, 128, w.g2, 128, false));
-    RUN(run_nn(st, m, w.g1 + 64, 128, 64, P + L.p_vcw, KV, 128, w.g2, 128, true));
+    //    (g1 = [g_views | g_view_confi]: one 128-row product per operand, rows 64.. go to the second layer)
+    RUN(run_tn(st, m, w.g1, 128, 128, w.sv.ft, 128, 1, 128, G + L.p_vw, KV, G + L.p_vb, G + L.p_vcw, G + L.p_vcb));
+    RUN(run_tn(st, m, w.g1, 128, 128, ped, ld_ped, xdiv_dir, 27, G + L.p_vw + 128, KV, nullptr, G + L.p_vcw + 128, nullptr));
+    RUN(run_nn(st, m, w.g1, 128, 128, P + L.p_vw, KV, 128, w.g2, 128, false, nullptr, nullptr, nullptr, P + L.p_vcw));
 
     // 3. feature_linear on gx = h5 * bc: weights, then g_g -> g1
     hipLaunchKernelGGL(mul_kernel, dim3(ew_blocks), dim3(256), 0, st, (const f32x4*)w.sv.h[5], (const f32x4*)w.sv.bc, (f32x4*)w.gx, n4);
