@@ -79,6 +79,11 @@ def test_fused_render_pass_matches_oracle_stage_by_stage(N, S, per_ray_ranges):
     close(fast["rgb"], want["rgb"], 1e-4); close(fast["depth"], want["depth"], 1e-4, 1e-5)
     close(fast["weights"], want["weights"], 2e-5, 1e-4)
     close(fast["rgb"], out["rgb"], 2e-6); close(fast["depth"], out["depth"], 5e-6, 1e-6)
+    # ... and the training forward from the repacked sources: row-major features straight from the channel-last gather
+    kept = rp(rays_d.to(DEV), z.to(DEV), near_far=None if near_far is None else near_far.to(DEV), keep=("raw", "feats"))
+    close(kept["feats"].view(N, S, -1), want["feats"], 2e-5, 1e-5)
+    close(kept["feats"], out["feats"], 2e-6, 1e-6)
+    close(kept["rgb"], out["rgb"], 2e-6); close(kept["raw"], out["raw"], 5e-6, 1e-5)
 
 
 def test_coarse_fine_pipeline_vs_reference_golden(sd_v7):
