@@ -323,8 +323,8 @@ __global__ void __launch_bounds__(1024) gemm_tn_kernel(TnArgs a) {
 // element-wise stages
 // ------------------------------------------------------------------------------------------------
 // Output stage (models.py:177-178 backwards) + both 4-wide heads, data AND weight gradients.  32 lanes per sample
-// (4 features each), eight samples per block pass, persistent blocks: every lane keeps the 4 x 4 products of its
-// features with the head gradients in registers across its samples, the eight sample slots of a block are summed
+// (4 features each), sixteen samples per block pass, persistent blocks (one per CU): every lane keeps the 4 x 4 products of its
+// features with the head gradients in registers across its samples, the sample slots of a block are summed
 // through LDS at the end and go to the flat gradient with one atomic per weight and block.  (As separate
 // weight-gradient GEMMs these four 1-to-3-row products cost a full pass over the activations each.)
 struct HeadArgs {
@@ -346,9 +346,10 @@ struct HeadArgs {
     float *gw_crgb, *gw_a1, *gw_rgb, *gw_a, *gb_crgb, *gb_a1, *gb_rgb, *gb_a;     // parameter gradients (accumulated)
 };
 
-__global__ void __launch_bounds__(256) head_bwd_kernel(HeadArgs a) {
-    __shared__ float red[8][32][33];                     // [sample slot][lane][value] (+1: conflict-free column sums)
-    __shared__ float redb[8][8];
+constexpr int HEAD_SLOTS = 16;                           // samples per block pass (32 lanes each)
+__global__ void __launch_bounds__(32 * HEAD_SLOTS) head_bwd_kernel(HeadArgs a) {
+    __shared__ float red[HEAD_SLOTS][32][33];            // [sample slot][lane][value] (+1: conflict-free column sums)
+    __shared__ float redb[HEAD_SLOTS][8];
     const int slot = threadIdx.x >> 5;
     const int c = threadIdx.x & 31;                      // features 4c..4c+3
     // weights of this lane's features (constant over samples)
@@ -370,9 +371,10 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(HeadArgs a) {
 #pragma unroll
     for (int o = 0; o < 8; ++o) bsum[o] = 0.f;
 
-    for (int s = blockIdx.x * 8 + slot; s < a.m; s += gridDim.x * 8) {
+    for (int s = blockIdx.x * HEAD_SLOTS + slot; s < a.m; s += gridDim.x * HEAD_SLOTS) {
         const f32x4 hv = reinterpret_cast<const f32x4*>(a.h5 + (size_t)s * 128)[c];
         const f32x4 vv = reinterpret_cast<const f32x4*>(a.vc + (size_t)s * 128)[c];
+        // this lane's share of the eight head pre-activations (4 of the 128 / 64 features each)
         float base[4], adapt[4];
 #pragma unroll
         for (int o = 0; o < 3; ++o) base[o] = hv.x * wc[o].x + hv.y * wc[o].y + hv.z * wc[o].z + hv.w * wc[o].w;
@@ -380,13 +382,6 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(HeadArgs a) {
 #pragma unroll
         for (int o = 0; o < 3; ++o) adapt[o] = vv.x * wr[o].x + vv.y * wr[o].y + vv.z * wr[o].z + vv.w * wr[o].w;
         adapt[3] = vv.x * wa.x + vv.y * wa.y + vv.z * wa.z + vv.w * wa.w;
-#pragma unroll
-        for (int d = 16; d > 0; d >>= 1)
-#pragma unroll
-            for (int o = 0; o < 4; ++o) { base[o] += __shfl_xor(base[o], d); adapt[o] += __shfl_xor(adapt[o], d); }
-#pragma unroll
-        for (int o = 0; o < 3; ++o) { base[o] += a.b_crgb[o]; adapt[o] += a.b_rgb[o]; }
-        base[3] += a.b_a1[0]; adapt[3] += a.b_a[0];
 
         const f32x4 raw = reinterpret_cast<const f32x4*>(a.raw)[s];
         const f32x4 gr = reinterpret_cast<const f32x4*>(a.g_raw)[s];
@@ -396,11 +391,16 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(HeadArgs a) {
                              raw.w > 0.f ? gr.w : 0.f};
         const float gb4[4] = {gp[0] * omu, gp[1] * omu, gp[2] * omu, gp[3] * u};
         const float ga4[4] = {gp[0] * u, gp[1] * u, gp[2] * u, gp[3] * omu};
+        // d/du needs the head outputs only through one linear combination: fold it per lane, then ONE value crosses the
+        // 32 lanes of the sample (instead of eight)
+        float gu = gp[0] * (adapt[0] - base[0]) + gp[1] * (adapt[1] - base[1]) + gp[2] * (adapt[2] - base[2]) + gp[3] * (base[3] - adapt[3]);
+#pragma unroll
+        for (int d = 16; d > 0; d >>= 1) gu += __shfl_xor(gu, d);
         if (c == 0) {
+            gu += gp[0] * (a.b_rgb[0] - a.b_crgb[0]) + gp[1] * (a.b_rgb[1] - a.b_crgb[1]) + gp[2] * (a.b_rgb[2] - a.b_crgb[2]) +
+                  gp[3] * (a.b_a1[0] - a.b_a[0]);
             reinterpret_cast<f32x4*>(a.g_base)[s] = f32x4{gb4[0], gb4[1], gb4[2], gb4[3]};
             reinterpret_cast<f32x4*>(a.g_adapt)[s] = f32x4{ga4[0], ga4[1], ga4[2], ga4[3]};
-            const float gu = gp[0] * (adapt[0] - base[0]) + gp[1] * (adapt[1] - base[1]) + gp[2] * (adapt[2] - base[2]) +
-                             gp[3] * (base[3] - adapt[3]);
             a.g_feats[(size_t)s * a.ldgf + a.F - 1] = -gu;          // u = 1 - confidence
 #pragma unroll
             for (int o = 0; o < 4; ++o) { bsum[o] += gb4[o]; bsum[4 + o] += ga4[o]; }
@@ -432,12 +432,12 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(HeadArgs a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = threadIdx.x + 256 * q;                        // 1024 = 32 lanes x 32 values
+    for (int q = 0; q < 1024 / (32 * HEAD_SLOTS); ++q) {
+        const int e = threadIdx.x + 32 * HEAD_SLOTS * q;            // 1024 = 32 lanes x 32 values
         const int cc = e >> 5, i = e & 31, o = (i & 15) >> 2, k = i & 3;
         float v = 0.f;
 #pragma unroll
-        for (int sl = 0; sl < 8; ++sl) v += red[sl][cc][i];
+        for (int sl = 0; sl < HEAD_SLOTS; ++sl) v += red[sl][cc][i];
         float* dst = nullptr;
         if (i < 16) dst = o < 3 ? a.gw_crgb + o * 128 + 4 * cc + k : a.gw_a1 + 4 * cc + k;
         else if (cc < 16) { if (o < 3) dst = a.gw_rgb + o * 64 + 4 * cc + k; }
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(HeadArgs a) {
     if (threadIdx.x < 8) {
         float v = 0.f;
 #pragma unroll
-        for (int sl = 0; sl < 8; ++sl) v += redb[sl][threadIdx.x];
+        for (int sl = 0; sl < HEAD_SLOTS; ++sl) v += redb[sl][threadIdx.x];
         const int o = threadIdx.x & 3;
         float* dst = threadIdx.x < 4 ? (o < 3 ? a.gb_crgb + o : a.gb_a1) : (o < 3 ? a.gb_rgb + o : a.gb_a);
         atomicAdd(dst, v);
@@ -674,9 +674,9 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     ha.gw_crgb = G + L.p_crw; ha.gw_a1 = G + L.p_a1w; ha.gw_rgb = G + L.p_rw; ha.gw_a = G + L.p_aw;
     ha.gb_crgb = G + L.p_crb; ha.gb_a1 = G + L.p_a1b; ha.gb_rgb = G + L.p_rb; ha.gb_a = G + L.p_ab;
     {
-        int blocks = cdiv(m, 8);
-        if (blocks > 4 * device_cus()) blocks = 4 * device_cus();
-        hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks), dim3(256), 0, st, ha);
+        int blocks = cdiv(m, HEAD_SLOTS);                 // one block per CU: the merge is one atomic per weight and block
+        if (blocks > device_cus()) blocks = device_cus();
+        hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks), dim3(32 * HEAD_SLOTS), 0, st, ha);
     }
     RUN(check_launch("mlp_bwd head"));
 
