@@ -188,6 +188,9 @@ struct TnArgs {
     float* gW_hi; float* gb_hi;   // optional: rows n >= 64 belong to a second layer (row n - 64 of these)
 };
 
+#ifndef UCNERF_TN_EXP
+#define UCNERF_TN_EXP 0
+#endif
 #ifndef UCNERF_TN_DEPTH2
 #define UCNERF_TN_DEPTH2 2      // stages (8 samples each) of loads in flight (measured: 1, 2 and 3 time the same -- the loop is not latency-bound)
 #endif
@@ -277,7 +280,11 @@ __global__ void __launch_bounds__(1024) gemm_tn_kernel(TnArgs a) {
 #pragma unroll
             for (int b = 0; b < NB; ++b)
                 if (it + b < n_full) {
+#if UCNERF_TN_EXP != 2              // (2 = timing experiment: MFMAs only)
                     if (it + b + DEPTH < n_full) load(it + b + DEPTH, sb[(b + DEPTH) % NB]);
+#else
+                    asm volatile("" : "+v"(sb[b].g[0]));
+#endif
                     mma(sb[b]);
                 }
         }
@@ -307,7 +314,11 @@ __global__ void __launch_bounds__(1024) gemm_tn_kernel(TnArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h, k = 32 * (ks * KT + kt) + i;
                 float* drow = a.gW_hi && n >= 64 ? a.gW_hi + (size_t)(n - 64) * a.ldw : a.gW + (size_t)n * a.ldw;
+#if UCNERF_TN_EXP == 3              // (timing experiment: no atomics)
+                if (n < a.Nout && k < a.Kin && acc[kt][r] == 1234.5f) drow[k] = 0.f;
+#else
                 if (n < a.Nout && k < a.Kin) atomicAdd(drow + k, acc[kt][r]);
+#endif
             }
         }
         __syncthreads();
