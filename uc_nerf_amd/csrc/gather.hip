@@ -289,13 +289,24 @@ __global__ void __launch_bounds__(256) feat_gather_bwd_cl_kernel(ucnerf_feat_gat
     }
 }
 
-// g[c][i] += scratch[i][c] for one source of `n` positions (single writer per element)
-__global__ void __launch_bounds__(256) add_transposed_kernel(const float4* __restrict__ src, float* __restrict__ dst, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float4 a = src[2 * i], b = src[2 * i + 1];
-    dst[i] += a.x; dst[n + i] += a.y; dst[2 * n + i] += a.z; dst[3 * n + i] += a.w;
-    dst[4 * n + i] += b.x; dst[5 * n + i] += b.y; dst[6 * n + i] += b.z; dst[7 * n + i] += b.w;
+// g[c][i] += scratch[i][c] for every source in one launch (blockIdx.y = source; single writer per element)
+struct AddTransposedArgs {
+    int count;
+    const float4* src[11];       // 3 volumes + up to 8 views
+    float* dst[11];
+    size_t n[11];                // positions per source
+};
+
+__global__ void __launch_bounds__(256) add_transposed_kernel(AddTransposedArgs a) {
+    const int k = blockIdx.y;
+    const size_t n = a.n[k];
+    const float4* __restrict__ src = a.src[k];
+    float* __restrict__ dst = a.dst[k];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float4 u = src[2 * i], v = src[2 * i + 1];
+        dst[i] += u.x; dst[n + i] += u.y; dst[2 * n + i] += u.z; dst[3 * n + i] += u.w;
+        dst[4 * n + i] += v.x; dst[5 * n + i] += v.y; dst[6 * n + i] += v.z; dst[7 * n + i] += v.w;
+    }
 }
 
 static int check_geometry(const ucnerf_feat_gather_params* p, const char* who) {
@@ -354,17 +365,24 @@ int ucnerf_feat_gather_bwd(const ucnerf_feat_gather_bwd_params* bp, void* stream
     if (bp->g_conf && (8 & (f.unit_mask ? f.unit_mask : ~0)))      // confidence: straight into the map (one channel), runs combined per wave
         hipLaunchKernelGGL(conf_bwd_kernel, dim3(cdiv(f.m, 256)), dim3(256), 0, st, *bp);
     const int mask = f.unit_mask ? f.unit_mask : ~0;
+    AddTransposedArgs at;
+    at.count = 0;
+    size_t n_max = 0;
+    auto add = [&](const float* src, float* dst, size_t n) {
+        at.src[at.count] = (const float4*)src; at.dst[at.count] = dst; at.n[at.count] = n; ++at.count;
+        if (n > n_max) n_max = n;
+    };
     for (int k = 0; k < 3; ++k)
-        if (bp->g_vol[k] && (mask & (1 << k))) {
-            const size_t n = (size_t)f.vol_d[k] * f.vol_h[k] * f.vol_w[k];
-            hipLaunchKernelGGL(add_transposed_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float4*)(bp->scratch + L.vol[k]), bp->g_vol[k], n);
-        }
+        if (bp->g_vol[k] && (mask & (1 << k))) add(bp->scratch + L.vol[k], bp->g_vol[k], (size_t)f.vol_d[k] * f.vol_h[k] * f.vol_w[k]);
     if (bp->g_img_feat) {
         const size_t hw = (size_t)f.H * f.W;
         for (int v = 0; v < f.V; ++v)
-            if (mask & (1 << (4 + v)))
-                hipLaunchKernelGGL(add_transposed_kernel, dim3(cdiv(hw, 256)), dim3(256), 0, st,
-                                   (const float4*)(bp->scratch + L.img + 8 * (size_t)v * hw), bp->g_img_feat + 8 * (size_t)v * hw, hw);
+            if (mask & (1 << (4 + v))) add(bp->scratch + L.img + 8 * (size_t)v * hw, bp->g_img_feat + 8 * (size_t)v * hw, hw);
+    }
+    if (at.count) {
+        int bx = cdiv(n_max, 256);
+        if (bx > 1024) bx = 1024;
+        hipLaunchKernelGGL(add_transposed_kernel, dim3(bx, at.count), dim3(256), 0, st, at);
     }
     return check_launch("feat_gather_bwd");
 }
