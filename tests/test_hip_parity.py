@@ -317,7 +317,7 @@ def test_composite_sample_counts_vs_oracle(S):
 
 
 # ---------------------------------------------------------------------------------------------- a6 backward
-@pytest.mark.parametrize("n_src,m,S", [(6, 96, 1), (3, 45, 9), (6, 2100, 3), (6, 9001, 1)])   # (ragged tiles, stages and blocks)
+@pytest.mark.parametrize("n_src,m,S", [(6, 96, 1), (3, 45, 9), (6, 2100, 3), (6, 9001, 1), (1, 70, 5), (8, 333, 3)])   # (ragged tiles, stages, blocks; 2..9 views)
 def test_mlp_backward_vs_oracle_autograd(n_src, m, S, sd_v7):
     """Parameter and feature gradients of sum(raw * r) against autograd through the CPU oracle (which
     tests/test_oracle_golden.py pins to the reference's own gradients, G6)."""
