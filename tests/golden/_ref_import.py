@@ -9,6 +9,11 @@ image (cv2, torchvision.transforms, kornia, warmup_scheduler, tkinter, inplace_a
 them is executed on the ray-marching hot path, so inert stand-in modules are registered in
 ``sys.modules`` before import; `Tensor.cuda` is made a no-op because
 network/models.py:40 calls `.cuda()` unconditionally and there is no GPU here.
+
+One exception, for the cost-volume fixtures (G12): ``homo_warp`` (utils/utils.py:1105) calls
+``kornia.utils.create_meshgrid`` (kornia >= 0.6.12, requirements.txt:12).  That one function is supplied here,
+restated from its published behaviour (pixel-coordinate grid [1,H,W,2], last dim (x, y)); everything else of kornia
+stays inert.
 """
 import importlib.util
 import os
@@ -49,8 +54,17 @@ def load():
     sys.modules["tkinter"].X = None
     sys.modules["inplace_abn"].InPlaceABN = _Inert
     sys.modules["warmup_scheduler"].GradualWarmupScheduler = _Inert
-    sys.modules["kornia"].create_meshgrid = _Inert
-    sys.modules["kornia.utils"].create_meshgrid = _Inert
+    def create_meshgrid(height, width, normalized_coordinates=True, device=None, dtype=torch.float32):
+        xs = torch.linspace(0, width - 1, width, device=device, dtype=dtype)
+        ys = torch.linspace(0, height - 1, height, device=device, dtype=dtype)
+        if normalized_coordinates:
+            xs = (xs / (width - 1) - 0.5) * 2
+            ys = (ys / (height - 1) - 0.5) * 2
+        base = torch.stack(torch.meshgrid([xs, ys], indexing="ij"), dim=-1)      # W x H x 2
+        return base.permute(1, 0, 2).unsqueeze(0)                                  # 1 x H x W x 2
+
+    sys.modules["kornia"].create_meshgrid = create_meshgrid
+    sys.modules["kornia.utils"].create_meshgrid = create_meshgrid
     sys.modules["kornia"].utils = sys.modules["kornia.utils"]
     sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
 
@@ -67,6 +81,8 @@ def load():
     spec = importlib.util.spec_from_file_location("ref_ray_utils", os.path.join(REF, "data", "ray_utils.py"))
     ref_ray_utils = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ref_ray_utils)
+    import network.mvs_models as ref_mvs       # noqa: E402  (DepthNet / homo_warp call site, for the cost-volume fixtures)
+    ref_utils.create_meshgrid = create_meshgrid   # utils/utils.py:1102 binds the name at import time
     torch.autograd.set_detect_anomaly(False)   # the reference switches it on at import
     return types.SimpleNamespace(utils=ref_utils, helpers=ref_helpers, renderer=ref_renderer,
-                                 models=ref_models, ray_utils=ref_ray_utils)
+                                 models=ref_models, ray_utils=ref_ray_utils, mvs=ref_mvs)

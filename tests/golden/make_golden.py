@@ -418,8 +418,59 @@ def g11():
          f_weights=f_w, c_sigma=c_raw[..., 3], sigma_head_scale=0.05, sigma_head_bias=0.05)
 
 
+# ------------------------------------------------------------------ G12 / G13 cost volume + depth regression (row f2)
+def mvs_setup(g, V, C, H, W, D, pad):
+    """Source feature maps, (src_proj @ ref_proj_inv)[:3] per source view, per-pixel depth hypotheses."""
+    K = torch.tensor([[0.9 * W, 0, 0.5 * W - 0.3], [0, 0.95 * W, 0.5 * H + 0.2], [0, 0, 1]])
+    K4 = torch.eye(4); K4[:3, :3] = K
+    w2c = [rand_pose(g, 0.05) for _ in range(V + 1)]                     # [0] = the target ("reference") view
+    affine = torch.stack([K4 @ m for m in w2c])                          # data/scared.py builds K @ w2c per view
+    affine_inv = torch.inverse(affine)
+    feats = [torch.randn(1, C, H, W, generator=g) for _ in range(V)]
+    imgs = torch.rand(1, V, 3, 2 * H, 2 * W, generator=g)
+    Hp, Wp = H + 2 * pad, W + 2 * pad
+    base = torch.linspace(1.2, 3.4, D).view(1, D, 1, 1)
+    depth_values = (base + 0.15 * torch.rand(1, D, H, W, generator=g)).contiguous()   # padded inside DepthNet (replicate)
+    return feats, imgs, affine, affine_inv, depth_values
+
+
+def g12_g13():
+    out12, out13 = {}, {}
+    for tag, (V, C, H, W, D, pad) in {"a": (3, 8, 16, 20, 6, 0), "b": (6, 16, 12, 14, 5, 2)}.items():
+        g = torch.Generator().manual_seed(1200 + len(tag) + V)
+        feats, imgs, affine, affine_inv, depth_values = mvs_setup(g, V, C, H, W, D, pad)
+        captured = {}
+
+        def cost_reg(v, captured=captured, g=g):
+            # stands where the 3D regularisation CNN is passed in (an argument of DepthNet.forward): records the variance
+            # volume it is given and returns seeded (features, logits)
+            captured["variance"] = v.detach().clone()
+            prob = torch.randn(v.shape[0], 1, *v.shape[2:], generator=g) * 2.0
+            captured["prob_pre"] = prob.squeeze(1).clone()
+            return v[:, :8] * 1.0, prob
+
+        prob_init = torch.randn(1, D, H + 2 * pad, W + 2 * pad, generator=g) * 0.5 if tag == "b" else None
+        net = ref.mvs.DepthNet()
+        with torch.no_grad():
+            o = net(feats, affine, affine_inv, depth_values, D, cost_reg, imgs, pad=pad,
+                    prob_volume_init=None if prob_init is None else prob_init.clone())
+        # the same warps through homo_warp directly (the function the kernel replaces)
+        dv_pad = torch.nn.functional.pad(depth_values, (pad, pad, pad, pad), "replicate") if pad > 0 else depth_values
+        proj = torch.stack([(affine[i + 1:i + 2] @ affine_inv[0:1])[0, :3] for i in range(V)])
+        warped0, grid0 = ref.utils.homo_warp(feats[0], proj[0:1], dv_pad, pad=pad)
+        out12.update({tag + "_" + k: v for k, v in dict(
+            V=V, C=C, H=H, W=W, D=D, pad=pad, feats=torch.cat(feats), proj=proj, depth_values=dv_pad[0],
+            variance=captured["variance"][0], warped0=warped0[0], grid0=grid0.reshape(D, -1, 2)).items()})
+        out13.update({tag + "_" + k: v for k, v in dict(
+            D=D, pad=pad, prob_pre=captured["prob_pre"][0], depth_values=o["depth_values"][0],
+            prob_init=torch.zeros(0) if prob_init is None else prob_init[0], prob_volume=o["prob_volume"][0],
+            depth=o["depth"][0], confidence=o["photometric_confidence"][0]).items()})
+    save("g12_cost_volume", **out12)
+    save("g13_depth_regress", **out13)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12_g13):
         if not only or fn.__name__ in only:
             fn()

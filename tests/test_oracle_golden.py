@@ -261,3 +261,33 @@ def test_g11_coarse_fine_composition(sd_v7):
     # free-running: almost every ray still lands within 1e-4 (a flipped searchsorted bin moves one sample)
     err = (out["rgb"] - g["f_rgb"]).abs().max(-1)[0]
     assert (err < 1e-4).float().mean() > 0.9 and err.median() < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- f2: the step in front
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g12_cost_volume_variance(tag):
+    """homo_warp (utils/utils.py:1105-1172) and the variance volume DepthNet hands to the regularisation net
+    (network/mvs_models.py:599-626), captured from the reference."""
+    from oracle import mvs_oracle as M
+    g = load_golden("g12_cost_volume")
+    f = lambda k: g[tag + "_" + k]                                       # noqa: E731
+    H, W, D, pad = int(f("H")), int(f("W")), int(f("D")), int(f("pad"))
+    grid = M.homo_warp_grid(f("proj")[0], f("depth_values"), H, W, pad)
+    assert torch.equal(grid, f("grid0"))
+    warped = M.sample_nearest_border(f("feats")[0], grid).reshape(f("warped0").shape)
+    assert torch.equal(warped, f("warped0"))
+    var, _ = M.cost_volume_variance(f("feats"), f("proj"), f("depth_values"), pad)
+    assert torch.equal(var, f("variance"))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g13_depth_regression_and_confidence(tag):
+    """softmax over depth, expected depth, 4-tap photometric confidence (network/mvs_models.py:629-646)."""
+    from oracle import mvs_oracle as M
+    g = load_golden("g13_depth_regress")
+    f = lambda k: g[tag + "_" + k]                                       # noqa: E731
+    init = f("prob_init") if f("prob_init").numel() else None
+    p, depth, conf = M.depth_regress(f("prob_pre"), f("depth_values"), init, int(f("pad")))
+    close(p, f("prob_volume"), 1e-7, 1e-6)
+    close(depth, f("depth"), 1e-6, 1e-6)
+    close(conf, f("confidence"), 1e-6, 1e-6)
