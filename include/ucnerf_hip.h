@@ -351,6 +351,37 @@ typedef struct {
 int ucnerf_merge_rows(const ucnerf_merge_rows_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * f2   the step in front of the path: cost-volume assembly and depth regression of one cascade stage.
+ *      ucnerf_cost_volume replaces the loop of network/mvs_models.py:609-626: homo_warp (utils/utils.py:1105-1172,
+ *      nearest-neighbour grid_sample, border padding, align_corners=True) of every source view's feature map onto the
+ *      D x Hp x Wp hypotheses of the target view, the in-frustum count and the variance volume handed to the
+ *      regularisation network.  (The warped-image volume of :614,617 is never used by the reference and is not built.)
+ *      ucnerf_depth_regress replaces network/mvs_models.py:629-646: softmax over depth (+ optional initial logits),
+ *      expected depth, 4-tap photometric confidence, cropped by `pad`.  Forward only.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t V, C, H, W;        /* source feature maps [V,C,H,W] */
+    int32_t D, pad;            /* hypotheses on the padded target grid: Hp = H + 2 pad, Wp = W + 2 pad */
+    const float* feats;        /* [V,C,H,W] */
+    const float* proj;         /* [V,12]: (src_proj @ ref_proj_inv)[:3], row-major 3x4 */
+    const float* depth_values; /* [D,Hp,Wp] */
+    float* variance;           /* [C,D,Hp,Wp] */
+    float* count;              /* [D,Hp,Wp] = 1 / (1 + views that see the voxel), or NULL */
+} ucnerf_cost_volume_params;
+int ucnerf_cost_volume(const ucnerf_cost_volume_params* p, void* stream);
+
+typedef struct {
+    int32_t D, Hp, Wp, pad;
+    const float* prob_pre;     /* [D,Hp,Wp] logits from the regularisation network */
+    const float* prob_init;    /* [D,Hp,Wp] added to the logits, or NULL */
+    const float* depth_values; /* [D,Hp,Wp] */
+    float* prob_volume;        /* [D,Hp,Wp] softmax over D */
+    float* depth;              /* [Hp - 2 pad, Wp - 2 pad] */
+    float* confidence;         /* [Hp - 2 pad, Wp - 2 pad] */
+} ucnerf_depth_regress_params;
+int ucnerf_depth_regress(const ucnerf_depth_regress_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a10  one fused render pass -- network/renderer.py:215-255 (rendering) with the projection of
  *      utils/utils.py:716-724 in front: rays + depths -> world points -> stage coordinates -> features ->
  *      PE + MLP -> composite.  Source views = pose entries 1..V of the reference's pose_ref

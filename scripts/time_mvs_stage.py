@@ -1,0 +1,55 @@
+"""Times ucnerf_cost_volume / ucnerf_depth_regress at the three cascade-stage shapes (6 source views, 256x320 images) and
+reports them against the HBM roofline; with CPU=1 also times the oracle (the reference's algorithm, torch-CPU) beside them."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from uc_nerf_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+gen = torch.Generator().manual_seed(0)
+V = 6
+stages = [("stage1", 32, 64, 80, 48), ("stage2", 16, 128, 160, 32), ("stage3", 8, 256, 320, 8)]
+cpu = os.environ.get("CPU") == "1"
+if cpu:
+    from oracle import mvs_oracle as M
+
+for name, C, H, W, D in stages:
+    f = 250.0 * W / 320
+    K4 = torch.eye(4); K4[0, 0] = K4[1, 1] = f; K4[0, 2] = W / 2; K4[1, 2] = H / 2
+    w2c = torch.eye(4).repeat(V + 1, 1, 1)
+    w2c[1:, 0, 3] = 0.01 * torch.arange(1, V + 1)
+    affine = K4 @ w2c
+    proj = (affine[1:] @ torch.inverse(affine)[0:1])[:, :3].contiguous()
+    feats = torch.randn(V, C, H, W, generator=gen)
+    dv = (torch.linspace(1.0, 4.0, D).view(D, 1, 1) + 0.02 * torch.rand(D, H, W, generator=gen)).contiguous()
+    logits = torch.randn(D, H, W, generator=gen)
+    fd, pd, dd, ld = feats.to(dev), proj.to(dev), dv.to(dev), logits.to(dev)
+    for _ in range(3):
+        var = ops.cost_volume(fd, pd, dd)
+        out = ops.depth_regress(ld, dd)
+    a, b, c = ops.Event(), ops.Event(), ops.Event()
+    torch.cuda.synchronize()
+    K = 20
+    a.record()
+    for _ in range(K):
+        var = ops.cost_volume(fd, pd, dd)
+    b.record()
+    for _ in range(K):
+        out = ops.depth_regress(ld, dd)
+    c.record()
+    torch.cuda.synchronize()
+    t_cv, t_dr = a.elapsed_ms(b) / K, b.elapsed_ms(c) / K
+    by_cv = 4 * (C * D * H * W + D * H * W + V * C * H * W)                 # volume written + hypotheses + source maps once
+    by_dr = 4 * (3 * D * H * W + 2 * H * W)                                  # logits, hypotheses read; probabilities written; 2 maps
+    line = "%s C=%d D=%d %dx%d: cost_volume %.1f us = %.2f TB/s (%.2f of 8), depth_regress %.1f us = %.2f TB/s (%.2f of 8)" % (
+        name, C, D, H, W, t_cv * 1e3, by_cv / t_cv / 1e9, by_cv / t_cv / 1e9 / 8, t_dr * 1e3, by_dr / t_dr / 1e9, by_dr / t_dr / 1e9 / 8)
+    if cpu:
+        t0 = time.perf_counter(); want, _ = M.cost_volume_variance(feats, proj, dv); t1 = time.perf_counter()
+        p, d, cf = M.depth_regress(logits, dv); t2 = time.perf_counter()
+        bad = ((var.cpu() - want).abs() > 1e-5 + 1e-5 * want.abs()).any(dim=0).float().mean().item()
+        line += " | CPU oracle %.0f ms / %.0f ms (%d threads); voxels differing %.2e" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, torch.get_num_threads(), bad)
+    print(line)

@@ -488,3 +488,65 @@ def test_bf16_mlp_is_deterministic_across_many_launches(precision):
         assert torch.isfinite(first).all()
         for _ in range(reps):
             assert torch.equal(ops().mlp_fwd(pw, ws, pts, dirs, feats, S=S), first)
+
+
+# ---------------------------------------------------------------------------------------------- f2: the step in front
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_cost_volume_matches_reference_fixture(tag):
+    """ucnerf_cost_volume against the variance volume the reference's DepthNet hands to its regularisation net (G12).
+    The sampling is nearest-neighbour: a coordinate within rounding of x.5 may pick the other pixel (the reference's
+    projection goes through a BLAS product whose summation order is not part of its contract), so a few voxels per
+    thousand may differ; everything else has to agree to float rounding."""
+    g = load_golden("g12_cost_volume")
+    f = lambda k: g[tag + "_" + k]                                       # noqa: E731
+    var, cnt = ops().cost_volume(dev(f("feats")), dev(f("proj")), dev(f("depth_values")), pad=int(f("pad")), want_count=True)
+    want = f("variance")
+    bad = ((var.cpu() - want).abs() > 1e-5 + 1e-5 * want.abs()).any(dim=0)
+    assert bad.float().mean().item() < 2e-3, "%.4f of the voxels differ" % bad.float().mean().item()
+    close(var.cpu()[:, ~bad], want[:, ~bad], 1e-5, 1e-5)
+    from oracle import mvs_oracle as M
+    _, cnt_want = M.cost_volume_variance(f("feats"), f("proj"), f("depth_values"), int(f("pad")))
+    assert (cnt.cpu() != cnt_want).float().mean().item() < 2e-3
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_depth_regress_matches_reference_fixture(tag):
+    g = load_golden("g13_depth_regress")
+    f = lambda k: g[tag + "_" + k]                                       # noqa: E731
+    init = dev(f("prob_init")) if f("prob_init").numel() else None
+    prob, depth, conf = ops().depth_regress(dev(f("prob_pre")), dev(f("depth_values")), init, pad=int(f("pad")))
+    close(prob, f("prob_volume"), 1e-6, 1e-5)
+    close(depth, f("depth"), 2e-6, 2e-6)
+    # the confidence reads the 4-tap window at floor(E[d]): an expectation within rounding of an integer may take either
+    bad = (conf.cpu() - f("confidence")).abs() > 2e-6
+    assert bad.float().mean().item() < 5e-3
+    
+
+def test_cost_volume_at_stage_sizes_against_the_oracle_and_depthnet_mirror():
+    """Stage-3 shape of the cascade (D = 8, 6 source views, 8 channels; quarter-size map to keep the CPU oracle quick)
+    and the DepthNet mirror end to end with a stand-in regularisation module."""
+    from oracle import mvs_oracle as M
+    from uc_nerf_amd.network.mvs_models import DepthNet
+    gen = torch.Generator().manual_seed(77)
+    V, Cc, H, W, D, pad = 6, 8, 64, 80, 8, 0
+    K4 = torch.eye(4); K4[0, 0] = K4[1, 1] = 62.5; K4[0, 2] = 40.0; K4[1, 2] = 32.0
+    w2c = torch.eye(4).repeat(V + 1, 1, 1)
+    w2c[1:, 0, 3] = 0.01 * torch.arange(1, V + 1) + 0.003 * torch.rand(V, generator=gen)
+    w2c[1:, 1, 3] = 0.004 * torch.rand(V, generator=gen)
+    affine = K4 @ w2c
+    feats = torch.randn(V, 1, Cc, H, W, generator=gen)
+    depth_values = (torch.linspace(1.0, 4.0, D).view(1, D, 1, 1) + 0.05 * torch.rand(1, D, H, W, generator=gen)).contiguous()
+    proj = (affine[1:] @ torch.inverse(affine)[0:1])[:, :3]
+    want, _ = M.cost_volume_variance(feats[:, 0], proj, depth_values[0], pad)
+    got = ops().cost_volume(dev(feats[:, 0]), dev(proj), dev(depth_values[0]), pad=pad)
+    bad = ((got.cpu() - want).abs() > 1e-5 + 1e-5 * want.abs()).any(dim=0)
+    assert bad.float().mean().item() < 2e-3
+    logits = torch.randn(1, 1, D, H, W, generator=gen)
+
+    def reg(v):
+        return v[:, :8], dev(logits) + 0.0 * v[:, :1]
+
+    out = DepthNet()([dev(x) for x in feats], dev(affine), dev(torch.inverse(affine)), dev(depth_values), D, reg, None, pad=pad)
+    p, d, c = M.depth_regress(logits[0, 0], depth_values[0])
+    close(out["prob_volume"][0], p, 1e-6, 1e-5); close(out["depth"][0], d, 2e-6, 2e-6)
+    assert ((out["photometric_confidence"][0].cpu() - c).abs() > 2e-6).float().mean().item() < 5e-3

@@ -100,6 +100,16 @@ class MergeRowsParams(C.Structure):
     _fields_ = [("n", i32), ("na", i32), ("nb", i32), ("width", i32), ("a", vp), ("b", vp), ("rank", vp), ("out", vp)]
 
 
+class CostVolumeParams(C.Structure):
+    _fields_ = [("V", i32), ("C", i32), ("H", i32), ("W", i32), ("D", i32), ("pad", i32), ("feats", vp), ("proj", vp),
+                ("depth_values", vp), ("variance", vp), ("count", vp)]
+
+
+class DepthRegressParams(C.Structure):
+    _fields_ = [("D", i32), ("Hp", i32), ("Wp", i32), ("pad", i32), ("prob_pre", vp), ("prob_init", vp), ("depth_values", vp),
+                ("prob_volume", vp), ("depth", vp), ("confidence", vp)]
+
+
 class RenderParams(C.Structure):
     _fields_ = [("n", i32), ("S", i32), ("white_bkgd", i32), ("max_blocks", i32), ("cfg", MlpConfig), ("rays_o", vp),
                 ("rays_d", vp), ("z", vp), ("w2c_ref", f32 * 12), ("K_ref", f32 * 9), ("w2c_dir", f32 * 12),
@@ -126,6 +136,7 @@ STRUCTS = {
     "ucnerf_composite_bwd_params": CompositeBwdParams, "ucnerf_sample_pdf_params": SamplePdfParams,
     "ucnerf_render_params": RenderParams, "ucnerf_render_bwd_params": RenderBwdParams,
     "ucnerf_merge_rows_params": MergeRowsParams,
+    "ucnerf_cost_volume_params": CostVolumeParams, "ucnerf_depth_regress_params": DepthRegressParams,
 }
 
 # every symbol include/ucnerf_hip.h declares: name -> (restype, argtypes)
@@ -163,6 +174,8 @@ SYMBOLS = {
     "ucnerf_composite_bwd": (C.c_int, [_P, _P]),
     "ucnerf_sample_pdf": (C.c_int, [_P, _P]),
     "ucnerf_merge_rows": (C.c_int, [_P, _P]),
+    "ucnerf_cost_volume": (C.c_int, [_P, _P]),
+    "ucnerf_depth_regress": (C.c_int, [_P, _P]),
     "ucnerf_render_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "ucnerf_render_fused_fwd": (C.c_int, [_P, _P]),
     "ucnerf_gather_repack_floats": (C.c_int64, [_P]),

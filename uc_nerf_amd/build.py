@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libucnerf_hip.so")
-SOURCES = ["rays.hip", "gather.hip", "gather_cl.hip", "mlp.hip", "mlp_bf16.hip", "mlp_bwd.hip", "composite.hip", "sample_pdf.hip", "render.hip"]
+SOURCES = ["rays.hip", "gather.hip", "gather_cl.hip", "mlp.hip", "mlp_bf16.hip", "mlp_bwd.hip", "composite.hip", "sample_pdf.hip", "render.hip", "mvs.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mlp_layout.h"), os.path.join(CSRC, "sincos_cw.h"),
            os.path.join(HERE, "..", "include", "ucnerf_hip.h")]
 # -ffp-contract=off: the sample_pdf / sampling kernels reproduce torch-CPU roundings (separate mul and add)

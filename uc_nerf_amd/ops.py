@@ -624,6 +624,45 @@ def merge_rows(a, b, rank):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ f2
+def cost_volume(feats, proj, depth_values, pad=0, want_count=False):
+    """Variance cost volume of one cascade stage (network/mvs_models.py:609-626 with utils/utils.py:1105-1172 inside).
+    feats [V,C,H,W] source-view feature maps, proj [V,3,4] = (src_proj @ ref_proj_inv)[:3], depth_values
+    [D,H+2pad,W+2pad].  Returns variance [C,D,H+2pad,W+2pad] (and count [D,Hp,Wp] if asked).  Forward only."""
+    feats, proj, depth_values = _f32(feats, "feats"), _f32(proj, "proj"), _f32(depth_values, "depth_values")
+    V, Cc, H, W = feats.shape
+    D, Hp, Wp = depth_values.shape
+    if tuple(proj.shape) != (V, 3, 4) or Hp != H + 2 * pad or Wp != W + 2 * pad:
+        raise RuntimeError("uc_nerf_amd.cost_volume: shape mismatch")
+    var = torch.empty(Cc, D, Hp, Wp, device=feats.device)
+    cnt = torch.empty(D, Hp, Wp, device=feats.device) if want_count else None
+    p = L.CostVolumeParams()
+    p.V, p.C, p.H, p.W, p.D, p.pad = V, Cc, H, W, D, int(pad)
+    p.feats, p.proj, p.depth_values, p.variance, p.count = _ptr(feats), _ptr(proj), _ptr(depth_values), _ptr(var), _ptr(cnt)
+    _launch("ucnerf_cost_volume", p, feats.device)
+    return (var, cnt) if want_count else var
+
+
+def depth_regress(prob_pre, depth_values, prob_init=None, pad=0):
+    """softmax over depth, expected depth and 4-tap photometric confidence (network/mvs_models.py:629-646).
+    prob_pre, depth_values (and prob_init) [D,Hp,Wp] -> (prob_volume [D,Hp,Wp], depth [H,W], confidence [H,W])."""
+    prob_pre, depth_values = _f32(prob_pre, "prob_pre"), _f32(depth_values, "depth_values")
+    prob_init = _f32(prob_init, "prob_init") if prob_init is not None else None
+    D, Hp, Wp = prob_pre.shape
+    if tuple(depth_values.shape) != (D, Hp, Wp) or (prob_init is not None and tuple(prob_init.shape) != (D, Hp, Wp)):
+        raise RuntimeError("uc_nerf_amd.depth_regress: shape mismatch")
+    dev = prob_pre.device
+    prob = torch.empty(D, Hp, Wp, device=dev)
+    depth = torch.empty(Hp - 2 * pad, Wp - 2 * pad, device=dev)
+    conf = torch.empty_like(depth)
+    p = L.DepthRegressParams()
+    p.D, p.Hp, p.Wp, p.pad = D, Hp, Wp, int(pad)
+    p.prob_pre, p.prob_init, p.depth_values = _ptr(prob_pre), _ptr(prob_init), _ptr(depth_values)
+    p.prob_volume, p.depth, p.confidence = _ptr(prob), _ptr(depth), _ptr(conf)
+    _launch("ucnerf_depth_regress", p, dev)
+    return prob, depth, conf
+
+
 # ------------------------------------------------------------------------------------------------ a10
 class RenderPass:
     """Pre-bound arguments of ucnerf_render_fused_fwd for one scene; call it with (rays_d, z)."""
