@@ -357,7 +357,7 @@ int ucnerf_merge_rows(const ucnerf_merge_rows_params* p, void* stream);
  *      D x Hp x Wp hypotheses of the target view, the in-frustum count and the variance volume handed to the
  *      regularisation network.  (The warped-image volume of :614,617 is never used by the reference and is not built.)
  *      ucnerf_depth_regress replaces network/mvs_models.py:629-646: softmax over depth (+ optional initial logits),
- *      expected depth, 4-tap photometric confidence, cropped by `pad`.  Forward only.
+ *      expected depth, 4-tap photometric confidence, cropped by `pad`.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
     int32_t V, C, H, W;        /* source feature maps [V,C,H,W] */
@@ -380,6 +380,25 @@ typedef struct {
     float* confidence;         /* [Hp - 2 pad, Wp - 2 pad] */
 } ucnerf_depth_regress_params;
 int ucnerf_depth_regress(const ucnerf_depth_regress_params* p, void* stream);
+
+/* Backward of the two kernels above (what autograd sends through them in the reference: into the source feature maps
+ * through the variance volume -- the sampling grid and the mask count carry no gradient, nearest-neighbour lookup -- and
+ * into the regularisation network's logits through depth and photometric confidence; floor(E[d]) and the clamp's
+ * inactive side pass nothing). */
+typedef struct {
+    ucnerf_cost_volume_params fwd;   /* variance / count are not used */
+    const float* g_variance;         /* [C,D,Hp,Wp] */
+    float* g_feats;                  /* [V,C,H,W], accumulated into (float atomics) */
+} ucnerf_cost_volume_bwd_params;
+int ucnerf_cost_volume_bwd(const ucnerf_cost_volume_bwd_params* p, void* stream);
+
+typedef struct {
+    ucnerf_depth_regress_params fwd; /* prob_volume = the forward's output (read); depth / confidence are not used */
+    const float* g_depth;            /* [Hp - 2 pad, Wp - 2 pad] or NULL */
+    const float* g_confidence;       /* [Hp - 2 pad, Wp - 2 pad] or NULL */
+    float* g_prob_pre;               /* [D,Hp,Wp] (also the gradient of prob_init) */
+} ucnerf_depth_regress_bwd_params;
+int ucnerf_depth_regress_bwd(const ucnerf_depth_regress_bwd_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a10  one fused render pass -- network/renderer.py:215-255 (rendering) with the projection of

@@ -25,7 +25,10 @@ for name, C, H, W, D in stages:
     affine = K4 @ w2c
     proj = (affine[1:] @ torch.inverse(affine)[0:1])[:, :3].contiguous()
     feats = torch.randn(V, C, H, W, generator=gen)
-    dv = (torch.linspace(1.0, 4.0, D).view(D, 1, 1) + 0.02 * torch.rand(D, H, W, generator=gen)).contiguous()
+    # hypothesis bands as the cascade produces them (mvs_models.py:699-735: 48 planes over [near, far] = [1, 4]; then
+    # 32 planes at twice, 8 planes at once the base interval (far - near) / 48 around the previous stage's depth)
+    lo, hi = (1.0, 4.0) if D >= 32 else (2.5 - 4 * 3.0 / 48, 2.5 + 4 * 3.0 / 48)
+    dv = (torch.linspace(lo, hi, D).view(D, 1, 1) + 0.02 * torch.rand(D, H, W, generator=gen)).contiguous()
     logits = torch.randn(D, H, W, generator=gen)
     fd, pd, dd, ld = feats.to(dev), proj.to(dev), dv.to(dev), logits.to(dev)
     for _ in range(3):
@@ -45,8 +48,36 @@ for name, C, H, W, D in stages:
     t_cv, t_dr = a.elapsed_ms(b) / K, b.elapsed_ms(c) / K
     by_cv = 4 * (C * D * H * W + D * H * W + V * C * H * W)                 # volume written + hypotheses + source maps once
     by_dr = 4 * (3 * D * H * W + 2 * H * W)                                  # logits, hypotheses read; probabilities written; 2 maps
+    # backward kernels (through the autograd wrappers: includes zeroing the feature-gradient maps)
+    fg, lg = fd.clone().requires_grad_(True), ld.clone().requires_grad_(True)
+    r_v = torch.randn_like(var)
+    r_d, r_c = torch.randn_like(out[1]), torch.randn_like(out[2])
+
+    def bwd_cv():
+        fg.grad = None
+        ops.cost_volume(fg, pd, dd).backward(r_v)
+
+    def bwd_dr():
+        lg.grad = None
+        _, d_, c_ = ops.depth_regress(lg, dd)
+        torch.autograd.backward([d_, c_], [r_d, r_c])
+
+    for fn in (bwd_cv, bwd_dr):
+        fn()
+    e0, e1, e2 = ops.Event(), ops.Event(), ops.Event()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(K):
+        bwd_cv()
+    e1.record()
+    for _ in range(K):
+        bwd_dr()
+    e2.record()
+    torch.cuda.synchronize()
+    t_cvb, t_drb = e0.elapsed_ms(e1) / K - t_cv, e1.elapsed_ms(e2) / K - t_dr      # forward + backward minus forward
     line = "%s C=%d D=%d %dx%d: cost_volume %.1f us = %.2f TB/s (%.2f of 8), depth_regress %.1f us = %.2f TB/s (%.2f of 8)" % (
         name, C, D, H, W, t_cv * 1e3, by_cv / t_cv / 1e9, by_cv / t_cv / 1e9 / 8, t_dr * 1e3, by_dr / t_dr / 1e9, by_dr / t_dr / 1e9 / 8)
+    line += "; backward %.1f us / %.1f us" % (t_cvb * 1e3, t_drb * 1e3)
     if cpu:
         t0 = time.perf_counter(); want, _ = M.cost_volume_variance(feats, proj, dv); t1 = time.perf_counter()
         p, d, cf = M.depth_regress(logits, dv); t2 = time.perf_counter()

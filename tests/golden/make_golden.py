@@ -440,31 +440,47 @@ def g12_g13():
         g = torch.Generator().manual_seed(1200 + len(tag) + V)
         feats, imgs, affine, affine_inv, depth_values = mvs_setup(g, V, C, H, W, D, pad)
         captured = {}
+        for f_ in feats:
+            f_.requires_grad_(True)
 
         def cost_reg(v, captured=captured, g=g):
             # stands where the 3D regularisation CNN is passed in (an argument of DepthNet.forward): records the variance
-            # volume it is given and returns seeded (features, logits)
+            # volume it is given and returns seeded (features, logits); the logits are a leaf so that their gradient --
+            # what the real network would receive -- can be captured
+            captured["v"] = v
             captured["variance"] = v.detach().clone()
-            prob = torch.randn(v.shape[0], 1, *v.shape[2:], generator=g) * 2.0
-            captured["prob_pre"] = prob.squeeze(1).clone()
-            return v[:, :8] * 1.0, prob
+            prob = (torch.randn(v.shape[0], 1, *v.shape[2:], generator=g) * 2.0).requires_grad_(True)
+            captured["prob"] = prob
+            captured["prob_pre"] = prob.detach().squeeze(1).clone()
+            return v[:, :8] * 1.0, prob * 1.0          # (non-leaf: DepthNet adds prob_volume_init in place)
 
         prob_init = torch.randn(1, D, H + 2 * pad, W + 2 * pad, generator=g) * 0.5 if tag == "b" else None
         net = ref.mvs.DepthNet()
-        with torch.no_grad():
-            o = net(feats, affine, affine_inv, depth_values, D, cost_reg, imgs, pad=pad,
-                    prob_volume_init=None if prob_init is None else prob_init.clone())
+        o = net(feats, affine, affine_inv, depth_values, D, cost_reg, imgs, pad=pad,
+                prob_volume_init=None if prob_init is None else prob_init.clone())
+        # gradients the reference's autograd sends back: into the feature maps through the variance volume, into the
+        # logits through depth and photometric confidence
+        r_var = torch.randn(captured["v"].shape, generator=g)
+        r_depth = torch.randn(o["depth"].shape, generator=g)
+        r_conf = torch.randn(o["photometric_confidence"].shape, generator=g)
+        ((captured["v"] * r_var).sum() + (o["depth"] * r_depth).sum() + (o["photometric_confidence"] * r_conf).sum()).backward()
+        g_feats = torch.cat([f_.grad for f_ in feats])
+        g_prob = captured["prob"].grad[0, 0]
+        feats = [f_.detach() for f_ in feats]
+        o = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in o.items()}
         # the same warps through homo_warp directly (the function the kernel replaces)
         dv_pad = torch.nn.functional.pad(depth_values, (pad, pad, pad, pad), "replicate") if pad > 0 else depth_values
         proj = torch.stack([(affine[i + 1:i + 2] @ affine_inv[0:1])[0, :3] for i in range(V)])
         warped0, grid0 = ref.utils.homo_warp(feats[0], proj[0:1], dv_pad, pad=pad)
         out12.update({tag + "_" + k: v for k, v in dict(
             V=V, C=C, H=H, W=W, D=D, pad=pad, feats=torch.cat(feats), proj=proj, depth_values=dv_pad[0],
-            variance=captured["variance"][0], warped0=warped0[0], grid0=grid0.reshape(D, -1, 2)).items()})
+            variance=captured["variance"][0], warped0=warped0[0], grid0=grid0.reshape(D, -1, 2), r_var=r_var[0],
+            g_feats=g_feats).items()})
         out13.update({tag + "_" + k: v for k, v in dict(
             D=D, pad=pad, prob_pre=captured["prob_pre"][0], depth_values=o["depth_values"][0],
             prob_init=torch.zeros(0) if prob_init is None else prob_init[0], prob_volume=o["prob_volume"][0],
-            depth=o["depth"][0], confidence=o["photometric_confidence"][0]).items()})
+            depth=o["depth"][0], confidence=o["photometric_confidence"][0], r_depth=r_depth[0], r_conf=r_conf[0],
+            g_prob_pre=g_prob).items()})
     save("g12_cost_volume", **out12)
     save("g13_depth_regress", **out13)
 

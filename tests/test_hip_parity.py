@@ -507,6 +507,13 @@ def test_cost_volume_matches_reference_fixture(tag):
     from oracle import mvs_oracle as M
     _, cnt_want = M.cost_volume_variance(f("feats"), f("proj"), f("depth_values"), int(f("pad")))
     assert (cnt.cpu() != cnt_want).float().mean().item() < 2e-3
+    # backward: what the reference's autograd sends into the source feature maps (captured with the fixture)
+    fd = dev(f("feats")).requires_grad_(True)
+    v2 = ops().cost_volume(fd, dev(f("proj")), dev(f("depth_values")), pad=int(f("pad")))
+    assert torch.equal(v2.detach(), var)
+    (v2 * dev(f("r_var"))).sum().backward()
+    gs = f("g_feats").abs().max().item()
+    close(fd.grad, f("g_feats"), 2e-6 * gs, 1e-4)
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
@@ -520,7 +527,17 @@ def test_depth_regress_matches_reference_fixture(tag):
     # the confidence reads the 4-tap window at floor(E[d]): an expectation within rounding of an integer may take either
     bad = (conf.cpu() - f("confidence")).abs() > 2e-6
     assert bad.float().mean().item() < 5e-3
-    
+    # backward: gradient at the regularisation net's logits from depth and photometric confidence
+    x = dev(f("prob_pre")).requires_grad_(True)
+    prob2, depth2, conf2 = ops().depth_regress(x, dev(f("depth_values")), init, pad=int(f("pad")))
+    assert not prob2.requires_grad                                       # prob_volume.detach() in the reference
+    ((depth2 * dev(f("r_depth"))).sum() + (conf2 * dev(f("r_conf"))).sum()).backward()
+    want = f("g_prob_pre")
+    # pixels whose window index differs (expectation within rounding of an integer) get a different gradient column
+    bad_px = ((x.grad.cpu() - want).abs() > 2e-6 + 1e-4 * want.abs()).any(dim=0)
+    assert bad_px.float().mean().item() < 5e-3
+    close(x.grad.cpu()[:, ~bad_px], want[:, ~bad_px], 2e-6, 1e-4)
+
 
 def test_cost_volume_at_stage_sizes_against_the_oracle_and_depthnet_mirror():
     """Stage-3 shape of the cascade (D = 8, 6 source views, 8 channels; quarter-size map to keep the CPU oracle quick)
@@ -550,3 +567,18 @@ def test_cost_volume_at_stage_sizes_against_the_oracle_and_depthnet_mirror():
     p, d, c = M.depth_regress(logits[0, 0], depth_values[0])
     close(out["prob_volume"][0], p, 1e-6, 1e-5); close(out["depth"][0], d, 2e-6, 2e-6)
     assert ((out["photometric_confidence"][0].cpu() - c).abs() > 2e-6).float().mean().item() < 5e-3
+    # gradients reach the feature maps (through the variance volume) and the logits, as in the reference
+    fl = [dev(x).requires_grad_(True) for x in feats]
+    lg = dev(logits).requires_grad_(True)
+    o2 = DepthNet()(fl, dev(affine), dev(torch.inverse(affine)), dev(depth_values), D, lambda v: (v[:, :8], lg + 0.0 * v[:, :1]), None)
+    (o2["volume_feature_no_ref"].sum() + o2["depth"].sum() + o2["photometric_confidence"].sum()).backward()
+    assert all(x.grad is not None and torch.isfinite(x.grad).all() and x.grad.abs().sum() > 0 for x in fl)
+    fo = [x.clone().requires_grad_(True) for x in feats]
+    vo, _ = M.cost_volume_variance(torch.cat(fo), proj, depth_values[0], pad)
+    vo[:8].sum().backward()
+    close(torch.cat([x.grad for x in fl]), torch.cat([x.grad for x in fo]), 1e-5, 1e-4)
+    lo = logits[0, 0].clone().requires_grad_(True)
+    _, d_o, c_o = M.depth_regress(lo, depth_values[0])
+    (d_o.sum() + c_o.sum()).backward()
+    bad_px = ((lg.grad[0, 0].cpu() - lo.grad).abs() > 2e-6 + 1e-4 * lo.grad.abs()).any(dim=0)
+    assert bad_px.float().mean().item() < 5e-3

@@ -276,8 +276,11 @@ def test_g12_cost_volume_variance(tag):
     assert torch.equal(grid, f("grid0"))
     warped = M.sample_nearest_border(f("feats")[0], grid).reshape(f("warped0").shape)
     assert torch.equal(warped, f("warped0"))
-    var, _ = M.cost_volume_variance(f("feats"), f("proj"), f("depth_values"), pad)
-    assert torch.equal(var, f("variance"))
+    feats = f("feats").clone().requires_grad_(True)
+    var, _ = M.cost_volume_variance(feats, f("proj"), f("depth_values"), pad)
+    assert torch.equal(var.detach(), f("variance"))
+    (var * f("r_var")).sum().backward()                                  # what autograd sends into the feature maps
+    close(feats.grad, f("g_feats"), 1e-6, 1e-5)
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
@@ -287,7 +290,10 @@ def test_g13_depth_regression_and_confidence(tag):
     g = load_golden("g13_depth_regress")
     f = lambda k: g[tag + "_" + k]                                       # noqa: E731
     init = f("prob_init") if f("prob_init").numel() else None
-    p, depth, conf = M.depth_regress(f("prob_pre"), f("depth_values"), init, int(f("pad")))
-    close(p, f("prob_volume"), 1e-7, 1e-6)
-    close(depth, f("depth"), 1e-6, 1e-6)
-    close(conf, f("confidence"), 1e-6, 1e-6)
+    x = f("prob_pre").clone().requires_grad_(True)
+    p, depth, conf = M.depth_regress(x, f("depth_values"), init, int(f("pad")))
+    close(p.detach(), f("prob_volume"), 1e-7, 1e-6)
+    close(depth.detach(), f("depth"), 1e-6, 1e-6)
+    close(conf.detach(), f("confidence"), 1e-6, 1e-6)
+    ((depth * f("r_depth")).sum() + (conf * f("r_conf")).sum()).backward()   # gradient at the regularisation net's logits
+    close(x.grad, f("g_prob_pre"), 1e-6, 1e-5)

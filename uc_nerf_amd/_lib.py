@@ -110,6 +110,14 @@ class DepthRegressParams(C.Structure):
                 ("prob_volume", vp), ("depth", vp), ("confidence", vp)]
 
 
+class CostVolumeBwdParams(C.Structure):
+    _fields_ = [("fwd", CostVolumeParams), ("g_variance", vp), ("g_feats", vp)]
+
+
+class DepthRegressBwdParams(C.Structure):
+    _fields_ = [("fwd", DepthRegressParams), ("g_depth", vp), ("g_confidence", vp), ("g_prob_pre", vp)]
+
+
 class RenderParams(C.Structure):
     _fields_ = [("n", i32), ("S", i32), ("white_bkgd", i32), ("max_blocks", i32), ("cfg", MlpConfig), ("rays_o", vp),
                 ("rays_d", vp), ("z", vp), ("w2c_ref", f32 * 12), ("K_ref", f32 * 9), ("w2c_dir", f32 * 12),
@@ -137,6 +145,7 @@ STRUCTS = {
     "ucnerf_render_params": RenderParams, "ucnerf_render_bwd_params": RenderBwdParams,
     "ucnerf_merge_rows_params": MergeRowsParams,
     "ucnerf_cost_volume_params": CostVolumeParams, "ucnerf_depth_regress_params": DepthRegressParams,
+    "ucnerf_cost_volume_bwd_params": CostVolumeBwdParams, "ucnerf_depth_regress_bwd_params": DepthRegressBwdParams,
 }
 
 # every symbol include/ucnerf_hip.h declares: name -> (restype, argtypes)
@@ -176,6 +185,8 @@ SYMBOLS = {
     "ucnerf_merge_rows": (C.c_int, [_P, _P]),
     "ucnerf_cost_volume": (C.c_int, [_P, _P]),
     "ucnerf_depth_regress": (C.c_int, [_P, _P]),
+    "ucnerf_cost_volume_bwd": (C.c_int, [_P, _P]),
+    "ucnerf_depth_regress_bwd": (C.c_int, [_P, _P]),
     "ucnerf_render_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "ucnerf_render_fused_fwd": (C.c_int, [_P, _P]),
     "ucnerf_gather_repack_floats": (C.c_int64, [_P]),

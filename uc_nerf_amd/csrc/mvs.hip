@@ -1,4 +1,5 @@
-// f2: the step in front of the ray-marching path -- cost-volume assembly and depth regression of one cascade MVS stage
+// f2: the step in front of the ray-marching path -- cost-volume assembly and depth regression of one cascade MVS stage,
+// forward and backward
 // (network/mvs_models.py:589-646, utils/utils.py:1105-1172).  The source maps (a few MB) stay in L2; the HBM traffic is
 // the volume that is written (cost volume) or read and written (regression) -- 3 to 50 MB at the reference's stage sizes,
 // i.e. tens of microseconds: launch latency and (for the cost volume) the projection arithmetic matter more than bandwidth.
@@ -163,6 +164,119 @@ __global__ void __launch_bounds__(DR_PIX * DR_DL) depth_regress_kernel(ucnerf_de
     }
 }
 
+// ---- backward of the cost volume: var = q * count - (s * count)^2  =>  d var / d v_i = 2 * count * (v_i - mean).
+// The hypotheses of one target pixel project onto a short epipolar segment of every source view, so neighbouring depths
+// keep landing on the same source pixel (stage 1: ~10 depths per pixel) and a scatter per voxel queues that many atomics
+// on one address.  A wave therefore holds 8 pixels x 8 consecutive depths (lane = 8 * depth position + pixel): per
+// channel and view, runs of equal source pixels along the depth positions are summed with a segmented suffix scan
+// (three shuffle steps) and only the first lane of a run issues the atomic.
+__device__ __forceinline__ void cv_run_atomic_add(float* base, int key, float v, int pos) {
+    const int kp = __shfl_up(key, 8), kn = __shfl_down(key, 8);          // (unconditionally: see gather.hip run_atomic_add)
+    const bool head = pos == 0 || kp != key;
+    int end = pos == 7 || kn != key;
+    float s = v;
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        const float sn = __shfl_down(s, 8 * d);
+        const int en = __shfl_down(end, 8 * d);
+        if (!end) { s += sn; end = en; }
+    }
+    if (head && key >= 0 && s != 0.f) atomicAdd(base + key, s);
+}
+
+__global__ void __launch_bounds__(256) cost_volume_bwd_kernel(ucnerf_cost_volume_bwd_params bp) {
+    const ucnerf_cost_volume_params& p = bp.fwd;
+    const int Hp = p.H + 2 * p.pad, Wp = p.W + 2 * p.pad;
+    const unsigned plane = (unsigned)Hp * Wp, total = plane * p.D;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = lane & 7, dpos = lane >> 3;
+    if ((blockIdx.y * 4 + wave) * 8 >= p.D) return;                      // (whole wave past the last depth; no block-level sync below)
+    const unsigned pix_raw = blockIdx.x * 8 + pl;
+    const int d_raw = (blockIdx.y * 4 + wave) * 8 + dpos;
+    const bool live = pix_raw < plane && d_raw < p.D;
+    const unsigned pix = pix_raw < plane ? pix_raw : plane - 1;
+    const int d = d_raw < p.D ? d_raw : p.D - 1;
+    const unsigned t = d * plane + pix;
+    const unsigned hw = (unsigned)p.H * p.W, chw = hw * p.C;
+    const float depth = p.depth_values[t];
+    int idx[CV_MAX_VIEWS];
+    float msum = 1.f;
+#pragma unroll
+    for (int i = 0; i < CV_MAX_VIEWS; ++i)
+        if (i < p.V) {
+            const CvHit h = cv_project(p, i, (int)pix, Wp, depth);
+            idx[i] = h.idx;
+            msum += h.mask;
+        }
+    const float count = 1.0f / msum;
+    for (int c = 0; c < p.C; ++c) {
+        float v[CV_MAX_VIEWS], s = 0.f;
+#pragma unroll
+        for (int i = 0; i < CV_MAX_VIEWS; ++i)
+            if (i < p.V) { v[i] = p.feats[i * chw + c * hw + (unsigned)idx[i]]; s = s + v[i]; }
+        const float mean = s * count;
+        const float g2 = live ? 2.f * count * bp.g_variance[(size_t)c * total + t] : 0.f;
+#pragma unroll
+        for (int i = 0; i < CV_MAX_VIEWS; ++i)
+            if (i < p.V) cv_run_atomic_add(bp.g_feats + (i * chw + c * hw), live ? idx[i] : -1, g2 * (v[i] - mean), dpos);
+    }
+}
+
+// ---- backward of the depth regression (same block shape as the forward, so that floor(E[d]) is recomputed from the very
+// same partial sums): g_p[d] = g_depth * depth_values[d] + g_conf * [d in the window and the clamp passes];
+// g_x = p * (g_p - sum_d p g_p).
+__global__ void __launch_bounds__(DR_PIX * DR_DL) depth_regress_bwd_kernel(ucnerf_depth_regress_bwd_params bp) {
+    const ucnerf_depth_regress_params& p = bp.fwd;
+    __shared__ float red[2][DR_DL][DR_PIX];
+    __shared__ float prs[DR_MAX_D][DR_PIX];
+    const long long plane = (long long)p.Hp * p.Wp;
+    const int px = threadIdx.x % DR_PIX, dl = threadIdx.x / DR_PIX;
+    const long long t_raw = (long long)blockIdx.x * DR_PIX + px;
+    const bool live = t_raw < plane;
+    const long long t = live ? t_raw : plane - 1;
+    float didx = 0.f;
+    for (int d = dl; d < p.D; d += DR_DL) {
+        const float pr = p.prob_volume[(size_t)d * plane + t];
+        prs[d][px] = pr;
+        didx += pr * (float)d;
+    }
+    red[0][dl][px] = didx;
+    __syncthreads();
+    didx = 0.f;
+#pragma unroll
+    for (int k = 0; k < DR_DL; ++k) didx += red[0][k][px];
+    int di = (int)didx;
+    di = di < 0 ? 0 : di > p.D - 1 ? p.D - 1 : di;
+    float s4 = 0.f;
+#pragma unroll
+    for (int k = -1; k <= 2; ++k) {
+        const int d = di + k;
+        s4 += (d >= 0 && d < p.D) ? prs[d][px] : 0.f;
+    }
+    s4 = 4.f * (s4 / 4.f);
+    const int yy = (int)(t / p.Wp) - p.pad, xx = (int)(t % p.Wp) - p.pad;
+    const int H = p.Hp - 2 * p.pad, W = p.Wp - 2 * p.pad;
+    const bool inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const float gd = inside && bp.g_depth ? bp.g_depth[(size_t)yy * W + xx] : 0.f;
+    float gc = inside && bp.g_confidence ? bp.g_confidence[(size_t)yy * W + xx] : 0.f;
+    if (!(s4 >= 0.f && s4 <= 1.f)) gc = 0.f;                              // clamp(0, 1) passes the gradient inside the range only
+    float dot = 0.f;
+    for (int d = dl; d < p.D; d += DR_DL) {
+        const float gp = gd * p.depth_values[(size_t)d * plane + t] + ((d >= di - 1 && d <= di + 2) ? gc : 0.f);
+        dot += prs[d][px] * gp;
+    }
+    red[1][dl][px] = dot;
+    __syncthreads();
+    dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < DR_DL; ++k) dot += red[1][k][px];
+    if (!live) return;
+    for (int d = dl; d < p.D; d += DR_DL) {
+        const float gp = gd * p.depth_values[(size_t)d * plane + t] + ((d >= di - 1 && d <= di + 2) ? gc : 0.f);
+        bp.g_prob_pre[(size_t)d * plane + t] = prs[d][px] * (gp - dot);
+    }
+}
+
 }  // namespace ucnerf
 
 using namespace ucnerf;
@@ -190,6 +304,28 @@ int ucnerf_depth_regress(const ucnerf_depth_regress_params* p, void* stream) {
     const long long plane = (long long)p->Hp * p->Wp;
     hipLaunchKernelGGL(depth_regress_kernel, dim3(cdiv(plane, DR_PIX)), dim3(DR_PIX * DR_DL), 0, (hipStream_t)stream, *p);
     return check_launch("depth_regress");
+}
+
+int ucnerf_cost_volume_bwd(const ucnerf_cost_volume_bwd_params* bp, void* stream) {
+    UCNERF_REQUIRE(bp, "cost_volume_bwd: null params");
+    const ucnerf_cost_volume_params* p = &bp->fwd;
+    UCNERF_REQUIRE(p->V >= 1 && p->V <= CV_MAX_VIEWS, "cost_volume_bwd: V = %d outside 1..%d", p->V, CV_MAX_VIEWS);
+    UCNERF_REQUIRE(p->C >= 1 && p->H >= 2 && p->W >= 2 && p->D >= 1 && p->pad >= 0, "cost_volume_bwd: bad sizes");
+    UCNERF_REQUIRE(p->feats && p->proj && p->depth_values && bp->g_variance && bp->g_feats, "cost_volume_bwd: null pointer");
+    const long long total = (long long)p->D * (p->H + 2 * p->pad) * (p->W + 2 * p->pad);
+    UCNERF_REQUIRE(total < (1ll << 31) && (long long)p->V * p->C * p->H * p->W < (1ll << 31), "cost_volume_bwd: volume / maps too large for 32-bit indices");
+    hipLaunchKernelGGL(cost_volume_bwd_kernel, dim3(cdiv(total / p->D, 8), cdiv(p->D, 32)), dim3(256), 0, (hipStream_t)stream, *bp);
+    return check_launch("cost_volume_bwd");
+}
+
+int ucnerf_depth_regress_bwd(const ucnerf_depth_regress_bwd_params* bp, void* stream) {
+    UCNERF_REQUIRE(bp, "depth_regress_bwd: null params");
+    const ucnerf_depth_regress_params* p = &bp->fwd;
+    UCNERF_REQUIRE(p->D >= 1 && p->D <= DR_MAX_D && p->pad >= 0 && p->Hp > 2 * p->pad && p->Wp > 2 * p->pad, "depth_regress_bwd: bad sizes");
+    UCNERF_REQUIRE(p->prob_volume && p->depth_values && bp->g_prob_pre, "depth_regress_bwd: null pointer");
+    const long long plane = (long long)p->Hp * p->Wp;
+    hipLaunchKernelGGL(depth_regress_bwd_kernel, dim3(cdiv(plane, DR_PIX)), dim3(DR_PIX * DR_DL), 0, (hipStream_t)stream, *bp);
+    return check_launch("depth_regress_bwd");
 }
 
 }  // extern "C"

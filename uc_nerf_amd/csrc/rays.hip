@@ -285,7 +285,7 @@ int ucnerf_sizeof(const char* name) {
     SZ(ucnerf_sample_stratified_params); SZ(ucnerf_sample_cascade_params); SZ(ucnerf_ndc_project_params);
     SZ(ucnerf_embed_params); SZ(ucnerf_feat_gather_params); SZ(ucnerf_feat_gather_bwd_params);
     SZ(ucnerf_mlp_config); SZ(ucnerf_mlp_params); SZ(ucnerf_mlp_bwd_params); SZ(ucnerf_composite_params);
-    SZ(ucnerf_composite_bwd_params); SZ(ucnerf_sample_pdf_params); SZ(ucnerf_merge_rows_params); SZ(ucnerf_cost_volume_params); SZ(ucnerf_depth_regress_params); SZ(ucnerf_render_params);
+    SZ(ucnerf_composite_bwd_params); SZ(ucnerf_sample_pdf_params); SZ(ucnerf_merge_rows_params); SZ(ucnerf_cost_volume_params); SZ(ucnerf_depth_regress_params); SZ(ucnerf_cost_volume_bwd_params); SZ(ucnerf_depth_regress_bwd_params); SZ(ucnerf_render_params);
     SZ(ucnerf_render_bwd_params);
 #undef SZ
     return -1;

@@ -3,9 +3,9 @@ path: `DepthNet` (mvs_models.py:585-646).  Same call signature and result keys; 
 + mask count + variance) and the depth regression run as the HIP kernels `ucnerf_cost_volume` / `ucnerf_depth_regress`,
 the 3D regularisation network stays the caller's `cost_regularization` module (MIOpen territory).
 
-Forward only in this round: the kernels carry no autograd, so gradients do not reach the feature maps through this
-module (the reference trains CasMVSNet jointly; that backward is listed under "next" in DESIGN.md).  `features` may be
-a list of [1,C,H,W] maps (as the reference passes) or a stacked tensor.
+Both kernels have backward kernels behind `torch.autograd.Function`s, so the feature network trains through the
+variance volume and the regularisation network through depth and photometric confidence, as in the reference.
+`features` may be a list of [1,C,H,W] maps (as the reference passes) or a stacked tensor.
 """
 import torch
 import torch.nn as nn
@@ -31,13 +31,11 @@ class DepthNet(nn.Module):
             depth_values = F.pad(depth_values, (pad, pad, pad, pad), "replicate")
         # (src_proj @ ref_proj_inv)[:3] per source view (mvs_models.py:612); entry 0 of the stage matrices is the target view
         proj = (affine_mat_stage[1:V + 1] @ affine_mat_inv_stage[0:1])[:, :3].contiguous()
-        with torch.no_grad():
-            variance = ops.cost_volume(features[:, 0], proj, depth_values[0], pad=pad)
+        variance = ops.cost_volume(features[:, 0], proj, depth_values[0], pad=pad)
         cost_feat_no_ref, prob = cost_regularization(variance.unsqueeze(0))
         prob_pre = prob.squeeze(1)
-        with torch.no_grad():
-            prob_volume, depth, conf = ops.depth_regress(prob_pre[0], depth_values[0],
-                                                         None if prob_volume_init is None else prob_volume_init[0], pad=pad)
+        prob_volume, depth, conf = ops.depth_regress(prob_pre[0], depth_values[0],
+                                                     None if prob_volume_init is None else prob_volume_init[0], pad=pad)
         return {"depth": depth.unsqueeze(0), "photometric_confidence": conf.unsqueeze(0),
                 "volume_feature_no_ref": cost_feat_no_ref, "depth_values": depth_values, "img_feats": features,
                 "prob_volume": prob_volume.unsqueeze(0)}

@@ -625,42 +625,104 @@ def merge_rows(a, b, rank):
 
 
 # ------------------------------------------------------------------------------------------------ f2
-def cost_volume(feats, proj, depth_values, pad=0, want_count=False):
-    """Variance cost volume of one cascade stage (network/mvs_models.py:609-626 with utils/utils.py:1105-1172 inside).
-    feats [V,C,H,W] source-view feature maps, proj [V,3,4] = (src_proj @ ref_proj_inv)[:3], depth_values
-    [D,H+2pad,W+2pad].  Returns variance [C,D,H+2pad,W+2pad] (and count [D,Hp,Wp] if asked).  Forward only."""
-    feats, proj, depth_values = _f32(feats, "feats"), _f32(proj, "proj"), _f32(depth_values, "depth_values")
+def _cost_volume_params(feats, proj, depth_values, pad):
     V, Cc, H, W = feats.shape
     D, Hp, Wp = depth_values.shape
     if tuple(proj.shape) != (V, 3, 4) or Hp != H + 2 * pad or Wp != W + 2 * pad:
         raise RuntimeError("uc_nerf_amd.cost_volume: shape mismatch")
-    var = torch.empty(Cc, D, Hp, Wp, device=feats.device)
-    cnt = torch.empty(D, Hp, Wp, device=feats.device) if want_count else None
     p = L.CostVolumeParams()
     p.V, p.C, p.H, p.W, p.D, p.pad = V, Cc, H, W, D, int(pad)
-    p.feats, p.proj, p.depth_values, p.variance, p.count = _ptr(feats), _ptr(proj), _ptr(depth_values), _ptr(var), _ptr(cnt)
+    p.feats, p.proj, p.depth_values = _ptr(feats), _ptr(proj), _ptr(depth_values)
+    return p
+
+
+def _cost_volume_fwd(feats, proj, depth_values, pad, want_count):
+    p = _cost_volume_params(feats, proj, depth_values, pad)
+    D, Hp, Wp = depth_values.shape
+    var = torch.empty(feats.shape[1], D, Hp, Wp, device=feats.device)
+    cnt = torch.empty(D, Hp, Wp, device=feats.device) if want_count else None
+    p.variance, p.count = _ptr(var), _ptr(cnt)
     _launch("ucnerf_cost_volume", p, feats.device)
-    return (var, cnt) if want_count else var
+    return var, cnt
+
+
+class _CostVolumeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, proj, depth_values, pad):
+        ctx.save_for_backward(feats, proj, depth_values)
+        ctx.pad = pad
+        return _cost_volume_fwd(feats, proj, depth_values, pad, False)[0]
+
+    @staticmethod
+    def backward(ctx, g_var):
+        feats, proj, depth_values = ctx.saved_tensors
+        bp = L.CostVolumeBwdParams()
+        bp.fwd = _cost_volume_params(feats, proj, depth_values, ctx.pad)
+        g_var = _f32(g_var, "g_variance")
+        g_feats = torch.zeros_like(feats)
+        bp.g_variance, bp.g_feats = _ptr(g_var), _ptr(g_feats)
+        _launch("ucnerf_cost_volume_bwd", bp, feats.device)
+        return g_feats, None, None, None
+
+
+def cost_volume(feats, proj, depth_values, pad=0, want_count=False):
+    """Variance cost volume of one cascade stage (network/mvs_models.py:609-626 with utils/utils.py:1105-1172 inside).
+    feats [V,C,H,W] source-view feature maps, proj [V,3,4] = (src_proj @ ref_proj_inv)[:3], depth_values
+    [D,H+2pad,W+2pad].  Returns variance [C,D,H+2pad,W+2pad] (and count [D,Hp,Wp] if asked).  Differentiable with
+    respect to `feats` (as in the reference: nearest-neighbour lookup, the grid and the mask count carry no gradient)."""
+    feats, proj, depth_values = _f32(feats, "feats"), _f32(proj, "proj"), _f32(depth_values, "depth_values")
+    if want_count:
+        return _cost_volume_fwd(feats.detach(), proj, depth_values, pad, True)
+    return _CostVolumeFn.apply(feats, proj.detach(), depth_values.detach(), int(pad))
+
+
+def _depth_regress_params(prob_pre, prob_init, depth_values, pad):
+    D, Hp, Wp = prob_pre.shape
+    if tuple(depth_values.shape) != (D, Hp, Wp) or (prob_init is not None and tuple(prob_init.shape) != (D, Hp, Wp)):
+        raise RuntimeError("uc_nerf_amd.depth_regress: shape mismatch")
+    p = L.DepthRegressParams()
+    p.D, p.Hp, p.Wp, p.pad = D, Hp, Wp, int(pad)
+    p.prob_pre, p.prob_init, p.depth_values = _ptr(prob_pre), _ptr(prob_init), _ptr(depth_values)
+    return p
+
+
+class _DepthRegressFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prob_pre, depth_values, prob_init, pad):
+        D, Hp, Wp = prob_pre.shape
+        dev = prob_pre.device
+        p = _depth_regress_params(prob_pre, prob_init, depth_values, pad)
+        prob = torch.empty(D, Hp, Wp, device=dev)
+        depth = torch.empty(Hp - 2 * pad, Wp - 2 * pad, device=dev)
+        conf = torch.empty_like(depth)
+        p.prob_volume, p.depth, p.confidence = _ptr(prob), _ptr(depth), _ptr(conf)
+        _launch("ucnerf_depth_regress", p, dev)
+        ctx.save_for_backward(prob, depth_values)
+        ctx.pad, ctx.has_init = pad, prob_init is not None
+        ctx.mark_non_differentiable(prob)                 # the reference returns prob_volume.detach() (mvs_models.py:646)
+        return prob, depth, conf
+
+    @staticmethod
+    def backward(ctx, _g_prob, g_depth, g_conf):
+        prob, depth_values = ctx.saved_tensors
+        bp = L.DepthRegressBwdParams()
+        bp.fwd = _depth_regress_params(prob, None, depth_values, ctx.pad)
+        bp.fwd.prob_volume = _ptr(prob)
+        g_depth = _f32(g_depth, "g_depth") if g_depth is not None else None
+        g_conf = _f32(g_conf, "g_confidence") if g_conf is not None else None
+        g_x = torch.empty_like(prob)
+        bp.g_depth, bp.g_confidence, bp.g_prob_pre = _ptr(g_depth), _ptr(g_conf), _ptr(g_x)
+        _launch("ucnerf_depth_regress_bwd", bp, prob.device)
+        return g_x, None, (g_x if ctx.has_init else None), None
 
 
 def depth_regress(prob_pre, depth_values, prob_init=None, pad=0):
     """softmax over depth, expected depth and 4-tap photometric confidence (network/mvs_models.py:629-646).
-    prob_pre, depth_values (and prob_init) [D,Hp,Wp] -> (prob_volume [D,Hp,Wp], depth [H,W], confidence [H,W])."""
+    prob_pre, depth_values (and prob_init) [D,Hp,Wp] -> (prob_volume [D,Hp,Wp] (detached, as in the reference), depth
+    [H,W], confidence [H,W]); depth and confidence are differentiable with respect to the logits."""
     prob_pre, depth_values = _f32(prob_pre, "prob_pre"), _f32(depth_values, "depth_values")
     prob_init = _f32(prob_init, "prob_init") if prob_init is not None else None
-    D, Hp, Wp = prob_pre.shape
-    if tuple(depth_values.shape) != (D, Hp, Wp) or (prob_init is not None and tuple(prob_init.shape) != (D, Hp, Wp)):
-        raise RuntimeError("uc_nerf_amd.depth_regress: shape mismatch")
-    dev = prob_pre.device
-    prob = torch.empty(D, Hp, Wp, device=dev)
-    depth = torch.empty(Hp - 2 * pad, Wp - 2 * pad, device=dev)
-    conf = torch.empty_like(depth)
-    p = L.DepthRegressParams()
-    p.D, p.Hp, p.Wp, p.pad = D, Hp, Wp, int(pad)
-    p.prob_pre, p.prob_init, p.depth_values = _ptr(prob_pre), _ptr(prob_init), _ptr(depth_values)
-    p.prob_volume, p.depth, p.confidence = _ptr(prob), _ptr(depth), _ptr(conf)
-    _launch("ucnerf_depth_regress", p, dev)
-    return prob, depth, conf
+    return _DepthRegressFn.apply(prob_pre, depth_values.detach(), prob_init, int(pad))
 
 
 # ------------------------------------------------------------------------------------------------ a10
