@@ -485,8 +485,102 @@ def g12_g13():
     save("g13_depth_regress", **out13)
 
 
+# ------------------------------------------------------------------ G14 on-disk formats (row f4)
+def g14():
+    """A tiny COLMAP model written with the reference's own writer (colmapUtils/read_write_model.py), an LLFF
+    poses_bounds array, and what the reference's readers / dataset code make of them."""
+    import shutil
+    import tempfile
+    import types
+    import colmapUtils.read_write_model as rw
+    if "imageio" not in sys.modules:
+        try:
+            import imageio  # noqa: F401
+        except ImportError:
+            sys.modules["imageio"] = types.ModuleType("imageio")          # only imported, never called here
+    if "data" not in sys.modules:                                          # data/__init__.py pulls in every dataset
+        pkg = types.ModuleType("data"); pkg.__path__ = [os.path.join(_ref_import.REF, "data")]; sys.modules["data"] = pkg
+    import data.scared as sc
+
+    rng = np.random.RandomState(14)
+    n_img, n_pts, W, H = 5, 60, 64, 48
+    cams = {1: rw.Camera(id=1, model="PINHOLE", width=W, height=H, params=np.array([50.0, 52.0, 31.5, 24.25]))}
+    pts_xyz = np.column_stack([rng.uniform(-1, 1, n_pts), rng.uniform(-0.8, 0.8, n_pts), rng.uniform(2.0, 6.0, n_pts)])
+    images, tracks = {}, {k + 1: [] for k in range(n_pts)}
+    names = ["frame_%03d.png" % k for k in (3, 0, 4, 1, 2)]                # file order != name order
+    for i in range(n_img):
+        ang = 0.05 * (i - 2)
+        R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+        t = np.array([0.1 * (i - 2), 0.02 * i, 0.0])
+        cam = pts_xyz @ R.T + t
+        xy = np.column_stack([50.0 * cam[:, 0] / cam[:, 2] + 31.5, 52.0 * cam[:, 1] / cam[:, 2] + 24.25])
+        sel = rng.permutation(n_pts)[:40]
+        ids = np.where(rng.rand(40) < 0.15, -1, sel + 1).astype(np.int64)  # some untriangulated keypoints
+        for j, pid in enumerate(ids):
+            if pid != -1:
+                tracks[int(pid)].append((i + 1, j))
+        images[i + 1] = rw.Image(id=i + 1, qvec=rw.rotmat2qvec(R), tvec=t, camera_id=1, name=names[i], xys=xy[sel], point3D_ids=ids)
+    points = {k: rw.Point3D(id=k, xyz=pts_xyz[k - 1], rgb=rng.randint(0, 255, 3), error=np.array(rng.uniform(0.2, 2.0)),
+                            image_ids=np.array([a for a, _ in tracks[k]], dtype=np.int64),
+                            point2D_idxs=np.array([b for _, b in tracks[k]], dtype=np.int64)) for k in tracks}
+    out_dir = os.path.join(HERE, "colmap_tiny", "sparse", "0")
+    shutil.rmtree(os.path.join(HERE, "colmap_tiny"), ignore_errors=True)
+    os.makedirs(out_dir)
+    rw.write_model(cams, images, points, out_dir, ext=".bin")
+
+    # LLFF poses_bounds: [N, 3x5 (rotation | translation | H, W, focal) + near, far]
+    pb = np.zeros((n_img, 17))
+    for i in range(n_img):
+        c2w = sc.ScaredDataset.get_poses(None, {1: images[i + 1]})[0]
+        m = np.concatenate([c2w[:3, :4], np.array([[H], [W], [50.0]])], 1)
+        pb[i, :15] = m.reshape(-1)
+        pb[i, 15:] = [1.5 + 0.1 * i, 7.0 - 0.2 * i]
+    np.save(os.path.join(HERE, "colmap_tiny", "poses_bounds.npy"), pb)
+
+    # what the reference reads back
+    r_cams = rw.read_cameras_binary(os.path.join(out_dir, "cameras.bin"))
+    r_imgs = rw.read_images_binary(os.path.join(out_dir, "images.bin"))
+    r_pts = rw.read_points3d_binary(os.path.join(out_dir, "points3D.bin"))
+    arrs = {"cam_params": r_cams[1].params, "cam_wh": np.array([r_cams[1].width, r_cams[1].height])}
+    for i in r_imgs:
+        arrs["img%d_qvec" % i] = r_imgs[i].qvec; arrs["img%d_tvec" % i] = r_imgs[i].tvec
+        arrs["img%d_xys" % i] = r_imgs[i].xys; arrs["img%d_ids" % i] = r_imgs[i].point3D_ids
+        arrs["img%d_R" % i] = r_imgs[i].qvec2rotmat()
+    arrs["img_names"] = np.array([r_imgs[i].name for i in r_imgs])
+    arrs["pt_ids"] = np.array(sorted(r_pts))
+    arrs["pt_xyz"] = np.stack([r_pts[k].xyz for k in sorted(r_pts)])
+    arrs["pt_err"] = np.array([float(r_pts[k].error) for k in sorted(r_pts)])
+    arrs["pt_rgb"] = np.stack([r_pts[k].rgb for k in sorted(r_pts)])
+    arrs["pt7_track"] = np.stack([r_pts[7].image_ids, r_pts[7].point2D_idxs])
+
+    # pose normalisation exactly as data/scared.py:222-244 applies it, with the reference's center_poses
+    poses = pb[:, :15].reshape(-1, 3, 5)
+    bounds = pb[:, -2:].copy()
+    blender2opencv = np.array([[1, 0, 0, 0], [0, -1, 0, 0], [0, 0, -1, 0], [0, 0, 0, 1]])
+    p2 = np.concatenate([poses[..., 1:2], -poses[..., :1], poses[..., 2:4]], -1)
+    scale = 1. / (bounds.min() * 0.75)
+    bounds *= scale
+    p2[..., 3] *= scale
+    centred, pose_avg = sc.center_poses(p2, blender2opencv)
+    arrs.update(poses_centred=centred, pose_avg=pose_avg, bounds_scaled=bounds, scale_factor=scale,
+                nearest=sc.get_nearest_pose_ids(centred[2], centred[[0, 1, 3, 4]], 3))
+
+    # sparse depth supervision (data/scared.py:285-344) through the reference's method on a stand-in `self`
+    tmp = tempfile.mkdtemp()
+    shutil.copytree(os.path.join(HERE, "colmap_tiny", "sparse"), os.path.join(tmp, "sparse"))
+    stub = types.SimpleNamespace(img_wh=(32, 24))
+    stub.get_poses = types.MethodType(sc.ScaredDataset.get_poses, stub)
+    lst = sc.ScaredDataset.load_colmap_depth(stub, tmp, factor=2.0, bd_factor=.75, bds_raw=pb[:, -2:].transpose([1, 0]))
+    shutil.rmtree(tmp)
+    arrs["sd_names"] = np.array([d["name"] for d in lst])
+    for k, d in enumerate(lst):
+        arrs["sd%d_depth" % k] = d["depth"]; arrs["sd%d_coord" % k] = d["coord"]; arrs["sd%d_weight" % k] = d["weight"]
+        arrs["sd%d_depth_img" % k] = d["depth_img"]; arrs["sd%d_weight_img" % k] = d["weight_img"]
+    save("g14_formats", **arrs)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12_g13):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12_g13, g14):
         if not only or fn.__name__ in only:
             fn()
