@@ -579,8 +579,52 @@ def g14():
     save("g14_formats", **arrs)
 
 
+# ------------------------------------------------------------------ G15 training losses (row f3)
+def g15():
+    """The trainer's loss terms (train.py:164-188) from the reference's own loss classes on seeded inputs, with the
+    gradients they send back into the rendered rgb / depth and the cascade depths."""
+    import importlib
+    L = importlib.import_module("utils.loss")
+    g = torch.Generator().manual_seed(15)
+    patch_num, ps, n_rays, n_depth = 6, 4, 6 * 16 + 40, 25
+    N = n_rays + n_depth
+    rgb = torch.rand(N, 3, generator=g).requires_grad_(True)
+    depth_pred = (1.0 + 3.0 * torch.rand(N, generator=g)).requires_grad_(True)
+    target_s = torch.rand(N, 3, generator=g)
+    target_depths = 1.0 + 3.0 * torch.rand(n_depth, generator=g)
+    target_weights = 2.0 * torch.rand(n_depth, generator=g)
+    patch_dpt = torch.rand(patch_num, ps, ps, 1, generator=g)
+    outputs, gt_ms, w_ms = {}, {}, {}
+    for k, (h, w) in {"stage1": (6, 8), "stage2": (12, 16), "stage3": (24, 32)}.items():
+        outputs[k] = {"depth": (1.0 + 3.0 * torch.rand(1, h, w, generator=g)).requires_grad_(True)}
+        m = torch.rand(1, h, w, generator=g) < 0.3
+        gt_ms[k] = torch.where(m, 1.0 + 3.0 * torch.rand(1, h, w, generator=g), torch.zeros(1, h, w))
+        w_ms[k] = torch.where(m, 0.1 + 1.9 * torch.rand(1, h, w, generator=g), torch.zeros(1, h, w))
+    outputs["depth"] = outputs["stage3"]["depth"]                       # CascadeMVSNet.forward also spreads the last stage
+    smooth, edge = ref.mvs.EdgePreservingSmoothnessLoss(), L.GradientLoss()      # (train.py:12,17,42-43)
+    patch_pts = patch_num * ps * ps
+    loss_mvs, _ = ref.mvs.cas_mvsnet_loss(outputs, gt_ms, w_ms)
+    patch_depth = depth_pred[:patch_pts].reshape(-1, ps, ps)
+    smooth_loss = smooth(patch_depth[:patch_num // 2, ...], patch_dpt[:patch_num // 2, ...])
+    loss_nerf_depth = torch.mean(((depth_pred[n_rays:] - target_depths) ** 2) * target_weights)
+    loss_si = edge(patch_depth[patch_num // 2:, ...], patch_dpt[patch_num // 2:, ...].squeeze(-1),
+                   torch.ones_like(patch_depth[patch_num // 2:, ...]))
+    depth_loss = loss_nerf_depth * 0.05 + loss_mvs * 0.05 + smooth_loss * 0.05 + loss_si * 0.008
+    img_loss = L.img2mse(rgb, target_s)
+    loss = depth_loss + img_loss * 5.0
+    loss.backward()
+    arrs = dict(patch_num=patch_num, patch_size=ps, n_rays=n_rays, rgb=rgb, depth_pred=depth_pred, target_s=target_s,
+                target_depths=target_depths, target_weights=target_weights, patch_dpt=patch_dpt, loss=loss, img_loss=img_loss,
+                loss_mvs=loss_mvs, smooth_loss=smooth_loss, loss_nerf_depth=loss_nerf_depth, loss_scaleinvariant=loss_si,
+                g_rgb=rgb.grad, g_depth=depth_pred.grad)
+    for k in ("stage1", "stage2", "stage3"):
+        arrs[k + "_depth"] = outputs[k]["depth"]; arrs[k + "_gt"] = gt_ms[k]; arrs[k + "_w"] = w_ms[k]
+        arrs[k + "_g"] = outputs[k]["depth"].grad
+    save("g15_losses", **arrs)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12_g13, g14):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12_g13, g14, g15):
         if not only or fn.__name__ in only:
             fn()

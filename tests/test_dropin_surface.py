@@ -170,6 +170,51 @@ def test_training_step_through_rendering_updates_parameters_and_sources(mods, sd
     assert losses[-1] < losses[0]
 
 
+def test_train_step_driver_with_the_reference_loss_mix(mods, sd_v7):
+    """Row f3: `TrainStep` (train.py:110-211 on a prepared batch) around the rendering mirror -- [2 patches of 2x2 | 10 other
+    rays | 6 sparse-depth rays] of the G10 batch; the loss equals the reference-shaped loss on the oracle's render and
+    goes down over a few Adam steps."""
+    from uc_nerf_amd.train_step import TrainStep
+    from uc_nerf_amd.utils import loss as L
+    g = load_golden("g10_rendering")
+    V = g["V"]
+    net = make_model(mods, V, sd_v7)
+    args = types.SimpleNamespace(view_num=V, feat_dim=97, img_downscale=1.0, use_color_volume=False, net_type="v2")
+    e_p, _ = mods.models.get_embedder(10, 0)
+    e_d, _ = mods.models.get_embedder(4, 0)
+    qfn = lambda pts, vd, f, fn: mods.renderer.run_network_mvs(pts, vd, f, fn, embed_fn=e_p, embeddirs_fn=e_d)
+    vf = {"stage%d" % (i + 1): {"volume_feature_no_ref": dev(g["vol%d" % (i + 1)])} for i in range(3)}
+    gen = torch.Generator().manual_seed(2)
+    N, patch_num, ps, n_rays = g["pts"].shape[0], 2, 2, 18
+    target_s = torch.rand(N, 3, generator=gen)
+    t_depth, t_w = 1 + 3 * torch.rand(N - n_rays, generator=gen), 2 * torch.rand(N - n_rays, generator=gen)
+    dpt = torch.rand(patch_num, ps, ps, 1, generator=gen)
+    mvs_out = {"stage%d" % k: {"depth": (1 + 3 * torch.rand(1, 4 * k, 5 * k, generator=gen))} for k in (1, 2, 3)}
+    gt = {k: torch.where(torch.rand(v["depth"].shape, generator=gen) < 0.4, v["depth"] + 0.1, torch.zeros_like(v["depth"])) for k, v in mvs_out.items()}
+    w = {k: (v > 0).float() * 0.7 for k, v in gt.items()}
+    ndc = _ndc(g)
+
+    def render(idx):
+        pose = {"w2cs": dev(g["w2cs"]).clone(), "intrinsics": dev(g["K"]).repeat(V, 1, 1)}
+        return mods.renderer.rendering(args, pose, dev(g["pts"])[idx], {k: v[idx] for k, v in ndc.items()}, dev(g["z"])[idx],
+                                       dev(g["rays_d"])[idx], vf, dev(g["imgs"]), network_fn=net, img_feat=dev(g["img_feat"]),
+                                       network_query_fn=qfn, confidence=dev(g["conf"]))
+
+    step = TrainStep(render, net.parameters(), torch.optim.Adam(net.parameters(), lr=5e-4), n_rays, patch_num, ps)
+    mvs_dev = {k: {"depth": dev(v["depth"])} for k, v in mvs_out.items()}
+    outs = [step(dev(target_s), dev(t_depth), dev(t_w), dev(dpt), mvs_dev, gt, w) for _ in range(4)]
+    # the same loss on the oracle's render of the same batch
+    p = {k: v.clone() for k, v in sd_v7.items()}
+    ondc = {"stage1": g["ndc1"], "stage2": g["ndc2"], "stage3": g["ndc3"], "ndc": g["ndc"]}
+    with torch.no_grad():
+        orgb, odepth = O.rendering(p, {"w2cs": g["w2cs"].clone(), "intrinsics": g["K"].repeat(V, 1, 1)}, g["pts"], ondc, g["z"],
+                                   g["rays_d"], [g["vol%d" % k] for k in (1, 2, 3)], g["imgs"], g["img_feat"], g["conf"], V)
+        want, parts = L.training_loss(orgb, odepth, target_s, t_depth, t_w, dpt, mvs_out, gt, w, n_rays=n_rays, patch_num=patch_num, patch_size=ps)
+    assert abs(float(outs[0]["loss"]) - want.item()) < 2e-4 * max(1.0, abs(want.item()))
+    assert abs(float(outs[0]["img_loss"]) - parts["img_loss"].item()) < 1e-4
+    assert float(outs[-1]["loss"]) < float(outs[0]["loss"])
+
+
 def test_ray_builders_and_helpers_against_reference_vectors(mods, monkeypatch):
     g = load_golden("g3_sampling")
     H, W, NS = g["bt_H"], g["bt_W"], g["bt_NS"]

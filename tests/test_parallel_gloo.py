@@ -130,3 +130,66 @@ def test_flat_bucket_allreduce_reproduces_the_single_rank_gradient():
     for k in results[0][0]:                                               # both ranks hold identical reduced grads
         if results[0][0][k] is not None:
             assert torch.equal(results[0][0][k], results[1][0][k])
+
+
+# ---- row f3: the training step's loss under ray sharding ------------------------------------------------------
+def _f3_problem():
+    g = torch.Generator().manual_seed(33)
+    patch_num, ps, n_rays, n_depth = 7, 4, 7 * 16 + 45, 23            # odd counts: unequal shards of every region
+    N = n_rays + n_depth
+    feats = torch.randn(N, 6, generator=g)
+    batch = dict(target_s=torch.rand(N, 3, generator=g), target_depths=1 + 3 * torch.rand(n_depth, generator=g),
+                 target_weights=2 * torch.rand(n_depth, generator=g), patch_dpt=torch.rand(patch_num, ps, ps, 1, generator=g))
+    gt, w = {}, {}
+    for k, (h, ww) in {"stage1": (4, 5), "stage2": (8, 10), "stage3": (16, 20)}.items():
+        m = torch.rand(1, h, ww, generator=g) < 0.4
+        gt[k] = torch.where(m, 1 + 3 * torch.rand(1, h, ww, generator=g), torch.zeros(1, h, ww))
+        w[k] = torch.where(m, 0.1 + torch.rand(1, h, ww, generator=g), torch.zeros(1, h, ww))
+    return patch_num, ps, n_rays, feats, batch, gt, w
+
+
+def _f3_model():
+    torch.manual_seed(7)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4))      # stands where the renderer is
+    mvs = torch.nn.ParameterDict({k: torch.nn.Parameter(1 + 3 * torch.rand(1, h, ww)) for k, (h, ww) in
+                                  {"stage1": (4, 5), "stage2": (8, 10), "stage3": (16, 20)}.items()})
+    return net, mvs
+
+
+def _f3_rank(rank, world):
+    from uc_nerf_amd.train_step import TrainStep
+    patch_num, ps, n_rays, feats, batch, gt, w = _f3_problem()
+    net, mvs = _f3_model()
+    params = list(net.parameters()) + list(mvs.parameters())
+
+    def render(idx):
+        o = net(feats[idx])
+        return torch.sigmoid(o[:, :3]), 1 + 3 * torch.sigmoid(o[:, 3])
+
+    step = TrainStep(render, params, torch.optim.SGD(params, lr=0.0), n_rays, patch_num, ps, rank, world)
+    out = step(batch["target_s"], batch["target_depths"], batch["target_weights"], batch["patch_dpt"],
+               {k: {"depth": v} for k, v in mvs.items()}, gt, w)
+    return {"loss": float(out["loss"]), "terms": [float(out[k]) for k in TrainStep.TERMS],
+            "grads": torch.cat([p.grad.reshape(-1) for p in params])}
+
+
+def test_sharded_training_step_reproduces_the_single_process_gradient():
+    """World-size 2 and 3 against the reference-shaped single-process loss (utils.loss.training_loss, pinned by G15)."""
+    from uc_nerf_amd.utils import loss as L
+    patch_num, ps, n_rays, feats, batch, gt, w = _f3_problem()
+    net, mvs = _f3_model()
+    params = list(net.parameters()) + list(mvs.parameters())
+    o = net(feats)
+    loss, parts = L.training_loss(torch.sigmoid(o[:, :3]), 1 + 3 * torch.sigmoid(o[:, 3]), batch["target_s"], batch["target_depths"],
+                                  batch["target_weights"], batch["patch_dpt"], {k: {"depth": v} for k, v in mvs.items()}, gt, w,
+                                  n_rays=n_rays, patch_num=patch_num, patch_size=ps)
+    loss.backward()
+    want = torch.cat([p.grad.reshape(-1) for p in params])
+    for world in (2, 3):
+        res = run_world(_f3_rank, world)
+        for r in res:
+            assert abs(r["loss"] - loss.item()) < 1e-5 * max(1.0, abs(loss.item()))
+            torch.testing.assert_close(r["grads"], want, atol=1e-6, rtol=1e-5)
+        assert abs(res[0]["terms"][0] - parts["img_loss"].item()) < 1e-6
+    one = _f3_rank(0, 1)                                                 # world = 1 is the reference's step
+    torch.testing.assert_close(one["grads"], want, atol=1e-7, rtol=1e-6)
