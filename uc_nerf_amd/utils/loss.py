@@ -54,18 +54,24 @@ class EdgePreservingSmoothnessLoss(nn.Module):
         super().__init__()
         self.patch_size, self.gamma = 4, 0.1
 
+    # the four neighbour directions as (row shift, column shift) pairs: right, down, down-right, up-right
+    _NEIGHBOURS = ((0, 1), (1, 0), (1, 1), (-1, 1))
+
+    @staticmethod
+    def _pair(x, dr, dc):
+        """x and its (dr, dc) neighbour, cropped to the overlap, for [n, rows, cols, ...] tensors."""
+        rows, cols = x.shape[1], x.shape[2]
+        r0, r1 = (0, rows - dr) if dr >= 0 else (-dr, rows)
+        return x[:, r0:r1, 0:cols - dc], x[:, r0 + dr:r1 + dr, dc:cols]
+
     def forward(self, inputs, weights):
-        bf = lambda x: torch.exp(-torch.abs(x).sum(-1) / self.gamma)      # noqa: E731
-        l1 = lambda x: torch.mean(torch.abs(x))                           # noqa: E731
-        w1 = bf(weights[:, :, :-1] - weights[:, :, 1:])
-        w2 = bf(weights[:, :-1, :] - weights[:, 1:, :])
-        w3 = bf(weights[:, :-1, :-1] - weights[:, 1:, 1:])
-        w4 = bf(weights[:, 1:, :-1] - weights[:, :-1, 1:])
-        L1 = l1(w1 * (inputs[:, :, :-1] - inputs[:, :, 1:]))
-        L2 = l1(w2 * (inputs[:, :-1, :] - inputs[:, 1:, :]))
-        L3 = l1(w3 * (inputs[:, :-1, :-1] - inputs[:, 1:, 1:]))
-        L4 = l1(w4 * (inputs[:, 1:, :-1] - inputs[:, :-1, 1:]))
-        return (L1 + L2 + L3 + L4) / 4
+        total = 0
+        for dr, dc in self._NEIGHBOURS:
+            wa, wb = self._pair(weights, dr, dc)
+            xa, xb = self._pair(inputs, dr, dc)
+            bilateral = torch.exp(-torch.abs(wa - wb).sum(-1) / self.gamma)
+            total = total + torch.mean(torch.abs(bilateral * (xa - xb)))
+        return total / 4
 
 
 def cas_mvsnet_loss(inputs, depth_gt_ms, weight_ms, with_weight=True, mvs_type=0, **kwargs):
