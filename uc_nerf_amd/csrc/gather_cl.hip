@@ -87,18 +87,15 @@ __device__ __forceinline__ void project_cl(const float* M, const float* K, float
       o[0] += a_.x * w_; o[1] += a_.y * w_; o[2] += a_.z * w_; o[3] += a_.w * w_;               \
       o[4] += b_.x * w_; o[5] += b_.y * w_; o[6] += b_.z * w_; o[7] += b_.w * w_; }
 
-__global__ void __launch_bounds__(256) feat_gather_cl_kernel(GatherClArgs a) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long M = (long long)a.n * a.S;
-    if (idx >= M) return;
-    const int unit = blockIdx.y;
+template <bool TILED>
+__device__ __forceinline__ void gather_cl_unit(const GatherClArgs& a, long long idx, int unit) {
     const int F = 24 + 12 * a.V + 1;
     const int r = (int)(idx / a.S);
     const float z = a.z[idx];
     const float x = a.rays_o[0] + z * a.rays_d[3 * r], y = a.rays_o[1] + z * a.rays_d[3 * r + 1],
                 w = a.rays_o[2] + z * a.rays_d[3 * r + 2];
-    const int fs = a.tiled ? 32 : 1;                                        // feature f at out[f * fs]
-    float* out = a.tiled ? a.feats + ((size_t)(idx >> 5) * F) * 32 + (idx & 31) : a.feats + (size_t)idx * F;
+    constexpr int fs = TILED ? 32 : 1;                                      // feature f at out[f * fs]
+    float* out = TILED ? a.feats + ((size_t)(idx >> 5) * F) * 32 + (idx & 31) : a.feats + (size_t)idx * F;
     if (unit < 4) {
         float qx, qy, qz;
         project_cl(a.w2c_ref, a.K_ref, x, y, w, &qx, &qy, &qz);
@@ -165,6 +162,19 @@ __global__ void __launch_bounds__(256) feat_gather_cl_kernel(GatherClArgs a) {
     }
 }
 
+// Tiled output (the inference path): grid.y = unit, every (tile, feature) row is one full 128-byte line whoever writes it.
+// Row-major output (the training forward keeps the features): a sample's 388-byte row shares cache lines with its
+// neighbours', and units running as separate sweeps leave every line partially written when it is evicted (measured:
+// 142 MB of HBM writes for 51 MB of features) -- there one thread walks all units so that the row completes in L2.
+template <bool TILED>
+__global__ void __launch_bounds__(256) feat_gather_cl_kernel(GatherClArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.n * a.S) return;
+    if (TILED) gather_cl_unit<true>(a, idx, blockIdx.y);
+    else
+        for (int unit = 0; unit < 4 + a.V; ++unit) gather_cl_unit<false>(a, idx, unit);
+}
+
 }  // namespace ucnerf
 
 using namespace ucnerf;
@@ -219,7 +229,8 @@ int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float
     a.feats = feats; a.tiled = tiled; a.ndc = ndc;
     UCNERF_REQUIRE(a.V >= 1 && a.V <= 8, "gather_cl: V = %d outside 1..8", a.V);
     const long long M = (long long)p->n * p->S;
-    hipLaunchKernelGGL(feat_gather_cl_kernel, dim3(cdiv(M, 256), 4 + a.V), dim3(256), 0, st, a);
+    if (tiled) hipLaunchKernelGGL(feat_gather_cl_kernel<true>, dim3(cdiv(M, 256), 4 + a.V), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(feat_gather_cl_kernel<false>, dim3(cdiv(M, 256), 1), dim3(256), 0, st, a);
     return check_launch("feat_gather_cl");
 }
 
