@@ -188,6 +188,35 @@ def main():
                  "max_abs_rgb_vs_f32": (op["rgb"] - ref["rgb"]).abs().max().item(),
                  "note": "NOT the headline and NOT within the 1e-4 parity bar: one bf16 MFMA per product (precision='bf16')"}
 
+    # third secondary number: a training-style step on this GPU -- source repack + forward + full backward (parameters,
+    # volumes, image features, confidence) of one fused render pass, 1024 rays x 128 depths, exact-f32 path
+    train = None
+    if not args.no_reuse:
+        n_t, s_t = min(1024, int(xs.shape[0])), 128
+        rt = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, precision="f32")
+        flat_t = flat_params_of(sd).to(dev)
+        rd_t, _, _ = ops.ray_gen(rt.K_host, rt.c2w_host, xs=xs[:n_t], ys=ys[:n_t])
+        z_t, _ = ops.sample_stratified(None, s_t, n=n_t, near=rt.near_host, far=rt.far_host, device=dev)
+        g_rgb, g_depth = torch.randn(n_t, 3, device=dev), torch.randn(n_t, device=dev)
+
+        def train_step():
+            rt.pass_.repack_sources()
+            kept = rt.pass_(rd_t, z_t, keep=("raw", "feats"))
+            return rt.pass_.backward(rd_t, z_t, kept, g_rgb, g_depth, flat_t)
+
+        for _ in range(5):
+            grads = train_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            grads = train_step()
+        barrier()
+        dt4 = (time.perf_counter() - t0) / 30
+        assert all(torch.isfinite(t).all() for t in grads if t is not None)
+        train = {"ms_per_step": dt4 * 1e3, "value": n_t / dt4, "unit": "rays/s", "rays": n_t, "samples_per_ray": s_t, "dtype": "f32",
+                 "note": "NOT the headline: source repack + forward + full backward of one fused render pass on one GPU "
+                         "(no optimizer, no collective)"}
+
     # dominant kernel (mlp_fwd): HIP events recorded around its two launches per step, on the launch stream
     mlp_ms = sum(a.elapsed_ms(b) for step in events for a, b in step)
     launches = 2 * args.steps
@@ -242,6 +271,8 @@ def main():
             line["parity_vs_f32"] = psnr_vs_f32
         if plain is not None:
             line["plain_bf16"] = plain
+        if train is not None:
+            line["train_step"] = train
         if dt2 is not None:
             line["reuse_coarse"] = {"value": args.rays * world * args.steps / dt2, "unit": "rays/s", "ms_per_step": dt2 / args.steps * 1e3,
                                     "note": "NOT the headline: fine pass evaluates only the 128 new depths and re-uses the coarse "
