@@ -473,51 +473,40 @@ __global__ void __launch_bounds__(256) mul_kernel(const f32x4* x, const f32x4* y
     }
 }
 
-// after feature_linear: g_h5 = g_g * bc + W_basehead^T g_base ;  g_bc = g_g * h5
-struct BcSplitArgs {
+// after feature_linear, down to the trunk's top layer in one pass over the activations (models.py:158-165 and the layer-5
+// relu / modulation backwards):  g_bc = g_g * h5;  g_h5 = g_g * bc + W_basehead^T g_base;  g_pre = g_h5 * [h5 > 0];
+// g_y = g_pre * bd (written over g_g in place);  g_bd = g_pre * (h5 / bd)
+struct TopArgs {
     size_t n4;
-    const f32x4* g_g; const f32x4* bc; const f32x4* h5;
+    f32x4* g;                // in: g_g, out: g_y of layer 5
+    const f32x4* bc; const f32x4* h5; const f32x4* bd;
     const float* g_base;     // [m,4]
     const float* w_crgb; const float* w_a1;
-    f32x4* g_h5; f32x4* g_bc;
+    f32x4* g_bc; f32x4* g_bd;
 };
 
-__global__ void __launch_bounds__(256) bc_split_kernel(BcSplitArgs a) {
+__global__ void __launch_bounds__(256) trunk_top_bwd_kernel(TopArgs a) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) {
         const size_t s = i >> 5;
         const int c = (int)(i & 31);
-        const f32x4 g = a.g_g[i], b = a.bc[i], h = a.h5[i];
+        const f32x4 g = a.g[i], b = a.bc[i], h = a.h5[i], d = a.bd[i];
         const f32x4 gb = reinterpret_cast<const f32x4*>(a.g_base)[s];
         const f32x4 w0 = ld4(a.w_crgb + 4 * c), w1 = ld4(a.w_crgb + 128 + 4 * c), w2 = ld4(a.w_crgb + 256 + 4 * c),
                     w3 = ld4(a.w_a1 + 4 * c);
-        f32x4 o;
-        o.x = g.x * b.x + gb.x * w0.x + gb.y * w1.x + gb.z * w2.x + gb.w * w3.x;
-        o.y = g.y * b.y + gb.x * w0.y + gb.y * w1.y + gb.z * w2.y + gb.w * w3.y;
-        o.z = g.z * b.z + gb.x * w0.z + gb.y * w1.z + gb.z * w2.z + gb.w * w3.z;
-        o.w = g.w * b.w + gb.x * w0.w + gb.y * w1.w + gb.z * w2.w + gb.w * w3.w;
-        a.g_h5[i] = o;
         a.g_bc[i] = f32x4{g.x * h.x, g.y * h.y, g.z * h.z, g.w * h.w};
-    }
-}
-
-// trunk layer: g_pre = g_h * [h > 0];  g_y = g_pre * bd;  g_bd (+)= g_pre * y, with y = h / bd where h > 0
-__global__ void __launch_bounds__(256) relu_mod_bwd_kernel(const f32x4* g_h, const f32x4* hh, const f32x4* bd, f32x4* g_y,
-                                                            f32x4* g_bd, int first, size_t n4) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const f32x4 g = g_h[i], h = hh[i], b = bd[i];
-        f32x4 acc = first ? f32x4{0.f, 0.f, 0.f, 0.f} : g_bd[i];
-        f32x4 y;
-#define ONE(C)                                            \
-        {                                                 \
-            const bool on = h.C > 0.f;                    \
-            const float gp = on ? g.C : 0.f;              \
-            y.C = gp * b.C;                               \
-            acc.C += on ? gp * (h.C / b.C) : 0.f;         \
+        f32x4 y, acc;
+#define ONE(C)                                                                                              \
+        {                                                                                                   \
+            const float gh = g.C * b.C + gb.x * w0.C + gb.y * w1.C + gb.z * w2.C + gb.w * w3.C;            \
+            const bool on = h.C > 0.f;                                                                      \
+            const float gp = on ? gh : 0.f;                                                                 \
+            y.C = gp * d.C;                                                                                 \
+            acc.C = on ? gp * (h.C / d.C) : 0.f;                                                            \
         }
         ONE(x) ONE(y) ONE(z) ONE(w)
 #undef ONE
-        g_y[i] = y;
-        g_bd[i] = acc;
+        a.g[i] = y;
+        a.g_bd[i] = acc;
     }
 }
 
@@ -704,21 +693,17 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     RUN(run_tn(st, m, w.g2, 128, 128, w.gx, 128, 1, 128, G + L.p_fw, 128, G + L.p_fb));
     RUN(run_nn(st, m, w.g2, 128, 128, P + L.p_fw, 128, 128, w.g1, 128, false));
 
-    // 4. g_h5 -> g2, g_bc -> g3; confidence-bias net
-    BcSplitArgs bs;
-    bs.n4 = n4; bs.g_g = (const f32x4*)w.g1; bs.bc = (const f32x4*)w.sv.bc; bs.h5 = (const f32x4*)w.sv.h[5];
-    bs.g_base = w.g_base; bs.w_crgb = P + L.p_crw; bs.w_a1 = P + L.p_a1w; bs.g_h5 = (f32x4*)w.g2; bs.g_bc = (f32x4*)w.g3;
-    hipLaunchKernelGGL(bc_split_kernel, dim3(ew_blocks), dim3(256), 0, st, bs);
-    RUN(check_launch("mlp_bwd bc_split"));
+    // 4. one pass: g_bc -> g3, and g_g (g1) becomes g_y of trunk layer 5 in place, g_bd initialised; confidence-bias net
+    TopArgs ta;
+    ta.n4 = n4; ta.g = (f32x4*)w.g1; ta.bc = (const f32x4*)w.sv.bc; ta.h5 = (const f32x4*)w.sv.h[5]; ta.bd = (const f32x4*)w.sv.bd;
+    ta.g_base = w.g_base; ta.w_crgb = P + L.p_crw; ta.w_a1 = P + L.p_a1w; ta.g_bc = (f32x4*)w.g3; ta.g_bd = (f32x4*)w.gbd;
+    hipLaunchKernelGGL(trunk_top_bwd_kernel, dim3(ew_blocks), dim3(256), 0, st, ta);
+    RUN(check_launch("mlp_bwd trunk_top"));
     RUN(run_tn(st, m, w.g3, 128, 128, f.feats + n_mvs, ldf, 1, n_img, G + L.p_bcw, n_img, G + L.p_bcb));
     RUN(run_nn(st, m, w.g3, 128, 128, P + L.p_bcw, n_img, n_img, bp->g_feats + n_mvs, ldgf, false));
 
-    // 5. trunk, layers 5..0.  g_h5 (g2) -> g_y of layer 5 (g1) by the element-wise kernel; below that the data-gradient
-    //    GEMM of layer l applies layer l-1's element-wise backward in its epilogue (g_y ping-pongs between g1 and g2,
-    //    g_bd accumulates in place)
-    hipLaunchKernelGGL(relu_mod_bwd_kernel, dim3(ew_blocks), dim3(256), 0, st, (const f32x4*)w.g2, (const f32x4*)w.sv.h[5],
-                       (const f32x4*)w.sv.bd, (f32x4*)w.g1, (f32x4*)w.gbd, 1, n4);
-    RUN(check_launch("mlp_bwd relu_mod"));
+    // 5. trunk, layers 5..0.  g_y of layer 5 is in g1 (step 4); below that the data-gradient GEMM of layer l applies
+    //    layer l-1's element-wise backward in its epilogue (g_y ping-pongs between g1 and g2, g_bd accumulates in place)
     float *gy = w.g1, *gnext = w.g2;
     for (int l = 5; l >= 0; --l) {
         if (l == 0) {
