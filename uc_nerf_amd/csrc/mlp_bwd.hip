@@ -465,17 +465,9 @@ __global__ void __launch_bounds__(32 * HEAD_SLOTS) head_bwd_kernel(HeadArgs a) {
     }
 }
 
-// gx = h5 * bc  (input of feature_linear)
-__global__ void __launch_bounds__(256) mul_kernel(const f32x4* x, const f32x4* y, f32x4* o, size_t n4) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const f32x4 a = x[i], b = y[i];
-        o[i] = f32x4{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w};
-    }
-}
-
 // after feature_linear, down to the trunk's top layer in one pass over the activations (models.py:158-165 and the layer-5
 // relu / modulation backwards):  g_bc = g_g * h5;  g_h5 = g_g * bc + W_basehead^T g_base;  g_pre = g_h5 * [h5 > 0];
-// g_y = g_pre * bd (written over g_g in place);  g_bd = g_pre * (h5 / bd)
+// g_y = g_pre * bd (written over g_g in place);  g_bd = g_pre * (h5 / bd);  also gx = h5 * bc for feature_linear's weights
 struct TopArgs {
     size_t n4;
     f32x4* g;                // in: g_g, out: g_y of layer 5
@@ -483,6 +475,7 @@ struct TopArgs {
     const float* g_base;     // [m,4]
     const float* w_crgb; const float* w_a1;
     f32x4* g_bc; f32x4* g_bd;
+    f32x4* gx;               // out: h5 * bc, the input of feature_linear (operand of its weight gradient)
 };
 
 __global__ void __launch_bounds__(256) trunk_top_bwd_kernel(TopArgs a) {
@@ -494,6 +487,7 @@ __global__ void __launch_bounds__(256) trunk_top_bwd_kernel(TopArgs a) {
         const f32x4 w0 = ld4(a.w_crgb + 4 * c), w1 = ld4(a.w_crgb + 128 + 4 * c), w2 = ld4(a.w_crgb + 256 + 4 * c),
                     w3 = ld4(a.w_a1 + 4 * c);
         a.g_bc[i] = f32x4{g.x * h.x, g.y * h.y, g.z * h.z, g.w * h.w};
+        a.gx[i] = f32x4{h.x * b.x, h.y * b.y, h.z * b.z, h.w * b.w};
         f32x4 y, acc;
 #define ONE(C)                                                                                              \
         {                                                                                                   \
@@ -687,18 +681,17 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     RUN(run_tn(st, m, w.g1, 128, 128, ped, ld_ped, xdiv_dir, 27, G + L.p_vw + 128, KV, nullptr, G + L.p_vcw + 128, nullptr));
     RUN(run_nn(st, m, w.g1, 128, 128, P + L.p_vw, KV, 128, w.g2, 128, false, nullptr, nullptr, nullptr, P + L.p_vcw));
 
-    // 3. feature_linear on gx = h5 * bc: weights, then g_g -> g1
-    hipLaunchKernelGGL(mul_kernel, dim3(ew_blocks), dim3(256), 0, st, (const f32x4*)w.sv.h[5], (const f32x4*)w.sv.bc, (f32x4*)w.gx, n4);
-    RUN(check_launch("mlp_bwd mul"));
-    RUN(run_tn(st, m, w.g2, 128, 128, w.gx, 128, 1, 128, G + L.p_fw, 128, G + L.p_fb));
+    // 3. feature_linear (input gx = h5 * bc): g_g = g_f * W_f -> g1; its weight gradient waits for gx, which step 4 writes
     RUN(run_nn(st, m, w.g2, 128, 128, P + L.p_fw, 128, 128, w.g1, 128, false));
 
     // 4. one pass: g_bc -> g3, and g_g (g1) becomes g_y of trunk layer 5 in place, g_bd initialised; confidence-bias net
     TopArgs ta;
     ta.n4 = n4; ta.g = (f32x4*)w.g1; ta.bc = (const f32x4*)w.sv.bc; ta.h5 = (const f32x4*)w.sv.h[5]; ta.bd = (const f32x4*)w.sv.bd;
     ta.g_base = w.g_base; ta.w_crgb = P + L.p_crw; ta.w_a1 = P + L.p_a1w; ta.g_bc = (f32x4*)w.g3; ta.g_bd = (f32x4*)w.gbd;
+    ta.gx = (f32x4*)w.gx;
     hipLaunchKernelGGL(trunk_top_bwd_kernel, dim3(ew_blocks), dim3(256), 0, st, ta);
     RUN(check_launch("mlp_bwd trunk_top"));
+    RUN(run_tn(st, m, w.g2, 128, 128, w.gx, 128, 1, 128, G + L.p_fw, 128, G + L.p_fb));      // (g2 = g_f is intact until the trunk loop)
     RUN(run_tn(st, m, w.g3, 128, 128, f.feats + n_mvs, ldf, 1, n_img, G + L.p_bcw, n_img, G + L.p_bcb));
     RUN(run_nn(st, m, w.g3, 128, 128, P + L.p_bcw, n_img, n_img, bp->g_feats + n_mvs, ldgf, false));
 
