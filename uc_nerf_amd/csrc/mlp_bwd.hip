@@ -382,9 +382,24 @@ __global__ void __launch_bounds__(32 * HEAD_SLOTS) head_bwd_kernel(HeadArgs a) {
 #pragma unroll
     for (int o = 0; o < 8; ++o) bsum[o] = 0.f;
 
-    for (int s = blockIdx.x * HEAD_SLOTS + slot; s < a.m; s += gridDim.x * HEAD_SLOTS) {
-        const f32x4 hv = reinterpret_cast<const f32x4*>(a.h5 + (size_t)s * 128)[c];
-        const f32x4 vv = reinterpret_cast<const f32x4*>(a.vc + (size_t)s * 128)[c];
+    // (operands of the next sample are fetched before this one's arithmetic: the loop is latency-bound otherwise)
+    struct In { f32x4 hv, vv, raw, gr; float conf; };
+    auto fetch = [&](int s) {
+        In x;
+        const int sc = s < a.m ? s : a.m - 1;
+        x.hv = reinterpret_cast<const f32x4*>(a.h5 + (size_t)sc * 128)[c];
+        x.vv = reinterpret_cast<const f32x4*>(a.vc + (size_t)sc * 128)[c];
+        x.raw = reinterpret_cast<const f32x4*>(a.raw)[sc];
+        x.gr = reinterpret_cast<const f32x4*>(a.g_raw)[sc];
+        x.conf = a.feats[(size_t)sc * a.ldf + a.F - 1];
+        return x;
+    };
+    const int stride = gridDim.x * HEAD_SLOTS;
+    In nxt = fetch(blockIdx.x * HEAD_SLOTS + slot);
+    for (int s = blockIdx.x * HEAD_SLOTS + slot; s < a.m; s += stride) {
+        const In cur = nxt;
+        nxt = fetch(s + stride);
+        const f32x4 hv = cur.hv, vv = cur.vv;
         // this lane's share of the eight head pre-activations (4 of the 128 / 64 features each)
         float base[4], adapt[4];
 #pragma unroll
@@ -394,9 +409,8 @@ __global__ void __launch_bounds__(32 * HEAD_SLOTS) head_bwd_kernel(HeadArgs a) {
         for (int o = 0; o < 3; ++o) adapt[o] = vv.x * wr[o].x + vv.y * wr[o].y + vv.z * wr[o].z + vv.w * wr[o].w;
         adapt[3] = vv.x * wa.x + vv.y * wa.y + vv.z * wa.z + vv.w * wa.w;
 
-        const f32x4 raw = reinterpret_cast<const f32x4*>(a.raw)[s];
-        const f32x4 gr = reinterpret_cast<const f32x4*>(a.g_raw)[s];
-        const float conf = a.feats[(size_t)s * a.ldf + a.F - 1];
+        const f32x4 raw = cur.raw, gr = cur.gr;
+        const float conf = cur.conf;
         const float u = 1.f - conf, omu = 1.f - u;
         const float gp[4] = {gr.x * raw.x * (1.f - raw.x), gr.y * raw.y * (1.f - raw.y), gr.z * raw.z * (1.f - raw.z),
                              raw.w > 0.f ? gr.w : 0.f};
