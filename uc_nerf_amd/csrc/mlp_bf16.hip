@@ -182,17 +182,39 @@ struct Frag { bf16x8 hi, lo; };
 // v_perm_b32 packs two of them), lo = bf16_rne(x - hi), exact before its rounding: 5 VALU per pair of values against
 // 7 for a round-to-nearest hi.  |lo| < 2^-7 |x| (not 2^-8), so the dropped lo*lo term is 2^-16 relative.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#ifndef UCNERF_BF16_SPLIT_DOT
+#define UCNERF_BF16_SPLIT_DOT 0     // 1: residual by v_dot2c_f32_bf16 against the packed hi pair (4 VALU per pair instead of 5;
+                                    //    bit-identical, scripts/micro/dot2_split.hip) -- measured 0.6 % SLOWER: the dot is not a full-rate op
+#endif
 __device__ __forceinline__ Frag split8(const float (&x)[8]) {
     u32x4 hi;
     Frag f;
+#if UCNERF_BF16_SPLIT_DOT
+    unsigned sel_lo = 0x0000bf80u, sel_hi = 0xbf800000u;
+    asm volatile("" : "+s"(sel_lo), "+s"(sel_hi));
+#endif
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
         const unsigned b0 = __builtin_bit_cast(unsigned, x[j]), b1 = __builtin_bit_cast(unsigned, x[j + 1]);
-        hi[j >> 1] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+        const unsigned packed = __builtin_amdgcn_perm(b1, b0, 0x07060302u);      // [hi(x[j+1]) | hi(x[j])]
+        hi[j >> 1] = packed;
+#if UCNERF_BF16_SPLIT_DOT
+        // x - hi = x + (-1) * hi + 0 * (the other hi): one dot2c per value, exact (the products are exact, the sum is
+        // representable), the hi pair read straight from its packed form -- no fp32 copy of hi is ever made
+        // (the two selectors (-1, 0) / (0, -1) are laundered into scalar registers: as literals the compiler turns them into
+        //  16-bit inline constants of the wrong format)
+        const bf16x2 hp = __builtin_bit_cast(bf16x2, packed);
+        const float l0 = __builtin_amdgcn_fdot2_f32_bf16(hp, __builtin_bit_cast(bf16x2, sel_lo), x[j], false);
+        const float l1 = __builtin_amdgcn_fdot2_f32_bf16(hp, __builtin_bit_cast(bf16x2, sel_hi), x[j + 1], false);
+        f.lo[j] = (__bf16)l0;
+        f.lo[j + 1] = (__bf16)l1;
+#else
         const f32x2 h = {__builtin_bit_cast(float, b0 & 0xffff0000u), __builtin_bit_cast(float, b1 & 0xffff0000u)};
         const f32x2 l = (f32x2){x[j], x[j + 1]} - h;
         f.lo[j] = (__bf16)l.x;
         f.lo[j + 1] = (__bf16)l.y;
+#endif
     }
     f.hi = __builtin_bit_cast(bf16x8, hi);
     return f;
