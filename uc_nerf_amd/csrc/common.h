@@ -36,4 +36,27 @@ struct Mat33 { float m[9]; };
 
 int device_cus();   // cached
 
+
+// Segmented pre-combination of float atomics inside a wave (HIP device code only).  Lanes STRIDE apart hold consecutive
+// positions of a run dimension (samples of a ray, depth hypotheses of a pixel; pos = lane / STRIDE); runs of equal `key`
+// along it are summed with a suffix scan in log2(64 / STRIDE) shuffle steps and only the first lane of a run issues the
+// atomic.  key < 0 = nothing to add.  Must be called by all 64 lanes.
+#ifdef __HIPCC__
+template <int STRIDE>                                                  // lanes STRIDE apart are consecutive samples; pos = lane / STRIDE
+__device__ __forceinline__ void run_atomic_add(float* base, int key, float v, int pos) {
+    constexpr int N = 64 / STRIDE;
+    const int kp = __shfl_up(key, STRIDE), kn = __shfl_down(key, STRIDE);   // (unconditionally: a shuffle inside `a || b` would run
+    const bool head = pos == 0 || kp != key;                                 //  with the short-circuited lanes masked off and read 0 from them)
+    int end = pos == N - 1 || kn != key;
+    float s = v;
+#pragma unroll
+    for (int d = 1; d < N; d <<= 1) {
+        const float sn = __shfl_down(s, STRIDE * d);
+        const int en = __shfl_down(end, STRIDE * d);
+        if (!end) { s += sn; end = en; }          // (no run end within the covered span -> lane pos + d exists)
+    }
+    if (head && key >= 0 && s != 0.f) atomicAdd(base + key, s);
+}
+#endif
+
 }  // namespace ucnerf

@@ -205,23 +205,8 @@ __host__ __device__ inline ScratchLayout scratch_layout(const ucnerf_feat_gather
 // Neighbouring samples of a ray fall into the same cell again and again (a ray crosses a source view along a short
 // epipolar segment and the reference frustum along one column), so most atomics of a wave would hit addresses another
 // lane of the same wave also hits.  The eight samples of a wave are therefore combined first: a segmented suffix sum
-// over runs of equal cell offsets along the sample dimension (lane stride 8), log2(run window) shuffle steps, and only the first
-// lane of a run issues the atomic.  key < 0 = nothing to add.  Must be called by all 64 lanes.
-template <int STRIDE>                                                  // lanes STRIDE apart are consecutive samples; pos = lane / STRIDE
-__device__ __forceinline__ void run_atomic_add(float* base, int key, float v, int pos) {
-    constexpr int N = 64 / STRIDE;
-    const int kp = __shfl_up(key, STRIDE), kn = __shfl_down(key, STRIDE);   // (unconditionally: a shuffle inside `a || b` would run
-    const bool head = pos == 0 || kp != key;                                 //  with the short-circuited lanes masked off and read 0 from them)
-    int end = pos == N - 1 || kn != key;
-    float s = v;
-#pragma unroll
-    for (int d = 1; d < N; d <<= 1) {
-        const float sn = __shfl_down(s, STRIDE * d);
-        const int en = __shfl_down(end, STRIDE * d);
-        if (!end) { s += sn; end = en; }          // (no run end within the covered span -> lane pos + d exists)
-    }
-    if (head && key >= 0 && s != 0.f) atomicAdd(base + key, s);
-}
+// over runs of equal cell offsets along the sample dimension (`run_atomic_add`, common.h), and only the first lane of a
+// run issues the atomic.
 
 // confidence map: thread = sample; the samples of a ray share their four pixels in the reference view
 __global__ void __launch_bounds__(256) conf_bwd_kernel(ucnerf_feat_gather_bwd_params bp) {

@@ -169,21 +169,7 @@ __global__ void __launch_bounds__(DR_PIX * DR_DL) depth_regress_kernel(ucnerf_de
 // keep landing on the same source pixel (stage 1: ~10 depths per pixel) and a scatter per voxel queues that many atomics
 // on one address.  A wave therefore holds 8 pixels x 8 consecutive depths (lane = 8 * depth position + pixel): per
 // channel and view, runs of equal source pixels along the depth positions are summed with a segmented suffix scan
-// (three shuffle steps) and only the first lane of a run issues the atomic.
-__device__ __forceinline__ void cv_run_atomic_add(float* base, int key, float v, int pos) {
-    const int kp = __shfl_up(key, 8), kn = __shfl_down(key, 8);          // (unconditionally: see gather.hip run_atomic_add)
-    const bool head = pos == 0 || kp != key;
-    int end = pos == 7 || kn != key;
-    float s = v;
-#pragma unroll
-    for (int d = 1; d < 8; d <<= 1) {
-        const float sn = __shfl_down(s, 8 * d);
-        const int en = __shfl_down(end, 8 * d);
-        if (!end) { s += sn; end = en; }
-    }
-    if (head && key >= 0 && s != 0.f) atomicAdd(base + key, s);
-}
-
+// (`run_atomic_add<8>`, common.h: three shuffle steps) and only the first lane of a run issues the atomic.
 __global__ void __launch_bounds__(256) cost_volume_bwd_kernel(ucnerf_cost_volume_bwd_params bp) {
     const ucnerf_cost_volume_params& p = bp.fwd;
     const int Hp = p.H + 2 * p.pad, Wp = p.W + 2 * p.pad;
@@ -218,7 +204,7 @@ __global__ void __launch_bounds__(256) cost_volume_bwd_kernel(ucnerf_cost_volume
         const float g2 = live ? 2.f * count * bp.g_variance[(size_t)c * total + t] : 0.f;
 #pragma unroll
         for (int i = 0; i < CV_MAX_VIEWS; ++i)
-            if (i < p.V) cv_run_atomic_add(bp.g_feats + (i * chw + c * hw), live ? idx[i] : -1, g2 * (v[i] - mean), dpos);
+            if (i < p.V) run_atomic_add<8>(bp.g_feats + (i * chw + c * hw), live ? idx[i] : -1, g2 * (v[i] - mean), dpos);
     }
 }
 
