@@ -120,6 +120,12 @@ def main():
     for _ in range(args.warmup):
         out = renderer.render(xs, ys, perturb=1.0, noise=noise)
     events = [[(ops.Event(), ops.Event()), (ops.Event(), ops.Event())] for _ in range(args.steps)]
+    # The host only issues launches (0.15-0.4 ms of Python per 1 ms step) and must stay ahead of the GPU's queue: a
+    # generational GC pass over the set-up objects (the CPU scene, the event list) stalls it for tens of milliseconds,
+    # which the queue cannot cover.  Park everything allocated so far in the permanent generation.
+    import gc
+    gc.collect()
+    gc.freeze()
     graph_ms = None
     if args.graph:                       # extra measurement: the same K steps as replays of one captured HIP graph
         g = renderer.capture(args.rays, perturb=1.0)
