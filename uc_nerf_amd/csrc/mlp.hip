@@ -332,7 +332,7 @@ __device__ __forceinline__ void save_rows(float* buf, int s, int h, bool valid, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 v = {x[nt][4 * q], x[nt][4 * q + 1], x[nt][4 * q + 2], x[nt][4 * q + 3]};
-            row[8 * nt + 2 * q + h] = v;
+            __builtin_nontemporal_store(v, &row[8 * nt + 2 * q + h]);      // (streaming hint: 670 MB per 131 k samples, read back a pass later; 411 -> 391 us)
         }
 }
 
