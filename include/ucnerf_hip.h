@@ -61,6 +61,9 @@ typedef struct {
     float* rays_d;        /* [n,3] out */
     float* rays_o;        /* [n,3] out or NULL (origin is c2w[:,3] for every ray) */
     float* pix;           /* [2,n] out (row, col) or NULL */
+    float w2c_dir[12];    /* with `angle`: rotation of the view-direction feature (see ucnerf_dir_feature) */
+    float* angle;         /* [n,3] out or NULL: (d/|d|) @ R_dir^T of the generated rays, same values as ucnerf_dir_feature
+                             on rays_d with has_ref = 1 -- saves that launch in the render passes (ucnerf_render_params.dir_feat) */
 } ucnerf_ray_gen_params;
 int ucnerf_ray_gen(const ucnerf_ray_gen_params* p, void* stream);
 
@@ -449,6 +452,8 @@ typedef struct {
     float* train_workspace;    /* optional (training forward; needs raw and feats): the workspace of the coming
                                   ucnerf_render_fused_bwd call -- the MLP activations are kept there, see
                                   ucnerf_render_bwd_params.saved_valid */
+    const float* dir_feat;     /* optional [n,3]: the view-direction feature already computed (ucnerf_ray_gen.angle or
+                                  ucnerf_dir_feature with w2c_dir); NULL: the pass computes it itself */
 } ucnerf_render_params;
 int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream);

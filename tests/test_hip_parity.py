@@ -61,6 +61,20 @@ def test_ray_gen_matches_reference_vectors():
     assert d.shape == (0, 3)
 
 
+def test_ray_gen_view_direction_feature_equals_dir_feature():
+    """ucnerf_ray_gen.angle (the view-direction feature from the ray launch) is bit-identical to ucnerf_dir_feature on the
+    generated rays; a render pass given it as `dir_feat` renders the same image as one that computes it itself."""
+    g = load_golden("g1_raygen")
+    gen = torch.Generator().manual_seed(5)
+    xs, ys = dev(torch.rand(333, generator=gen) * 19), dev(torch.rand(333, generator=gen) * 15)
+    w2c = torch.eye(4)[:3]
+    w2c[:, :3] = torch.linalg.qr(torch.randn(3, 3, generator=gen))[0]
+    rays_d, _, _, angle = ops().ray_gen(g["K"], g["c2w"], xs=xs, ys=ys, w2c_dir=w2c)
+    want, _ = ops().dir_feature(rays_d, w2c)
+    assert torch.equal(angle, want)
+    assert torch.equal(rays_d, ops().ray_gen(g["K"], g["c2w"], xs=xs, ys=ys)[0])
+
+
 def test_ndc_rays_both_variants():
     g = load_golden("g2_ndc_rays")
     o, d = ops().ndc_rays(g["H"], g["W"], g["focal2"][0], g["focal2"][1], g["near"], dev(g["rays_o"]), dev(g["rays_d"]), 0)

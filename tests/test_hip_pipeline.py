@@ -73,6 +73,10 @@ def test_fused_render_pass_matches_oracle_stage_by_stage(N, S, per_ray_ranges):
     # the lean configuration (tiled features kept in the workspace, nothing stored) gives the same image
     lean = rp(rays_d.to(DEV), z.to(DEV), near_far=None if near_far is None else near_far.to(DEV), want=())
     assert torch.equal(lean["rgb"], out["rgb"]) and torch.equal(lean["depth"], out["depth"])
+    # a precomputed view-direction feature (what ray_gen emits) gives the same render as computing it inside the pass
+    ang, _ = ops.dir_feature(rays_d.to(DEV), sc["w2cs"][0])
+    pre = rp(rays_d.to(DEV), z.to(DEV), near_far=None if near_far is None else near_far.to(DEV), dir_feat=ang)
+    assert torch.equal(pre["rgb"], out["rgb"]) and torch.equal(pre["depth"], out["depth"])
     # the fast path: channel-last source copies + coordinates derived inside the gather
     rp.repack_sources()
     fast = rp(rays_d.to(DEV), z.to(DEV), near_far=None if near_far is None else near_far.to(DEV))

@@ -17,7 +17,7 @@ vp = C.c_void_p     # device pointers travel as integers
 
 class RayGenParams(C.Structure):
     _fields_ = [("n", i32), ("H", i32), ("W", i32), ("grid_start", i32), ("opengl", i32), ("K", f32 * 9),
-                ("c2w", f32 * 12), ("xs", vp), ("ys", vp), ("rays_d", vp), ("rays_o", vp), ("pix", vp)]
+                ("c2w", f32 * 12), ("xs", vp), ("ys", vp), ("rays_d", vp), ("rays_o", vp), ("pix", vp), ("w2c_dir", f32 * 12), ("angle", vp)]
 
 
 class NdcRaysParams(C.Structure):
@@ -125,7 +125,7 @@ class RenderParams(C.Structure):
                 ("vol_h", i32 * 3), ("vol_w", i32 * 3), ("vol", vp * 3), ("conf", vp), ("imgs", vp), ("img_feat", vp),
                 ("w2cs", vp), ("intrinsics", vp), ("wstream", vp), ("sources_cl", vp), ("workspace", vp), ("rgb_map", vp),
                 ("depth_map", vp), ("acc_map", vp), ("weights", vp), ("var", vp), ("raw", vp), ("feats", vp),
-                ("ev_mlp_start", vp), ("ev_mlp_stop", vp), ("train_workspace", vp)]
+                ("ev_mlp_start", vp), ("ev_mlp_stop", vp), ("train_workspace", vp), ("dir_feat", vp)]
 
 
 class RenderBwdParams(C.Structure):

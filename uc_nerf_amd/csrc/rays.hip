@@ -43,9 +43,18 @@ __global__ void ray_gen_kernel(ucnerf_ray_gen_params p) {
         dz = 1.0f;
     }
     const float* R = p.c2w;
-    p.rays_d[3 * i + 0] = dx * R[0] + dy * R[1] + dz * R[2];
-    p.rays_d[3 * i + 1] = dx * R[4] + dy * R[5] + dz * R[6];
-    p.rays_d[3 * i + 2] = dx * R[8] + dy * R[9] + dz * R[10];
+    const float wx = dx * R[0] + dy * R[1] + dz * R[2], wy = dx * R[4] + dy * R[5] + dz * R[6], wz = dx * R[8] + dy * R[9] + dz * R[10];
+    p.rays_d[3 * i + 0] = wx;
+    p.rays_d[3 * i + 1] = wy;
+    p.rays_d[3 * i + 2] = wz;
+    if (p.angle) {                             // the arithmetic of dir_feature_kernel on the values just stored
+        const float c = sqrtf(wx * wx + wy * wy + wz * wz);
+        const float ux = wx / c, uy = wy / c, uz = wz / c;
+        const float* Q = p.w2c_dir;
+        p.angle[3 * i + 0] = ux * Q[0] + uy * Q[1] + uz * Q[2];
+        p.angle[3 * i + 1] = ux * Q[4] + uy * Q[5] + uz * Q[6];
+        p.angle[3 * i + 2] = ux * Q[8] + uy * Q[9] + uz * Q[10];
+    }
     if (p.rays_o) {
         p.rays_o[3 * i + 0] = R[3];
         p.rays_o[3 * i + 1] = R[7];

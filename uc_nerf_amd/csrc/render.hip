@@ -136,9 +136,10 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
         g.feats = keep_feats ? p->feats : w->feats;
         if ((rc = ucnerf_feat_gather_fwd(&g, st))) return rc;
     }
-    if ((rc = launch_dirs(p, st, w))) return rc;
+    if (!p->dir_feat && (rc = launch_dirs(p, st, w))) return rc;
     ucnerf_mlp_params m;
     mlp_args(p, w, g.feats, g.out_tiled, p->raw ? p->raw : w->raw, &m);
+    if (p->dir_feat) m.dirs = p->dir_feat;
     if (p->ev_mlp_start && (rc = ucnerf_event_record(p->ev_mlp_start, st))) return rc;
     if (p->train_workspace && keep_feats && p->raw) {    // training forward: activations go straight into the backward's workspace
         Workspace wb;

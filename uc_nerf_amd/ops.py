@@ -48,9 +48,10 @@ def _launch(name, params, device):
 
 # ------------------------------------------------------------------------------------------------ a1/a2
 def ray_gen(K, c2w, xs=None, ys=None, H=0, W=0, grid_start=0, n=None, opengl=False, want_origin=False, want_pix=False,
-            device=None):
+            device=None, w2c_dir=None):
     """Pinhole rays.  Either (xs, ys) pixel lists or a row-major grid range [grid_start, grid_start+n) of an
-    HxW image.  Returns (rays_d[n,3], rays_o[n,3] or None, pix[2,n] or None)."""
+    HxW image.  Returns (rays_d[n,3], rays_o[n,3] or None, pix[2,n] or None); with `w2c_dir` a fourth element, the
+    view-direction feature (d/|d|) @ R_dir^T [n,3] (what `dir_feature(rays_d, w2c_dir)` gives, from the same launch)."""
     p = L.RayGenParams()
     if xs is not None:
         xs, ys = _f32(xs, "xs"), _f32(ys, "ys")
@@ -70,8 +71,13 @@ def ray_gen(K, c2w, xs=None, ys=None, H=0, W=0, grid_start=0, n=None, opengl=Fal
     rays_o = torch.empty(n, 3, device=device) if want_origin else None
     pix = torch.empty(2, n, device=device) if want_pix else None
     p.rays_d, p.rays_o, p.pix = _ptr(rays_d), _ptr(rays_o), _ptr(pix)
+    angle = None
+    if w2c_dir is not None:
+        _mat(p.w2c_dir, w2c_dir, 3, 4)
+        angle = torch.empty(n, 3, device=device)
+        p.angle = _ptr(angle)
     _launch("ucnerf_ray_gen", p, device)
-    return rays_d, rays_o, pix
+    return (rays_d, rays_o, pix) if w2c_dir is None else (rays_d, rays_o, pix, angle)
 
 
 def ndc_rays(H, W, focal_x, focal_y, near, rays_o, rays_d, variant):
@@ -754,8 +760,9 @@ class RenderPass:
             L.check(L.lib().ucnerf_gather_repack(C.addressof(self.p), _ptr(self._cl), _stream()), "ucnerf_gather_repack")
         self.p.sources_cl = _ptr(self._cl)
 
-    def __call__(self, rays_d, z, near_far=None, want=("acc", "weights", "var"), keep=(), events=None):
+    def __call__(self, rays_d, z, near_far=None, want=("acc", "weights", "var"), keep=(), events=None, dir_feat=None):
         rays_d, z = _f32(rays_d, "rays_d"), _f32(z, "z")
+        dir_feat = _f32(dir_feat, "dir_feat") if dir_feat is not None else None
         n, S = z.shape
         dev = z.device
         p = self.p
@@ -780,6 +787,7 @@ class RenderPass:
         p.weights, p.var, p.raw, p.feats = _ptr(out.get("weights")), _ptr(out.get("var")), _ptr(out.get("raw")), _ptr(out.get("feats"))
         p.ev_mlp_start, p.ev_mlp_stop = events if events is not None else (None, None)
         p.train_workspace = None
+        p.dir_feat = _ptr(dir_feat)
         self._saved_for = None
         if "raw" in keep and "feats" in keep and self.pw.cfg.precision == 0:
             # training forward: keep the MLP activations in the backward's workspace so that backward() need not

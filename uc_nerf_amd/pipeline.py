@@ -37,6 +37,7 @@ class CoarseFineRenderer:
         # camera matrices and depth range travel BY VALUE in the ABI structs: keep host copies so that a render call
         # never reads device memory back (a read-back would drain the stream once per batch)
         self.K_host, self.c2w_host = scene["K"].detach().cpu(), scene["c2w"].detach().cpu()
+        self.w2c_dir_host = w2c_ref.detach().cpu()
         self.near_host, self.far_host = float(scene["near"]), float(scene["far"])
 
     def set_params(self, flat_params):
@@ -53,20 +54,21 @@ class CoarseFineRenderer:
         sc = self.scene
         if repack:
             self.pass_.repack_sources()
-        rays_d, _, _ = ops.ray_gen(self.K_host, self.c2w_host, xs=xs, ys=ys)
+        # rays and their view-direction feature from one launch; both passes take the feature as an input
+        rays_d, _, _, angle = ops.ray_gen(self.K_host, self.c2w_host, xs=xs, ys=ys, w2c_dir=self.w2c_dir_host)
         n = rays_d.shape[0]
         z_c, _ = ops.sample_stratified(None, self.n_coarse, perturb=perturb, noise=noise, n=n, near=self.near_host,
                                        far=self.far_host, device=self.dev)
         ev = [(a.h, b.h) for a, b in events] if events else (None, None)
-        coarse = self.pass_(rays_d, z_c, want=("weights",), events=ev[0], keep=("raw",) if reuse_coarse else ())
+        coarse = self.pass_(rays_d, z_c, want=("weights",), events=ev[0], keep=("raw",) if reuse_coarse else (), dir_feat=angle)
         hs = ops.sample_pdf(None, coarse["weights"], self.u_det if u is None else u, z_merge=z_c, want_inds=False,
                             from_coarse=True, want_rank=reuse_coarse)
         if reuse_coarse:
-            new = self.pass_(rays_d, hs["samples"], want=(), events=ev[1], keep=("raw",))
+            new = self.pass_(rays_d, hs["samples"], want=(), events=ev[1], keep=("raw",), dir_feat=angle)
             raw = ops.merge_rows(new["raw"], coarse["raw"], hs["merge_rank"])      # cat(samples, z_coarse) order
             out = ops.composite_fwd(raw, hs["z_sorted"], 0, self.white_bkgd)
         else:
-            out = self.pass_(rays_d, hs["z_sorted"], want=("acc", "weights", "var"), events=ev[1])
+            out = self.pass_(rays_d, hs["z_sorted"], want=("acc", "weights", "var"), events=ev[1], dir_feat=angle)
         out.update(z_coarse=z_c, z_fine=hs["z_sorted"], z_samples=hs["samples"], coarse=coarse, rays_d=rays_d)
         return out
 
