@@ -11,26 +11,35 @@
 namespace ucnerf {
 
 // ------------------------------------------------------------------------------------------------ repack
-__global__ void __launch_bounds__(256) repack_volume_kernel(const float* __restrict__ src, float4* __restrict__ dst, size_t n_vox) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_vox) return;
-    float c[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) c[k] = src[(size_t)k * n_vox + i];
-    dst[2 * i] = make_float4(c[0], c[1], c[2], c[3]);
-    dst[2 * i + 1] = make_float4(c[4], c[5], c[6], c[7]);
-}
+// One launch for all four sources (blockIdx.y = source; blocks past a source's size exit): the three volumes and the
+// image stack are 5-13 us of copying each, so four launches were mostly launch latency.
+struct RepackArgs {
+    const float* vol[3]; float4* vol_dst[3]; size_t n_vox[3];
+    const float* imgs; const float* feat; float4* img_dst; int V; size_t hw;
+};
 
-__global__ void __launch_bounds__(256) repack_images_kernel(const float* __restrict__ imgs, const float* __restrict__ feat,
-                                                            float4* __restrict__ dst, int V, size_t hw) {
+__global__ void __launch_bounds__(256) repack_sources_kernel(RepackArgs a) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)V * hw) return;
-    const size_t v = i / hw, px = i % hw;
-    const float* im = imgs + v * 3 * hw + px;
-    const float* ft = feat + v * 8 * hw + px;
-    dst[3 * i] = make_float4(im[0], im[hw], im[2 * hw], ft[0]);
-    dst[3 * i + 1] = make_float4(ft[hw], ft[2 * hw], ft[3 * hw], ft[4 * hw]);
-    dst[3 * i + 2] = make_float4(ft[5 * hw], ft[6 * hw], ft[7 * hw], 0.f);
+    const int k = blockIdx.y;
+    if (k < 3) {
+        const size_t n_vox = a.n_vox[k];
+        if (i >= n_vox) return;
+        const float* __restrict__ src = a.vol[k];
+        float c[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c[q] = src[(size_t)q * n_vox + i];
+        a.vol_dst[k][2 * i] = make_float4(c[0], c[1], c[2], c[3]);
+        a.vol_dst[k][2 * i + 1] = make_float4(c[4], c[5], c[6], c[7]);
+    } else {
+        const size_t hw = a.hw;
+        if (i >= (size_t)a.V * hw) return;
+        const size_t v = i / hw, px = i % hw;
+        const float* im = a.imgs + v * 3 * hw + px;
+        const float* ft = a.feat + v * 8 * hw + px;
+        a.img_dst[3 * i] = make_float4(im[0], im[hw], im[2 * hw], ft[0]);
+        a.img_dst[3 * i + 1] = make_float4(ft[hw], ft[2 * hw], ft[3 * hw], ft[4 * hw]);
+        a.img_dst[3 * i + 2] = make_float4(ft[5 * hw], ft[6 * hw], ft[7 * hw], 0.f);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ gather
@@ -196,16 +205,18 @@ int ucnerf_gather_repack(const ucnerf_render_params* p, float* dst, void* stream
     UCNERF_REQUIRE(p && dst, "gather_repack: null pointer");
     UCNERF_REQUIRE(p->vol[0] && p->vol[1] && p->vol[2] && p->imgs && p->img_feat, "gather_repack: null source");
     UCNERF_REQUIRE(((uintptr_t)dst & 15) == 0, "gather_repack: destination must be 16-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
+    RepackArgs a;
     float* o = dst;
+    size_t n_max = 0;
     for (int k = 0; k < 3; ++k) {
-        const size_t nv = (size_t)p->vol_d[k] * p->vol_h[k] * p->vol_w[k];
-        hipLaunchKernelGGL(repack_volume_kernel, dim3(cdiv(nv, 256)), dim3(256), 0, st, p->vol[k], (float4*)o, nv);
-        o += 8 * nv;
+        a.n_vox[k] = (size_t)p->vol_d[k] * p->vol_h[k] * p->vol_w[k];
+        a.vol[k] = p->vol[k]; a.vol_dst[k] = (float4*)o;
+        o += 8 * a.n_vox[k];
+        if (a.n_vox[k] > n_max) n_max = a.n_vox[k];
     }
-    const size_t hw = (size_t)p->H * p->W;
-    hipLaunchKernelGGL(repack_images_kernel, dim3(cdiv(hw * p->cfg.n_src, 256)), dim3(256), 0, st, p->imgs, p->img_feat,
-                       (float4*)o, p->cfg.n_src, hw);
+    a.imgs = p->imgs; a.feat = p->img_feat; a.img_dst = (float4*)o; a.V = p->cfg.n_src; a.hw = (size_t)p->H * p->W;
+    if (a.hw * a.V > n_max) n_max = a.hw * a.V;
+    hipLaunchKernelGGL(repack_sources_kernel, dim3(cdiv(n_max, 256), 4), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("gather_repack");
 }
 
