@@ -1,8 +1,8 @@
 """CPU oracle for the step in front of the ray-marching path: cost-volume assembly and depth regression of the
 cascade MVS stage.
 
-*** TEST INFRASTRUCTURE -- NOT PRODUCT CODE. ***  Same rules as ``oracle/ucnerf_oracle.py``: only ``tests/`` (and timing
-scripts' CPU legs) may import it; the product package never does.
+*** TEST INFRASTRUCTURE -- NOT PRODUCT CODE. ***  Same rules as ``oracle/ucnerf_oracle.py``: only ``tests/`` may import it;
+the product package never does.
 
 Parity status: PINNED by ``tests/golden/g12_cost_volume.npz`` and ``g13_depth_regress.npz``, captured by running the
 reference's own ``homo_warp`` (utils/utils.py:1105-1172) and ``DepthNet.forward`` (network/mvs_models.py:589-646) in

@@ -1,8 +1,7 @@
-"""Times ucnerf_cost_volume / ucnerf_depth_regress at the three cascade-stage shapes (6 source views, 256x320 images) and
-reports them against the HBM roofline; with CPU=1 also times the oracle (the reference's algorithm, torch-CPU) beside them."""
+"""Times ucnerf_cost_volume / ucnerf_depth_regress (forward and backward) at the three cascade-stage shapes (6 source views,
+256x320 images) and reports them against the HBM roofline."""
 import os
 import sys
-import time
 
 import torch
 
@@ -13,9 +12,6 @@ dev = torch.device("cuda:0")
 gen = torch.Generator().manual_seed(0)
 V = 6
 stages = [("stage1", 32, 64, 80, 48), ("stage2", 16, 128, 160, 32), ("stage3", 8, 256, 320, 8)]
-cpu = os.environ.get("CPU") == "1"
-if cpu:
-    from oracle import mvs_oracle as M
 
 for name, C, H, W, D in stages:
     f = 250.0 * W / 320
@@ -78,9 +74,4 @@ for name, C, H, W, D in stages:
     line = "%s C=%d D=%d %dx%d: cost_volume %.1f us = %.2f TB/s (%.2f of 8), depth_regress %.1f us = %.2f TB/s (%.2f of 8)" % (
         name, C, D, H, W, t_cv * 1e3, by_cv / t_cv / 1e9, by_cv / t_cv / 1e9 / 8, t_dr * 1e3, by_dr / t_dr / 1e9, by_dr / t_dr / 1e9 / 8)
     line += "; backward %.1f us / %.1f us" % (t_cvb * 1e3, t_drb * 1e3)
-    if cpu:
-        t0 = time.perf_counter(); want, _ = M.cost_volume_variance(feats, proj, dv); t1 = time.perf_counter()
-        p, d, cf = M.depth_regress(logits, dv); t2 = time.perf_counter()
-        bad = ((var.cpu() - want).abs() > 1e-5 + 1e-5 * want.abs()).any(dim=0).float().mean().item()
-        line += " | CPU oracle %.0f ms / %.0f ms (%d threads); voxels differing %.2e" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, torch.get_num_threads(), bad)
     print(line)
