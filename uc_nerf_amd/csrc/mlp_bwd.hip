@@ -191,6 +191,9 @@ struct TnArgs {
 #ifndef UCNERF_TN_EXP
 #define UCNERF_TN_EXP 0
 #endif
+#ifndef UCNERF_TN_BF16X3
+#define UCNERF_TN_BF16X3 1        // weight-gradient contraction on the bf16 matrix cores with split operands (0: exact fp32 MFMA)
+#endif
 #ifndef UCNERF_TN_DEPTH2
 #define UCNERF_TN_DEPTH2 2      // stages (8 samples each) of loads in flight (measured: 1, 2 and 3 time the same -- the loop is not latency-bound)
 #endif
@@ -198,19 +201,45 @@ struct TnArgs {
 #define UCNERF_TN_EXP 0
 #endif
 
-template <int KT>
-struct TnStage { float g[4], x[4][KT]; };
+template <int KT, int NE>
+struct TnStage { float g[NE], x[NE][KT]; };
+
+// split-bf16 operands for the bf16 matrix cores (same scheme as the forward's bf16x3 kernel, csrc/mlp_bf16.hip): x = hi + lo
+// with hi the truncated top 16 bits and lo = bf16_rne(x - hi); a product is hi*hi + hi*lo + lo*hi, the dropped term 2^-16.
+typedef __bf16 tn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned tn_u32x4 __attribute__((ext_vector_type(4)));
+typedef float tn_f32x2 __attribute__((ext_vector_type(2)));
+struct TnFrag { tn_bf16x8 hi, lo; };
+__device__ __forceinline__ TnFrag tn_split8(const float (&x)[8]) {
+    tn_u32x4 hi;
+    TnFrag f;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const unsigned b0 = __builtin_bit_cast(unsigned, x[j]), b1 = __builtin_bit_cast(unsigned, x[j + 1]);
+        hi[j >> 1] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+        const tn_f32x2 l = (tn_f32x2){x[j], x[j + 1]} - (tn_f32x2){__builtin_bit_cast(float, b0 & 0xffff0000u), __builtin_bit_cast(float, b1 & 0xffff0000u)};
+        f.lo[j] = (__bf16)l.x;
+        f.lo[j + 1] = (__bf16)l.y;
+    }
+    f.hi = __builtin_bit_cast(tn_bf16x8, hi);
+    return f;
+}
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // KT column tiles per wave, KSPLIT waves share a row tile (each with its own KT column tiles), DEPTH stages of loads in
 // flight ahead of the MFMAs.  16 waves = (4 / KSPLIT sample groups) x 4 row tiles x KSPLIT.
-template <int KT, int KSPLIT, int DEPTH, bool DIV>
+// BF: the contraction runs on the bf16 matrix cores with split operands (three 32x32x16 MFMAs per 16 samples and tile
+// instead of eight fp32 32x32x2 ones): fp32-grade weight gradients (relative error ~1e-5) at 2.4x the loop rate.
+template <int KT, int KSPLIT, int DEPTH, bool DIV, bool BF>
 __global__ void __launch_bounds__(1024) gemm_tn_kernel(TnArgs a) {
     constexpr int GROUPS = 4 / KSPLIT, NB = DEPTH + 1;
+    constexpr int NE = BF ? 8 : 4;                 // operand elements per lane and stage
+    constexpr int SPS = BF ? 16 : 8;               // samples per stage
     __shared__ f32x4 red[(GROUPS - 1) * 4 * KSPLIT * 4 * 64];     // [writer wave][q][lane], <= 48 KB
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: uniform branches)
     const int nt = wave & 3, ks = (wave >> 2) % KSPLIT, g = wave / (4 * KSPLIT);
-    const int per = a.chunk / GROUPS;                             // multiple of 8
+    const int per = a.chunk / GROUPS;                             // multiple of SPS (the host picks the chunk)
     const int ws0 = blockIdx.x * a.chunk + g * per;
     const int ws1 = ws0 + per < a.m ? ws0 + per : a.m;
     const bool rows = 32 * nt < a.Nout && 32 * ks * KT < a.Kin;   // (wave-uniform) this wave's tiles exist
@@ -227,52 +256,70 @@ __global__ void __launch_bounds__(1024) gemm_tn_kernel(TnArgs a) {
 
     if (rows && ws0 < ws1) {
         // addresses = wave-uniform base + 32-bit byte offset (lane constant + uniform row term): one v_add per load
+        // element e of a stage is sample  (fp32) 2e + h  /  (BF) 8h + e  of the stage: the lane-half term rides in the lane
+        // constant, the element term in NE uniform base pointers
+        constexpr int HS = BF ? 8 : 1, ES = BF ? 1 : 2;            // row strides of the lane half and of the element index
         const char* Gw = reinterpret_cast<const char*>(a.G + (size_t)ws0 * a.ldg);
         const char* Xw = reinterpret_cast<const char*>(a.X + (DIV ? (size_t)0 : (size_t)ws0 * a.ldx));
-        const unsigned g_lane = 4u * (unsigned)(h * a.ldg + gcol), g_row = 4u * (unsigned)a.ldg;
-        const unsigned x_row = 4u * (unsigned)a.ldx;
+        const unsigned g_row = 4u * (unsigned)a.ldg, x_row = 4u * (unsigned)a.ldx;
+        const unsigned g_lane = 4u * (unsigned)(HS * h * a.ldg + gcol);
         unsigned x_lane[KT];
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) x_lane[kt] = 4u * (unsigned)((DIV ? 0 : h * a.ldx) + xcol[kt]);
+        for (int kt = 0; kt < KT; ++kt) x_lane[kt] = 4u * (unsigned)((DIV ? 0 : HS * h * a.ldx) + xcol[kt]);
         auto ldf = [](const char* base, unsigned off) { return *reinterpret_cast<const float*>(base + off); };
-        // stage `it` = samples ws0 + 8 it .. + 7: k-step u contracts samples 8 it + 2u + h
-        // (the k-step term rides in four uniform base pointers, so the per-lane offsets are 1 + KT registers)
-        const char *Gu[4], *Xu[4];
+        const char *Gu[NE], *Xu[NE];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { Gu[u] = Gw + (size_t)(2 * u) * g_row; Xu[u] = Xw + (DIV ? (size_t)0 : (size_t)(2 * u) * x_row); }
-        auto load = [&](int it, TnStage<KT>& st) {
-            const unsigned go = g_lane + (unsigned)(8 * it) * g_row;
+        for (int e = 0; e < NE; ++e) { Gu[e] = Gw + (size_t)(ES * e) * g_row; Xu[e] = Xw + (DIV ? (size_t)0 : (size_t)(ES * e) * x_row); }
+        auto load = [&](int it, TnStage<KT, NE>& st) {
+            const unsigned go = g_lane + (unsigned)(SPS * it) * g_row;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                st.g[u] = ldf(Gu[u], go);
-                const unsigned xo = DIV ? (unsigned)((ws0 + 8 * it + 2 * u + h) / a.xdiv) * x_row : (unsigned)(8 * it) * x_row;
+            for (int e = 0; e < NE; ++e) {
+                st.g[e] = ldf(Gu[e], go);
+                const unsigned xo = DIV ? (unsigned)((ws0 + SPS * it + ES * e + HS * h) / a.xdiv) * x_row : (unsigned)(SPS * it) * x_row;
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) st.x[u][kt] = ldf(Xu[u], x_lane[kt] + xo);
+                for (int kt = 0; kt < KT; ++kt) st.x[e][kt] = ldf(Xu[e], x_lane[kt] + xo);
             }
         };
-        auto load_tail = [&](int it, TnStage<KT>& st) {          // ragged last stage: clamped row, zeroed G
+        auto load_tail = [&](int it, TnStage<KT, NE>& st) {      // ragged last stage: clamped row, zeroed operands
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int sl = 8 * it + 2 * u + h;
+            for (int e = 0; e < NE; ++e) {
+                const int sl = SPS * it + ES * e + HS * h;
                 const bool ok = ws0 + sl < ws1;
                 const int sc = ok ? sl : ws1 - 1 - ws0;
                 const float gv = ldf(Gw, 4u * (unsigned)gcol + (unsigned)sc * g_row);
-                st.g[u] = ok ? gv : 0.f;
+                st.g[e] = ok ? gv : 0.f;
                 const unsigned xo = (DIV ? (unsigned)((ws0 + sc) / a.xdiv) : (unsigned)sc) * x_row;
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) { const float xv = ldf(Xw, 4u * (unsigned)xcol[kt] + xo); st.x[u][kt] = ok ? xv : 0.f; }
+                for (int kt = 0; kt < KT; ++kt) { const float xv = ldf(Xw, 4u * (unsigned)xcol[kt] + xo); st.x[e][kt] = ok ? xv : 0.f; }
             }
         };
-        auto mma = [&](const TnStage<KT>& st) {
+        auto mma = [&](const TnStage<KT, NE>& st) {
+            if constexpr (BF) {
+                float gv[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                colsum += st.g[u];
+                for (int e = 0; e < 8; ++e) { gv[e] = st.g[e]; colsum += st.g[e]; }
+                const TnFrag gf = tn_split8(gv);
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) acc[kt] = MFMA(st.g[u], st.x[u][kt], acc[kt]);
+                for (int kt = 0; kt < KT; ++kt) {
+                    float xv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv[e] = st.x[e][kt];
+                    const TnFrag xf = tn_split8(xv);
+                    acc[kt] = MFMA16(gf.hi, xf.hi, acc[kt]);
+                    acc[kt] = MFMA16(gf.hi, xf.lo, acc[kt]);
+                    acc[kt] = MFMA16(gf.lo, xf.hi, acc[kt]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    colsum += st.g[u];
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) acc[kt] = MFMA(st.g[u], st.x[u][kt], acc[kt]);
+                }
             }
         };
-        const int n_full = (ws1 - ws0) >> 3;
-        TnStage<KT> sb[NB];                                      // register ring (indices are compile-time after unrolling)
+        const int n_full = (ws1 - ws0) / SPS;
+        TnStage<KT, NE> sb[NB];                                  // register ring (indices are compile-time after unrolling)
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
             if (d < n_full) load(d, sb[d]);
@@ -288,7 +335,7 @@ __global__ void __launch_bounds__(1024) gemm_tn_kernel(TnArgs a) {
                     mma(sb[b]);
                 }
         }
-        if ((ws1 - ws0) & 7) { load_tail(n_full, sb[0]); mma(sb[0]); }
+        if ((ws1 - ws0) % SPS) { load_tail(n_full, sb[0]); mma(sb[0]); }
     }
 
     // sum the sample groups: one column tile at a time through LDS, group 0 keeps the total
@@ -575,7 +622,7 @@ static int run_tn(hipStream_t st, int m, const float* G, int ldg, int Nout, cons
                   int ldw, float* gb, float* gW_hi = nullptr, float* gb_hi = nullptr) {
     // samples per block: about one block per CU for a training batch (~1e5 samples), so that the float atomics of the
     // merge stay a small part of the launch; larger batches get proportionally larger chunks
-    int chunk = 32 * cdiv(cdiv(m, device_cus()), 32);
+    int chunk = 64 * cdiv(cdiv(m, device_cus()), 64);           // (a multiple of 64: every sample group is whole 16-sample stages)
     if (chunk < 512) chunk = 512;
     if (chunk > 8192) chunk = 8192;
     for (int k0 = 0; k0 < Kin; k0 += 128) {               // at most 4 accumulator tiles per launch
@@ -584,12 +631,13 @@ static int run_tn(hipStream_t st, int m, const float* G, int ldg, int Nout, cons
                  gW_hi ? gW_hi + k0 : nullptr, k0 == 0 ? gb_hi : nullptr};
         dim3 grid(cdiv(m, chunk)), block(1024);
         const int kt = cdiv(kin, 32);
+        constexpr bool BF = UCNERF_TN_BF16X3 != 0;
         if (xdiv != 1) {
             if (kt != 1) return fail(UCNERF_EINVAL, "mlp_bwd: gemm_tn with shared rows is built for <= 32 columns");
-            hipLaunchKernelGGL((gemm_tn_kernel<1, 1, 2, true>), grid, block, 0, st, a);
-        } else if (kt == 1) hipLaunchKernelGGL((gemm_tn_kernel<1, 1, UCNERF_TN_DEPTH2, false>), grid, block, 0, st, a);
-        else if (kt == 2) hipLaunchKernelGGL((gemm_tn_kernel<2, 1, UCNERF_TN_DEPTH2, false>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, UCNERF_TN_DEPTH2, false>), grid, block, 0, st, a);     // 3 or 4 column tiles: two waves per row tile
+            hipLaunchKernelGGL((gemm_tn_kernel<1, 1, 2, true, false>), grid, block, 0, st, a);
+        } else if (kt == 1) hipLaunchKernelGGL((gemm_tn_kernel<1, 1, BF ? 1 : UCNERF_TN_DEPTH2, false, BF>), grid, block, 0, st, a);
+        else if (kt == 2) hipLaunchKernelGGL((gemm_tn_kernel<2, 1, BF ? 1 : UCNERF_TN_DEPTH2, false, BF>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, BF ? 1 : UCNERF_TN_DEPTH2, false, BF>), grid, block, 0, st, a);     // 3 or 4 column tiles: two waves per row tile
         int rc = check_launch("mlp_bwd gemm_tn");
         if (rc) return rc;
     }
