@@ -274,10 +274,19 @@ __global__ void __launch_bounds__(1024) gemm_tn_kernel(TnArgs a) {
             const unsigned go = g_lane + (unsigned)(SPS * it) * g_row;
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
+#if UCNERF_TN_EXP == 4              // (timing experiment: no G loads)
+                st.g[e] = __builtin_bit_cast(float, go);
+#else
                 st.g[e] = ldf(Gu[e], go);
+#endif
                 const unsigned xo = DIV ? (unsigned)((ws0 + SPS * it + ES * e + HS * h) / a.xdiv) * x_row : (unsigned)(SPS * it) * x_row;
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) st.x[e][kt] = ldf(Xu[e], x_lane[kt] + xo);
+                for (int kt = 0; kt < KT; ++kt)
+#if UCNERF_TN_EXP == 5              // (timing experiment: no X loads)
+                    st.x[e][kt] = __builtin_bit_cast(float, xo + kt);
+#else
+                    st.x[e][kt] = ldf(Xu[e], x_lane[kt] + xo);
+#endif
             }
         };
         auto load_tail = [&](int it, TnStage<KT, NE>& st) {      // ragged last stage: clamped row, zeroed operands
