@@ -21,9 +21,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef UCNERF_MLP_WAVES
 #define UCNERF_MLP_WAVES 8
 #endif
-#ifndef UCNERF_FEAT_AUX
-#define UCNERF_FEAT_AUX 2          // cache-policy bits of the feature loads: nt (streaming; every feature is read once, -0.4 % per f32 step)
-#endif
+// cache policy of the feature loads: nt (streaming) for the tiled layout, where every 128-byte line is consumed by one load
+// (-0.4 % per f32 step); the row-major layout (training) reads its lines four bytes at a time and needs them cached
+// (nt there: 391 -> 481 us)
+constexpr int FEAT_AUX_TILED = 2, FEAT_AUX_ROWS = 0;
 constexpr int MLP_WAVES = UCNERF_MLP_WAVES;   // waves per block: 8 = two per SIMD (waves w and w+4 share one)
 
 // ------------------------------------------------------------------------------------------------
@@ -183,8 +184,9 @@ struct FeatSrc {
     int voff;
 };
 
+template <bool TILED>
 __device__ __forceinline__ float load_feat(const FeatSrc& F, int soff_bytes) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(F.rs, F.voff, soff_bytes, UCNERF_FEAT_AUX));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(F.rs, F.voff, soff_bytes, TILED ? FEAT_AUX_TILED : FEAT_AUX_ROWS));
 }
 
 // accumulators <- bias block of section `sec` (LDS copy of the constants)
@@ -234,9 +236,10 @@ __device__ __forceinline__ void gemm_stash(Stream& S, const float* stash, int la
 // refill: they are streamed, never cached) and early, so the latency hides under VALU work issued in between.
 constexpr int KS_FEAT_MAX = 32;       // k-steps of a bias net at most: (24 + 4*8)/2 = 28, 8*8/2 = 32
 
+template <bool TILED>
 __device__ __forceinline__ void load_section_feats(const FeatSrc& F, int first, int step, int ks, float (&b)[KS_FEAT_MAX]) {
 #pragma unroll
-    for (int t = 0; t < KS_FEAT_MAX; ++t) b[t] = t < ks ? load_feat(F, first + t * step) : 0.f;
+    for (int t = 0; t < KS_FEAT_MAX; ++t) b[t] = t < ks ? load_feat<TILED>(F, first + t * step) : 0.f;
 }
 
 // ks (runtime, multiple of RING, <= KS_FEAT_MAX) k-steps on prefetched feature operands
@@ -410,8 +413,8 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         float pn[3] = {0.f, 0.f, 0.f};
 
         // ---- (1) all operands of the depth-bias net + the confidence, in flight before any arithmetic
-        load_section_feats(FS, h * fstride * 4, 2 * fstride * 4, kd, fsec);
-        const float conf = load_feat(FS, (g.F - 1) * fstride * 4);
+        load_section_feats<TILED>(FS, h * fstride * 4, 2 * fstride * 4, kd, fsec);
+        const float conf = load_feat<TILED>(FS, (g.F - 1) * fstride * 4);
         const size_t ray = p.dirs_per_sample ? (size_t)s : (size_t)(s / p.S);
 
         // ---- (2) point encoding (from registers), stashed in LDS for the skip connection
@@ -462,7 +465,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         DIAG_STAMP(6)
         EPILOGUE_RELU_MOD(hin, acc, bd)
         // operands of the confidence-bias net: issued now (b_d's registers are free), they land during the base heads
-        load_section_feats(FS, (g.f_img + h) * fstride * 4, 2 * fstride * 4, kc, fsec);
+        load_section_feats<TILED>(FS, (g.f_img + h) * fstride * 4, 2 * fstride * 4, kc, fsec);
         if (SAVE) save_rows(sv.h[5], s, h, valid, hin);
 
         // ---- base heads: confi_rgb_linear, alpha_linear_1                       (models.py:161-162)

@@ -481,8 +481,10 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int c = 16 * q + e;                  // feature c + 8h
-                // (streaming loads: every feature is read exactly once; kept out of the L2 they leave the gather's sources there)
-                nfs[q][e] = q >= kd16 ? 0.f : (NSRC && c + 8 < F) ? __builtin_nontemporal_load(&fh[c * fstride]) : __builtin_nontemporal_load(&fb[(size_t)min(c + 8 * h, F - 1) * fstride]);
+                // (tiled layout: streaming loads -- every 128-byte line is consumed by one load; kept out of the L2 they leave the
+                //  gather's sources there.  Row-major rows are read four bytes at a time and need the cache.)
+                const float* src_ = (NSRC && c + 8 < F) ? &fh[c * fstride] : &fb[(size_t)min(c + 8 * h, F - 1) * fstride];
+                nfs[q][e] = q >= kd16 ? 0.f : TILED ? __builtin_nontemporal_load(src_) : *src_;
             }
         nconf = fb[(size_t)(F - 1) * fstride];
         const float* prow = p.pts + (size_t)s * 3;
@@ -624,7 +626,8 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                            _Pragma("unroll")
                            for (int e = 0; e < 8; ++e) {
                                const int c = f_img + 16 * qq + e;
-                               fsec[qq][e] = qq >= kc16 ? 0.f : (NSRC && c + 8 < F) ? __builtin_nontemporal_load(&fhb[c * fstride]) : __builtin_nontemporal_load(&fb[(size_t)min(c + 8 * h, F - 1) * fstride]);
+                               const float* src_ = (NSRC && c + 8 < F) ? &fhb[c * fstride] : &fb[(size_t)min(c + 8 * h, F - 1) * fstride];
+                               fsec[qq][e] = qq >= kc16 ? 0.f : TILED ? __builtin_nontemporal_load(src_) : *src_;
                            }
                        int ray = s_here;
                        if (!p.dirs_per_sample) { int S = p.S; asm volatile("" : "+s"(S)); ray = s_here / S; }   // (opaque: no reciprocal hoisted into a loop-long VGPR)
