@@ -45,11 +45,14 @@ __device__ float aten_row_sum(int n, Item item) {
     return acc[0][0];
 }
 
+// MAXB / MAXS size the per-ray LDS arrays: the common shapes (<= 128 bins, <= 512 merged depths) take 3.5 KB per ray, so
+// that a CU holds 32 rays at once; with the full-size arrays (20 KB) it holds 8 and 4096 rays need two rounds.
+template <int MAXB, int MAXS>
 __global__ void __launch_bounds__(64) sample_pdf_kernel(ucnerf_sample_pdf_params p) {
-    __shared__ float w[PDF_MAX_BINS];       // weights + 1e-5, then pdf
-    __shared__ float cdf[PDF_MAX_BINS];
-    __shared__ float srt[PDF_MAX_SORT];
-    __shared__ float bins[PDF_MAX_BINS];
+    __shared__ float w[MAXB];               // weights + 1e-5, then pdf
+    __shared__ float cdf[MAXB];
+    __shared__ float srt[MAXS];
+    __shared__ float bins[MAXB];
     __shared__ float lane_part[8];
     __shared__ float total;
     const int ray = blockIdx.x, lane = threadIdx.x;
@@ -223,7 +226,10 @@ extern "C" int ucnerf_sample_pdf(const ucnerf_sample_pdf_params* p, void* stream
     UCNERF_REQUIRE(p->samples || p->inds || p->cdf || p->z_sorted, "sample_pdf: no outputs requested");
     UCNERF_REQUIRE(!p->merge_rank || p->z_sorted, "sample_pdf: merge_rank needs z_sorted");
     if (p->n <= 0) return UCNERF_OK;
-    hipLaunchKernelGGL(sample_pdf_kernel, dim3(p->n), dim3(64), 0, (hipStream_t)stream, *p);
+    if (p->n_bins <= 128 && p->n_merge + p->n_samples <= 512)
+        hipLaunchKernelGGL((sample_pdf_kernel<128, 512>), dim3(p->n), dim3(64), 0, (hipStream_t)stream, *p);
+    else
+        hipLaunchKernelGGL((sample_pdf_kernel<PDF_MAX_BINS, PDF_MAX_SORT>), dim3(p->n), dim3(64), 0, (hipStream_t)stream, *p);
     return check_launch("sample_pdf");
 }
 
