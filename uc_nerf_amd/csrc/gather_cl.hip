@@ -8,6 +8,10 @@
 // 4-byte reads.  Semantics are those of gather.hip (grid_sample restated; reference lines cited there).
 #include "common.h"
 
+#ifndef UCNERF_GATHER_EXP
+#define UCNERF_GATHER_EXP 0     // timing experiments (wrong results), bit mask: 1 no stores, 2 all source loads within 32 KB, 4 no source loads
+#endif
+
 namespace ucnerf {
 
 // ------------------------------------------------------------------------------------------------ repack
@@ -60,6 +64,7 @@ struct GatherClArgs {
     float* feats;              // tiled [ceil(M/32)][F][32], or row-major [M][F] (tiled = 0: the training forward keeps them)
     int tiled;
     float* ndc;                // [M,3] (x, y, scene-normalised z) for the MLP's positional encoding, or NULL
+    unsigned M, div_m, div_sh; // n * S; idx / S = umulhi(idx, div_m) >> div_sh for idx < 2^31 (S >= 2)
 };
 
 __device__ __forceinline__ float unnorm_cl(float g, int size, bool align) {
@@ -91,22 +96,52 @@ __device__ __forceinline__ void project_cl(const float* M, const float* K, float
     *qz = cx * K[6] + cy * K[7] + cz * K[8];
 }
 
-#define ACC8(V0, V1, WT)                                                                         \
-    { const float4 a_ = (V0), b_ = (V1); const float w_ = (WT);                                 \
-      o[0] += a_.x * w_; o[1] += a_.y * w_; o[2] += a_.z * w_; o[3] += a_.w * w_;               \
-      o[4] += b_.x * w_; o[5] += b_.y * w_; o[6] += b_.z * w_; o[7] += b_.w * w_; }
+typedef float gf2 __attribute__((ext_vector_type(2)));
+
+// 16 bytes at a 32-bit byte offset from a block-uniform base: the address is one scalar pair + one VGPR (no 64-bit
+// vector arithmetic per corner); every repacked source is far below 4 GB.
+__device__ __forceinline__ float4 ld16(const char* base, unsigned off) {
+#if UCNERF_GATHER_EXP & 2
+    off &= 0x7ff0u;
+#endif
+#if UCNERF_GATHER_EXP & 4
+    const float f_ = __uint_as_float(off | 0x3f000000u);
+    return make_float4(f_, f_, f_, f_);
+#endif
+    return *(const float4*)(base + off);
+}
+
+// o += v * w on four packed pairs (v_pk_fma_f32: the products are not rounded separately -- the reference's own CUDA
+// grid_sample contracts the same way; the parity bar on the features is 2e-5).
+#define FMA4(O, A, WT)                                                                           \
+    { const float4 a_ = (A); const gf2 w_ = {(WT), (WT)};                                        \
+      O[0] = __builtin_elementwise_fma((gf2){a_.x, a_.y}, w_, O[0]);                             \
+      O[1] = __builtin_elementwise_fma((gf2){a_.z, a_.w}, w_, O[1]); }
+
+struct SampleIn { unsigned r; float z, dx, dy, dz; };        // what a sample reads before it can compute anything
+
+__device__ __forceinline__ SampleIn sample_in(const GatherClArgs& a, unsigned idx) {
+    SampleIn s;
+    s.r = a.S == 1 ? idx : (__umulhi(idx, a.div_m) >> a.div_sh);                     // idx / S (host-side magic, idx < 2^31)
+    s.z = a.z[idx];
+    s.dx = a.rays_d[3 * s.r]; s.dy = a.rays_d[3 * s.r + 1]; s.dz = a.rays_d[3 * s.r + 2];
+    return s;
+}
 
 template <bool TILED>
-__device__ __forceinline__ void gather_cl_unit(const GatherClArgs& a, long long idx, int unit) {
+__device__ __forceinline__ void gather_cl_unit(const GatherClArgs& a, unsigned idx, int unit, const SampleIn& in) {
     const int F = 24 + 12 * a.V + 1;
-    const int r = (int)(idx / a.S);
-    const float z = a.z[idx];
-    const float x = a.rays_o[0] + z * a.rays_d[3 * r], y = a.rays_o[1] + z * a.rays_d[3 * r + 1],
-                w = a.rays_o[2] + z * a.rays_d[3 * r + 2];
+    const unsigned r = in.r;
+    const float z = in.z;
+    const float x = a.rays_o[0] + z * in.dx, y = a.rays_o[1] + z * in.dy, w = a.rays_o[2] + z * in.dz;
     constexpr int fs = TILED ? 32 : 1;                                      // feature f at out[f * fs]
     // Tiled rows are full 128-byte lines written once and read once by the MLP: stream them past the L2 so that the sources
     // stay there (-19 us per step).  Row-major rows are completed piecewise by one thread and want the L2.
+#if UCNERF_GATHER_EXP & 1      // timing experiment: loads and arithmetic only (a store no value ever takes)
+#define PUT(IDX, VAL) do { const float v_ = (VAL); if (v_ == 12345.678f) out[(IDX)] = v_; } while (0)
+#else
 #define PUT(IDX, VAL) do { if (TILED) __builtin_nontemporal_store((float)(VAL), &out[(IDX)]); else out[(IDX)] = (VAL); } while (0)
+#endif
     float* out = TILED ? a.feats + ((size_t)(idx >> 5) * F) * 32 + (idx & 31) : a.feats + (size_t)idx * F;
     if (unit < 4) {
         float qx, qy, qz;
@@ -114,7 +149,7 @@ __device__ __forceinline__ void gather_cl_unit(const GatherClArgs& a, long long 
         const float u = (qx / qz + 0.0f) / (float)(a.W - 1), v = (qy / qz + 0.0f) / (float)(a.H - 1);
         if (unit == 3) {
             if (a.ndc) {
-                a.ndc[3 * idx] = u; a.ndc[3 * idx + 1] = v; a.ndc[3 * idx + 2] = (qz - a.near) / (a.far - a.near);
+                a.ndc[3 * (size_t)idx] = u; a.ndc[3 * (size_t)idx + 1] = v; a.ndc[3 * (size_t)idx + 2] = (qz - a.near) / (a.far - a.near);
             }
             const LerpCl ax = axis_cl(u * 2.f - 1.0f, a.W, false), ay = axis_cl(v * 2.f - 1.0f, a.H, false);
             const float* c = a.conf;
@@ -131,61 +166,62 @@ __device__ __forceinline__ void gather_cl_unit(const GatherClArgs& a, long long 
         const int D = a.vol_d[unit], hh = a.vol_h[unit], ww = a.vol_w[unit];
         const LerpCl ax = axis_cl(u * 2.f - 1.0f, ww, false), ay = axis_cl(v * 2.f - 1.0f, hh, false),
                      az = axis_cl(zn * 2.f - 1.0f, D, false);
-        const float4* vol = a.vol[unit];
-        const size_t o00 = ((size_t)az.i0 * hh + ay.i0) * ww, o01 = ((size_t)az.i0 * hh + ay.i1) * ww,
-                     o10 = ((size_t)az.i1 * hh + ay.i0) * ww, o11 = ((size_t)az.i1 * hh + ay.i1) * ww;
+        const char* vol = (const char*)a.vol[unit];
+        // byte offsets of the four (z, y) rows at x0, and the step to x1 (0 at the clamped border)
+        const unsigned o00 = (unsigned)((az.i0 * hh + ay.i0) * ww + ax.i0) * 32u, o01 = (unsigned)((az.i0 * hh + ay.i1) * ww + ax.i0) * 32u,
+                       o10 = (unsigned)((az.i1 * hh + ay.i0) * ww + ax.i0) * 32u, o11 = (unsigned)((az.i1 * hh + ay.i1) * ww + ax.i0) * 32u;
+        const unsigned dx = (unsigned)(ax.i1 - ax.i0) * 32u;
         const float w00 = az.w0 * ay.w0, w01 = az.w0 * ay.w1, w10 = az.w1 * ay.w0, w11 = az.w1 * ay.w1;
-        float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        gf2 lo[2] = {{0, 0}, {0, 0}}, hi[2] = {{0, 0}, {0, 0}};
         // same accumulation order as gather.hip: (z0,y0), (z0,y1), (z1,y0), (z1,y1), x0 before x1
-        ACC8(vol[2 * (o00 + ax.i0)], vol[2 * (o00 + ax.i0) + 1], w00 * ax.w0)
-        ACC8(vol[2 * (o00 + ax.i1)], vol[2 * (o00 + ax.i1) + 1], w00 * ax.w1)
-        ACC8(vol[2 * (o01 + ax.i0)], vol[2 * (o01 + ax.i0) + 1], w01 * ax.w0)
-        ACC8(vol[2 * (o01 + ax.i1)], vol[2 * (o01 + ax.i1) + 1], w01 * ax.w1)
-        ACC8(vol[2 * (o10 + ax.i0)], vol[2 * (o10 + ax.i0) + 1], w10 * ax.w0)
-        ACC8(vol[2 * (o10 + ax.i1)], vol[2 * (o10 + ax.i1) + 1], w10 * ax.w1)
-        ACC8(vol[2 * (o11 + ax.i0)], vol[2 * (o11 + ax.i0) + 1], w11 * ax.w0)
-        ACC8(vol[2 * (o11 + ax.i1)], vol[2 * (o11 + ax.i1) + 1], w11 * ax.w1)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) PUT((8 * unit + c) * fs, o[c]);
+#define CORNER8(O, WT) { const float w__ = (WT); FMA4(lo, ld16(vol, (O)), w__) FMA4(hi, ld16(vol, (O) + 16u), w__) }
+        CORNER8(o00, w00 * ax.w0) CORNER8(o00 + dx, w00 * ax.w1)
+        CORNER8(o01, w01 * ax.w0) CORNER8(o01 + dx, w01 * ax.w1)
+        CORNER8(o10, w10 * ax.w0) CORNER8(o10 + dx, w10 * ax.w1)
+        CORNER8(o11, w11 * ax.w0) CORNER8(o11 + dx, w11 * ax.w1)
+#undef CORNER8
+        PUT((8 * unit + 0) * fs, lo[0].x); PUT((8 * unit + 1) * fs, lo[0].y); PUT((8 * unit + 2) * fs, lo[1].x); PUT((8 * unit + 3) * fs, lo[1].y);
+        PUT((8 * unit + 4) * fs, hi[0].x); PUT((8 * unit + 5) * fs, hi[0].y); PUT((8 * unit + 6) * fs, hi[1].x); PUT((8 * unit + 7) * fs, hi[1].y);
     } else {
         const int vi = unit - 4;
         float qx, qy, qz;
         project_cl(a.w2cs + 12 * vi, a.Ks + 9 * vi, x, y, w, &qx, &qy, &qz);
         const float gx = (qx / qz + 0.0f) / (float)(a.W - 1) * 2.0f - 1.0f, gy = (qy / qz + 0.0f) / (float)(a.H - 1) * 2.0f - 1.0f;
         const LerpCl ax = axis_cl(gx, a.W, true), ay = axis_cl(gy, a.H, true);
-        const float4* img = a.img + (size_t)vi * a.H * a.W * 3;
-        const size_t p00 = ((size_t)ay.i0 * a.W + ax.i0) * 3, p01 = ((size_t)ay.i0 * a.W + ax.i1) * 3,
-                     p10 = ((size_t)ay.i1 * a.W + ax.i0) * 3, p11 = ((size_t)ay.i1 * a.W + ax.i1) * 3;
+        const char* img = (const char*)(a.img + (size_t)vi * a.H * a.W * 3);
+        const unsigned p00 = (unsigned)(ay.i0 * a.W + ax.i0) * 48u, p10 = (unsigned)(ay.i1 * a.W + ax.i0) * 48u;
+        const unsigned dx = (unsigned)(ax.i1 - ax.i0) * 48u;
         const float w00 = ay.w0 * ax.w0, w01 = ay.w0 * ax.w1, w10 = ay.w1 * ax.w0, w11 = ay.w1 * ax.w1;
-        float o[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define ACC12(P, WT)                                                                              \
-        { const float4 a_ = img[(P)], b_ = img[(P) + 1], c_ = img[(P) + 2]; const float w_ = (WT);  \
-          o[0] += a_.x * w_; o[1] += a_.y * w_; o[2] += a_.z * w_; o[3] += a_.w * w_;                \
-          o[4] += b_.x * w_; o[5] += b_.y * w_; o[6] += b_.z * w_; o[7] += b_.w * w_;                \
-          o[8] += c_.x * w_; o[9] += c_.y * w_; o[10] += c_.z * w_; }
-        ACC12(p00, w00) ACC12(p01, w01) ACC12(p10, w10) ACC12(p11, w11)
-#undef ACC12
-        PUT((24 + 4 * vi) * fs, o[0]);
-        PUT((24 + 4 * vi + 1) * fs, o[1]);
-        PUT((24 + 4 * vi + 2) * fs, o[2]);
+        gf2 c0[2] = {{0, 0}, {0, 0}}, c1[2] = {{0, 0}, {0, 0}}, c2[2] = {{0, 0}, {0, 0}};      // (r g b f0) (f1..f4) (f5 f6 f7 -)
+#define CORNER12(P, WT) { const float w__ = (WT); FMA4(c0, ld16(img, (P)), w__) FMA4(c1, ld16(img, (P) + 16u), w__) FMA4(c2, ld16(img, (P) + 32u), w__) }
+        CORNER12(p00, w00) CORNER12(p00 + dx, w01) CORNER12(p10, w10) CORNER12(p10 + dx, w11)
+#undef CORNER12
+        PUT((24 + 4 * vi) * fs, c0[0].x);
+        PUT((24 + 4 * vi + 1) * fs, c0[0].y);
+        PUT((24 + 4 * vi + 2) * fs, c0[1].x);
         PUT((24 + 4 * vi + 3) * fs, (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.f : 0.f);
+        const float f8[8] = {c0[1].y, c1[0].x, c1[0].y, c1[1].x, c1[1].y, c2[0].x, c2[0].y, c2[1].x};
 #pragma unroll
-        for (int c = 0; c < 8; ++c) PUT((24 + 4 * a.V + 8 * vi + c) * fs, o[3 + c]);
-#undef PUT
+        for (int c = 0; c < 8; ++c) PUT((24 + 4 * a.V + 8 * vi + c) * fs, f8[c]);
     }
+#undef PUT
 }
 
 // Tiled output (the inference path): grid.y = unit, every (tile, feature) row is one full 128-byte line whoever writes it.
 // Row-major output (the training forward keeps the features): a sample's 388-byte row shares cache lines with its
 // neighbours', and units running as separate sweeps leave every line partially written when it is evicted (measured:
 // 142 MB of HBM writes for 51 MB of features) -- there one thread walks all units so that the row completes in L2.
+#ifndef UCNERF_GATHER_WAVES
+#define UCNERF_GATHER_WAVES 1     // min waves per SIMD asked of the compiler (8 = 64 VGPRs: measured no faster than the 7 it gets by itself)
+#endif
 template <bool TILED>
-__global__ void __launch_bounds__(256) feat_gather_cl_kernel(GatherClArgs a) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)a.n * a.S) return;
-    if (TILED) gather_cl_unit<true>(a, idx, blockIdx.y);
+__global__ void __launch_bounds__(256, TILED ? UCNERF_GATHER_WAVES : 1) feat_gather_cl_kernel(GatherClArgs a) {
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= a.M) return;
+    const SampleIn in = sample_in(a, idx);
+    if (TILED) gather_cl_unit<true>(a, idx, blockIdx.y, in);
     else
-        for (int unit = 0; unit < 4 + a.V; ++unit) gather_cl_unit<false>(a, idx, unit);
+        for (int unit = 0; unit < 4 + a.V; ++unit) gather_cl_unit<false>(a, idx, unit, in);
 }
 
 }  // namespace ucnerf
@@ -244,6 +280,14 @@ int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float
     a.feats = feats; a.tiled = tiled; a.ndc = ndc;
     UCNERF_REQUIRE(a.V >= 1 && a.V <= 8, "gather_cl: V = %d outside 1..8", a.V);
     const long long M = (long long)p->n * p->S;
+    UCNERF_REQUIRE(M < (1ll << 31), "gather_cl: %lld samples in one pass (limit 2^31 - 1)", M);
+    a.M = (unsigned)M;
+    {   // magic for idx / S: l = ceil(log2 S), m = ceil(2^(31+l) / S) < 2^32, exact for idx < 2^31
+        unsigned l = 1;
+        while ((1u << l) < (unsigned)p->S) ++l;
+        a.div_m = (unsigned)((((unsigned long long)1 << (31 + l)) + (unsigned)p->S - 1) / (unsigned)p->S);
+        a.div_sh = l - 1;
+    }
     if (tiled) hipLaunchKernelGGL(feat_gather_cl_kernel<true>, dim3(cdiv(M, 256), 4 + a.V), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(feat_gather_cl_kernel<false>, dim3(cdiv(M, 256), 1), dim3(256), 0, st, a);
     return check_launch("feat_gather_cl");
