@@ -43,7 +43,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef UCNERF_BF16_EXP
-#define UCNERF_BF16_EXP 0      // timing experiments only (results are wrong): 1 no DMA wait, 2 no barrier, 4 no DMA, 64 no interleave hints, 128 no epilogue arithmetic, 256 half the LDS fragment reads
+#define UCNERF_BF16_EXP 0      // timing experiments only (results are wrong): 1 no DMA wait, 2 no barrier, 4 no DMA, 64 no interleave hints, 128 no epilogue arithmetic, 256 half the LDS fragment reads, 512 no point-encoding arithmetic
 #endif
 #ifndef UCNERF_BF16_HINT_V
 #define UCNERF_BF16_HINT_V 7   // VALU instructions the scheduler may place after each MFMA of a half-step
@@ -520,7 +520,12 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         {
             const float px[3] = {npx[0], npx[1], npx[2]};
             float pe[KS_PE_PTS];
+#if UCNERF_BF16_EXP & 512       // timing experiment: no point encoding arithmetic (wrong results) -- what moving it out of the kernel could buy
+#pragma unroll
+            for (int e = 0; e < KS_PE_PTS; ++e) pe[e] = px[e % 3];
+#else
             encode16<10, KS_PE_PTS>(px, h, pe);
+#endif
 #ifdef UCNERF_MLP_DIAG
             pin(pe[0]); pin(pe[14]); pin(pe[29]);
             DIAG_STAMP(14)
@@ -530,7 +535,18 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                 float t[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t[e] = pe[8 * q + e];
+#if UCNERF_BF16_EXP & 512
+                u32x4 uh_, ul_;                                               // finite bf16 pairs at one instruction each
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    uh_[e] = (__builtin_bit_cast(unsigned, t[e]) & 0x007f007fu) | 0x3c003c00u;
+                    ul_[e] = (__builtin_bit_cast(unsigned, t[4 + e]) & 0x007f007fu) | 0x38003800u;
+                }
+                Frag f_; f_.hi = __builtin_bit_cast(bf16x8, uh_); f_.lo = __builtin_bit_cast(bf16x8, ul_);
+                stash[q * 64] = f_;
+#else
                 stash[q * 64] = split8(t);
+#endif
             }
         }
         DIAG_STAMP(1)
