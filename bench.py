@@ -241,15 +241,20 @@ def main():
                        "max_abs_rgb": (out["rgb"] - ref["rgb"]).abs().max().item(),
                        "max_abs_depth": (out["depth"] - ref["depth"]).abs().max().item()}
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_mlp_bf16_hbm_traffic.json" if bf16 else "r01_mlp_fwd_hbm_traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            traffic = json.load(f).get("bytes_per_launch")
+    # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, scripts/pmc_mlp.sh), which
+    # cannot run inside this process: the figure is READ BACK from the committed profile and labelled as such
+    traffic, traffic_source = None, None
+    for name in (("r02_mlp_bf16_hbm_traffic.json", "r01_mlp_bf16_hbm_traffic.json") if bf16 else ("r02_mlp_fwd_hbm_traffic.json", "r01_mlp_fwd_hbm_traffic.json")):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("bytes_per_launch")
+            traffic_source = "profiles/%s (rocprofv3 PMC passes of this command on an earlier box; not measured in this run)" % name
+            break
 
     if rank == 0:
         roof = {"bound": "mfma", "kernel": "mlp_fwd_bf16_kernel" if bf16 else "mlp_fwd_kernel", "achieved": achieved,
-                "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": mlp_ms / launches, "flop_per_launch_avg": samples_per_step * FLOP_PER_SAMPLE / 2}
         if bf16:
             # achieved / frac count ALGORITHMIC flops (one multiply-accumulate per weight and sample) against the dense bf16

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UCNERF_ABI_VERSION 1
+#define UCNERF_ABI_VERSION 2
 
 #define UCNERF_OK 0
 #define UCNERF_EINVAL (-1)   /* bad argument (null pointer, unsupported size/config) */
@@ -184,6 +184,8 @@ typedef struct {
     const float* w2cs;         /* [V,12] rows 0..2 of each 4x4 */
     const float* intrinsics;   /* [V,9] */
     float* feats;              /* out */
+    float* u_out;              /* optional [m] out: the per-sample uncertainty u = 1 - (sampled confidence) that the MLP
+                                  blends its two heads with (network/models.py:149); written by the confidence unit */
 } ucnerf_feat_gather_params;
 int ucnerf_feat_gather_fwd(const ucnerf_feat_gather_params* p, void* stream);
 
@@ -299,6 +301,9 @@ typedef struct {
     float* disp_map;       /* [n] or NULL */
     float* weights;        /* [n,S] or NULL */
     float* var;            /* [n] unbiased variance of the weights, or NULL (variant 0 only) */
+    const float* u;        /* optional [n,S] per-sample uncertainty (ucnerf_feat_gather_params.u_out) ... */
+    float* wu;             /* ... and [n] out: sum_i w_i u_i, the composited uncertainty of the ray (a build extra: the
+                              reference keeps u per sample only, network/models.py:149,177-178) */
 } ucnerf_composite_params;
 int ucnerf_composite_fwd(const ucnerf_composite_params* p, void* stream);
 
@@ -454,6 +459,17 @@ typedef struct {
                                   ucnerf_render_bwd_params.saved_valid */
     const float* dir_feat;     /* optional [n,3]: the view-direction feature already computed (ucnerf_ray_gen.angle or
                                   ucnerf_dir_feature with w2c_dir); NULL: the pass computes it itself */
+    /* opt-in uncertainty outputs (SURVEY.md 8(a) note): */
+    float* u_sampled;          /* [n,S] or NULL: u = 1 - confidence sampled at every depth (network/models.py:149) */
+    float* wu_map;             /* [n] or NULL: sum_i w_i u_i */
+    /* Coordinates GIVEN by the caller instead of derived from (rays_d, z): what rendering() of the reference receives
+     * from build_rays / build_rays_test (network/renderer.py:215-255: rays_pts, rays_ndc).  All five or none; when set,
+     * rays_o / rays_d / z are used for the view direction and the compositing only and near_far is ignored. */
+    const float* pts_in;       /* [n*S,3] world points */
+    const float* ndc1_in;      /* [n*S,3] stage coordinates in ~[0,1] */
+    const float* ndc2_in;
+    const float* ndc3_in;
+    const float* ndc_in;       /* [n*S,3] scene-normalised copy fed to the positional encoding */
 } ucnerf_render_params;
 int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream);

@@ -564,8 +564,11 @@ def rendering(p, pose_ref, rays_pts, rays_ndc, depth_candidates, rays_dir, vols,
     raw = run_network_mvs(p, rays_ndc["ndc"], angle, feats, n_src=imgs.shape[1], **mlp_kw)
     rgb_map, disp, acc, w, depth_map, _, var = raw2outputs_live(raw, depth_candidates, white_bkgd)
     if full:
+        # opt-in uncertainty outputs (SURVEY.md 8(a) note): u = 1 - sampled confidence is what the network blends its
+        # heads with (network/models.py:149,177-178); its composite sum_i w_i u_i is a build extra (no reference line)
+        u = 1 - feats[..., -1]
         return dict(rgb=rgb_map, depth=depth_map, acc=acc, weights=w, var=var, disp=disp, raw=raw, feats=feats,
-                    u_sampled=1 - feats[..., -1])
+                    u_sampled=u, wu=(w * u).sum(-1))
     return rgb_map, depth_map
 
 

@@ -418,6 +418,128 @@ def g11():
          f_weights=f_w, c_sigma=c_raw[..., 3], sigma_head_scale=0.05, sigma_head_bias=0.05)
 
 
+# ------------------------------------------------------------------ G16 rendering() in the Hamlyn configuration (V = 4)
+def recompose_rendering(a, pose, pts, ndc, z, rays_d, volume_feature, imgs, net, img_feat, conf, qfn):
+    """The body of rendering() (network/renderer.py:232-252) step by step, to capture what it discards: features,
+    raw network output, weights, acc, var and the per-sample uncertainty u = 1 - confidence (network/models.py:149).
+    Checked bit for bit against rendering() itself by the callers."""
+    cos_angle = torch.norm(rays_d, dim=-1)
+    angle = ref.renderer.gen_dir_feature(pose["w2cs"][0], rays_d / cos_angle.unsqueeze(-1))
+    src = {"w2cs": pose["w2cs"][1:], "intrinsics": pose["intrinsics"][1:]}
+    feats = ref.renderer.gen_pts_feats(imgs, volume_feature, pts, src, ndc, a.feat_dim, img_feat, confidence=conf)
+    raw = qfn(ndc["ndc"], angle, feats, net)
+    rgb_map, disp, acc, w, depth, _, var = ref.renderer.raw2outputs(raw, z, None, False, "v2")
+    u = 1 - feats[..., -1]
+    return dict(feats=feats, raw=raw, rgb=rgb_map, depth=depth, acc=acc, weights=w, var=var, u=u, wu=(w * u).sum(-1))
+
+
+def g16():
+    """configs[3] (Hamlyn, 3 source views -> view_num 4, feat_dim 61, data/hamlyn.py:208): rendering() first and second
+    call, everything its body computes, and the gradients autograd sends into the network and the gather sources.  The
+    stage coordinates carry per-ray cascade ranges (as build_rays produces them), the target camera differs from the
+    reference view."""
+    g = torch.Generator().manual_seed(116)
+    V, H, W = 4, 32, 40
+    vols, imgs, img_feat, conf, K, w2cs = tiny_scene(g, V, H, W)
+    net = make_net(V)
+    with torch.no_grad():      # non-trivial weights along the ray
+        net.nerf.alpha_linear.weight.mul_(0.1); net.nerf.alpha_linear_1.weight.mul_(0.1)
+        net.nerf.alpha_linear.bias.add_(0.05); net.nerf.alpha_linear_1.bias.add_(0.05)
+    e_p, _ = ref.models.get_embedder(10, 0)
+    e_d, _ = ref.models.get_embedder(4, 0)
+    qfn = lambda pts, vd, f, fn: ref.renderer.run_network_mvs(pts, vd, f, fn, embed_fn=e_p, embeddirs_fn=e_d, netchunk=16)
+    N, S = 40, 18
+    c2w = rand_pose(g, 0.05)
+    xs, ys = torch.randint(0, W, (N,), generator=g).float(), torch.randint(0, H, (N,), generator=g).float()
+    dirs = torch.stack([(xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1], torch.ones_like(xs)], -1)
+    rays_d = dirs @ c2w[:3, :3].T
+    z = torch.sort(1.0 + 3.0 * torch.rand(N, S, generator=g), -1)[0]
+    pts = c2w[:3, 3].reshape(1, 1, 3) + rays_d[:, None] * z[..., None]
+    inv_scale = torch.tensor([W - 1, H - 1])
+    lo = 0.8 + 0.4 * torch.rand(N, 3, generator=g)
+    ranges = torch.stack([lo[:, 0], lo[:, 0] + 3.0, lo[:, 1], lo[:, 1] + 2.5, lo[:, 2], lo[:, 2] + 3.5], -1)     # [N,6]
+    nf = {}
+    for i, k in enumerate(("near_1", "far_1", "near_2", "far_2", "near_3", "far_3")):
+        nf[k] = ranges[:, i].reshape(N, 1, 1).expand(N, S, 1)
+    nf["near"], nf["far"] = torch.tensor(1.0), torch.tensor(4.0)
+    ndc = ref.utils.get_ndc_coordinate(w2cs[0], K, pts.clone(), inv_scale, nf)
+    for v in vols + [img_feat, conf]:
+        v.requires_grad_(True)
+    volume_feature = {"stage%d" % (i + 1): {"volume_feature_no_ref": vols[i]} for i in range(3)}
+    a = mk_args(V)
+    pose = {"w2cs": w2cs.clone(), "intrinsics": K.repeat(V, 1, 1)}
+    rgb1, d1 = ref.renderer.rendering(a, pose, pts, ndc, z, rays_d, volume_feature, imgs, network_fn=net, img_feat=img_feat,
+                                      network_query_fn=qfn, confidence=conf)
+    n_after = pose["w2cs"].shape[0]
+    r3, r1 = torch.randn(N, 3, generator=g), torch.randn(N, generator=g)
+    ((rgb1 * r3).sum() + (d1 * r1).sum()).backward()
+    grads = {"g_vol1": vols[0].grad, "g_vol2": vols[1].grad, "g_vol3": vols[2].grad, "g_img_feat": img_feat.grad, "g_conf": conf.grad}
+    grads.update({"grad." + k: p.grad for k, p in net.named_parameters() if p.grad is not None})
+    with torch.no_grad():
+        rgb2, d2 = ref.renderer.rendering(a, pose, pts, ndc, z, rays_d, volume_feature, imgs, network_fn=net, img_feat=img_feat,
+                                          network_query_fn=qfn, confidence=conf)
+        full = recompose_rendering(a, {"w2cs": w2cs.clone(), "intrinsics": K.repeat(V, 1, 1)}, pts, ndc, z, rays_d, volume_feature,
+                                   imgs, net, img_feat, conf, qfn)
+    assert torch.equal(full["rgb"], rgb1.detach()) and torch.equal(full["depth"], d1.detach())
+    save("g16_rendering_v4", V=V, H=H, W=W, K=K, w2cs=w2cs, c2w=c2w, xs=xs, ys=ys, z=z, pts=pts, rays_d=rays_d, ranges=ranges,
+         vol1=vols[0], vol2=vols[1], vol3=vols[2], imgs=imgs, img_feat=img_feat, conf=conf,
+         ndc1=ndc["stage1"], ndc2=ndc["stage2"], ndc3=ndc["stage3"], ndc=ndc["ndc"], rgb_first=rgb1, depth_first=d1,
+         rgb_second=rgb2, depth_second=d2, n_w2cs_after_first=n_after, r3=r3, r1=r1,
+         feats=full["feats"], raw=full["raw"], acc=full["acc"], weights=full["weights"], var=full["var"], u_sampled=full["u"],
+         wu=full["wu"], sigma_head_scale=0.1, sigma_head_bias=0.05, **grads)     # network = g6_mlp_v4's "sd." entries, sigma heads rescaled
+
+
+# ------------------------------------------------------------------ G17 the opt-in uncertainty outputs on the G10 / G11 scenes
+def g17():
+    """What rendering() computes and discards on the (already committed) G10 and G11 inputs: per-sample uncertainty
+    u = 1 - sampled confidence (network/models.py:149), weights / acc / var (network/renderer.py:129) and the composite
+    sum_i w_i u_i.  The G10 / G11 fixtures themselves are read, not regenerated; the recomposed body is checked bit for bit
+    against their stored renders."""
+    def load(name):
+        with np.load(os.path.join(HERE, name + ".npz")) as f:
+            return {k: (torch.from_numpy(f[k].copy()) if f[k].ndim else f[k].item()) for k in f.files if f[k].dtype.kind not in "US"}
+    sd = load("sd_v7")
+    e_p, _ = ref.models.get_embedder(10, 0)
+    e_d, _ = ref.models.get_embedder(4, 0)
+    out = {}
+    with torch.no_grad():
+        g = load("g10_rendering")
+        V = g["V"]
+        net = make_net(V)
+        net.load_state_dict(sd)
+        qfn = lambda pts, vd, f, fn: ref.renderer.run_network_mvs(pts, vd, f, fn, embed_fn=e_p, embeddirs_fn=e_d, netchunk=8)
+        vf = {"stage%d" % k: {"volume_feature_no_ref": g["vol%d" % k]} for k in (1, 2, 3)}
+        ndc = {"stage1": g["ndc1"], "stage2": g["ndc2"], "stage3": g["ndc3"], "ndc": g["ndc"]}
+        full = recompose_rendering(mk_args(V), {"w2cs": g["w2cs"].clone(), "intrinsics": g["K"].repeat(V, 1, 1)}, g["pts"], ndc, g["z"],
+                                   g["rays_d"], vf, g["imgs"], net, g["img_feat"], g["conf"], qfn)
+        assert torch.equal(full["rgb"], g["rgb_first"]) and torch.equal(full["depth"], g["depth_first"])
+        out.update({"g10_" + k: full[k] for k in ("u", "wu", "weights", "acc", "var")})
+
+        g = load("g11_coarse_fine")
+        V, H, W = g["V"], g["H"], g["W"]
+        with torch.no_grad():
+            net.nerf.alpha_linear.weight.mul_(g["sigma_head_scale"]); net.nerf.alpha_linear_1.weight.mul_(g["sigma_head_scale"])
+            net.nerf.alpha_linear.bias.add_(g["sigma_head_bias"]); net.nerf.alpha_linear_1.bias.add_(g["sigma_head_bias"])
+        qfn = lambda pts, vd, f, fn: ref.renderer.run_network_mvs(pts, vd, f, fn, embed_fn=e_p, embeddirs_fn=e_d, netchunk=64)
+        vf = {"stage%d" % k: {"volume_feature_no_ref": g["vol%d" % k]} for k in (1, 2, 3)}
+        K = g["K"]
+        dirs = torch.stack([(g["xs"] - K[0, 2]) / K[0, 0], (g["ys"] - K[1, 2]) / K[1, 1], torch.ones_like(g["xs"])], -1)
+        rd = dirs @ torch.eye(3)
+        for tag, z in (("c", g["z_coarse"]), ("f", g["z_fine"])):
+            N, S = z.shape
+            pts = rd[:, None] * z[..., None]
+            nf = {}
+            for k in ("1", "2", "3"):
+                nf["near_" + k] = torch.full((N, S, 1), 1.0); nf["far_" + k] = torch.full((N, S, 1), 4.0)
+            nf["near"], nf["far"] = torch.tensor(1.0), torch.tensor(4.0)
+            ndc = ref.utils.get_ndc_coordinate(g["w2cs"][0], K, pts.clone(), torch.tensor([W - 1, H - 1]), nf)
+            full = recompose_rendering(mk_args(V), {"w2cs": g["w2cs"].clone(), "intrinsics": K.repeat(V, 1, 1)}, pts, ndc, z, rd, vf,
+                                       g["imgs"], net, g["img_feat"], g["conf"], qfn)
+            assert torch.equal(full["rgb"], g[tag + "_rgb"]) and torch.equal(full["weights"], g[tag + "_weights"])
+            out.update({"g11_%s_%s" % (tag, k): full[k] for k in ("u", "wu")})
+    save("g17_uncertainty", **out)
+
+
 # ------------------------------------------------------------------ G12 / G13 cost volume + depth regression (row f2)
 def mvs_setup(g, V, C, H, W, D, pad):
     """Source feature maps, (src_proj @ ref_proj_inv)[:3] per source view, per-pixel depth hypotheses."""
@@ -625,6 +747,6 @@ def g15():
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12_g13, g14, g15):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12_g13, g14, g15, g16, g17):
         if not only or fn.__name__ in only:
             fn()

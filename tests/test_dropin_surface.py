@@ -109,8 +109,8 @@ def test_rendering_first_and_second_call_with_pose_trim(mods, sd_v7):
         pose = {"w2cs": dev(g["w2cs"]).clone(), "intrinsics": dev(g["K"]).repeat(V, 1, 1)}
         rgbw, _ = mods.renderer.rendering(args, pose, dev(g["pts"]), _ndc(g), dev(g["z"]), dev(g["rays_d"]), vf, dev(g["imgs"]),
                                           white_bkgd=True, **kw)
-    close(rgb1, g["rgb_first"], 1e-4, 0); close(d1, g["depth_first"], 1e-4, 1e-4)
-    close(rgb2, g["rgb_second"], 1e-4, 0); close(d2, g["depth_second"], 1e-4, 1e-4)
+    close(rgb1, g["rgb_first"], 1e-4, 0); close(d1, g["depth_first"], 1e-4, 0)
+    close(rgb2, g["rgb_second"], 1e-4, 0); close(d2, g["depth_second"], 1e-4, 0)
     close(rgbw, g["rgb_white"], 1e-4, 0)
     # the generic (non-fused) run_network_mvs branch: explicit embed -> cat -> batchify over UCNeRF.forward(x)
     e_h, _ = mods.helpers.get_embedder(10, 0)          # interleaved layout cannot fuse with the live dir embedder

@@ -37,7 +37,7 @@ def flat_params(sd):
 def test_native_library_is_loaded():
     import uc_nerf_amd._lib as L
     lib = L.lib()
-    assert lib.ucnerf_abi_version() == 1
+    assert lib.ucnerf_abi_version() == 2
     assert lib.ucnerf_device_cus() >= 200          # MI355X: 256 CUs
 
 
@@ -432,7 +432,8 @@ def test_render_pass_backward_reaches_volumes_features_confidence_and_parameters
 
 
 # ---------------------------------------------------------------------------------------------- a6, bf16x3 precision
-@pytest.mark.parametrize("n_src,m,S", [(6, 4096, 64), (6, 777, 3), (3, 1000, 10), (6, 1, 1)])
+@pytest.mark.parametrize("n_src,m,S", [(6, 4096, 64), (6, 777, 3), (3, 1000, 10), (6, 1, 1), (4, 1500, 15), (1, 333, 3), (2, 640, 1),
+                                       (5, 999, 9), (7, 1024, 64), (8, 2049, 1)])    # every view count 2..9 (4 = opt.py's default view_num 5)
 def test_mlp_bf16x3_matches_fp64_within_split_precision(n_src, m, S, sd_v7):
     """Split-bf16 evaluation (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the bf16 matrix cores): error vs the float64
     oracle must be at the 2^-16 level, i.e. a few 1e-5 relative on sigma and < 2e-5 on rgb -- and it must sit
@@ -462,6 +463,32 @@ def test_mlp_bf16x3_matches_fp64_within_split_precision(n_src, m, S, sd_v7):
     tiled = ft.view(mt // 32, 32, F).permute(0, 2, 1).contiguous().reshape(-1)
     raw_t = ops().mlp_fwd(pw, ws, dev(pts), dev(dirs), dev(tiled), S=S, feats_tiled=True, max_blocks=2)
     assert torch.equal(raw_t.cpu().double(), raw)
+
+
+@pytest.mark.parametrize("n_src,m,S", [(6, 2048, 64), (4, 1500, 15), (3, 1000, 10), (1, 333, 3), (8, 2049, 1), (2, 97, 1), (5, 640, 5), (7, 64, 64)])
+def test_mlp_plain_bf16_every_view_count_against_fp64(n_src, m, S, sd_v7):
+    """precision="bf16" (one bf16 MFMA per product) for every source-view count: outside the 1e-4 bar by construction, so the
+    bar here is the bf16 rounding level itself -- and the exact-f32 kernel on the same inputs must sit orders of magnitude
+    closer to fp64 (i.e. the instantiation evaluates the right network, only coarser)."""
+    from uc_nerf_amd.synthetic import init_ucnerf_state_dict
+    sd = sd_v7 if n_src == 6 else init_ucnerf_state_dict(seed=9, n_src=n_src)
+    gen = torch.Generator().manual_seed(m + S)
+    F = 24 + 12 * n_src + 1
+    pts = torch.rand(m, 3, generator=gen) * 1.2 - 0.1
+    feats = torch.randn(m, F, generator=gen)
+    feats[:, -1] = torch.rand(m, generator=gen)
+    dirs = torch.nn.functional.normalize(torch.randn(m // S, 3, generator=gen), dim=-1)
+    ref64 = O.run_network_mvs({k: v.double() for k, v in sd.items()}, pts.view(m // S, S, 3).double(), dirs.double(),
+                              feats.view(m // S, S, F).double(), n_src=n_src).reshape(m, 4)
+    pw = ops().PackedWeights.get(n_src, 0, torch.device(DEV), "bf16")
+    raw = ops().mlp_fwd(pw, pw.pack(dev(flat_params(sd))), dev(pts), dev(dirs), dev(feats), S=S).cpu().double()
+    scale = max(1.0, ref64[:, 3].abs().max().item())
+    e_rgb, e_sig = (raw[:, :3] - ref64[:, :3]).abs(), (raw[:, 3] - ref64[:, 3]).abs()
+    assert e_rgb.max() < 0.15 and e_rgb.mean() < 6e-3, (e_rgb.max(), e_rgb.mean())              # unscaled random network: pre-activations of O(10)
+    assert e_sig.max() < 0.08 * scale and e_sig.mean() < 4e-3 * scale, (e_sig.max(), e_sig.mean())
+    pw32 = ops().PackedWeights.get(n_src, 0, torch.device(DEV))
+    raw32 = ops().mlp_fwd(pw32, pw32.pack(dev(flat_params(sd))), dev(pts), dev(dirs), dev(feats), S=S).cpu().double()
+    assert (raw32[:, :3] - ref64[:, :3]).abs().max() < 2e-5
 
 
 def test_merge_rows_applies_the_sort_permutation_and_handles_empty_input():

@@ -66,7 +66,7 @@ def test_fused_render_pass_matches_oracle_stage_by_stage(N, S, per_ray_ranges):
     scale = max(1.0, want["raw"][..., 3].abs().max().item())
     close(out["raw"][..., :3], want["raw"][..., :3], 2e-5)
     close(out["raw"][..., 3], want["raw"][..., 3], 2e-5 * scale, 1e-5)
-    close(out["rgb"], want["rgb"], 1e-4); close(out["depth"], want["depth"], 1e-4, 1e-5)
+    close(out["rgb"], want["rgb"], 1e-4); close(out["depth"], want["depth"], 1e-4)
     close(out["acc"], want["acc"], 1e-4); close(out["weights"], want["weights"], 2e-5, 1e-4)
     if S >= 2:
         close(out["var"], want["var"], 1e-5, 1e-3)
@@ -80,7 +80,7 @@ def test_fused_render_pass_matches_oracle_stage_by_stage(N, S, per_ray_ranges):
     # the fast path: channel-last source copies + coordinates derived inside the gather
     rp.repack_sources()
     fast = rp(rays_d.to(DEV), z.to(DEV), near_far=None if near_far is None else near_far.to(DEV))
-    close(fast["rgb"], want["rgb"], 1e-4); close(fast["depth"], want["depth"], 1e-4, 1e-5)
+    close(fast["rgb"], want["rgb"], 1e-4); close(fast["depth"], want["depth"], 1e-4)
     close(fast["weights"], want["weights"], 2e-5, 1e-4)
     close(fast["rgb"], out["rgb"], 2e-6); close(fast["depth"], out["depth"], 5e-6, 1e-6)
     # ... and the training forward from the repacked sources: row-major features straight from the channel-last gather
@@ -113,7 +113,7 @@ def test_coarse_fine_pipeline_vs_reference_golden(sd_v7):
     assert torch.equal(hs["z_sorted"].cpu(), g["z_fine"])
     # stage 3 teacher-forced: the reference's fine depths through the fused pass -> 1e-4
     fine = r.pass_(out["rays_d"], g["z_fine"].to(DEV))
-    close(fine["rgb"][ok], g["f_rgb"][ok], 1e-4); close(fine["depth"][ok], g["f_depth"][ok], 1e-4, 1e-4)
+    close(fine["rgb"][ok], g["f_rgb"][ok], 1e-4); close(fine["depth"][ok], g["f_depth"][ok], 1e-4)       # absolute, depths in [1, 4]
     close(fine["acc"][ok], g["f_acc"][ok], 1e-4); close(fine["var"][ok], g["f_var"][ok], 1e-5, 1e-3)
     close(fine["weights"][ok], g["f_weights"][ok], 2e-5, 1e-3)
     # free-running end to end: a flipped searchsorted bin moves single samples on few rays
@@ -149,7 +149,7 @@ def test_full_size_properties_4096_rays():
     interior = ((ys > 0) & (ys < 255)).nonzero().flatten()      # skip knife-edge in-mask rows (see G11 test)
     sel = interior[::64]
     ref = O.render_coarse_fine(sd, scene, xs[sel], ys[sel], 64, 128, z_fine_override=zf[sel].cpu())
-    close(out["rgb"][sel], ref["rgb"], 1e-4); close(out["depth"][sel], ref["depth"], 1e-4, 1e-5)
+    close(out["rgb"][sel], ref["rgb"], 1e-4); close(out["depth"][sel], ref["depth"], 1e-4)
 
 
 def test_bf16x3_pipeline_meets_the_1e4_parity_bar(sd_v7):
@@ -164,7 +164,7 @@ def test_bf16x3_pipeline_meets_the_1e4_parity_bar(sd_v7):
     ok = (g["ys"] > 0) & (g["ys"] < g["H"] - 1)
     close(out["coarse"]["weights"][ok], g["c_weights"][ok], 5e-5, 1e-3)
     fine = r.pass_(out["rays_d"], g["z_fine"].to(DEV))
-    close(fine["rgb"][ok], g["f_rgb"][ok], 1e-4); close(fine["depth"][ok], g["f_depth"][ok], 1e-4, 1e-4)
+    close(fine["rgb"][ok], g["f_rgb"][ok], 1e-4); close(fine["depth"][ok], g["f_depth"][ok], 1e-4)       # absolute
     close(fine["acc"][ok], g["f_acc"][ok], 1e-4)
     # full size, both precisions on the same fine depths
     scene = make_scene(seed=0)
@@ -174,7 +174,7 @@ def test_bf16x3_pipeline_meets_the_1e4_parity_bar(sd_v7):
     r16 = CoarseFineRenderer(to_dev(scene), flat_params_of(sd).to(DEV), 64, 128, precision="bf16x3")
     o32 = r32.render(xs.to(DEV), ys.to(DEV))
     f16 = r16.pass_(o32["rays_d"], o32["z_fine"])
-    close(f16["rgb"], o32["rgb"], 1e-4); close(f16["depth"], o32["depth"], 1e-4, 1e-4)
+    close(f16["rgb"], o32["rgb"], 1e-4); close(f16["depth"], o32["depth"], 1e-4)
     o16 = r16.render(xs.to(DEV), ys.to(DEV))
     err = (o16["rgb"] - o32["rgb"]).abs().max(-1)[0]
     assert (err < 1e-4).float().mean() > 0.97      # free-running: a flipped searchsorted bin moves single samples

@@ -255,7 +255,7 @@ def test_g11_coarse_fine_composition(sd_v7):
     assert torch.equal(O.merge_sorted(z_s, zc), g["z_fine"])
     # stage 3, teacher-forced: reference z_fine -> final render within 1e-4
     fine = O.render_coarse_fine(sd, scene, g["xs"], g["ys"], 64, 128, z_fine_override=g["z_fine"])
-    close(fine["rgb"], g["f_rgb"], 1e-4, 0); close(fine["depth"], g["f_depth"], 1e-4, 1e-4)
+    close(fine["rgb"], g["f_rgb"], 1e-4, 0); close(fine["depth"], g["f_depth"], 1e-4, 0)
     close(fine["acc"], g["f_acc"], 1e-4, 0); close(fine["var"], g["f_var"], 1e-5, 1e-3)
     close(fine["weights"], g["f_weights"], 2e-5, 1e-3)
     # free-running: almost every ray still lands within 1e-4 (a flipped searchsorted bin moves one sample)
@@ -297,3 +297,59 @@ def test_g13_depth_regression_and_confidence(tag):
     close(conf.detach(), f("confidence"), 1e-6, 1e-6)
     ((depth * f("r_depth")).sum() + (conf * f("r_conf")).sum()).backward()   # gradient at the regularisation net's logits
     close(x.grad, f("g_prob_pre"), 1e-6, 1e-5)
+
+
+def sd_v4_for_g16(g):
+    """The V = 4 network of G16: G6 v4's state dict with the sigma heads rescaled as the fixture records."""
+    return scaled_sd(state_dict_from(load_golden("g6_mlp_v4")), g["sigma_head_scale"], g["sigma_head_bias"])
+
+
+def test_g16_rendering_hamlyn_view_count_with_everything_the_body_computes():
+    """configs[3]: 3 source views (view_num 4, feat_dim 61), per-ray cascade ranges, first and second call, the
+    discarded intermediates, and the gradients into the network and the gather sources."""
+    g = load_golden("g16_rendering_v4")
+    V = g["V"]
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd_v4_for_g16(g).items()}
+    vols = [g["vol%d" % k].clone().requires_grad_(True) for k in (1, 2, 3)]
+    img_feat, conf = g["img_feat"].clone().requires_grad_(True), g["conf"].clone().requires_grad_(True)
+    pose = {"w2cs": g["w2cs"].clone(), "intrinsics": g["K"].repeat(V, 1, 1)}
+    args = (g["pts"], _ndc_dict(g), g["z"], g["rays_d"], vols, g["imgs"], img_feat, conf, V)
+    out = O.rendering(sd, pose, *args, full=True)
+    assert pose["w2cs"].shape[0] == g["n_w2cs_after_first"] == V - 1
+    close(out["feats"], g["feats"], 2e-5, 1e-5)
+    close(out["raw"], g["raw"], 2e-5, 1e-4)
+    close(out["rgb"], g["rgb_first"], 2e-5, 1e-4); close(out["depth"], g["depth_first"], 5e-5, 1e-4)
+    close(out["acc"], g["acc"], 2e-5, 1e-4); close(out["weights"], g["weights"], 1e-5, 1e-4); close(out["var"], g["var"], 1e-6, 1e-3)
+    close(out["u_sampled"], g["u_sampled"], 1e-6, 0); close(out["wu"], g["wu"], 2e-5, 1e-4)
+    ((out["rgb"] * g["r3"]).sum() + (out["depth"] * g["r1"]).sum()).backward()
+    for got, name in zip(vols + [img_feat, conf], ("g_vol1", "g_vol2", "g_vol3", "g_img_feat", "g_conf")):
+        w = g[name]
+        torch.testing.assert_close(got.grad, w, atol=2e-4 * w.abs().max().item() + 1e-8, rtol=2e-3)
+    n_checked = 0
+    for k, p in sd.items():
+        if ("grad." + k) in g:
+            w = g["grad." + k]
+            torch.testing.assert_close(p.grad, w, atol=2e-4 * w.abs().max().item() + 1e-8, rtol=2e-3, msg=lambda s: k + ": " + s)
+            n_checked += 1
+    assert n_checked == 30                                                  # SURVEY.md 3.2: 30 of 36 tensors receive gradients
+    with torch.no_grad():
+        rgb2, d2 = O.rendering({k: v.detach() for k, v in sd.items()}, pose, g["pts"], _ndc_dict(g), g["z"], g["rays_d"],
+                               [v.detach() for v in vols], g["imgs"], img_feat.detach(), conf.detach(), V)
+    close(rgb2, g["rgb_second"], 2e-5, 1e-4); close(d2, g["depth_second"], 5e-5, 1e-4)
+
+
+def test_g17_uncertainty_outputs_on_the_g10_and_g11_scenes(sd_v7):
+    u17 = load_golden("g17_uncertainty")
+    g = load_golden("g10_rendering")
+    V = g["V"]
+    out = O.rendering(sd_v7, {"w2cs": g["w2cs"].clone(), "intrinsics": g["K"].repeat(V, 1, 1)}, g["pts"], _ndc_dict(g), g["z"],
+                      g["rays_d"], [g["vol1"], g["vol2"], g["vol3"]], g["imgs"], g["img_feat"], g["conf"], V, full=True)
+    close(out["u_sampled"], u17["g10_u"], 1e-6, 0); close(out["wu"], u17["g10_wu"], 2e-5, 1e-4)
+    close(out["weights"], u17["g10_weights"], 1e-5, 1e-4); close(out["acc"], u17["g10_acc"], 2e-5, 1e-4)
+    close(out["var"], u17["g10_var"], 1e-6, 1e-3)
+    g = load_golden("g11_coarse_fine")
+    sd = scaled_sd(sd_v7, g["sigma_head_scale"], g["sigma_head_bias"])
+    ref = O.render_coarse_fine(sd, scene_from_golden(g), g["xs"], g["ys"], 64, 128, z_fine_override=g["z_fine"])
+    close(ref["coarse"]["u_sampled"], u17["g11_c_u"], 1e-6, 0); close(ref["u_sampled"], u17["g11_f_u"], 1e-6, 0)
+    ok = (g["ys"] > 0) & (g["ys"] < g["H"] - 1)          # rows 0 / H-1 sit on the in-mask discontinuity (see test_g11)
+    close(ref["coarse"]["wu"][ok], u17["g11_c_wu"][ok], 2e-5, 1e-4); close(ref["wu"][ok], u17["g11_f_wu"][ok], 2e-5, 1e-4)

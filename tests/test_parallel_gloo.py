@@ -120,7 +120,7 @@ def test_flat_bucket_allreduce_reproduces_the_single_rank_gradient():
     loss.backward()
     results = run_world(_sharded_grads, 2)
     for grads, red_loss, numel in results:
-        assert numel == 181642 + 1                                       # ONE bucket: all MLP grads + the loss scalar
+        assert numel == 181642 + 1 + 36                                  # ONE bucket: all MLP grads + the loss scalar + 36 has-gradient flags
         assert abs(red_loss - loss.item()) < 1e-6
         for k, v in params.items():
             if v.grad is None:
@@ -130,6 +130,38 @@ def test_flat_bucket_allreduce_reproduces_the_single_rank_gradient():
     for k in results[0][0]:                                               # both ranks hold identical reduced grads
         if results[0][0][k] is not None:
             assert torch.equal(results[0][0][k], results[1][0][k])
+
+
+def _empty_shard_rank(rank, world):
+    """Rank 1 holds no rays this step (no backward at all); one parameter is never used by any rank."""
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.Tanh(), torch.nn.Linear(8, 2))
+    unused = torch.nn.Parameter(torch.ones(3))
+    params = list(net.parameters()) + [unused]
+    bucket = P.FlatGradBucket(params, n_scalars=2)
+    out = []
+    for step in range(2):                                # second step runs on the cached has-gradient mask
+        for p in params:
+            p.grad = None
+        x = torch.randn(6, 4, generator=torch.Generator().manual_seed(step))
+        if rank == 0:
+            loss = net(x).pow(2).mean()
+            loss.backward()
+            red = bucket.allreduce(1.0, [loss.detach(), torch.tensor(1.0)])
+        else:
+            red = bucket.allreduce(0.0, [0.0, torch.tensor(0.0)])
+        out.append(([None if p.grad is None else p.grad.clone() for p in params], red.clone()))
+    return out
+
+
+def test_flat_bucket_keeps_replicas_identical_when_a_shard_is_empty():
+    res = run_world(_empty_shard_rank, 2)
+    for step in range(2):
+        (g0, r0), (g1, r1) = res[0][step], res[1][step]
+        assert torch.equal(r0, r1) and r0[1].item() == 1.0
+        for a, b in zip(g0[:-1], g1[:-1]):
+            assert a is not None and b is not None and torch.equal(a, b) and a.abs().sum() > 0
+        assert g0[-1] is None and g1[-1] is None         # a parameter no rank differentiated keeps grad = None (as in the reference)
 
 
 # ---- row f3: the training step's loss under ray sharding ------------------------------------------------------

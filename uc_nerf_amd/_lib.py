@@ -9,6 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UCNERF_LIB") or os.path.join(_HERE, "libucnerf_hip.so")   # override: A/B builds
 
+ABI_VERSION = 2    # UCNERF_ABI_VERSION of include/ucnerf_hip.h this binding mirrors
+
 fp = C.POINTER(C.c_float)
 i32 = C.c_int32
 f32 = C.c_float
@@ -55,7 +57,7 @@ class FeatGatherParams(C.Structure):
     _fields_ = [("m", i32), ("V", i32), ("H", i32), ("W", i32), ("vol_d", i32 * 3), ("vol_h", i32 * 3),
                 ("vol_w", i32 * 3), ("out_tiled", i32), ("unit_mask", i32), ("pts", vp), ("ndc1", vp), ("ndc2", vp), ("ndc3", vp),
                 ("vol", vp * 3), ("conf", vp), ("imgs", vp), ("img_feat", vp), ("w2cs", vp), ("intrinsics", vp),
-                ("feats", vp)]
+                ("feats", vp), ("u_out", vp)]
 
 
 class FeatGatherBwdParams(C.Structure):
@@ -81,7 +83,7 @@ class MlpBwdParams(C.Structure):
 class CompositeParams(C.Structure):
     _fields_ = [("n", i32), ("S", i32), ("variant", i32), ("white_bkgd", i32), ("raw", vp), ("z", vp), ("rays_d", vp),
                 ("noise", vp), ("rgb_map", vp), ("depth_map", vp), ("acc_map", vp), ("disp_map", vp), ("weights", vp),
-                ("var", vp)]
+                ("var", vp), ("u", vp), ("wu", vp)]
 
 
 class CompositeBwdParams(C.Structure):
@@ -125,7 +127,8 @@ class RenderParams(C.Structure):
                 ("vol_h", i32 * 3), ("vol_w", i32 * 3), ("vol", vp * 3), ("conf", vp), ("imgs", vp), ("img_feat", vp),
                 ("w2cs", vp), ("intrinsics", vp), ("wstream", vp), ("sources_cl", vp), ("workspace", vp), ("rgb_map", vp),
                 ("depth_map", vp), ("acc_map", vp), ("weights", vp), ("var", vp), ("raw", vp), ("feats", vp),
-                ("ev_mlp_start", vp), ("ev_mlp_stop", vp), ("train_workspace", vp), ("dir_feat", vp)]
+                ("ev_mlp_start", vp), ("ev_mlp_stop", vp), ("train_workspace", vp), ("dir_feat", vp), ("u_sampled", vp),
+                ("wu_map", vp), ("pts_in", vp), ("ndc1_in", vp), ("ndc2_in", vp), ("ndc3_in", vp), ("ndc_in", vp)]
 
 
 class RenderBwdParams(C.Structure):
@@ -220,7 +223,7 @@ def lib():
         except AttributeError as e:
             raise RuntimeError("uc_nerf_amd: %s does not export %s" % (LIB_PATH, name)) from e
         fn.restype, fn.argtypes = res, args
-    if L.ucnerf_abi_version() != 1:
+    if L.ucnerf_abi_version() != ABI_VERSION:
         raise RuntimeError("uc_nerf_amd: ABI version mismatch")
     for cname, cls in STRUCTS.items():
         got = L.ucnerf_sizeof(cname.encode())

@@ -12,6 +12,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libucnerf_hip.so")
 SOURCES = ["rays.hip", "gather.hip", "gather_cl.hip", "mlp.hip", "mlp_bf16.hip", "mlp_bwd.hip", "composite.hip", "sample_pdf.hip", "render.hip", "mvs.hip"]
+# (source, object name, extra flags): translation units built more than once with different switches
+VARIANTS = [("mlp_bf16.hip", "mlp_bf16_plain.o", ["-DUCNERF_BF16_BUILD_TERMS=1"])]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mlp_layout.h"), os.path.join(CSRC, "sincos_cw.h"),
            os.path.join(HERE, "..", "include", "ucnerf_hip.h")]
 # -ffp-contract=off: the sample_pdf / sampling kernels reproduce torch-CPU roundings (separate mul and add)
@@ -43,6 +45,11 @@ def build(force=False, verbose=False):
         if force or _stale(obj, [src] + HEADERS):
             jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
 
+    for s, oname, extra in VARIANTS:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ, oname)
+        if force or _stale(obj, [src] + HEADERS):
+            jobs.append([hipcc] + FLAGS + extra + ["-c", src, "-o", obj])
+
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -51,11 +58,11 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
         return r.stderr
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         for err in ex.map(run, jobs):
             if verbose and err.strip():
                 print(err)
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in srcs]
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in srcs] + [os.path.join(OBJ, o) for _, o, _ in VARIANTS]
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB

@@ -34,7 +34,12 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 struct Mat34 { float m[12]; };
 struct Mat33 { float m[9]; };
 
-int device_cus();   // cached
+int device_cus();   // of the CURRENT device, cached per device (thread-safe)
+
+// Opt-in for more than 64 KB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize).  The attribute belongs to the
+// (device, function) pair, so it is set once per pair -- keyed on hipGetDevice(), under a lock -- and a failure is
+// reported through fail().  Returns UCNERF_OK or UCNERF_EHIP.
+int ensure_dynamic_lds(const void* kernel, int bytes, const char* what);
 
 
 // Segmented pre-combination of float atomics inside a wave (HIP device code only).  Lanes STRIDE apart hold consecutive

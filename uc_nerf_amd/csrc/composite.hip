@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) composite_fwd_kernel(ucnerf_composite_par
         prod *= sm[e].f;
     }
     const float pre = wave_excl_prod(prod, lane);
-    float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+    float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f, su = 0.f;
     float w[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -93,10 +93,12 @@ __global__ void __launch_bounds__(256) composite_fwd_kernel(ucnerf_composite_par
             sr += w[e] * sm[e].r; sg += w[e] * sm[e].g; sb += w[e] * sm[e].b;
             sd += w[e] * p.z[(size_t)ray * p.S + i];
             sa += w[e];
+            if (p.wu) su += w[e] * p.u[(size_t)ray * p.S + i];      // composited uncertainty sum_i w_i u_i (u: network/models.py:149)
             if (p.weights) p.weights[(size_t)ray * p.S + i] = w[e];
         }
     }
     sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
+    if (p.wu) su = wave_sum(su);
     float var = 0.f;
     if (p.var) {                                // torch.var_mean(weights, dim=1): unbiased
         const float mean = sa / (float)p.S;
@@ -116,6 +118,7 @@ __global__ void __launch_bounds__(256) composite_fwd_kernel(ucnerf_composite_par
             p.disp_map[ray] = q != q ? q : 1.f / fmaxf(1e-10f, q);
         }
         if (p.var) p.var[ray] = var;
+        if (p.wu) p.wu[ray] = su;
     }
 }
 
@@ -196,6 +199,7 @@ int ucnerf_composite_fwd(const ucnerf_composite_params* p, void* stream) {
     UCNERF_REQUIRE(p->variant == 0 || (p->variant == 1 && p->rays_d), "composite_fwd: variant %d (variant 1 needs rays_d)", p->variant);
     UCNERF_REQUIRE(!p->var || (p->variant == 0 && p->S >= 2), "composite_fwd: var needs the live variant and S >= 2");
     UCNERF_REQUIRE(((uintptr_t)p->raw & 15) == 0, "composite_fwd: raw must be 16-byte aligned");
+    UCNERF_REQUIRE(!p->wu || p->u, "composite_fwd: wu (sum of w*u) needs the per-sample uncertainty u");
     if (p->n <= 0) return UCNERF_OK;
     hipStream_t st = (hipStream_t)stream;
     const int E = cdiv(p->S, 64);

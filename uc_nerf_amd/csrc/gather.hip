@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(256) feat_gather_fwd_kernel(ucnerf_feat_gather
         acc += c[(size_t)ay.i1 * p.W + ax.i0] * (ay.w1 * ax.w0);
         acc += c[(size_t)ay.i1 * p.W + ax.i1] * (ay.w1 * ax.w1);
         p.feats[out_index(p, F, s, F - 1)] = acc;
+        if (p.u_out) p.u_out[s] = 1.f - acc;        // network/models.py:149
     } else {
         const int v = unit - 4;
         float gx, gy;

@@ -64,6 +64,10 @@ struct GatherClArgs {
     float* feats;              // tiled [ceil(M/32)][F][32], or row-major [M][F] (tiled = 0: the training forward keeps them)
     int tiled;
     float* ndc;                // [M,3] (x, y, scene-normalised z) for the MLP's positional encoding, or NULL
+    float* u_out;              // [M] 1 - sampled confidence (network/models.py:149), or NULL
+    // GIVEN coordinates (rendering() hands over rays_pts / rays_ndc, network/renderer.py:215-255) instead of (ray, depth)
+    const float* pts_in;       // [M,3] world points
+    const float* ndc_in[3];    // [M,3] stage coordinates
     unsigned M, div_m, div_sh; // n * S; idx / S = umulhi(idx, div_m) >> div_sh for idx < 2^31 (S >= 2)
 };
 
@@ -128,12 +132,16 @@ __device__ __forceinline__ SampleIn sample_in(const GatherClArgs& a, unsigned id
     return s;
 }
 
-template <bool TILED>
+template <bool TILED, bool GIVEN>
 __device__ __forceinline__ void gather_cl_unit(const GatherClArgs& a, unsigned idx, int unit, const SampleIn& in) {
     const int F = 24 + 12 * a.V + 1;
     const unsigned r = in.r;
     const float z = in.z;
-    const float x = a.rays_o[0] + z * in.dx, y = a.rays_o[1] + z * in.dy, w = a.rays_o[2] + z * in.dz;
+    float x, y, w;                                                          // world point
+    if (GIVEN) {
+        if (unit >= 4) { const float* q = a.pts_in + 3 * (size_t)idx; x = q[0]; y = q[1]; w = q[2]; }
+        else x = y = w = 0.f;
+    } else { x = a.rays_o[0] + z * in.dx; y = a.rays_o[1] + z * in.dy; w = a.rays_o[2] + z * in.dz; }
     constexpr int fs = TILED ? 32 : 1;                                      // feature f at out[f * fs]
     // Tiled rows are full 128-byte lines written once and read once by the MLP: stream them past the L2 so that the sources
     // stay there (-19 us per step).  Row-major rows are completed piecewise by one thread and want the L2.
@@ -144,11 +152,17 @@ __device__ __forceinline__ void gather_cl_unit(const GatherClArgs& a, unsigned i
 #endif
     float* out = TILED ? a.feats + ((size_t)(idx >> 5) * F) * 32 + (idx & 31) : a.feats + (size_t)idx * F;
     if (unit < 4) {
-        float qx, qy, qz;
-        project_cl(a.w2c_ref, a.K_ref, x, y, w, &qx, &qy, &qz);
-        const float u = (qx / qz + 0.0f) / (float)(a.W - 1), v = (qy / qz + 0.0f) / (float)(a.H - 1);
+        float u, v, qz = 0.f, zn_given = 0.f;
+        if (GIVEN) {                                                        // unit 3 (confidence) samples with the stage-3 grid
+            const float* g = a.ndc_in[unit == 3 ? 2 : unit] + 3 * (size_t)idx;
+            u = g[0]; v = g[1]; zn_given = g[2];
+        } else {
+            float qx, qy;
+            project_cl(a.w2c_ref, a.K_ref, x, y, w, &qx, &qy, &qz);
+            u = (qx / qz + 0.0f) / (float)(a.W - 1); v = (qy / qz + 0.0f) / (float)(a.H - 1);
+        }
         if (unit == 3) {
-            if (a.ndc) {
+            if (!GIVEN && a.ndc) {
                 a.ndc[3 * (size_t)idx] = u; a.ndc[3 * (size_t)idx + 1] = v; a.ndc[3 * (size_t)idx + 2] = (qz - a.near) / (a.far - a.near);
             }
             const LerpCl ax = axis_cl(u * 2.f - 1.0f, a.W, false), ay = axis_cl(v * 2.f - 1.0f, a.H, false);
@@ -158,11 +172,15 @@ __device__ __forceinline__ void gather_cl_unit(const GatherClArgs& a, unsigned i
             acc += c[(size_t)ay.i1 * a.W + ax.i0] * (ay.w1 * ax.w0);
             acc += c[(size_t)ay.i1 * a.W + ax.i1] * (ay.w1 * ax.w1);
             PUT((F - 1) * fs, acc);
+            if (a.u_out) a.u_out[idx] = 1.f - acc;
             return;
         }
-        float nk = a.near, fk = a.far;
-        if (a.near_far) { nk = a.near_far[6 * (size_t)r + 2 * unit]; fk = a.near_far[6 * (size_t)r + 2 * unit + 1]; }
-        const float zn = (qz - nk) / (fk - nk);
+        float zn = zn_given;
+        if (!GIVEN) {
+            float nk = a.near, fk = a.far;
+            if (a.near_far) { nk = a.near_far[6 * (size_t)r + 2 * unit]; fk = a.near_far[6 * (size_t)r + 2 * unit + 1]; }
+            zn = (qz - nk) / (fk - nk);
+        }
         const int D = a.vol_d[unit], hh = a.vol_h[unit], ww = a.vol_w[unit];
         const LerpCl ax = axis_cl(u * 2.f - 1.0f, ww, false), ay = axis_cl(v * 2.f - 1.0f, hh, false),
                      az = axis_cl(zn * 2.f - 1.0f, D, false);
@@ -214,14 +232,15 @@ __device__ __forceinline__ void gather_cl_unit(const GatherClArgs& a, unsigned i
 #ifndef UCNERF_GATHER_WAVES
 #define UCNERF_GATHER_WAVES 1     // min waves per SIMD asked of the compiler (8 = 64 VGPRs: measured no faster than the 7 it gets by itself)
 #endif
-template <bool TILED>
+template <bool TILED, bool GIVEN>
 __global__ void __launch_bounds__(256, TILED ? UCNERF_GATHER_WAVES : 1) feat_gather_cl_kernel(GatherClArgs a) {
     const unsigned idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= a.M) return;
-    const SampleIn in = sample_in(a, idx);
-    if (TILED) gather_cl_unit<true>(a, idx, blockIdx.y, in);
+    SampleIn in = {0u, 0.f, 0.f, 0.f, 0.f};
+    if (!GIVEN) in = sample_in(a, idx);
+    if (TILED) gather_cl_unit<true, GIVEN>(a, idx, blockIdx.y, in);
     else
-        for (int unit = 0; unit < 4 + a.V; ++unit) gather_cl_unit<false>(a, idx, unit, in);
+        for (int unit = 0; unit < 4 + a.V; ++unit) gather_cl_unit<false, GIVEN>(a, idx, unit, in);
 }
 
 }  // namespace ucnerf
@@ -262,6 +281,7 @@ namespace ucnerf {
 
 // called by render.hip: gather (+ ndc) for one pass from the repacked sources
 int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float* feats, int tiled, float* ndc, hipStream_t st) {
+    const bool given = p->pts_in != nullptr;
     GatherClArgs a;
     memset(&a, 0, sizeof(a));
     a.n = p->n; a.S = p->S; a.V = p->cfg.n_src; a.H = p->H; a.W = p->W;
@@ -277,7 +297,8 @@ int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float
     memcpy(a.w2c_ref, p->w2c_ref, sizeof(a.w2c_ref));
     memcpy(a.K_ref, p->K_ref, sizeof(a.K_ref));
     a.w2cs = p->w2cs; a.Ks = p->intrinsics;
-    a.feats = feats; a.tiled = tiled; a.ndc = ndc;
+    a.feats = feats; a.tiled = tiled; a.ndc = ndc; a.u_out = p->u_sampled;
+    a.pts_in = p->pts_in; a.ndc_in[0] = p->ndc1_in; a.ndc_in[1] = p->ndc2_in; a.ndc_in[2] = p->ndc3_in;
     UCNERF_REQUIRE(a.V >= 1 && a.V <= 8, "gather_cl: V = %d outside 1..8", a.V);
     const long long M = (long long)p->n * p->S;
     UCNERF_REQUIRE(M < (1ll << 31), "gather_cl: %lld samples in one pass (limit 2^31 - 1)", M);
@@ -288,8 +309,11 @@ int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float
         a.div_m = (unsigned)((((unsigned long long)1 << (31 + l)) + (unsigned)p->S - 1) / (unsigned)p->S);
         a.div_sh = l - 1;
     }
-    if (tiled) hipLaunchKernelGGL(feat_gather_cl_kernel<true>, dim3(cdiv(M, 256), 4 + a.V), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(feat_gather_cl_kernel<false>, dim3(cdiv(M, 256), 1), dim3(256), 0, st, a);
+    const dim3 grid(cdiv(M, 256), tiled ? 4 + a.V : 1), block(256);
+    if (tiled && !given) hipLaunchKernelGGL((feat_gather_cl_kernel<true, false>), grid, block, 0, st, a);
+    else if (tiled) hipLaunchKernelGGL((feat_gather_cl_kernel<true, true>), grid, block, 0, st, a);
+    else if (!given) hipLaunchKernelGGL((feat_gather_cl_kernel<false, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((feat_gather_cl_kernel<false, true>), grid, block, 0, st, a);
     return check_launch("feat_gather_cl");
 }
 

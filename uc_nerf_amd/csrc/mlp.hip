@@ -592,7 +592,8 @@ int build_pack_index_bf16(const ucnerf_mlp_config* cfg, int32_t* idx);
 int64_t bf16_index_count(const ucnerf_mlp_config* cfg);
 int64_t bf16_stream_floats(const ucnerf_mlp_config* cfg);
 int launch_pack_bf16(const ucnerf_mlp_config* cfg, const float* flat, const int32_t* idx, float* out, hipStream_t st);
-int launch_mlp_fwd_bf16(const ucnerf_mlp_params* p, hipStream_t st);
+int launch_mlp_fwd_bf16x3(const ucnerf_mlp_params* p, hipStream_t st);      // mlp_bf16.hip built with TERMS = 3
+int launch_mlp_fwd_bf16_plain(const ucnerf_mlp_params* p, hipStream_t st);   // ... and with TERMS = 1
 
 }  // namespace ucnerf
 
@@ -655,7 +656,8 @@ int ucnerf_mlp_unpack_grad(const float* g, const int32_t* idx, float* gflat, int
 }
 
 int ucnerf_mlp_fwd(const ucnerf_mlp_params* p, void* stream) {
-    if (p && p->cfg.precision != 0) return launch_mlp_fwd_bf16(p, (hipStream_t)stream);
+    if (p && p->cfg.precision == 1) return launch_mlp_fwd_bf16x3(p, (hipStream_t)stream);
+    if (p && p->cfg.precision == 2) return launch_mlp_fwd_bf16_plain(p, (hipStream_t)stream);
     return launch_mlp_fwd(p, nullptr, (hipStream_t)stream);
 }
 

@@ -35,6 +35,12 @@
 #include <cstdlib>
 #include <vector>
 
+// This file is compiled twice (uc_nerf_amd/build.py): UCNERF_BF16_BUILD_TERMS = 3 gives the split-bf16 launcher
+// (launch_mlp_fwd_bf16x3) plus the host-side packing shared by both precisions, = 1 the plain-bf16 launcher only.
+#ifndef UCNERF_BF16_BUILD_TERMS
+#define UCNERF_BF16_BUILD_TERMS 3
+#endif
+
 namespace ucnerf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -72,7 +78,7 @@ struct Bf16Layout {
     int64_t const_off_bytes, total_bytes;
 };
 
-bool bf16_layout(int v, Bf16Layout* B) {
+static bool bf16_layout(int v, Bf16Layout* B) {
     if (v < 1 || v > 8) return false;
     B->v = v; B->F = 24 + 12 * v + 1;
     B->kd16 = (24 + 4 * v + 15) / 16; B->kc16 = (8 * v + 15) / 16;
@@ -85,6 +91,7 @@ bool bf16_layout(int v, Bf16Layout* B) {
 // feature held by element j of lane-half hh in hidden k16-step q = (kt, s): accumulator register 8s + j of row-tile kt
 __host__ __device__ inline int hid_feature16(int kt, int s, int j, int hh) { return 32 * kt + (j & 3) + 8 * (2 * s + (j >> 2)) + 4 * hh; }
 
+#if UCNERF_BF16_BUILD_TERMS == 3
 // ------------------------------------------------------------------------------------------------ host: pack index
 // idx16[e] for every bf16 element e of the stream: flat parameter index | (part << 30) (part 0 = hi, 1 = lo), -1 = zero.
 // Half-steps appear in the order the kernel consumes them (see the schedule in mlp_fwd_bf16_kernel):
@@ -174,6 +181,8 @@ __global__ void pack_bf16_kernel(const float* __restrict__ flat, const int32_t* 
     }
     out[i] = r;
 }
+
+#endif   // UCNERF_BF16_BUILD_TERMS == 3 (host-side packing)
 
 // ------------------------------------------------------------------------------------------------ device helpers
 struct Frag { bf16x8 hi, lo; };
@@ -761,7 +770,11 @@ constexpr size_t bf16_smem_bytes() {
     return (size_t)NBUF * SLOT_BYTES + ((CONST_FLOATS * 4 + 15) & ~15) + (size_t)BW * KS16_PE_PTS * 64 * sizeof(Frag) + (size_t)BW * 64 * sizeof(float);
 }
 
-int launch_mlp_fwd_bf16(const ucnerf_mlp_params* p, hipStream_t st) {
+#if UCNERF_BF16_BUILD_TERMS == 3
+int launch_mlp_fwd_bf16x3(const ucnerf_mlp_params* p, hipStream_t st) {
+#else
+int launch_mlp_fwd_bf16_plain(const ucnerf_mlp_params* p, hipStream_t st) {
+#endif
     UCNERF_REQUIRE(p, "mlp_fwd: null params");
     if (p->m == 0) return UCNERF_OK;
     UCNERF_REQUIRE(p->pts && p->dirs && p->feats && p->wstream && p->raw, "mlp_fwd: null pointer");
@@ -784,28 +797,28 @@ int launch_mlp_fwd_bf16(const ucnerf_mlp_params* p, hipStream_t st) {
 #ifdef UCNERF_MLP_DIAG
     { const char* e = getenv("UCNERF_MLP_DIAG_PTR"); g.diag = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
-    // compile-time view counts for the reference's two configurations (7 views: SCARED, 4 views: Hamlyn); others run
-    // the generic instantiation (runtime section lengths: correct, but the compiler spills there)
-    static bool attr_set = false;
+    // One instantiation per source-view count (1..8: SCARED scripts 6, Hamlyn 3, the reference's opt.py default 4, ...):
+    // with the section lengths known at compile time no instantiation carries the spills of a runtime-length version.
+    // This translation unit is compiled twice (uc_nerf_amd/build.py): -DUCNERF_BF16_BUILD_TERMS=3 (bf16x3) and =1 (bf16).
     const size_t smem = bf16_smem_bytes();
-#define UCNERF_BF16_FOR_ALL(X) X(true, 6, 3) X(false, 6, 3) X(true, 3, 3) X(false, 3, 3) X(true, 0, 3) X(false, 0, 3) X(true, 6, 1) X(false, 6, 1) X(true, 0, 1) X(false, 0, 1)
-    if (!attr_set) {
-#define X(T, N, K) (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<T, N, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        UCNERF_BF16_FOR_ALL(X)
-#undef X
-        attr_set = true;
-    }
     dim3 grid(blocks), block(64 * BW);
     const bool tiled = p->feats_tiled != 0;
-    const int terms = p->cfg.precision == 2 ? 1 : 3;
-    const int nsrc = B.v == 6 ? 6 : (B.v == 3 && terms == 3 ? 3 : 0);
-#define X(T, N, K) if (tiled == T && nsrc == N && terms == K) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<T, N, K>), grid, block, smem, st, *p, g, n_tiles);
+    constexpr int K = UCNERF_BF16_BUILD_TERMS;
+#define UCNERF_BF16_FOR_ALL(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#define X(N)                                                                                                                   \
+    if (B.v == N) {                                                                                                            \
+        const void* fn = tiled ? (const void*)mlp_fwd_bf16_kernel<true, N, K> : (const void*)mlp_fwd_bf16_kernel<false, N, K>; \
+        if (int rc = ensure_dynamic_lds(fn, (int)smem, "mlp_fwd (bf16)")) return rc;                                          \
+        if (tiled) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, K>), grid, block, smem, st, *p, g, n_tiles);               \
+        else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, N, K>), grid, block, smem, st, *p, g, n_tiles);                    \
+    }
     UCNERF_BF16_FOR_ALL(X)
 #undef X
 #undef UCNERF_BF16_FOR_ALL
     return check_launch("mlp_fwd_bf16");
 }
 
+#if UCNERF_BF16_BUILD_TERMS == 3
 int64_t bf16_index_count(const ucnerf_mlp_config* cfg) {
     Bf16Layout B;
     if (!bf16_layout(cfg->n_src, &B)) return -1;
@@ -832,5 +845,7 @@ int launch_pack_bf16(const ucnerf_mlp_config* cfg, const float* flat, const int3
                        reinterpret_cast<float*>(reinterpret_cast<char*>(out) + B.const_off_bytes), CONST_FLOATS);
     return check_launch("mlp_pack (bf16x3)");
 }
+
+#endif   // UCNERF_BF16_BUILD_TERMS == 3
 
 }  // namespace ucnerf

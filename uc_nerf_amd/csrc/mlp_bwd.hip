@@ -597,13 +597,8 @@ static size_t carve_bwd(float* base, int m, int n_dirs, BwdWork* w) {
 
 template <int KH, int NT, int EPI>
 static int launch_nn(hipStream_t st, const NnArgs& a) {
-    static bool attr_set = false;                                         // > 64 KB of dynamic LDS needs the opt-in
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nn_kernel<KH, NT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                nn_lds_bytes<KH, NT>()) != hipSuccess)
-            return fail(UCNERF_EHIP, "mlp_bwd: cannot reserve %d bytes of LDS for gemm_nn", nn_lds_bytes<KH, NT>());
-        attr_set = true;
-    }
+    // > 64 KB of dynamic LDS needs the opt-in, per device
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_nn_kernel<KH, NT, EPI>), nn_lds_bytes<KH, NT>(), "mlp_bwd gemm_nn")) return rc;
     const int n_tiles = cdiv(a.m, 32);
     int blocks = cdiv(n_tiles, NN_WAVES);
     if (blocks > device_cus()) blocks = device_cus();                     // persistent: the weights are staged once per block

@@ -2,20 +2,43 @@
 #include "common.h"
 #include "sincos_cw.h"
 
+#include <atomic>
+#include <mutex>
+#include <set>
+#include <utility>
+
 namespace ucnerf {
 
 thread_local char g_err[512] = "";
 char* last_error_buf() { return g_err; }
 
+// Per-device caches (a process may drive several GPUs, from several threads).
+constexpr int MAX_DEVICES = 64;
+
 int device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-        cus = prop.multiProcessorCount;
+    static std::atomic<int> cus[MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return -1;
+    int c = cus[dev].load(std::memory_order_relaxed);
+    if (c == 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) return -1;
+        cus[dev].store(c, std::memory_order_relaxed);
     }
-    return cus;
+    return c;
+}
+
+int ensure_dynamic_lds(const void* kernel, int bytes, const char* what) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(UCNERF_EHIP, "%s: no current device", what);
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(dev, kernel);
+    if (done.count(key)) return UCNERF_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(UCNERF_EHIP, "%s: cannot reserve %d bytes of dynamic LDS on device %d: %s", what, bytes, dev, hipGetErrorString(e));
+    done.insert(key);
+    return UCNERF_OK;
 }
 
 // ------------------------------------------------------------------------------------------- a1

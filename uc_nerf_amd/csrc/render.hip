@@ -87,18 +87,22 @@ static int launch_points(const ucnerf_render_params* p, hipStream_t st, Workspac
     return check_launch("render_points");
 }
 
+// coordinates handed over by the caller (rendering() of the reference receives rays_pts / rays_ndc) instead of derived here
+static inline bool coords_given(const ucnerf_render_params* p) { return p->pts_in != nullptr; }
+
 static void gather_geometry(const ucnerf_render_params* p, const Workspace* w, ucnerf_feat_gather_params* g) {
     memset(g, 0, sizeof(*g));
     g->m = p->n * p->S; g->V = p->cfg.n_src; g->H = p->H; g->W = p->W;
     for (int k = 0; k < 3; ++k) { g->vol_d[k] = p->vol_d[k]; g->vol_h[k] = p->vol_h[k]; g->vol_w[k] = p->vol_w[k]; g->vol[k] = p->vol[k]; }
-    g->pts = w->pts; g->ndc1 = w->ndc1; g->ndc2 = w->ndc2; g->ndc3 = w->ndc3;
+    if (coords_given(p)) { g->pts = p->pts_in; g->ndc1 = p->ndc1_in; g->ndc2 = p->ndc2_in; g->ndc3 = p->ndc3_in; }
+    else { g->pts = w->pts; g->ndc1 = w->ndc1; g->ndc2 = w->ndc2; g->ndc3 = w->ndc3; }
     g->conf = p->conf; g->imgs = p->imgs; g->img_feat = p->img_feat; g->w2cs = p->w2cs; g->intrinsics = p->intrinsics;
 }
 
 static void mlp_args(const ucnerf_render_params* p, const Workspace* w, const float* feats, int tiled, float* raw, ucnerf_mlp_params* m) {
     memset(m, 0, sizeof(*m));
     m->cfg = p->cfg; m->m = p->n * p->S; m->S = p->S; m->dirs_per_sample = 0; m->feats_tiled = tiled; m->max_blocks = p->max_blocks;
-    m->pts = w->ndc; m->dirs = w->angle; m->feats = feats; m->wstream = p->wstream; m->raw = raw;
+    m->pts = coords_given(p) ? p->ndc_in : w->ndc; m->dirs = w->angle; m->feats = feats; m->wstream = p->wstream; m->raw = raw;
 }
 
 static int launch_dirs(const ucnerf_render_params* p, hipStream_t st, Workspace* w) {
@@ -130,10 +134,11 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
         g.feats = keep_feats ? p->feats : w->feats;
         if ((rc = launch_gather_cl(p, p->sources_cl, g.feats, g.out_tiled, w->ndc, st))) return rc;
     } else {
-        if ((rc = launch_points(p, st, w))) return rc;
+        if (!coords_given(p) && (rc = launch_points(p, st, w))) return rc;
         gather_geometry(p, w, &g);
         g.out_tiled = keep_feats ? 0 : 1;
         g.feats = keep_feats ? p->feats : w->feats;
+        g.u_out = p->u_sampled;
         if ((rc = ucnerf_feat_gather_fwd(&g, st))) return rc;
     }
     if (!p->dir_feat && (rc = launch_dirs(p, st, w))) return rc;
@@ -154,6 +159,7 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
     c.n = p->n; c.S = p->S; c.variant = 0; c.white_bkgd = p->white_bkgd;
     c.raw = m.raw; c.z = p->z;
     c.rgb_map = p->rgb_map; c.depth_map = p->depth_map; c.acc_map = p->acc_map; c.weights = p->weights; c.var = p->var;
+    c.u = p->u_sampled; c.wu = p->wu_map;
     return ucnerf_composite_fwd(&c, st);
 }
 
@@ -193,7 +199,7 @@ int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* bp, void* stream) {
     int rc;
     ucnerf_render_params q = *p;            // points / coordinates / directions are recomputed into OUR workspace
     q.workspace = bp->workspace;
-    if ((rc = launch_points(&q, st, &w))) return rc;
+    if (!coords_given(&q) && (rc = launch_points(&q, st, &w))) return rc;
     if ((rc = launch_dirs(&q, st, &w))) return rc;
 
     ucnerf_composite_bwd_params cb;
@@ -230,6 +236,9 @@ int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream) {
     UCNERF_REQUIRE(p->S >= 1 && p->S <= 1024, "render_fused_fwd: S = %d outside 1..1024", p->S);
     UCNERF_REQUIRE((long long)p->n * p->S < (1ll << 31), "render_fused_fwd: n*S overflows int32");
     UCNERF_REQUIRE(((uintptr_t)p->workspace & 15) == 0, "render_fused_fwd: workspace must be 16-byte aligned");
+    UCNERF_REQUIRE(!p->wu_map || p->u_sampled, "render_fused_fwd: wu_map needs u_sampled");
+    const int n_given = !!p->pts_in + !!p->ndc1_in + !!p->ndc2_in + !!p->ndc3_in + !!p->ndc_in;
+    UCNERF_REQUIRE(n_given == 0 || n_given == 5, "render_fused_fwd: pts_in / ndc1_in / ndc2_in / ndc3_in / ndc_in must be given together");
     if (p->n <= 0) return UCNERF_OK;
     Workspace w;
     return run_forward(p, (hipStream_t)stream, &w);

@@ -262,7 +262,8 @@ def _opt(t):
     return _f32(t) if t is not None else None
 
 
-def feat_gather_fwd(src, pts, ndc1, ndc2, ndc3, tiled=False):
+def feat_gather_fwd(src, pts, ndc1, ndc2, ndc3, tiled=False, u_out=None):
+    """u_out: optional [m] float32 tensor receiving the per-sample uncertainty 1 - sampled confidence."""
     pts, ndc1, ndc2, ndc3 = _opt(pts), _opt(ndc1), _opt(ndc2), _opt(ndc3)
     lead = next(t for t in (pts, ndc1, ndc3) if t is not None)
     m = lead.numel() // 3
@@ -272,6 +273,10 @@ def feat_gather_fwd(src, pts, ndc1, ndc2, ndc3, tiled=False):
     n_out = ((m + 31) // 32) * 32 * src.F if tiled else m * src.F
     feats = torch.empty(n_out, device=lead.device) if src.full else torch.zeros(n_out, device=lead.device)
     p.pts, p.ndc1, p.ndc2, p.ndc3, p.feats = _ptr(pts), _ptr(ndc1), _ptr(ndc2), _ptr(ndc3), _ptr(feats)
+    if u_out is not None:
+        if u_out.numel() != m or u_out.dtype != torch.float32 or not u_out.is_contiguous() or src.conf is None:
+            raise RuntimeError("uc_nerf_amd.feat_gather_fwd: u_out must be a contiguous float32 [m] tensor (and the confidence map given)")
+        p.u_out = _ptr(u_out)
     _launch("ucnerf_feat_gather_fwd", p, lead.device)
     return feats if tiled else feats.view(*lead.shape[:-1], src.F)
 
@@ -514,7 +519,8 @@ def mlp_encoded(flat, x, pw):
 
 
 # ------------------------------------------------------------------------------------------------ a9
-def composite_fwd(raw, z, variant=0, white_bkgd=False, rays_d=None, noise=None, want_var=True):
+def composite_fwd(raw, z, variant=0, white_bkgd=False, rays_d=None, noise=None, want_var=True, u=None):
+    """u: optional [n,S] per-sample uncertainty -> out["wu"] [n] = sum_i w_i u_i (composited uncertainty)."""
     raw, z = _f32(raw, "raw"), _f32(z, "z")
     n, S = z.shape
     dev = z.device
@@ -529,6 +535,12 @@ def composite_fwd(raw, z, variant=0, white_bkgd=False, rays_d=None, noise=None, 
     p.raw, p.z, p.rays_d, p.noise = _ptr(raw), _ptr(z), _ptr(rays_d), _ptr(noise)
     p.rgb_map, p.depth_map, p.acc_map, p.disp_map = _ptr(out["rgb"]), _ptr(out["depth"]), _ptr(out["acc"]), _ptr(out["disp"])
     p.weights, p.var = _ptr(out["weights"]), _ptr(out.get("var"))
+    if u is not None:
+        u = _f32(u, "u")
+        if tuple(u.shape) != (n, S):
+            raise RuntimeError("uc_nerf_amd.composite_fwd: u must be [n,S]")
+        out["wu"] = torch.empty(n, device=dev)
+        p.u, p.wu = _ptr(u), _ptr(out["wu"])
     _launch("ucnerf_composite_fwd", p, dev)
     return out
 
@@ -760,7 +772,23 @@ class RenderPass:
             L.check(L.lib().ucnerf_gather_repack(C.addressof(self.p), _ptr(self._cl), _stream()), "ucnerf_gather_repack")
         self.p.sources_cl = _ptr(self._cl)
 
-    def __call__(self, rays_d, z, near_far=None, want=("acc", "weights", "var"), keep=(), events=None, dir_feat=None):
+    @staticmethod
+    def _coords(p, coords, m):
+        """Coordinates handed over by the caller (dict pts, stage1, stage2, stage3, ndc; each [n,S,3]) instead of derived
+        from (rays_d, z) -- what rendering() of the reference receives.  Returns the tensors to keep alive."""
+        if coords is None:
+            p.pts_in = p.ndc1_in = p.ndc2_in = p.ndc3_in = p.ndc_in = None
+            return ()
+        keep = [_f32(coords[k], k) for k in ("pts", "stage1", "stage2", "stage3", "ndc")]
+        for t in keep:
+            if t.numel() != 3 * m:
+                raise RuntimeError("uc_nerf_amd.RenderPass: given coordinates must be [n,S,3]")
+        p.pts_in, p.ndc1_in, p.ndc2_in, p.ndc3_in, p.ndc_in = (_ptr(t) for t in keep)
+        return keep
+
+    def __call__(self, rays_d, z, near_far=None, want=("acc", "weights", "var"), keep=(), events=None, dir_feat=None, coords=None):
+        """want may also name "u" (per-sample uncertainty u = 1 - sampled confidence [n,S], network/models.py:149) and
+        "wu" (its composite sum_i w_i u_i [n]) -- the opt-in uncertainty outputs of SURVEY.md 8(a)."""
         rays_d, z = _f32(rays_d, "rays_d"), _f32(z, "z")
         dir_feat = _f32(dir_feat, "dir_feat") if dir_feat is not None else None
         n, S = z.shape
@@ -782,6 +810,12 @@ class RenderPass:
             out["raw"] = torch.empty(n, S, 4, device=dev)
         if "feats" in keep:
             out["feats"] = torch.empty(n * S, self.src.F, device=dev)
+        if "u" in want or "wu" in want:
+            out["u"] = torch.empty(n, S, device=dev)
+        if "wu" in want:
+            out["wu"] = torch.empty(n, device=dev)
+        p.u_sampled, p.wu_map = _ptr(out.get("u")), _ptr(out.get("wu"))
+        _alive = self._coords(p, coords, n * S)      # noqa: F841 (kept until the launch is enqueued)
         p.rays_d, p.z, p.near_far, p.workspace = _ptr(rays_d), _ptr(z), _ptr(near_far), _ptr(self._ws)
         p.rgb_map, p.depth_map, p.acc_map = _ptr(out["rgb"]), _ptr(out["depth"]), _ptr(out.get("acc"))
         p.weights, p.var, p.raw, p.feats = _ptr(out.get("weights")), _ptr(out.get("var")), _ptr(out.get("raw")), _ptr(out.get("feats"))
@@ -800,7 +834,7 @@ class RenderPass:
         _launch("ucnerf_render_fused_fwd", p, dev)
         return out
 
-    def backward(self, rays_d, z, kept, g_rgb, g_depth, flat, near_far=None, need=(True, True, True, True, True)):
+    def backward(self, rays_d, z, kept, g_rgb, g_depth, flat, near_far=None, need=(True, True, True, True, True), coords=None):
         """Backward of the last-style forward call: `kept` = its outputs with keep=("raw", "feats").
         Returns (g_flat, g_vol1, g_vol2, g_vol3, g_conf, g_img_feat)."""
         rays_d, z, flat, g_rgb = _f32(rays_d), _f32(z), _f32(flat), _f32(g_rgb)
@@ -813,6 +847,8 @@ class RenderPass:
         near_far = _f32(near_far) if near_far is not None else None
         p.rays_d, p.z, p.near_far = _ptr(rays_d), _ptr(z), _ptr(near_far)
         p.raw, p.feats = _ptr(kept["raw"]), _ptr(kept["feats"])
+        p.u_sampled = p.wu_map = None
+        _alive = self._coords(p, coords, n * S)      # noqa: F841
         p.ev_mlp_start = p.ev_mlp_stop = None
         saved = getattr(self, "_saved_for", None) == (n, S, kept["raw"].data_ptr())
         ws = self._bwd_ws if saved else torch.empty(L.lib().ucnerf_render_bwd_workspace_floats(n, S, self.src.V), device=dev)

@@ -71,18 +71,27 @@ class FlatGradBucket:
 
     Shards of unequal size are handled by weighting: each rank's gradient is that of the MEAN loss over its own
     rays, so the global mean-loss gradient is sum_r (n_r / n) g_r -- pass `weight = n_r / n` (1/world for equal
-    shards, which reproduces plain gradient averaging).  Parameters the backward did not touch (the reference
-    leaves six tensors without gradient) contribute zeros and keep grad = None."""
+    shards, which reproduces plain gradient averaging).
+
+    Which parameters receive a gradient is a property of the model and the loss, not of the step (the reference leaves
+    six tensors without one) -- except on a rank whose shard is empty, where NO parameter gets one.  Every
+    rank must still end up with the same gradients, so the bucket also carries one has-gradient flag per parameter; the
+    reduced flags are read back ONCE (the only host synchronisation this class ever makes) and cached: parameters some
+    rank differentiated get their p.grad materialised from the reduced segment on every rank, parameters no rank touched
+    keep grad = None as in the reference.  Nothing else reads device memory: scalars are written into the bucket with a
+    device-side copy."""
 
     def __init__(self, params, n_scalars=0):
         self.params = [p for p in params if p.requires_grad]
         self.sizes = [p.numel() for p in self.params]
         self.n_scalars = n_scalars
-        self.numel = sum(self.sizes) + n_scalars
+        self.n_grads = sum(self.sizes)
+        self.numel = self.n_grads + n_scalars + len(self.params)
         self.flat = None
+        self.has_grad = None         # cached after the first reduction: list of bool, one per parameter
 
     def allreduce(self, weight, scalars=(), group=None):
-        """In place on p.grad.  Returns the reduced scalars (e.g. global loss terms) as a tensor."""
+        """In place on p.grad.  Returns the reduced scalars (e.g. global loss terms) as a device tensor."""
         if len(scalars) != self.n_scalars:
             raise ValueError("expected %d scalars, got %d" % (self.n_scalars, len(scalars)))
         dev = self.params[0].device
@@ -94,19 +103,28 @@ class FlatGradBucket:
             if p.grad is None:
                 seg.zero_()
             else:
-                seg.copy_(p.grad.reshape(-1))
-                seg.mul_(weight)
+                torch.mul(p.grad.reshape(-1), weight, out=seg)
             off += n
-        for k, s in enumerate(scalars):
-            self.flat[off + k] = float(s) * weight
+        if self.n_scalars:
+            vals = torch.stack([torch.as_tensor(s, dtype=torch.float32, device=dev).reshape(()) for s in scalars])
+            torch.mul(vals, weight, out=self.flat[off:off + self.n_scalars])
+        off += self.n_scalars
+        if self.has_grad is None:
+            self.flat[off:].copy_(torch.tensor([0.0 if p.grad is None else 1.0 for p in self.params]), non_blocking=True)
+        else:
+            self.flat[off:].zero_()
         if dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        if self.has_grad is None:
+            self.has_grad = [bool(v > 0) for v in self.flat[off:].tolist()]       # the one read-back, first step only
         off = 0
-        for p, n in zip(self.params, self.sizes):
+        for p, n, has in zip(self.params, self.sizes, self.has_grad):
             if p.grad is not None:
                 p.grad.copy_(self.flat[off:off + n].view_as(p.grad))
+            elif has:                                                              # e.g. an empty shard on this rank
+                p.grad = self.flat[off:off + n].view_as(p).clone()
             off += n
-        return self.flat[off:off + self.n_scalars].clone()
+        return self.flat[self.n_grads:self.n_grads + self.n_scalars].clone()
 
 
 def all_gather_rays(local, n_total, rank, world, group=None):
