@@ -89,6 +89,9 @@ typedef struct {
     const float* rays_d;  /* [n,3] */
     float* angle;         /* [n,3] (or [n*repeat,3]) out */
     float* cos_angle;     /* [n] out or NULL */
+    const float* w2c_ref_dev; /* optional DEVICE pointer to the same matrix, row-major with 4 columns (a 3x4 or 4x4 tensor): used
+                                 instead of w2c_ref when non-NULL (has_ref is then implied), so that a caller holding the pose
+                                 on the device -- rendering() gets pose_ref['w2cs'] as a device tensor -- need not read it back */
 } ucnerf_dir_feature_params;
 int ucnerf_dir_feature(const ucnerf_dir_feature_params* p, void* stream);
 

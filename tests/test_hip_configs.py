@@ -298,7 +298,7 @@ def test_full_batch_errors_against_the_fp32_oracle_with_knife_edge_rays_characte
     over = (e_rgb > 1e-4) | (e_depth > 1e-4) | (e_acc > 1e-4)
     edge = (ys == 0) | (ys == 255)
     record("configs1_4096x(64+128)_%s_vs_fp32_oracle" % precision, rays=n, knife_edge_rows=int(edge.sum()), flipped_mask_rays=int(flipped.sum()),
-           rays_over_1e-4=int(over.sum()), max_abs_rgb_unflipped=e_rgb[~flipped].max().item(),
+           rays_over_1e4=int(over.sum()), max_abs_rgb_unflipped=e_rgb[~flipped].max().item(),
            max_abs_depth_unflipped=e_depth[~flipped].max().item(), max_abs_acc_unflipped=e_acc[~flipped].max().item(),
            max_abs_rgb_flipped=e_rgb[flipped].max().item() if flipped.any() else 0.0,
            max_abs_depth_flipped=e_depth[flipped].max().item() if flipped.any() else 0.0)

@@ -29,7 +29,7 @@ class NdcRaysParams(C.Structure):
 
 class DirFeatureParams(C.Structure):
     _fields_ = [("n", i32), ("has_ref", i32), ("repeat", i32), ("w2c_ref", f32 * 12), ("rays_d", vp), ("angle", vp),
-                ("cos_angle", vp)]
+                ("cos_angle", vp), ("w2c_ref_dev", vp)]
 
 
 class SampleStratifiedParams(C.Structure):

@@ -119,8 +119,8 @@ __global__ void dir_feature_kernel(ucnerf_dir_feature_params p) {
     dx /= c; dy /= c; dz /= c;
     if (p.cos_angle && idx % rep == 0) p.cos_angle[i] = c;
     float* o = p.angle + 3 * idx;
-    if (p.has_ref) {
-        const float* R = p.w2c_ref;
+    if (p.has_ref || p.w2c_ref_dev) {
+        const float* R = p.w2c_ref_dev ? p.w2c_ref_dev : p.w2c_ref;
         o[0] = dx * R[0] + dy * R[1] + dz * R[2];
         o[1] = dx * R[4] + dy * R[5] + dz * R[6];
         o[2] = dx * R[8] + dy * R[9] + dz * R[10];

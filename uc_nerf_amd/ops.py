@@ -92,11 +92,15 @@ def ndc_rays(H, W, focal_x, focal_y, near, rays_o, rays_d, variant):
 
 
 def dir_feature(rays_d, w2c_ref=None):
-    """Returns (angle[n,3], cos_angle[n]): normalised direction rotated into the reference camera."""
+    """Returns (angle[n,3], cos_angle[n]): normalised direction rotated into the reference camera.  A float32 w2c_ref
+    already on the rays' device ([3,4] or [4,4], contiguous) is read by the kernel in place -- no host read-back."""
     rays_d = _f32(rays_d, "rays_d")
     p = L.DirFeatureParams()
     p.n, p.has_ref = rays_d.shape[0], int(w2c_ref is not None)
-    if w2c_ref is not None:
+    if (torch.is_tensor(w2c_ref) and w2c_ref.is_cuda and w2c_ref.dtype == torch.float32 and w2c_ref.device == rays_d.device
+            and w2c_ref.dim() == 2 and w2c_ref.shape[0] >= 3 and w2c_ref.shape[1] == 4 and w2c_ref.is_contiguous()):
+        p.w2c_ref_dev = _ptr(w2c_ref)
+    elif w2c_ref is not None:
         _mat(p.w2c_ref, w2c_ref, 3, 4)
     angle = torch.empty_like(rays_d)
     cos = torch.empty(rays_d.shape[0], device=rays_d.device)
