@@ -4,17 +4,25 @@
 
   python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W [--scaling strong] [--mode train]
 
-One process per GPU.  Rays are independent, so the batch is sharded across ranks with no data-path
-collective (weak scaling: 4096 rays per GPU); the only collectives are the barrier and the MAX of the
-timed interval.  Rank 0 prints ONE JSON line.
+One process per GPU.  Rays are independent, so the batch is sharded across ranks with no data-path collective:
+  --scaling weak   (default) 4096 rays per GPU, global batch 4096 N
+  --scaling strong a 4096-ray global batch split N ways (512 rays per GPU at N = 8: the north-star's strong-scaling regime)
+The only collectives of the render mode are the barrier and the MAX of the timed interval.  Rank 0 prints ONE JSON line.
+  --mode train     the line's metric becomes training rays/sec: rendering() drop-in forward + backward on this rank's
+                   shard of a live-path batch (2000 rays x 90 cascade samples per GPU), ONE flat-bucket all-reduce of the
+                   gradients over RCCL (parallel.FlatGradBucket, 0.73 MB), Adam step.
+In render mode with N > 1 a short data-parallel training run is appended as the secondary field `train_dp`, so that the
+RCCL bucket all-reduce is exercised and timed whenever the driver runs the scaling series.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
+import types
 
 import torch
 
@@ -54,47 +62,208 @@ def cpu_baseline(scene_cpu, sd, n_rays, n_coarse, n_fine, budget_s=20.0):
                       % (n_rays, n_coarse, n_fine, len(times))}
 
 
+class Ctx:
+    """Process-wide state of one bench run (rank / world / device / collectives)."""
+
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, self.world))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+        # one rank per GPU; UCNERF_BENCH_BACKEND=gloo is a rehearsal mode for a box with fewer GPUs than ranks (ranks then
+        # share devices round-robin and the collectives go through gloo) -- the driver's runs use RCCL ("nccl")
+        self.backend = os.environ.get("UCNERF_BENCH_BACKEND", "nccl")
+        n_dev = torch.cuda.device_count()
+        if local >= n_dev and self.backend == "nccl":
+            raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPUs visible" % (local, n_dev))
+        torch.cuda.set_device(local % n_dev)
+        self.dev = torch.device("cuda", local % n_dev)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+            self.dist = dist
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt):
+        if self.dist is None:
+            return dt
+        t = torch.tensor([dt], device=self.dev if self.backend == "nccl" else "cpu", dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.item()
+
+    def timed(self, fn, steps, warmup):
+        """W untimed calls, barrier + synchronize, K timed calls, barrier + synchronize; seconds per call, MAX over ranks."""
+        for _ in range(warmup):
+            fn()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0) / steps
+
+
+def guarded(fn, key=None):
+    """Secondary measurements never take the headline line down with them.  With `key` the failure is reported as
+    {key: {"error": ...}} (for measurements that contribute several fields via dict.update)."""
+    try:
+        return fn()
+    except Exception as e:       # noqa: BLE001
+        err = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        return {key: err} if key else err
+
+
+# ------------------------------------------------------------------------------------------------ live-path (drop-in) workloads
+def dropin_setup(scene, sd, dev):
+    import uc_nerf_amd
+    uc_nerf_amd.install_dropin()
+    import network.models as models
+    from uc_nerf_amd.synthetic import cascade_outputs
+    a = types.SimpleNamespace(multires=10, multires_views=4, i_embed=0, netdepth=6, netwidth=128, feat_dim=97, net_type="v2", view_num=7,
+                              netchunk=1024, perturb=1.0, N_samples=90, use_viewdirs=True, white_bkgd=False, raw_noise_std=0.0, ckpt=None,
+                              device=str(dev), img_downscale=1.0, use_color_volume=False)
+    kw_train, _, _, grad_vars = models.create_ucnerf(a, dir_embedder=True, pts_embedder=True)      # as train.py:36-37
+    net = kw_train["network_fn"]
+    net.load_state_dict(sd)
+    outputs = cascade_outputs(scene)
+    return a, kw_train, net, grad_vars, outputs
+
+
+def dropin_call(a, kw, scene, outputs, batch, confidence=None, vols=None, img_feat=None):
+    import network.renderer as renderer
+    vf = outputs if vols is None else {"stage%d" % (k + 1): {"volume_feature_no_ref": vols[k]} for k in range(3)}
+    pose = batch["pose_ref"]                                  # trimmed in place by the first call, as in train.py
+    return renderer.rendering(a, pose, batch["rays_pts"], batch["rays_ndc"], batch["depth_candidates"], batch["rays_dir"], vf, scene["imgs"],
+                              img_feat=scene["img_feat"] if img_feat is None else img_feat,
+                              confidence=scene["confidence"] if confidence is None else confidence,
+                              network_fn=kw["network_fn"], network_query_fn=kw["network_query_fn"], white_bkgd=kw["white_bkgd"])
+
+
+def bench_dropin(ctx, scene, sd, steps=40, warmup=10):
+    """rendering() -- the reference's call surface -- on the shapes train.py runs it on, next to the library's own RenderPass."""
+    import uc_nerf_amd
+    from uc_nerf_amd import ops
+    from uc_nerf_amd.pipeline import flat_params_of
+    from uc_nerf_amd.synthetic import live_path_batch
+    dev = ctx.dev
+    a, kw, net, grad_vars, outputs = dropin_setup(scene, sd, dev)
+    out = {}
+    # evaluation: one 1024-pixel chunk x 90 samples under no_grad (train.py:254-272)
+    ev = live_path_batch(scene, outputs, 1024, 90, seed=3, chunk_idx=7)
+    with torch.no_grad():
+        for prec in ("f32", "bf16x3"):
+            uc_nerf_amd.set_inference_precision(prec)
+            dt = ctx.timed(lambda: dropin_call(a, kw, scene, outputs, ev), steps * 4, warmup * 4)
+            out["dropin_eval_" + prec] = {"ms_per_call": dt * 1e3, "value": 1024 / dt, "unit": "rays/s", "rays": 1024, "samples_per_ray": 90}
+        uc_nerf_amd.set_inference_precision("f32")
+        # the same chunk through the library's own RenderPass (coordinates derived in-kernel from ray + depth + cascade ranges)
+        src = ops.GatherSources(scene["vols"], scene["confidence"], scene["imgs"], scene["img_feat"], scene["w2cs"][1:], scene["intrinsics"][1:])
+        for prec in ("f32", "bf16x3"):
+            pw = ops.PackedWeights.get(6, 0, dev, prec)
+            rp = ops.RenderPass(src, pw, pw.pack(flat_params_of(sd).to(dev)), scene["c2w"][:3, 3].to(dev), scene["w2cs"][0], scene["intrinsics"][0],
+                                scene["w2cs"][0], scene["near"], scene["far"])
+            rp.repack_sources()
+            ang, _ = ops.dir_feature(ev["rays_dir"], scene["w2cs"][0])
+            dt = ctx.timed(lambda: rp(ev["rays_dir"], ev["depth_candidates"], near_far=ev["ranges"], want=(), dir_feat=ang), steps * 4, warmup * 4)
+            out["render_pass_1024x90_" + prec] = {"ms_per_call": dt * 1e3, "value": 1024 / dt, "unit": "rays/s"}
+        for prec in ("f32", "bf16x3"):
+            out["dropin_eval_" + prec]["speed_vs_render_pass"] = (out["render_pass_1024x90_" + prec]["ms_per_call"]
+                                                                  / out["dropin_eval_" + prec]["ms_per_call"])
+    # training: 2000 rays x 90 samples, forward + loss + backward into the network AND the gather sources + Adam (train.py:147-188, 85-92)
+    tr = live_path_batch(scene, outputs, 2000, 90, seed=4)
+    vols = [v.detach().clone().requires_grad_(True) for v in scene["vols"]]
+    img_feat = scene["img_feat"].detach().clone().requires_grad_(True)
+    conf = scene["confidence"].detach().clone().requires_grad_(True)
+    target = torch.rand(2000, 3, device=dev)
+    opt = torch.optim.Adam(grad_vars, lr=5e-4, betas=(0.9, 0.999))
+
+    def train_step():
+        opt.zero_grad(set_to_none=True)
+        for t in vols + [img_feat, conf]:
+            t.grad = None
+        rgb, depth = dropin_call(a, kw, scene, outputs, tr, confidence=conf, vols=vols, img_feat=img_feat)
+        loss = torch.mean((rgb - target) ** 2) * 5.0 + 0.05 * torch.mean((depth - 2.0) ** 2)
+        loss.backward()
+        opt.step()
+        return loss
+
+    dt = ctx.timed(train_step, steps, warmup)
+    assert torch.isfinite(train_step()).all()
+    out["dropin_train"] = {"ms_per_step": dt * 1e3, "value": 2000 / dt, "unit": "rays/s", "rays": 2000, "samples_per_ray": 90, "dtype": "f32",
+                           "note": "rendering() forward (activations kept) + img/depth loss + backward into MLP parameters, cascade volumes, "
+                                   "img_feats and confidence + Adam step; the weight stream is repacked once per step"}
+    return out
+
+
+def bench_train_dp(ctx, scene, sd, rays_per_rank, steps=30, warmup=8):
+    """Data-parallel training steps: rendering() drop-in on this rank's rays, backward, ONE flat-bucket all-reduce over the
+    process group (RCCL when backend = nccl), Adam.  Returns per-step time and the all-reduce's share."""
+    from uc_nerf_amd import parallel as P
+    from uc_nerf_amd.synthetic import live_path_batch
+    dev = ctx.dev
+    a, kw, net, grad_vars, outputs = dropin_setup(scene, sd, dev)
+    tr = live_path_batch(scene, outputs, rays_per_rank, 90, seed=10 + ctx.rank)
+    target = torch.rand(rays_per_rank, 3, device=dev)
+    opt = torch.optim.Adam(grad_vars, lr=5e-4, betas=(0.9, 0.999))
+    bucket = P.FlatGradBucket(grad_vars, n_scalars=1)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    k = [-warmup]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        rgb, depth = dropin_call(a, kw, scene, outputs, tr)
+        loss = torch.mean((rgb - target) ** 2) * 5.0 + 0.05 * torch.mean((depth - 2.0) ** 2)
+        loss.backward()
+        if k[0] >= 0:
+            ev[k[0]][0].record()
+        bucket.allreduce(1.0 / ctx.world, [loss.detach()])
+        if k[0] >= 0:
+            ev[k[0]][1].record()
+        opt.step()
+        k[0] += 1
+
+    dt = ctx.timed(step, steps, warmup)
+    ar_ms = sorted(a_.elapsed_time(b_) for a_, b_ in ev)[len(ev) // 2]
+    return {"ms_per_step": dt * 1e3, "value": rays_per_rank * ctx.world / dt, "unit": "rays/s", "rays_per_gpu": rays_per_rank, "samples_per_ray": 90,
+            "ranks_seen": ctx.dist.get_world_size() if ctx.dist is not None else 1, "backend": ctx.backend if ctx.dist is not None else "none",
+            "allreduce_ms_median": ar_ms, "bucket_bytes": bucket.numel * 4,
+            "note": "rendering() fwd + bwd + one flat-bucket gradient all-reduce (pack + collective + unpack timed together) + Adam"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)      # ~0.2 s of GPU time: the clocks need ~100 steps to settle
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
+    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step (weak) / global rays per step (strong)")
     ap.add_argument("--coarse", type=int, default=64)
     ap.add_argument("--fine", type=int, default=128)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--mode", choices=["render", "train"], default="render")
     ap.add_argument("--cpu-rays", type=int, default=512, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--max-blocks", type=int, default=0)
-    ap.add_argument("--no-reuse", action="store_true", help="skip the secondary measurements (reuse_coarse, plain bf16): profiling runs")
+    ap.add_argument("--no-reuse", "--headline-only", dest="no_reuse", action="store_true",
+                    help="skip the secondary measurements: profiling runs")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (no per-kernel HIP events)")
     ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default="bf16x3",
                     help="MLP arithmetic: exact fp32 MFMA; split-bf16 (3 bf16 MFMAs per product, fp32 accumulate, within the "
                          "1e-4 parity bar); plain bf16 (1 MFMA per product, NOT within the parity bar: PSNR reported)")
     args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
-    # one rank per GPU; UCNERF_BENCH_BACKEND=gloo is a rehearsal mode for a box with fewer GPUs than ranks (ranks then
-    # share devices round-robin and the barrier / MAX go through gloo) -- the driver's runs use RCCL ("nccl")
-    backend = os.environ.get("UCNERF_BENCH_BACKEND", "nccl")
-    n_dev = torch.cuda.device_count()
-    if local >= n_dev and backend == "nccl":
-        raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPUs visible" % (local, n_dev))
-    local_dev = local % n_dev
-    torch.cuda.set_device(local_dev)
-    dev = torch.device("cuda", local_dev)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    ctx = Ctx(args)
+    rank, world, dev = ctx.rank, ctx.world, ctx.dev
 
     from uc_nerf_amd import ops
     from uc_nerf_amd.pipeline import CoarseFineRenderer, flat_params_of
@@ -103,19 +272,32 @@ def main():
     scene_cpu = make_scene(seed=0)
     sd = init_ucnerf_state_dict(seed=0, n_src=6, sigma_scale=0.05, sigma_bias=0.05)
     scene = scene_to(scene_cpu, dev)
+
+    if args.mode == "train":
+        rays = 2000 if args.rays == 4096 else args.rays
+        per_rank = rays if args.scaling == "weak" else max(1, rays // world)
+        res = bench_train_dp(ctx, scene, sd, per_rank, steps=args.steps, warmup=max(args.warmup, 5))
+        if rank == 0:
+            print(json.dumps({"metric": "training rays/sec (rendering() fwd+bwd, 90 samples, flat-bucket all-reduce, Adam)", "value": res["value"],
+                              "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 5), "ms_per_step": res["ms_per_step"],
+                              "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": "live path: %d rays/GPU x 90 cascade samples, V=7 views 256x320" % per_rank,
+                                         "parallelism": "ray-sharded x%d, one flat gradient bucket all-reduced per step" % world}, "train": res}), flush=True)
+        if ctx.dist is not None:
+            ctx.dist.barrier()
+            ctx.dist.destroy_process_group()
+        return
+
+    rays = args.rays if args.scaling == "weak" else max(1, args.rays // world)           # per rank
+    global_rays = rays * world
     renderer = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, max_blocks=args.max_blocks,
                                   precision=args.precision)
-    # this rank's shard of the global batch of rays*world pixels: contiguous block split
-    xs_all, ys_all = random_pixels(args.rays * world, scene_cpu["H"], scene_cpu["W"], seed=0)
-    xs = xs_all[rank * args.rays:(rank + 1) * args.rays].to(dev)
-    ys = ys_all[rank * args.rays:(rank + 1) * args.rays].to(dev)
-    noise = torch.rand(args.rays, args.coarse, generator=torch.Generator().manual_seed(100 + rank)).to(dev)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    # this rank's shard of the global batch: contiguous block split
+    xs_all, ys_all = random_pixels(global_rays, scene_cpu["H"], scene_cpu["W"], seed=0)
+    xs = xs_all[rank * rays:(rank + 1) * rays].to(dev)
+    ys = ys_all[rank * rays:(rank + 1) * rays].to(dev)
+    noise = torch.rand(rays, args.coarse, generator=torch.Generator().manual_seed(100 + rank)).to(dev)
+    barrier = ctx.barrier
 
     # The chip needs ~100 ms of load before its clocks settle (a 20-step run reads 7 % lower than a 200-step one): whatever
     # W is, at least 120 untimed steps run before the timed region; the extra ones are reported as `clock_settle_steps`.
@@ -131,15 +313,9 @@ def main():
     gc.freeze()
     graph_ms = None
     if args.graph:                       # extra measurement: the same K steps as replays of one captured HIP graph
-        g = renderer.capture(args.rays, perturb=1.0)
-        for _ in range(args.warmup):
-            og = g(xs, ys, noise)
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            og = g(xs, ys, noise)
-        barrier()
-        graph_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        g = renderer.capture(rays, perturb=1.0)
+        graph_ms = ctx.timed(lambda: g(xs, ys, noise), args.steps, args.warmup) * 1e3
+        og = g(xs, ys, noise)
         ref = renderer.render(xs, ys, perturb=1.0, noise=noise)
         assert torch.equal(og["rgb"], ref["rgb"]) and torch.equal(og["depth"], ref["depth"])
     barrier()
@@ -147,97 +323,125 @@ def main():
     for k in range(args.steps):
         out = renderer.render(xs, ys, perturb=1.0, noise=noise, events=events[k])
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    dt = ctx.max_over_ranks(time.perf_counter() - t0)
     assert torch.isfinite(out["rgb"]).all() and torch.isfinite(out["depth"]).all()
-
-    # secondary number (not `value`): the same steps with the fine pass re-using the coarse pass's network outputs for the
-    # 64 coarse depths (bit-identical renders, tests/test_hip_pipeline.py) -- 192 instead of 256 evaluations per ray
-    dt2 = None
-    if not args.no_reuse:
-        for _ in range(args.warmup):
-            out2 = renderer.render(xs, ys, perturb=1.0, noise=noise, reuse_coarse=True)
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            out2 = renderer.render(xs, ys, perturb=1.0, noise=noise, reuse_coarse=True)
-        barrier()
-        dt2 = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt2], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt2 = t.item()
-        assert torch.equal(out2["rgb"], out["rgb"]) and torch.equal(out2["depth"], out["depth"])
-
-    # second secondary number: plain-bf16 operands (the dtype BASELINE.json's configs[1] names), which is NOT within the 1e-4
-    # parity bar -- reported with its PSNR against the exact-f32 render of the same depths
-    plain = None
-    if not args.no_reuse and args.precision == "bf16x3":
-        rp = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, max_blocks=args.max_blocks, precision="bf16")
-        for _ in range(args.warmup):
-            op = rp.render(xs, ys, perturb=1.0, noise=noise)
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            op = rp.render(xs, ys, perturb=1.0, noise=noise)
-        barrier()
-        dt3 = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt3], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt3 = t.item()
-        r32 = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, precision="f32")
-        ref = r32.pass_(op["rays_d"], op["z_fine"])
-        mse = torch.mean((op["rgb"] - ref["rgb"]) ** 2).item()
-        plain = {"value": args.rays * world * args.steps / dt3, "unit": "rays/s", "ms_per_step": dt3 / args.steps * 1e3,
-                 "psnr_db_vs_f32": -10.0 * __import__("math").log10(max(mse, 1e-20)),
-                 "max_abs_rgb_vs_f32": (op["rgb"] - ref["rgb"]).abs().max().item(),
-                 "note": "NOT the headline and NOT within the 1e-4 parity bar: one bf16 MFMA per product (precision='bf16')"}
-
-    # third secondary number: a training-style step on this GPU -- source repack + forward + full backward (parameters,
-    # volumes, image features, confidence) of one fused render pass, 1024 rays x 128 depths, exact-f32 path
-    train = None
-    if not args.no_reuse:
-        n_t, s_t = min(1024, int(xs.shape[0])), 128
-        rt = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, precision="f32")
-        flat_t = flat_params_of(sd).to(dev)
-        rd_t, _, _ = ops.ray_gen(rt.K_host, rt.c2w_host, xs=xs[:n_t], ys=ys[:n_t])
-        z_t, _ = ops.sample_stratified(None, s_t, n=n_t, near=rt.near_host, far=rt.far_host, device=dev)
-        g_rgb, g_depth = torch.randn(n_t, 3, device=dev), torch.randn(n_t, device=dev)
-
-        def train_step():
-            rt.pass_.repack_sources()
-            kept = rt.pass_(rd_t, z_t, keep=("raw", "feats"))
-            return rt.pass_.backward(rd_t, z_t, kept, g_rgb, g_depth, flat_t)
-
-        for _ in range(5):
-            grads = train_step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(30):
-            grads = train_step()
-        barrier()
-        dt4 = (time.perf_counter() - t0) / 30
-        assert all(torch.isfinite(t).all() for t in grads if t is not None)
-        train = {"ms_per_step": dt4 * 1e3, "value": n_t / dt4, "unit": "rays/s", "rays": n_t, "samples_per_ray": s_t, "dtype": "f32",
-                 "note": "NOT the headline: source repack + forward + full backward of one fused render pass on one GPU "
-                         "(no optimizer, no collective)"}
 
     # dominant kernel (mlp_fwd): HIP events recorded around its two launches per step, on the launch stream
     mlp_ms = sum(a.elapsed_ms(b) for step in events for a, b in step)
     launches = 2 * args.steps
-    samples_per_step = args.rays * (args.coarse + args.coarse + args.fine)
+    samples_per_step = rays * (args.coarse + args.coarse + args.fine)
     achieved = samples_per_step * args.steps * FLOP_PER_SAMPLE / (mlp_ms * 1e-3) / 1e12
     bf16 = args.precision != "f32"
+
+    extra = {}
+    secondary = not args.no_reuse
+    if secondary:
+        # reuse_coarse: the fine pass evaluates only the 128 new depths (bit-identical renders, tests/test_hip_pipeline.py)
+        def reuse():
+            dt2 = ctx.timed(lambda: renderer.render(xs, ys, perturb=1.0, noise=noise, reuse_coarse=True), args.steps, args.warmup)
+            out2 = renderer.render(xs, ys, perturb=1.0, noise=noise, reuse_coarse=True)
+            assert torch.equal(out2["rgb"], out["rgb"]) and torch.equal(out2["depth"], out["depth"])
+            return {"value": global_rays / dt2, "unit": "rays/s", "ms_per_step": dt2 * 1e3,
+                    "note": "NOT the headline: fine pass evaluates only the 128 new depths and re-uses the coarse pass's outputs for the "
+                            "64 coarse ones; renders verified bit-identical in this run"}
+        extra["reuse_coarse"] = guarded(reuse)
+
+        def other_precisions():
+            res = {}
+            r32 = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, precision="f32")
+            if args.precision != "f32":          # the exact-fp32 kernel, driver-timed in the same line (roofline of ITS dominant kernel)
+                ev32 = [[(ops.Event(), ops.Event()), (ops.Event(), ops.Event())] for _ in range(40)]
+                k32 = [-10]
+
+                def step32():
+                    r32.render(xs, ys, perturb=1.0, noise=noise, events=ev32[k32[0]] if k32[0] >= 0 else None)
+                    k32[0] += 1
+                dt32 = ctx.timed(step32, 40, 10)
+                ms32 = sum(a.elapsed_ms(b) for st in ev32 for a, b in st)
+                ach32 = samples_per_step * 40 * FLOP_PER_SAMPLE / (ms32 * 1e-3) / 1e12
+                res["exact_f32"] = {"value": global_rays / dt32, "unit": "rays/s", "ms_per_step": dt32 * 1e3,
+                                    "roofline": {"bound": "mfma", "kernel": "mlp_fwd_kernel", "achieved": ach32, "peak": PEAK_F32_MFMA_TFLOPS,
+                                                 "unit": "TFLOP/s", "frac": ach32 / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": ms32 / 80},
+                                    "note": "NOT the headline: precision='f32' (v_mfma_f32_32x32x2_f32, exact fp32 products)"}
+            if args.precision == "bf16x3":       # plain-bf16 operands (the dtype configs[1] names): NOT within the 1e-4 parity bar
+                rp = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, max_blocks=args.max_blocks, precision="bf16")
+                dt3 = ctx.timed(lambda: rp.render(xs, ys, perturb=1.0, noise=noise), args.steps, args.warmup)
+                op = rp.render(xs, ys, perturb=1.0, noise=noise)
+                ref = r32.pass_(op["rays_d"], op["z_fine"])
+                mse = torch.mean((op["rgb"] - ref["rgb"]) ** 2).item()
+                res["plain_bf16"] = {"value": global_rays / dt3, "unit": "rays/s", "ms_per_step": dt3 * 1e3,
+                                     "psnr_db_vs_f32": -10.0 * math.log10(max(mse, 1e-20)),
+                                     "max_abs_rgb_vs_f32": (op["rgb"] - ref["rgb"]).abs().max().item(),
+                                     "note": "NOT the headline and NOT within the 1e-4 parity bar: one bf16 MFMA per product (precision='bf16')"}
+            return res
+        extra.update(guarded(other_precisions, "other_precisions"))
+
+        def micro():
+            """SURVEY.md 8(d) secondary micro-bench (north_star's literal '4096-ray x 128-sample'): single pass, S = 128,
+            PRECOMPUTED input_feat ~ randn [4096,128,97] -> positional encoding + MLP + compositing only."""
+            n, S = 4096, 128
+            g = torch.Generator().manual_seed(5)
+            feats = torch.randn(n * S, 97, generator=g)
+            feats[:, -1] = torch.rand(n * S, generator=g)
+            feats = feats.to(dev)
+            pts = torch.rand(n * S, 3, generator=g).to(dev)
+            dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+            z = torch.sort(1 + 3 * torch.rand(n, S, generator=g), -1)[0].to(dev)
+            pw, ws = renderer.pw, renderer.wstream
+
+            def step():
+                raw = ops.mlp_fwd(pw, ws, pts, dirs, feats, S)
+                return ops.composite_fwd(raw.view(n, S, 4), z)
+            dtm = ctx.timed(step, 60, 20)
+            return {"value": n * world / dtm, "unit": "rays/s", "ms_per_step": dtm * 1e3, "rays": n, "samples_per_ray": S, "precision": args.precision,
+                    "tflops_algorithmic": n * S * FLOP_PER_SAMPLE / dtm / 1e12,
+                    "note": "single pass on precomputed [4096,128,97] features: PE + MLP + composite (no gather, no sampling)"}
+        extra["micro_4096x128_precomputed_feats"] = guarded(micro)
+
+        def fused_train():
+            """A training-style step of the library's fused pass: source repack + forward + full backward (parameters, volumes,
+            image features, confidence), 1024 rays x 128 depths, exact-f32 path."""
+            n_t, s_t = min(1024, int(xs.shape[0])), 128
+            rt = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, precision="f32")
+            flat_t = flat_params_of(sd).to(dev)
+            rd_t, _, _ = ops.ray_gen(rt.K_host, rt.c2w_host, xs=xs[:n_t], ys=ys[:n_t])
+            z_t, _ = ops.sample_stratified(None, s_t, n=n_t, near=rt.near_host, far=rt.far_host, device=dev)
+            g_rgb, g_depth = torch.randn(n_t, 3, device=dev), torch.randn(n_t, device=dev)
+
+            def train_step():
+                rt.pass_.repack_sources()
+                kept = rt.pass_(rd_t, z_t, keep=("raw", "feats"))
+                return rt.pass_.backward(rd_t, z_t, kept, g_rgb, g_depth, flat_t)
+            dt4 = ctx.timed(train_step, 30, 5)
+            assert all(torch.isfinite(t).all() for t in train_step() if t is not None)
+            return {"ms_per_step": dt4 * 1e3, "value": n_t / dt4, "unit": "rays/s", "rays": n_t, "samples_per_ray": s_t, "dtype": "f32",
+                    "note": "NOT the headline: source repack + forward + full backward of one fused render pass on one GPU "
+                            "(no optimizer, no collective)"}
+        extra["train_step"] = guarded(fused_train)
+
+        if world == 1:
+            extra.update(guarded(lambda: bench_dropin(ctx, scene, sd), "dropin"))
+
+            def strong_512():
+                """The per-GPU share of the north-star's strong-scaling point (4096 rays over 8 GPUs) measured on this one GPU."""
+                n = 512
+                x5, y5, nz5 = xs[:n].contiguous(), ys[:n].contiguous(), noise[:n].contiguous()
+                dt5 = ctx.timed(lambda: renderer.render(x5, y5, perturb=1.0, noise=nz5, repack=False), 300, 60)
+                dt5r = ctx.timed(lambda: renderer.render(x5, y5, perturb=1.0, noise=nz5, repack=True), 300, 60)
+                return {"ms_per_step": dt5 * 1e3, "ms_per_step_with_repack": dt5r * 1e3, "rays": n,
+                        "projected_speedup_at_8_gpus": (dt / args.steps) / dt5 if rays == 4096 else None,
+                        "note": "512 rays x (64+128) on one GPU, sources constant across batches (repack hoisted); the projection "
+                                "divides this run's 4096-ray step by it and ignores the (collective-free) gather of 80 KB of outputs"}
+            extra["strong_512"] = guarded(strong_512)
+        else:
+            extra["train_dp"] = guarded(lambda: bench_train_dp(ctx, scene, sd, 2000 if args.scaling == "weak" else max(1, 2000 // world)))
+
     psnr_vs_f32 = None
     if args.precision == "bf16":         # outside the parity bar by construction: report the distance to the exact render
         r32 = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, precision="f32")
         ref = r32.pass_(out["rays_d"], out["z_fine"])            # same fine depths: isolates the network arithmetic
         mse = torch.mean((out["rgb"] - ref["rgb"]) ** 2).item()
-        psnr_vs_f32 = {"psnr_db": -10.0 * __import__("math").log10(max(mse, 1e-20)),
+        psnr_vs_f32 = {"psnr_db": -10.0 * math.log10(max(mse, 1e-20)),
                        "max_abs_rgb": (out["rgb"] - ref["rgb"]).abs().max().item(),
                        "max_abs_depth": (out["depth"] - ref["depth"]).abs().max().item()}
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
@@ -267,36 +471,30 @@ def main():
                         if terms == 3 else "plain bf16: NOT within the 1e-4 parity bar, see parity_vs_f32")
         line = {
             "metric": "rendered rays/sec (coarse+fine, 64+128 samples)",
-            "value": args.rays * world * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "clock_settle_steps": settle, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
+            "value": global_rays * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "clock_settle_steps": settle, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 via split-bf16 (bf16x3) MFMA, f32 accumulate",
                       "bf16": "bf16 operands, f32 accumulate"}[args.precision], "data": "synthetic",
             "config": {"workload": "configs[1] shapes: %d rays/GPU x (%d coarse + %d fine -> %d merged) samples, V=7 views "
                                    "256x320, cascade volumes 48x64x80/32x128x160/8x256x320, UCNeRF D=6 W=128 random init"
-                                   % (args.rays, args.coarse, args.fine, args.coarse + args.fine),
-                       "global_rays": args.rays * world, "parallelism": "ray-sharded x%d, no data-path collective" % world,
+                                   % (rays, args.coarse, args.fine, args.coarse + args.fine),
+                       "global_rays": global_rays, "parallelism": "ray-sharded x%d, no data-path collective" % world,
                        "precision": args.precision},
             "roofline": roof,
             "mlp_share_of_step": mlp_ms / (dt * 1e3),
+            "ranks_seen": ctx.dist.get_world_size() if ctx.dist is not None else 1,
             **({"hip_graph_ms_per_step": graph_ms} if graph_ms is not None else {}),
         }
         if psnr_vs_f32 is not None:
             line["parity_vs_f32"] = psnr_vs_f32
-        if plain is not None:
-            line["plain_bf16"] = plain
-        if train is not None:
-            line["train_step"] = train
-        if dt2 is not None:
-            line["reuse_coarse"] = {"value": args.rays * world * args.steps / dt2, "unit": "rays/s", "ms_per_step": dt2 / args.steps * 1e3,
-                                    "note": "NOT the headline: fine pass evaluates only the 128 new depths and re-uses the coarse "
-                                            "pass's outputs for the 64 coarse ones; renders verified bit-identical in this run"}
+        line.update(extra)
         if world == 1 and args.cpu_rays > 0:
             line["cpu_baseline"] = cpu_baseline(scene_cpu, sd, args.cpu_rays, args.coarse, args.fine)
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

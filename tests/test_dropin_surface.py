@@ -315,3 +315,95 @@ def test_create_ucnerf_contract(mods):
     assert "N_samples" not in train
     train.pop("network_mvs")
     assert next(train["network_fn"].parameters()).is_cuda
+
+
+# ---------------------------------------------------------------------------------------------- the fused route behind rendering()
+def _g10_call(mods, g, net, qfn, vols=None, img_feat=None, conf=None, **kw):
+    V = g["V"]
+    args = types.SimpleNamespace(view_num=V, feat_dim=24 + 12 * (V - 1) + 1, img_downscale=1.0, use_color_volume=False, net_type="v2",
+                                 **kw.pop("args_extra", {}))
+    vols = vols if vols is not None else [dev(g["vol%d" % k]) for k in (1, 2, 3)]
+    vf = {"stage%d" % (i + 1): {"volume_feature_no_ref": vols[i]} for i in range(3)}
+    pose = {"w2cs": dev(g["w2cs"]).clone(), "intrinsics": dev(g["K"]).repeat(V, 1, 1)}
+    return mods.renderer.rendering(args, pose, dev(g["pts"]), _ndc(g), dev(g["z"]), dev(g["rays_d"]), vf, dev(g["imgs"]), network_fn=net,
+                                   img_feat=img_feat if img_feat is not None else dev(g["img_feat"]), network_query_fn=qfn,
+                                   confidence=conf if conf is not None else dev(g["conf"]), **kw)
+
+
+def test_rendering_takes_the_fused_route_and_its_caches_follow_parameter_and_source_updates(mods, sd_v7, monkeypatch):
+    from uc_nerf_amd import dropin
+    g = load_golden("g10_rendering")
+    net = make_model(mods, g["V"], sd_v7)
+    e_p, _ = mods.models.get_embedder(10, 0)
+    e_d, _ = mods.models.get_embedder(4, 0)
+    qfn = lambda pts, vd, f, fn: mods.renderer.run_network_mvs(pts, vd, f, fn, embed_fn=e_p, embeddirs_fn=e_d, netchunk=8)
+    assert dropin.query_layout(qfn) == 0                                           # create_ucnerf-style query function: fusable
+    e_h, _ = mods.helpers.get_embedder(10, 0)                                      # interleaved points + live directions: not fusable
+    assert dropin.query_layout(lambda pts, vd, f, fn: mods.renderer.run_network_mvs(pts, vd, f, fn, embed_fn=e_h, embeddirs_fn=e_d)) is None
+    assert dropin.query_layout(lambda pts, vd, f, fn: fn(torch.cat([pts, f], -1))) is None
+    with torch.no_grad():
+        rgb, depth = _g10_call(mods, g, net, qfn)
+        sess = dropin.session_of(net)
+        assert ("f32", 0) in sess.passes and sess.passes[("f32", 0)].use_cl     # fused pass + channel-last gather were used
+        close(rgb, g["rgb_first"], 1e-4, 0); close(depth, g["depth_first"], 1e-4, 0)
+        ws0, src0 = sess.weights[("f32", 0)][3], sess.src
+        rgb_b, _ = _g10_call(mods, g, net, qfn)                                    # new tensor objects, same content: same render,
+        assert torch.equal(rgb_b, rgb) and sess.weights[("f32", 0)][3] is ws0     # weight stream reused (sources re-bound: new objects)
+        # extras: the opt-in outputs
+        u17 = load_golden("g17_uncertainty")
+        _, _, ex = _g10_call(mods, g, net, qfn, extras=("acc", "weights", "var", "u", "wu"))
+        close(ex["u"], u17["g10_u"], 2e-6, 0); close(ex["wu"], u17["g10_wu"], 1e-4, 0); close(ex["weights"], u17["g10_weights"], 2e-5, 1e-3)
+        # an in-place parameter update (what an optimizer step is) invalidates the packed stream ...
+        net.nerf.rgb_linear.bias.add_(0.3)
+        rgb_c, _ = _g10_call(mods, g, net, qfn)
+        sd2 = {k: v.clone() for k, v in sd_v7.items()}
+        sd2["nerf.rgb_linear.bias"] += 0.3
+        V = g["V"]
+        want, _ = O.rendering(sd2, {"w2cs": g["w2cs"].clone(), "intrinsics": g["K"].repeat(V, 1, 1)}, g["pts"],
+                              {"stage1": g["ndc1"], "stage2": g["ndc2"], "stage3": g["ndc3"], "ndc": g["ndc"]}, g["z"], g["rays_d"],
+                              [g["vol1"], g["vol2"], g["vol3"]], g["imgs"], g["img_feat"], g["conf"], V)
+        close(rgb_c, want, 1e-4, 0)
+        assert sess.weights[("f32", 0)][3] is not ws0 and (rgb_c - rgb).abs().max() > 1e-3
+        # ... and an in-place write to a source invalidates the channel-last copies; the same objects again hit the cache
+        vols = [dev(g["vol%d" % k]) for k in (1, 2, 3)]
+        img_feat, conf = dev(g["img_feat"]), dev(g["conf"])
+        imgs_same = dev(g["imgs"])
+        call = lambda: _g10_call(mods, dict(g, imgs=imgs_same), net, qfn, vols=vols, img_feat=img_feat, conf=conf)
+        r1, _ = call()
+        cl1 = sess.src._cl
+        r1b, _ = call()                                                            # same heavy sources, new pose tensors:
+        assert sess.src._cl is cl1 and torch.equal(r1, r1b)                        # the channel-last copies are inherited, not rebuilt
+        vols[2].mul_(0.5)
+        r2, _ = call()
+        assert sess.src._cl is not cl1 and (r2 - r1).abs().max() > 1e-4
+        fresh, _ = _g10_call(mods, g, net, qfn, vols=[v.clone() for v in vols], img_feat=img_feat, conf=conf)
+        assert torch.equal(fresh, r2)
+        # inference precision on request: split-bf16 matrix cores, within the bar of the exact render but not the same bits
+        dropin.set_inference_precision("bf16x3")
+        try:
+            r3, d3 = _g10_call(mods, g, net, qfn, vols=vols, img_feat=img_feat, conf=conf)
+        finally:
+            dropin.set_inference_precision("f32")
+        r2d = _g10_call(mods, g, net, qfn, vols=vols, img_feat=img_feat, conf=conf)
+        close(r3, r2d[0], 1e-4, 0); close(d3, r2d[1], 1e-4, 0)
+        assert not torch.equal(r3, r2d[0])
+        r4, _ = _g10_call(mods, g, net, qfn, vols=vols, img_feat=img_feat, conf=conf, args_extra={"inference_precision": "bf16x3"})
+        assert torch.equal(r4, r3)
+        # a feature buffer past the 2 GiB addressing range is split over rays: same image
+        monkeypatch.setattr(dropin, "_MAX_FEATURE_BYTES", 7 * 32 * 97 * 4)         # 7 rays per chunk
+        r5 = _g10_call(mods, g, net, qfn, vols=vols, img_feat=img_feat, conf=conf)
+        assert torch.equal(r5[0], r2d[0]) and torch.equal(r5[1], r2d[1])
+    # training through chunks: gradients add up over the chunks
+    for p in net.parameters():
+        p.grad = None
+    rgb_t, d_t = _g10_call(mods, g, net, qfn, vols=vols, img_feat=img_feat, conf=conf)
+    (rgb_t.sum() + d_t.sum()).backward()
+    g_chunked = net.nerf.pts_linears[2].weight.grad.clone()
+    monkeypatch.undo()
+    for p in net.parameters():
+        p.grad = None
+    rgb_t, d_t = _g10_call(mods, g, net, qfn, vols=vols, img_feat=img_feat, conf=conf)
+    (rgb_t.sum() + d_t.sum()).backward()
+    want_g = net.nerf.pts_linears[2].weight.grad
+    torch.testing.assert_close(g_chunked, want_g, atol=1e-4 * want_g.abs().max().item(), rtol=1e-3)
+    assert net.nerf.confi_linear.weight.grad is None and net.nerf.feature_linear_1.bias.grad is None      # as in the reference

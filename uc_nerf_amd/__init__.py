@@ -8,7 +8,13 @@ Layers:
 
 GPU only: there is no CPU or PyTorch fallback; calls on CPU tensors raise.
 """
-__version__ = "0.1.0"
+__version__ = "0.2.0"
+
+
+def set_inference_precision(precision):
+    """MLP arithmetic of the `rendering()` drop-in under torch.no_grad(): "f32" (default), "bf16x3" or "bf16" (dropin.py)."""
+    from . import dropin
+    dropin.set_inference_precision(precision)
 
 
 def install_dropin():

@@ -200,7 +200,7 @@ int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* bp, void* stream) {
     ucnerf_render_params q = *p;            // points / coordinates / directions are recomputed into OUR workspace
     q.workspace = bp->workspace;
     if (!coords_given(&q) && (rc = launch_points(&q, st, &w))) return rc;
-    if ((rc = launch_dirs(&q, st, &w))) return rc;
+    if (!p->dir_feat && (rc = launch_dirs(&q, st, &w))) return rc;
 
     ucnerf_composite_bwd_params cb;
     memset(&cb, 0, sizeof(cb));
@@ -211,6 +211,7 @@ int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* bp, void* stream) {
     ucnerf_mlp_bwd_params mb;
     memset(&mb, 0, sizeof(mb));
     mlp_args(&q, &w, p->feats, 0, nullptr, &mb.fwd);
+    if (p->dir_feat) mb.fwd.dirs = p->dir_feat;
     mb.fwd.raw = g_raw;                      // placeholder (not written by the backward)
     mb.g_raw = g_raw; mb.flat_params = bp->flat_params; mb.g_feats = g_feats; mb.g_flat = bp->g_flat; mb.workspace = mlp_ws;
     mb.saved_valid = bp->saved_valid;

@@ -1,0 +1,229 @@
+"""Host-side engine behind the reference-named `rendering()` (network/renderer.py:215-255): routes the call surface
+train.py uses onto the kernels the benchmark is quoted on.
+
+What one `rendering()` call becomes on the device (training, grad enabled):
+
+    dir_feature -> [channel-last repack of the sources, only if they changed] -> channel-last gather on the GIVEN
+    coordinates (rays_pts / rays_ndc as build_rays produced them) -> PE + MLP (training forward: activations kept) ->
+    composite;   backward: composite_bwd -> layer-by-layer MLP backward from the kept activations -> gather backward.
+
+and under `torch.no_grad()` (evaluation, train.py:254-272) the lean pass: tiled features, nothing kept, optionally the
+split-bf16 matrix-core MLP (`set_inference_precision("bf16x3")`, or an `inference_precision` attribute on `args`).
+
+State that survives between calls lives in one `FusedSession` per network module:
+  * the packed weight stream per precision, rebuilt only when a parameter's version counter (or storage) changed, i.e.
+    once per optimizer step, not once per call;
+  * the `GatherSources` + their channel-last copies, rebuilt only when a source tensor object / version changed, i.e. once
+    per image in evaluation (80 chunks share them) and once per step in training;
+  * the render / backward workspaces.
+"""
+import weakref
+
+import torch
+
+from . import ops
+
+_INFERENCE_PRECISION = "f32"
+_MAX_FEATURE_BYTES = (1 << 31) - (1 << 20)       # the MLP kernels address a pass's feature buffer with 32-bit byte offsets
+
+
+def set_inference_precision(precision):
+    """MLP arithmetic of `rendering()` under torch.no_grad(): "f32" (exact fp32 MFMA, default), "bf16x3" (split-bf16 matrix
+    cores, within the 1e-4 parity bar) or "bf16" (plain bf16 operands, NOT within the bar).  Training always runs f32."""
+    global _INFERENCE_PRECISION
+    if precision not in ops.PackedWeights.PRECISIONS:
+        raise ValueError("uc_nerf_amd: unknown precision %r" % (precision,))
+    _INFERENCE_PRECISION = precision
+
+
+def inference_precision(args=None):
+    return getattr(args, "inference_precision", None) or _INFERENCE_PRECISION
+
+
+# Parameters the reference's autograd never reaches: they keep grad = None here too.
+_NO_GRAD = ("pts_bias_confidence_1.", "feature_linear_1.", "confi_linear.")
+
+
+def _tensor_sig(t):
+    """Identity of a tensor's CONTENT as far as torch can vouch for it: the base tensor object (by id, kept honest by a
+    weakref), its version counter (bumped by every in-place write), and the view geometry."""
+    if t is None:
+        return None, None
+    base = t._base if t._base is not None else t
+    return (id(base), base._version, t.storage_offset(), tuple(t.shape), tuple(t.stride())), weakref.ref(base)
+
+
+class FusedSession:
+    def __init__(self, net):
+        nerf = getattr(net, "nerf", net)
+        self.n_src = nerf.view_num
+        named = list(net.named_parameters())
+        self.params = [p for _, p in named]
+        self.grad_mask = [not any(tag in name for tag in _NO_GRAD) for name, _ in named]
+        self.sizes = [p.numel() for p in self.params]
+        self.weights = {}            # (precision, layout) -> (signature, flat, pw, wstream)
+        self.passes = {}             # (precision, layout) -> ops.RenderPass
+        self.src, self.src_sig, self.src_refs = None, None, None
+
+    # ---- caches
+    def packed(self, precision, layout):
+        sig = tuple((p._version, p.data_ptr()) for p in self.params)
+        ent = self.weights.get((precision, layout))
+        if ent is None or ent[0] != sig:
+            dev = self.params[0].device
+            flat = torch.cat([p.detach().reshape(-1) for p in self.params]).float()
+            pw = ops.PackedWeights.get(self.n_src, layout, dev, precision)
+            ent = (sig, flat, pw, pw.pack(flat))
+            self.weights[(precision, layout)] = ent
+        return ent[1], ent[2], ent[3]
+
+    def sources(self, vols, conf, imgs, img_feat, w2cs, intrinsics):
+        """GatherSources for these tensors.  Two signatures: the HEAVY sources (volumes, images, image features -- what the
+        channel-last repack copies, ~150 MB of traffic) and the light ones (confidence map, poses).  Same heavy + same light:
+        the cached object; same heavy only: a new object that inherits the channel-last copies."""
+        heavy = [_tensor_sig(t) for t in list(vols) + [imgs, img_feat]]
+        light = [_tensor_sig(t) for t in (conf, w2cs, intrinsics)]
+        hsig, lsig = tuple(s for s, _ in heavy), tuple(s for s, _ in light)
+        old = self.src
+        heavy_ok = old is not None and hsig == self.src_sig[0] and all(r is None or r() is not None for r in self.src_refs[0])
+        if heavy_ok and lsig == self.src_sig[1] and all(r is None or r() is not None for r in self.src_refs[1]):
+            return old
+        self.src = ops.GatherSources(vols, conf, imgs, img_feat, w2cs, intrinsics)
+        if heavy_ok:
+            self.src._cl = old._cl
+        self.src_sig, self.src_refs = (hsig, lsig), ([r for _, r in heavy], [r for _, r in light])
+        return self.src
+
+    def render_pass(self, precision, layout, src, white_bkgd):
+        flat, pw, ws = self.packed(precision, layout)
+        rp = self.passes.get((precision, layout))
+        if rp is None:
+            rp = self.passes[(precision, layout)] = ops.RenderPass(src, pw, ws, white_bkgd=white_bkgd)
+        if rp.src is not src:
+            rp.set_sources(src)
+        if rp.wstream is not ws:
+            rp.set_weights(pw, ws)
+        rp.set_white_bkgd(white_bkgd)
+        if not rp.use_cl:
+            rp.repack_sources(force=False)           # a copy made for these very sources through another precision's pass is reused
+        return rp, flat
+
+
+def session_of(net):
+    s = net.__dict__.get("_ucnerf_session")
+    if s is None or s.params[0] is not next(net.parameters()):
+        s = FusedSession(net)
+        net.__dict__["_ucnerf_session"] = s
+    return s
+
+
+class _FusedRender(torch.autograd.Function):
+    """One rendering() call under autograd.  Differentiable inputs: the three cascade volumes, confidence, img_feat and the
+    network parameters (never positions: SURVEY.md 3.2)."""
+
+    @staticmethod
+    def forward(ctx, sess, layout, white_bkgd, coords, z, rays_dir, angle, imgs, w2cs, intrinsics, vol1, vol2, vol3, conf, img_feat, *params):
+        src = sess.sources([vol1, vol2, vol3], conf, imgs, img_feat, w2cs, intrinsics)
+        rp, flat = sess.render_pass("f32", layout, src, white_bkgd)
+        out = rp(rays_dir, z, want=(), keep=("raw", "feats"), dir_feat=angle, coords=coords)
+        ctx.sess, ctx.rp, ctx.src, ctx.pw, ctx.ws, ctx.flat, ctx.white_bkgd = sess, rp, src, rp.pw, rp.wstream, flat, white_bkgd
+        ctx.coords, ctx.kept = coords, {"raw": out["raw"], "feats": out["feats"]}
+        ctx.geom = (z, rays_dir, angle)
+        ctx.shapes = tuple(t.shape for t in (vol1, vol2, vol3, conf, img_feat))
+        return out["rgb"], out["depth"]
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth):
+        rp, sess = ctx.rp, ctx.sess
+        z, rays_dir, angle = ctx.geom
+        if rp.src is not ctx.src:                    # another forward re-bound the pass since: bind this call's state again
+            rp.set_sources(ctx.src)
+        if rp.wstream is not ctx.ws:
+            rp.set_weights(ctx.pw, ctx.ws)
+        rp.set_white_bkgd(ctx.white_bkgd)
+        if g_rgb is None:
+            g_rgb = torch.zeros(z.shape[0], 3, device=z.device)
+        need = tuple(ctx.needs_input_grad[10:15])                            # vol1, vol2, vol3, conf, img_feat
+        need = (need[0], need[1], need[2], need[3], need[4])
+        g_flat, gv1, gv2, gv3, gc, gi = rp.backward(rays_dir, z, ctx.kept, g_rgb.contiguous(), g_depth, ctx.flat, need=need,
+                                                    coords=ctx.coords, dir_feat=angle)
+        grads = [g.reshape(s) if g is not None else None for g, s in zip((gv1, gv2, gv3, gc, gi), ctx.shapes)]
+        g_params = []
+        for piece, p, has, req in zip(torch.split(g_flat, sess.sizes), sess.params, sess.grad_mask, ctx.needs_input_grad[15:]):
+            g_params.append(piece.view_as(p) if (has and req) else None)
+        ctx.kept = None
+        return (None,) * 10 + tuple(grads) + tuple(g_params)
+
+
+def fused_rendering(net, layout, args, w2c_dir, rays_pts, rays_ndc, z, rays_dir, vols, imgs, img_feat, conf, w2cs, intrinsics,
+                    white_bkgd=False, extras=()):
+    """The body of rendering() on the fast kernels.  Returns (rgb [N,3], depth [N]) or, with `extras` (any of "acc",
+    "weights", "var", "u", "wu"; inference only), (rgb, depth, dict)."""
+    sess = session_of(net)
+    N, S = z.shape[0], z.shape[1]
+    F = 24 + 12 * sess.n_src + 1
+    max_rays = max(1, _MAX_FEATURE_BYTES // (((S + 31) // 32 * 32) * F * 4))
+    if N > max_rays:                                 # the reference's netchunk loop, only where the address range forces it
+        parts = [fused_rendering(net, layout, args, w2c_dir, rays_pts[a:a + max_rays], {k: v[a:a + max_rays] for k, v in rays_ndc.items()},
+                                 z[a:a + max_rays], rays_dir[a:a + max_rays], vols, imgs, img_feat, conf, w2cs, intrinsics, white_bkgd, extras)
+                 for a in range(0, N, max_rays)]
+        if extras:
+            return (torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]),
+                    {k: torch.cat([p[2][k] for p in parts]) for k in parts[0][2]})
+        return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+    angle, _ = ops.dir_feature(rays_dir, w2c_dir)
+    coords = {"pts": rays_pts, "stage1": rays_ndc["stage1"], "stage2": rays_ndc["stage2"], "stage3": rays_ndc["stage3"], "ndc": rays_ndc["ndc"]}
+    diff = [t for t in list(vols) + [conf, img_feat] if t is not None and t.requires_grad]
+    train = torch.is_grad_enabled() and (bool(diff) or any(p.requires_grad for p in sess.params))
+    if train:
+        if extras:
+            raise RuntimeError("uc_nerf_amd.rendering: extras are an inference-time option (call under torch.no_grad())")
+        return _FusedRender.apply(sess, layout, bool(white_bkgd), coords, z, rays_dir, angle, imgs, w2cs, intrinsics,
+                                  vols[0], vols[1], vols[2], conf, img_feat, *sess.params)
+    src = sess.sources(vols, conf, imgs, img_feat, w2cs, intrinsics)
+    rp, _ = sess.render_pass(inference_precision(args), layout, src, white_bkgd)
+    out = rp(rays_dir, z, want=tuple(extras), dir_feat=angle, coords=coords)
+    if extras:
+        return out["rgb"], out["depth"], {k: out[k] for k in extras if k in out}
+    return out["rgb"], out["depth"]
+
+
+# ------------------------------------------------------------------------------------------------ query-function probe
+class _Probed(Exception):
+    pass
+
+
+class _FusionProbe:
+    """Stands where the network goes in one dry call of a `network_query_fn`: if the query function is this package's
+    run_network_mvs with fusable embedders it calls forward_raw(pts, viewdirs, feats, layout) -- which records the layout."""
+
+    def __init__(self):
+        self.layout = None
+
+    def forward_raw(self, pts, viewdirs, feats, pe_layout=0):
+        self.layout = pe_layout
+        raise _Probed()
+
+
+_probe_cache = weakref.WeakKeyDictionary()
+
+
+def query_layout(network_query_fn):
+    """PE layout (0 / 1) if `network_query_fn(pts, viewdirs, feats, fn)` is the fusable encode -> cat -> MLP of this package's
+    run_network_mvs (what create_ucnerf builds, network/models.py:233-236), else None.  Found by one dry call with sentinels."""
+    try:
+        return _probe_cache[network_query_fn]
+    except (KeyError, TypeError):
+        pass
+    probe, layout = _FusionProbe(), None
+    try:
+        network_query_fn(object(), object(), object(), probe)
+    except _Probed:
+        layout = probe.layout
+    except Exception:
+        layout = None
+    try:
+        _probe_cache[network_query_fn] = layout
+    except TypeError:
+        pass
+    return layout

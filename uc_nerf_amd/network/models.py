@@ -114,18 +114,29 @@ class BaseAdapt_Renderer(nn.Module):
         # the reference's forward_alpha reads self.pts_bias, which does not exist (AttributeError there too)
         raise AttributeError("'BaseAdapt_Renderer' object has no attribute 'pts_bias'")
 
+    def _flat_and_stream(self, pe_layout):
+        """(flat parameter vector for autograd, packer, packed stream).  The stream -- and, when no gradient is wanted, the
+        flat vector too -- comes from the per-network cache, rebuilt only when a parameter changed (dropin.FusedSession)."""
+        from .. import dropin
+        flat, pw, ws = dropin.session_of(self).packed("f32", pe_layout)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            flat = self.flat_parameters()
+        return flat, pw, ws
+
     def forward(self, x, pe_layout=0):
         """x [..., 63 + F + 27] = [encoded pts | features | encoded dirs] -> [..., 4] (rgb, sigma)."""
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
-        out = ops.mlp_encoded(self.flat_parameters(), x2, self.packer(pe_layout))
+        flat, pw, ws = self._flat_and_stream(pe_layout)
+        out = ops.mlp_encoded(flat, x2, pw, ws)
         return out.view(*lead, 4)
 
     def forward_raw(self, pts, viewdirs, feats, pe_layout=0):
         """Fused entry used by run_network_mvs: raw 3-vectors in, encodings computed inside the kernel.
         pts [N,S,3], viewdirs [N,3] or [N,S,3], feats [N,S,F] -> [N,S,4]."""
         N, S = pts.shape[0], pts.shape[1]
-        out = ops.mlp(self.flat_parameters(), feats, pts, viewdirs, self.packer(pe_layout), S)
+        flat, pw, ws = self._flat_and_stream(pe_layout)
+        out = ops.mlp(flat, feats, pts, viewdirs, pw, S, ws)
         return out.view(N, S, 4)
 
 

@@ -3,7 +3,7 @@ every computation is a libucnerf_hip.so kernel (feature gather, fused PE+MLP, co
 """
 import torch
 
-from .. import ops
+from .. import dropin, ops
 
 
 def depth2dist(z_vals, cos_angle):
@@ -86,14 +86,33 @@ def gen_pts_feats(imgs, volume_feature, rays_pts, pose_ref, rays_ndc, feat_dim, 
 def rendering(args, pose_ref, rays_pts, rays_ndc, depth_candidates, rays_dir, volume_feature=None, imgs=None,
               network_fn=None, near_fars=None, img_feat=None, network_query_fn=None, white_bkgd=False, confidence=None,
               **kwargs):
-    """network/renderer.py:215-255 -> (rgb_map [N,3], depth_map [N]), including the in-place trim of pose_ref."""
-    if pose_ref is not None:
-        angle, _ = ops.dir_feature(rays_dir, pose_ref['w2cs'][0])
-    else:
-        angle, _ = ops.dir_feature(rays_dir, None)
+    """network/renderer.py:215-255 -> (rgb_map [N,3], depth_map [N]), including the in-place trim of pose_ref.
+
+    With this package's UCNeRF behind a query function built like create_ucnerf's (encode -> cat -> MLP with the live
+    embedders) the whole body is the fused pass of `dropin.fused_rendering`: channel-last gather on the coordinates handed
+    in, PE + MLP with the activations kept for the backward, compositing -- the kernels the benchmark is quoted on, with the
+    weight stream and the source repack cached across calls.  `netchunk` needs no loop there (the pass is chunked only where
+    a feature buffer would exceed 2 GiB).  Any other network / query function takes the reference's op-by-op route below.
+    `extras=("acc", "weights", "var", "u", "wu")` (inference only) returns a third value: the opt-in outputs of SURVEY.md 8(a)."""
+    w2c_dir = pose_ref['w2cs'][0]                           # the view direction is rotated by entry 0 AT CALL TIME (:236)
     if pose_ref['w2cs'].shape[0] == args.view_num:          # renderer.py:241-243: callers observe this mutation
         pose_ref['w2cs'] = pose_ref['w2cs'][1:]
         pose_ref['intrinsics'] = pose_ref['intrinsics'][1:]
+    extras = tuple(kwargs.get("extras", ()))
+    layout = None
+    if (hasattr(network_fn, "forward_raw") and isinstance(network_fn, torch.nn.Module) and not args.use_color_volume
+            and None not in (volume_feature, imgs, img_feat, confidence)):
+        layout = dropin.query_layout(network_query_fn)
+    if layout is not None:
+        vols = [volume_feature["stage%d" % k]["volume_feature_no_ref"] for k in (1, 2, 3)]
+        if args.feat_dim != 24 + 12 * imgs.shape[-4] + 1:
+            raise RuntimeError("uc_nerf_amd.rendering: feat_dim %d but %d source views give %d"
+                               % (args.feat_dim, imgs.shape[-4], 24 + 12 * imgs.shape[-4] + 1))
+        return dropin.fused_rendering(network_fn, layout, args, w2c_dir, rays_pts, rays_ndc, depth_candidates, rays_dir, vols, imgs,
+                                      img_feat, confidence, pose_ref['w2cs'], pose_ref['intrinsics'], white_bkgd, extras)
+    if extras:
+        raise RuntimeError("uc_nerf_amd.rendering: extras need the fused route (this package's UCNeRF and embedders)")
+    angle, _ = ops.dir_feature(rays_dir, w2c_dir)
     input_feat = gen_pts_feats(imgs, volume_feature, rays_pts, pose_ref, rays_ndc, args.feat_dim, img_feat, near_fars,
                                args.img_downscale, args.use_color_volume, args.net_type, confidence=confidence)
     raw = network_query_fn(rays_ndc['ndc'], angle, input_feat, network_fn)

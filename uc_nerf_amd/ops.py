@@ -248,6 +248,8 @@ class GatherSources:
         self.F = 24 + 12 * self.V + 1
         self.device = dev
         self.full = self.mask == (0b1111 | (((1 << self.V) - 1) << 4))
+        self._cl = None              # channel-last copies read by the fast gather (RenderPass.repack_sources), shared by
+                                     # every RenderPass bound to these sources
 
     def fill(self, p):
         p.V, p.H, p.W = self.V, self.H, self.W
@@ -446,8 +448,8 @@ class _MLP(torch.autograd.Function):
     """raw = MLP(PE(pts), feats, PE(dirs)); differentiable w.r.t. the flat parameters and feats."""
 
     @staticmethod
-    def forward(ctx, flat, feats, pts, dirs, pw, S):
-        ws = pw.pack(flat)
+    def forward(ctx, flat, feats, pts, dirs, pw, S, ws=None):
+        ws = pw.pack(flat) if ws is None else ws        # (a stream already packed from these very parameters may be handed in)
         ctx.pw, ctx.S = pw, S
         ctx.save_for_backward(flat, feats, pts, dirs, ws)
         return mlp_fwd(pw, ws, pts, dirs, feats.reshape(-1, feats.shape[-1]), S)
@@ -456,11 +458,11 @@ class _MLP(torch.autograd.Function):
     def backward(ctx, g_raw):
         flat, feats, pts, dirs, ws = ctx.saved_tensors
         g_feats, g_flat = mlp_bwd(ctx.pw, ws, flat, pts, dirs, feats.reshape(-1, feats.shape[-1]), ctx.S, g_raw)
-        return g_flat, g_feats.view(feats.shape), None, None, None, None
+        return g_flat, g_feats.view(feats.shape), None, None, None, None, None
 
 
-def mlp(flat, feats, pts, dirs, pw, S):
-    return _MLP.apply(flat, feats, pts, dirs, pw, S)
+def mlp(flat, feats, pts, dirs, pw, S, wstream=None):
+    return _MLP.apply(flat, feats, pts, dirs, pw, S, wstream)
 
 
 def _encoded_params(p, pw, x):
@@ -492,8 +494,8 @@ class _MLPEncoded(torch.autograd.Function):
     columns of x; the encoded pts/dir columns get zeros (positions are not differentiable on this path)."""
 
     @staticmethod
-    def forward(ctx, flat, x, pw):
-        ws = pw.pack(flat)
+    def forward(ctx, flat, x, pw, ws=None):
+        ws = pw.pack(flat) if ws is None else ws
         x = _f32(x, "x")
         ctx.pw = pw
         ctx.save_for_backward(flat, x, ws)
@@ -515,11 +517,11 @@ class _MLPEncoded(torch.autograd.Function):
         bp.g_raw, bp.flat_params, bp.g_flat, bp.workspace = _ptr(g_raw), _ptr(flat), _ptr(g_flat), _ptr(work)
         bp.g_feats, bp.g_feat_stride = g_x.data_ptr() + 4 * 63, X
         _launch("ucnerf_mlp_bwd", bp, x.device)
-        return g_flat, g_x, None
+        return g_flat, g_x, None, None
 
 
-def mlp_encoded(flat, x, pw):
-    return _MLPEncoded.apply(flat, x, pw)
+def mlp_encoded(flat, x, pw, wstream=None):
+    return _MLPEncoded.apply(flat, x, pw, wstream)
 
 
 # ------------------------------------------------------------------------------------------------ a9
@@ -749,32 +751,56 @@ def depth_regress(prob_pre, depth_values, prob_init=None, pad=0):
 
 # ------------------------------------------------------------------------------------------------ a10
 class RenderPass:
-    """Pre-bound arguments of ucnerf_render_fused_fwd for one scene; call it with (rays_d, z)."""
+    """Pre-bound arguments of ucnerf_render_fused_fwd for one scene; call it with (rays_d, z).
 
-    def __init__(self, src, pw, wstream, rays_o, w2c_ref, K_ref, w2c_dir, near, far, white_bkgd=False, max_blocks=0):
+    rays_o / w2c_ref / K_ref / w2c_dir / near / far describe how the pass derives sample coordinates and the view-direction
+    feature itself; a caller that hands both over (`coords=`, `dir_feat=`: the rendering() drop-in) may leave them None."""
+
+    def __init__(self, src, pw, wstream, rays_o=None, w2c_ref=None, K_ref=None, w2c_dir=None, near=0.0, far=1.0, white_bkgd=False,
+                 max_blocks=0):
         # pw / wstream may be packed for either precision ("f32" or "bf16x3"); the backward needs "f32"
-        self.src, self.pw, self.wstream = src, pw, wstream
-        self.rays_o = _f32(rays_o.reshape(-1)[:3].clone(), "rays_o")
+        eye34, eye33 = torch.eye(3, 4), torch.eye(3)
+        self.rays_o = (_f32(rays_o.reshape(-1)[:3].clone(), "rays_o") if rays_o is not None else torch.zeros(3, device=src.device))
         self.p = p = L.RenderParams()
-        src.fill(p)
-        p.cfg = pw.cfg
-        p.white_bkgd, p.max_blocks = int(white_bkgd), int(max_blocks)
-        _mat(p.w2c_ref, w2c_ref, 3, 4)
-        _mat(p.K_ref, K_ref, 3, 3)
-        _mat(p.w2c_dir, w2c_dir, 3, 4)
+        p.max_blocks = int(max_blocks)
+        _mat(p.w2c_ref, w2c_ref if w2c_ref is not None else eye34, 3, 4)
+        _mat(p.K_ref, K_ref if K_ref is not None else eye33, 3, 3)
+        _mat(p.w2c_dir, w2c_dir if w2c_dir is not None else eye34, 3, 4)
         p.near, p.far = float(near), float(far)
-        p.rays_o, p.wstream = _ptr(self.rays_o), _ptr(wstream)
+        p.rays_o = _ptr(self.rays_o)
+        self.set_sources(src)
+        self.set_weights(pw, wstream)
+        self.set_white_bkgd(white_bkgd)
         self._ws = None
-        self._cl = None
 
-    def repack_sources(self):
-        """(Re)builds the channel-last copies the fast gather reads; call whenever the sources changed."""
+    def set_sources(self, src):
+        """Binds (other) gather sources; the fast gather is used once repack_sources() has run for them."""
+        self.src = src
+        src.fill(self.p)
+        self.use_cl = False
+        self.p.sources_cl = None
+
+    def set_weights(self, pw, wstream):
+        self.pw, self.wstream = pw, wstream
+        self.p.cfg = pw.cfg
+        self.p.wstream = _ptr(wstream)
+
+    def set_white_bkgd(self, white_bkgd):
+        self.p.white_bkgd = int(bool(white_bkgd))
+
+    def repack_sources(self, force=True):
+        """(Re)builds the channel-last copies the fast gather reads; call whenever the sources changed.  The copies belong
+        to the sources object: with force=False an existing copy (made through any RenderPass bound to them) is reused."""
+        src = self.src
         n = L.lib().ucnerf_gather_repack_floats(C.addressof(self.p))
-        if self._cl is None or self._cl.numel() != n:
-            self._cl = torch.empty(n, device=self.src.device)
-        with torch.cuda.device(self.src.device):
-            L.check(L.lib().ucnerf_gather_repack(C.addressof(self.p), _ptr(self._cl), _stream()), "ucnerf_gather_repack")
-        self.p.sources_cl = _ptr(self._cl)
+        fresh = src._cl is None or src._cl.numel() != n
+        if fresh:
+            src._cl = torch.empty(n, device=src.device)
+        if fresh or force:
+            with torch.cuda.device(src.device):
+                L.check(L.lib().ucnerf_gather_repack(C.addressof(self.p), _ptr(src._cl), _stream()), "ucnerf_gather_repack")
+        self.p.sources_cl = _ptr(src._cl)
+        self.use_cl = True
 
     @staticmethod
     def _coords(p, coords, m):
@@ -838,7 +864,8 @@ class RenderPass:
         _launch("ucnerf_render_fused_fwd", p, dev)
         return out
 
-    def backward(self, rays_d, z, kept, g_rgb, g_depth, flat, near_far=None, need=(True, True, True, True, True), coords=None):
+    def backward(self, rays_d, z, kept, g_rgb, g_depth, flat, near_far=None, need=(True, True, True, True, True), coords=None,
+                 dir_feat=None):
         """Backward of the last-style forward call: `kept` = its outputs with keep=("raw", "feats").
         Returns (g_flat, g_vol1, g_vol2, g_vol3, g_conf, g_img_feat)."""
         rays_d, z, flat, g_rgb = _f32(rays_d), _f32(z), _f32(flat), _f32(g_rgb)
@@ -853,6 +880,8 @@ class RenderPass:
         p.raw, p.feats = _ptr(kept["raw"]), _ptr(kept["feats"])
         p.u_sampled = p.wu_map = None
         _alive = self._coords(p, coords, n * S)      # noqa: F841
+        dir_feat = _f32(dir_feat, "dir_feat") if dir_feat is not None else None
+        p.dir_feat = _ptr(dir_feat)
         p.ev_mlp_start = p.ev_mlp_stop = None
         saved = getattr(self, "_saved_for", None) == (n, S, kept["raw"].data_ptr())
         ws = self._bwd_ws if saved else torch.empty(L.lib().ucnerf_render_bwd_workspace_floats(n, S, self.src.V), device=dev)

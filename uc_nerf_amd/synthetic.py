@@ -92,3 +92,50 @@ def random_pixels(n, H, W, seed=0):
     ys = torch.randint(0, H, (n,), generator=g).float()
     xs = torch.randint(0, W, (n,), generator=g).float()
     return xs, ys
+
+
+def cascade_outputs(scene, seed=0):
+    """Stand-in for the consistency learner's per-stage outputs that the ray builders read (utils/utils.py:659-683): depth
+    hypotheses `depth_values` [1,D,h,w] per cascade stage (48 / 32 / 8 planes, nested ranges around a smooth depth map) and the
+    three `volume_feature_no_ref` volumes of the scene.  Tensors on the scene's device."""
+    dev = scene["confidence"].device
+    g = torch.Generator().manual_seed(seed)
+    H, W, near, far = scene["H"], scene["W"], scene["near"], scene["far"]
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    depth = near + (far - near) * (0.35 + 0.3 * torch.sin(3 * xx) * torch.cos(2 * yy) + 0.05 * torch.rand(H, W, generator=g))
+    out = {}
+    for k, (div, D, half) in enumerate(((4, 48, 1.0), (2, 32, 0.5), (1, 8, 0.15))):
+        d = depth[::div, ::div]
+        lo, hi = (d - half * (far - near) / 2).clamp(min=near), (d + half * (far - near) / 2).clamp(max=far)
+        t = torch.linspace(0, 1, D).view(D, 1, 1)
+        out["stage%d" % (k + 1)] = {"depth_values": (lo[None] * (1 - t) + hi[None] * t)[None].contiguous().to(dev),
+                                    "volume_feature_no_ref": scene["vols"][k]}
+    return out
+
+
+def live_path_batch(scene, outputs, n_rays, n_samples=90, seed=0, chunk_idx=None):
+    """Inputs of one `rendering()` call shaped as the reference's live path builds them (train.py:147-163: `build_rays`,
+    2000 rays x 90 cascade-guided samples; train.py:254-272: `build_rays_test`, chunks of 1024 pixels x 90): rays through
+    random pixels (chunk_idx None) or through chunk `chunk_idx` of the image, per-ray cascade ranges from `outputs`, sorted +
+    jittered depths, world points and the four normalised coordinate sets.  Returns a dict of device tensors + `pose_ref`."""
+    from . import ops
+    from .utils import utils as U
+    dev = scene["confidence"].device
+    H, W = scene["H"], scene["W"]
+    torch.manual_seed(seed)
+    if chunk_idx is None:
+        xs, ys = random_pixels(n_rays, H, W, seed=seed)
+        rays_d, _, _ = ops.ray_gen(scene["K"], scene["c2w"], xs=xs.to(dev), ys=ys.to(dev))
+        pix = torch.stack([ys, xs]).long().to(dev)
+    else:
+        rays_d, _, pixf = ops.ray_gen(scene["K"], scene["c2w"], H=H, W=W, grid_start=chunk_idx * n_rays, n=n_rays, device=dev, want_pix=True)
+        pix = pixf.long()
+    rays_o = scene["c2w"][:3, 3].to(dev)
+    ranges = U._stage_ranges(outputs, pix)
+    t_rand = torch.rand(n_rays, n_samples, device=dev)
+    z, pts = ops.sample_cascade(ranges, n_samples, t_rand, rays_o, rays_d)
+    near_far = U._near_far_dict(ranges, n_samples, scene["near"], scene["far"])
+    inv_scale = torch.tensor([W - 1, H - 1])
+    ndc = U.get_ndc_coordinate(scene["w2cs"][0], scene["intrinsics"][0], pts, inv_scale, near_far)
+    pose_ref = {"w2cs": scene["w2cs"].to(dev).clone(), "intrinsics": scene["intrinsics"].to(dev).clone()}
+    return dict(rays_pts=pts, rays_ndc=ndc, depth_candidates=z, rays_dir=rays_d, ranges=ranges, pose_ref=pose_ref)
