@@ -1,11 +1,12 @@
 #!/bin/bash
-# Per-kernel rocprofv3 times of the headline step for library variants (GPU box): scripts/prof_bench_variants.sh <suffix>...  ("-" = default)
+# Per-kernel rocprofv3 times of the headline step for library variants (GPU box): [RAYS=4096] scripts/prof_bench_variants.sh <suffix>...  ("-" = default)
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   if [ "$v" = "-" ]; then unset UCNERF_LIB; else export UCNERF_LIB=$R/uc_nerf_amd/libucnerf_hip_$v.so; fi
   rm -rf $R/gpurun_out/bv_$v
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/bv_$v -- python3 $R/bench.py --steps 100 --warmup 20 --no-reuse --cpu-rays 0 > $R/gpurun_out/bv_$v.log 2>&1 || exit 1
+  [ -n "$RAYS" ] && echo "-- rays per step: $RAYS"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/bv_$v -- python3 $R/bench.py --rays ${RAYS:-4096} --steps 100 --warmup 20 --no-reuse --cpu-rays 0 > $R/gpurun_out/bv_$v.log 2>&1 || exit 1
   echo "== $v"
   python3 - "$R/gpurun_out/bv_$v" <<'PY'
 import csv, glob, sys

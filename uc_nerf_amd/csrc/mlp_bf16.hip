@@ -23,8 +23,10 @@
 //     stream (half-steps in consumption order) is copied into a 4-slot LDS ring (8 KB = two half-steps per slot) by
 //     global_load_lds (two 1-KB pieces per wave per slot, issued 3.5 slots ahead, counted vmcnt + one raw s_barrier
 //     per slot), and every wave reads its A fragments with ds_read_b128, one half-step ahead of the MFMAs;
-//   * a block is 4 waves = one per SIMD, and TWO blocks share a CU: the two waves of a SIMD belong to different
-//     blocks, are never coupled by a barrier and drift apart, which hides what is left exposed.
+//   * a block is 8 waves = two per SIMD, one block per CU: the whole CU shares one ring, so the stream crosses L2 -> LDS once per
+//     eight tiles.  (Round 1 ran two 4-wave blocks per CU so that the two waves of a SIMD never met at a barrier; measured in
+//     round 2: the chip is power-limited under this kernel -- one wave per SIMD renders 93 % of what two do -- so what pays is
+//     less data movement per tile, not more overlap.)
 #include "common.h"
 #include "mlp_layout.h"
 #include "sincos_cw.h"
@@ -49,7 +51,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef UCNERF_BF16_EXP
-#define UCNERF_BF16_EXP 0      // timing experiments only (results are wrong): 1 no DMA wait, 2 no barrier, 4 no DMA, 64 no interleave hints, 128 no epilogue arithmetic, 256 half the LDS fragment reads, 512 no point-encoding arithmetic
+#define UCNERF_BF16_EXP 0      // timing experiments only (results are wrong): 1 no DMA wait, 2 no barrier, 4 no DMA, 64 no interleave hints, 128 no epilogue arithmetic, 256 half the LDS fragment reads, 512 no point-encoding arithmetic, 1024 no feature / point loads: zeros instead (compare with a launch on all-zero inputs: same values, same power draw), 2048 every feature load issued TWICE (the second from another tile's rows, weighted 0: same values, same power -- what the loads cost is what the copy adds)
 #endif
 #ifndef UCNERF_BF16_HINT_V
 #define UCNERF_BF16_HINT_V 7   // VALU instructions the scheduler may place after each MFMA of a half-step
@@ -60,10 +62,22 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef UCNERF_BF16_PRIO_GEMM
 #define UCNERF_BF16_PRIO_GEMM 0     // ... and during the GEMM phases
 #endif
+#ifndef UCNERF_BF16_NO_PK
+#define UCNERF_BF16_NO_PK 0    // 1: element-wise work beside the MFMAs in scalar fp32 instructions (v_mul / v_sub / v_fma), never the packed
+                               //    v_pk_* forms: MI355X_MICROARCH.md prices a packed fp32 op at +22..26 cycles per MFMA gap over its two scalar ones
+#endif
+// scalar fp32 ops the SLP vectoriser cannot re-pack (one empty asm per result keeps every op its own instruction)
+__device__ __forceinline__ float sc_mul(float a, float b) { float r = a * b; asm volatile("" : "+v"(r)); return r; }
+__device__ __forceinline__ float sc_sub(float a, float b) { float r = a - b; asm volatile("" : "+v"(r)); return r; }
+__device__ __forceinline__ float sc_fma(float a, float b, float c) { float r = __builtin_fmaf(a, b, c); asm volatile("" : "+v"(r)); return r; }
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define SB0 __builtin_amdgcn_sched_barrier(0)
 
-constexpr int BW = 4;                 // waves per block (one per SIMD; two blocks per CU)
+#ifndef UCNERF_BF16_BW
+#define UCNERF_BF16_BW 8       // 8: one 512-thread block per CU, all eight waves share ONE weight ring -- half the LDS-DMA traffic and DMA issues
+                               //    per tile of two 4-wave blocks; measured -3.3 % on the launch (profiles/r02_mlp_bf16_experiments.md)
+#endif
+constexpr int BW = UCNERF_BF16_BW;    // waves per block sharing one weight ring: 4 (one per SIMD, two blocks per CU) or 8 (two per SIMD, one block per CU)
 constexpr int SLOT_BYTES = 8192;      // two half-steps: [2][hi0, lo0, hi1, lo1][64 lanes][16 B]
 constexpr int HALF_BYTES = 4096;
 #ifndef UCNERF_BF16_NBUF
@@ -219,10 +233,16 @@ __device__ __forceinline__ Frag split8(const float (&x)[8]) {
         f.lo[j] = (__bf16)l0;
         f.lo[j + 1] = (__bf16)l1;
 #else
+#if UCNERF_BF16_NO_PK
+        const float l0_ = sc_sub(x[j], __builtin_bit_cast(float, b0 & 0xffff0000u)), l1_ = sc_sub(x[j + 1], __builtin_bit_cast(float, b1 & 0xffff0000u));
+        f.lo[j] = (__bf16)l0_;
+        f.lo[j + 1] = (__bf16)l1_;
+#else
         const f32x2 h = {__builtin_bit_cast(float, b0 & 0xffff0000u), __builtin_bit_cast(float, b1 & 0xffff0000u)};
         const f32x2 l = (f32x2){x[j], x[j + 1]} - h;
         f.lo[j] = (__bf16)l.x;
         f.lo[j + 1] = (__bf16)l.y;
+#endif
 #endif
     }
     f.hi = __builtin_bit_cast(bf16x8, hi);
@@ -248,8 +268,13 @@ __device__ __forceinline__ Frag frag_of(const f32x16& a, const f32x16& m, int s)
     float t[8];
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
+#if UCNERF_BF16_NO_PK
+        f32x2 v = {a[8 * s + j], a[8 * s + j + 1]};
+        if (MODE >= 1) { v.x = sc_mul(v.x, m[8 * s + j]); v.y = sc_mul(v.y, m[8 * s + j + 1]); }
+#else
         f32x2 v = {a[8 * s + j], a[8 * s + j + 1]};
         if (MODE >= 1) v = v * (f32x2){m[8 * s + j], m[8 * s + j + 1]};
+#endif
         t[j] = MODE == 2 ? fmaxf(v.x, 0.f) : v.x;
         t[j + 1] = MODE == 2 ? fmaxf(v.y, 0.f) : v.y;
     }
@@ -380,9 +405,14 @@ __device__ __forceinline__ void head_part(HeadAcc& a, const float* hd, int h, co
         if (i >= r0 && i < r0 + n) {
             const f32x4 wv = w[i];
             const float xv = map(x[i]);
+#if UCNERF_BF16_NO_PK
+            a.s01.x = sc_fma(xv, wv.x, a.s01.x); a.s01.y = sc_fma(xv, wv.y, a.s01.y);
+            a.s23.x = sc_fma(xv, wv.z, a.s23.x); a.s23.y = sc_fma(xv, wv.w, a.s23.y);
+#else
             const f32x2 xx = {xv, xv};
             a.s01 = __builtin_elementwise_fma(xx, (f32x2){wv.x, wv.y}, a.s01);
             a.s23 = __builtin_elementwise_fma(xx, (f32x2){wv.z, wv.w}, a.s23);
+#endif
         }
     pin(a.s01); pin(a.s23);
 }
@@ -436,7 +466,7 @@ __device__ __forceinline__ void encode16(const float (&x)[3], int h, float (&pe)
 
 template <bool TILED, int NSRC, int TERMS>       // TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only)
 #ifndef UCNERF_BF16_WPS
-#define UCNERF_BF16_WPS 2      // waves per SIMD (= blocks per CU): 2 -> 256 VGPRs per wave, 1 -> 512
+#define UCNERF_BF16_WPS 2      // waves per SIMD: 2 -> 256 VGPRs per wave, 1 -> 512
 #endif
 __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(ucnerf_mlp_params p, BGeom g, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // ONE shared object: [ring][constants][pe stash]
@@ -479,7 +509,12 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     float nfs[4][8], nconf, npx[3];
     // (j and the parked-scalar address are re-derived from `lane` at each use: as loop-long values they get spilled)
     auto sample_of = [&](int tile) { const int s_raw = tile * 32 + (opaque(lane) & 31); return s_raw < p.m ? s_raw : p.m - 1; };
+#if UCNERF_BF16_EXP & 4096      // timing experiment: every feature load falls into the rows of eight tiles (cache resident): instruction and wait
+                                // cost of the loads without their HBM traffic (compare on all-zero inputs)
+    auto feat_base = [&](int s) { return TILED ? p.feats + ((size_t)((s >> 5) & 7) * F * 32 + (s & 31)) : p.feats + (size_t)(s & 255) * g.feat_stride; };
+#else
     auto feat_base = [&](int s) { return TILED ? p.feats + ((size_t)(s >> 5) * F * 32 + (s & 31)) : p.feats + (size_t)s * g.feat_stride; };
+#endif
     constexpr int fstride = TILED ? 32 : 1;
     auto fetch = [&](int tile) {
         const int s = sample_of(tile);
@@ -493,11 +528,29 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                 // (tiled layout: streaming loads -- every 128-byte line is consumed by one load; kept out of the L2 they leave the
                 //  gather's sources there.  Row-major rows are read four bytes at a time and need the cache.)
                 const float* src_ = (NSRC && c + 8 < F) ? &fh[c * fstride] : &fb[(size_t)min(c + 8 * h, F - 1) * fstride];
+#if UCNERF_BF16_EXP & 1024
+                { float z_ = 0.f; asm volatile("" : "+v"(z_)); nfs[q][e] = z_; }      // (opaque zero: keeps the split arithmetic)
+                (void)src_;
+#elif UCNERF_BF16_EXP & 2048
+                {
+                    const float* src2_ = src_ + (tile + 1 < n_tiles / 2 ? (size_t)(n_tiles / 2) * F * 32 : 0);      // the same row of a tile half a buffer away
+                    float a_ = q >= kd16 ? 0.f : TILED ? __builtin_nontemporal_load(src_) : *src_;
+                    const float b_ = q >= kd16 ? 0.f : TILED ? __builtin_nontemporal_load(src2_) : *src2_;
+                    float zero_ = 0.f;
+                    asm volatile("" : "+v"(zero_));
+                    nfs[q][e] = a_ + zero_ * b_;
+                }
+#else
                 nfs[q][e] = q >= kd16 ? 0.f : TILED ? __builtin_nontemporal_load(src_) : *src_;
+#endif
             }
+#if UCNERF_BF16_EXP & 1024
+        { float z_ = 0.f; asm volatile("" : "+v"(z_)); nconf = z_; npx[0] = z_; npx[1] = z_; npx[2] = z_; }
+#else
         nconf = fb[(size_t)(F - 1) * fstride];
         const float* prow = p.pts + (size_t)s * 3;
         npx[0] = prow[0]; npx[1] = prow[1]; npx[2] = prow[2];
+#endif
     };
     fetch(blockIdx.x * BW + wave);
 
@@ -652,7 +705,21 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                            for (int e = 0; e < 8; ++e) {
                                const int c = f_img + 16 * qq + e;
                                const float* src_ = (NSRC && c + 8 < F) ? &fhb[c * fstride] : &fb[(size_t)min(c + 8 * h, F - 1) * fstride];
+#if UCNERF_BF16_EXP & 1024
+                               { float z_ = 0.f; asm volatile("" : "+v"(z_)); fsec[qq][e] = z_; }
+                               (void)src_;
+#elif UCNERF_BF16_EXP & 2048
+                               {
+                                   const float* src2_ = src_ + (tile + 1 < n_tiles / 2 ? (size_t)(n_tiles / 2) * F * 32 : 0);
+                                   const float a_ = qq >= kc16 ? 0.f : TILED ? __builtin_nontemporal_load(src_) : *src_;
+                                   const float b_ = qq >= kc16 ? 0.f : TILED ? __builtin_nontemporal_load(src2_) : *src2_;
+                                   float zero_ = 0.f;
+                                   asm volatile("" : "+v"(zero_));
+                                   fsec[qq][e] = a_ + zero_ * b_;
+                               }
+#else
                                fsec[qq][e] = qq >= kc16 ? 0.f : TILED ? __builtin_nontemporal_load(src_) : *src_;
+#endif
                            }
                        int ray = s_here;
                        if (!p.dirs_per_sample) { int S = p.S; asm volatile("" : "+s"(S)); ray = s_here / S; }   // (opaque: no reciprocal hoisted into a loop-long VGPR)
@@ -787,7 +854,7 @@ int launch_mlp_fwd_bf16_plain(const ucnerf_mlp_params* p, hipStream_t st) {
     const int cus = device_cus();
     if (cus <= 0) return fail(UCNERF_EHIP, "mlp_fwd: no device");
     int blocks = cdiv(n_tiles, BW);
-    const int cap = p->max_blocks > 0 ? p->max_blocks : UCNERF_BF16_WPS * cus;
+    const int cap = p->max_blocks > 0 ? p->max_blocks : UCNERF_BF16_WPS * 4 / BW * cus;      // blocks per CU = waves per SIMD * 4 / BW
     if (blocks > cap) blocks = cap;
     BGeom g;
     g.F = B.F; g.kd16 = B.kd16; g.kc16 = B.kc16; g.f_img = 24 + 4 * B.v; g.slots = B.slots;
