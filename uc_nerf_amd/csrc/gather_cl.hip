@@ -243,6 +243,79 @@ __global__ void __launch_bounds__(256, TILED ? UCNERF_GATHER_WAVES : 1) feat_gat
         for (int unit = 0; unit < 4 + a.V; ++unit) gather_cl_unit<false, GIVEN>(a, idx, unit, in);
 }
 
+
+// ------------------------------------------------------------------------------------------------ gather with corner reuse
+// The per-sample kernel above is bound by the bytes its corner reads pull through the CU's vector-memory path (2.1 KB per
+// sample, TA busy 0.83) although consecutive samples of a ray hardly move: a ray crosses a source view along a short epipolar
+// segment (~0.06 px per sample at the bench's poses) and the reference frustum along one (x, y) column.  Here a thread owns a
+// RUN of four consecutive samples, works out their footprints first and then sweeps the sources one 16-byte channel group at
+// a time, keeping the previous sample's corners in registers: it reloads everything when (x0, y0) moved, one z-plane when the
+// depth index advanced by one, nothing otherwise.  Four consecutive samples are 16 contiguous bytes of every tiled feature
+// row, so each feature leaves as one float4 store per thread (eight threads complete a 128-byte line).  blockIdx.y = source view.
+// Arithmetic (projection, weights, accumulation order per channel) is the per-sample kernel's: the features are bit-identical.
+// The four units of the reference frustum (three volumes + confidence) stay on the per-sample kernel: the same scheme for them
+// (one projection per sample, z-plane sliding) was built and needs ~170 live registers per thread -- hipcc spills 350-600 bytes
+// per lane at every occupancy tried, and the source views carry 60 % of the gathered bytes anyway.
+constexpr int RUN = 4;
+constexpr int RUN_THREADS = 256;
+typedef float gf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ gf4 ld16v(const char* base, unsigned off) { return *(const gf4*)(base + off); }
+#define FMA4V(O, A, WT)                                                                          \
+    { const gf4 a_ = (A); const gf2 w_ = {(WT), (WT)};                                           \
+      O[0] = __builtin_elementwise_fma(a_.xy, w_, O[0]);                                         \
+      O[1] = __builtin_elementwise_fma(a_.zw, w_, O[1]); }
+
+template <bool GIVEN>
+__global__ void __launch_bounds__(RUN_THREADS, 4) feat_gather_run_kernel(GatherClArgs a) {
+    const unsigned base = (blockIdx.x * RUN_THREADS + threadIdx.x) * RUN;
+    if (base >= a.M) return;
+    const int F = 24 + 12 * a.V + 1;
+    float* row = a.feats + ((size_t)(base >> 5) * F) * 32 + (base & 31);       // feature f of samples base..base+3 at row[f * 32 .. +3]
+#define PUT4(FEAT, O) __builtin_nontemporal_store((gf4){(O)[0], (O)[1], (O)[2], (O)[3]}, reinterpret_cast<gf4*>(row + (size_t)(FEAT) * 32));
+    {
+        const int vi = blockIdx.y;
+        const char* img = (const char*)(a.img + (size_t)vi * a.H * a.W * 3);
+        unsigned p00[RUN], p10[RUN], dx[RUN];
+        float w00[RUN], w01[RUN], w10[RUN], w11[RUN], mask[RUN];
+#pragma unroll
+        for (int j = 0; j < RUN; ++j) {
+            const unsigned idx = min(base + j, a.M - 1);
+            float x, y, w;
+            if (GIVEN) { const float* q = a.pts_in + 3 * (size_t)idx; x = q[0]; y = q[1]; w = q[2]; }
+            else { const SampleIn in = sample_in(a, idx); x = a.rays_o[0] + in.z * in.dx; y = a.rays_o[1] + in.z * in.dy; w = a.rays_o[2] + in.z * in.dz; }
+            float qx, qy, qz;
+            project_cl(a.w2cs + 12 * vi, a.Ks + 9 * vi, x, y, w, &qx, &qy, &qz);
+            const float gx = (qx / qz + 0.0f) / (float)(a.W - 1) * 2.0f - 1.0f, gy = (qy / qz + 0.0f) / (float)(a.H - 1) * 2.0f - 1.0f;
+            const LerpCl ax = axis_cl(gx, a.W, true), ay = axis_cl(gy, a.H, true);
+            p00[j] = (unsigned)(ay.i0 * a.W + ax.i0) * 48u; p10[j] = (unsigned)(ay.i1 * a.W + ax.i0) * 48u;
+            dx[j] = (unsigned)(ax.i1 - ax.i0) * 48u;
+            w00[j] = ay.w0 * ax.w0; w01[j] = ay.w0 * ax.w1; w10[j] = ay.w1 * ax.w0; w11[j] = ay.w1 * ax.w1;
+            mask[j] = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.f : 0.f;
+        }
+        const int fc = 24 + 4 * vi, fb = 24 + 4 * a.V + 8 * vi;
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp) {            // (r g b f0) (f1 f2 f3 f4) (f5 f6 f7 -)
+            const unsigned co = 16u * comp;
+            gf4 p[4];
+            float out[4][RUN];
+#pragma unroll
+            for (int j = 0; j < RUN; ++j) {
+                if (!(j > 0 && p00[j] == p00[j - 1])) {   // (p00 fixes x0, y0 and with them x1, y1)
+                    p[0] = ld16v(img, p00[j] + co); p[1] = ld16v(img, p00[j] + dx[j] + co);
+                    p[2] = ld16v(img, p10[j] + co); p[3] = ld16v(img, p10[j] + dx[j] + co);
+                }
+                gf2 acc[2] = {{0, 0}, {0, 0}};
+                FMA4V(acc, p[0], w00[j]) FMA4V(acc, p[1], w01[j]) FMA4V(acc, p[2], w10[j]) FMA4V(acc, p[3], w11[j])
+                out[0][j] = acc[0].x; out[1][j] = acc[0].y; out[2][j] = acc[1].x; out[3][j] = acc[1].y;
+            }
+            if (comp == 0) { PUT4(fc + 0, out[0]) PUT4(fc + 1, out[1]) PUT4(fc + 2, out[2]) PUT4(fc + 3, mask) PUT4(fb + 0, out[3]) }
+            else if (comp == 1) { PUT4(fb + 1, out[0]) PUT4(fb + 2, out[1]) PUT4(fb + 3, out[2]) PUT4(fb + 4, out[3]) }
+            else { PUT4(fb + 5, out[0]) PUT4(fb + 6, out[1]) PUT4(fb + 7, out[2]) }
+        }
+    }
+#undef PUT4
+}
+
 }  // namespace ucnerf
 
 using namespace ucnerf;
@@ -310,7 +383,22 @@ int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float
         a.div_sh = l - 1;
     }
     const dim3 grid(cdiv(M, 256), tiled ? 4 + a.V : 1), block(256);
-    if (tiled && !given) hipLaunchKernelGGL((feat_gather_cl_kernel<true, false>), grid, block, 0, st, a);
+#ifndef UCNERF_GATHER_RUN
+#define UCNERF_GATHER_RUN 0       // tiled layout: 1 = source views on the corner-reuse kernel (a run of four samples per thread), 0 = one sample per
+                                  // thread for every unit.  Measured (profiles/r02_gather_experiments.md): 3x fewer corner loads, but 36.5 us for the
+                                  // six views against ~32 us on the per-sample kernel at 7 waves per SIMD -- the default stays 0
+#endif
+    if (tiled && UCNERF_GATHER_RUN) {
+        const dim3 grid_ref(cdiv(M, 256), 4), grid_r(cdiv(cdiv(M, RUN), RUN_THREADS), a.V), block_r(RUN_THREADS);
+        if (!given) {
+            hipLaunchKernelGGL((feat_gather_cl_kernel<true, false>), grid_ref, block, 0, st, a);        // volumes + confidence (+ ndc, u)
+            hipLaunchKernelGGL((feat_gather_run_kernel<false>), grid_r, block_r, 0, st, a);            // source views
+        } else {
+            hipLaunchKernelGGL((feat_gather_cl_kernel<true, true>), grid_ref, block, 0, st, a);
+            hipLaunchKernelGGL((feat_gather_run_kernel<true>), grid_r, block_r, 0, st, a);
+        }
+    }
+    else if (tiled && !given) hipLaunchKernelGGL((feat_gather_cl_kernel<true, false>), grid, block, 0, st, a);
     else if (tiled) hipLaunchKernelGGL((feat_gather_cl_kernel<true, true>), grid, block, 0, st, a);
     else if (!given) hipLaunchKernelGGL((feat_gather_cl_kernel<false, false>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((feat_gather_cl_kernel<false, true>), grid, block, 0, st, a);
