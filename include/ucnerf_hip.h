@@ -111,6 +111,10 @@ typedef struct {
 } ucnerf_sample_stratified_params;
 int ucnerf_sample_stratified(const ucnerf_sample_stratified_params* p, void* stream);
 
+/* a1 + a3 in one launch: the rays of ucnerf_ray_gen and their stratified depths (scalar near / far form: rays = pts = NULL) --
+ * data/ray_utils.py:32-53 followed by :176-194, as ray_marcher chains them.  Same results as the two calls. */
+int ucnerf_ray_gen_sample(const ucnerf_ray_gen_params* rays, const ucnerf_sample_stratified_params* depths, void* stream);
+
 typedef struct {
     int32_t n, S;         /* S must be a multiple of 3, S <= 768 */
     const float* near_far;/* [n,6] = (near_1, far_1, near_2, far_2, near_3, far_3) per ray */

@@ -623,3 +623,18 @@ def test_cost_volume_at_stage_sizes_against_the_oracle_and_depthnet_mirror():
     (d_o.sum() + c_o.sum()).backward()
     bad_px = ((lg.grad[0, 0].cpu() - lo.grad).abs() > 2e-6 + 1e-4 * lo.grad.abs()).any(dim=0)
     assert bad_px.float().mean().item() < 5e-3
+
+
+def test_ray_gen_sample_equals_the_two_calls_it_folds():
+    g = load_golden("g1_raygen")
+    gen = torch.Generator().manual_seed(8)
+    n, S = 777, 64
+    xs, ys = torch.randint(0, 20, (n,), generator=gen).float(), torch.randint(0, 16, (n,), generator=gen).float()
+    noise = torch.rand(n, S, generator=gen)
+    d0, _, _, a0 = ops().ray_gen(g["K"], g["c2w"], xs=dev(xs), ys=dev(ys), w2c_dir=g["c2w"])
+    for perturb in (0.0, 1.0):
+        z0, _ = ops().sample_stratified(None, S, perturb=perturb, noise=dev(noise), n=n, near=1.25, far=3.5, device=torch.device(DEV))
+        d1, a1, z1 = ops().ray_gen_sample(g["K"], g["c2w"], dev(xs), dev(ys), S, 1.25, 3.5, perturb=perturb, noise=dev(noise), w2c_dir=g["c2w"])
+        assert torch.equal(d0, d1) and torch.equal(a0, a1) and torch.equal(z0, z1)
+    d2, a2, z2 = ops().ray_gen_sample(g["K"], g["c2w"], dev(xs[:0]), dev(ys[:0]), S, 1.0, 4.0)
+    assert d2.shape == (0, 3) and a2 is None and z2.shape == (0, S)

@@ -166,6 +166,7 @@ SYMBOLS = {
     "ucnerf_ndc_rays": (C.c_int, [_P, _P]),
     "ucnerf_dir_feature": (C.c_int, [_P, _P]),
     "ucnerf_sample_stratified": (C.c_int, [_P, _P]),
+    "ucnerf_ray_gen_sample": (C.c_int, [_P, _P, _P]),
     "ucnerf_sample_cascade": (C.c_int, [_P, _P]),
     "ucnerf_ndc_project": (C.c_int, [_P, _P]),
     "ucnerf_embed": (C.c_int, [_P, _P]),

@@ -51,7 +51,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef UCNERF_BF16_EXP
-#define UCNERF_BF16_EXP 0      // timing experiments only (results are wrong): 1 no DMA wait, 2 no barrier, 4 no DMA, 64 no interleave hints, 128 no epilogue arithmetic, 256 half the LDS fragment reads, 512 no point-encoding arithmetic, 1024 no feature / point loads: zeros instead (compare with a launch on all-zero inputs: same values, same power draw), 2048 every feature load issued TWICE (the second from another tile's rows, weighted 0: same values, same power -- what the loads cost is what the copy adds)
+#define UCNERF_BF16_EXP 0      // timing experiments only (results are wrong): 1 no DMA wait, 2 no barrier, 4 no DMA, 64 no interleave hints, 128 no epilogue arithmetic, 256 half the LDS fragment reads, 512 no point-encoding arithmetic, 1024 no feature / point loads: zeros instead (compare with a launch on all-zero inputs: same values, same power draw), 8192 one more VALU per split value, 2048 every feature load issued TWICE (the second from another tile's rows, weighted 0: same values, same power -- what the loads cost is what the copy adds)
 #endif
 #ifndef UCNERF_BF16_HINT_V
 #define UCNERF_BF16_HINT_V 7   // VALU instructions the scheduler may place after each MFMA of a half-step
@@ -219,7 +219,14 @@ __device__ __forceinline__ Frag split8(const float (&x)[8]) {
 #endif
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
+#if UCNERF_BF16_EXP & 8192      // timing experiment: ONE MORE vector instruction per split value (an AND with an opaque all-ones mask: same values, same
+                                // operand toggling) -- the inverse of removing one, to price the split's instruction count
+        unsigned ones_ = 0xffffffffu;
+        asm volatile("" : "+v"(ones_));
+        const unsigned b0 = __builtin_bit_cast(unsigned, x[j]) & ones_, b1 = __builtin_bit_cast(unsigned, x[j + 1]) & ones_;
+#else
         const unsigned b0 = __builtin_bit_cast(unsigned, x[j]), b1 = __builtin_bit_cast(unsigned, x[j + 1]);
+#endif
         const unsigned packed = __builtin_amdgcn_perm(b1, b0, 0x07060302u);      // [hi(x[j+1]) | hi(x[j])]
         hi[j >> 1] = packed;
 #if UCNERF_BF16_SPLIT_DOT

@@ -42,9 +42,7 @@ int ensure_dynamic_lds(const void* kernel, int bytes, const char* what) {
 }
 
 // ------------------------------------------------------------------------------------------- a1
-__global__ void ray_gen_kernel(ucnerf_ray_gen_params p) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
+__device__ __forceinline__ void ray_gen_one(const ucnerf_ray_gen_params& p, int i) {
     float x, y;
     if (p.xs) {
         x = p.xs[i];
@@ -87,6 +85,12 @@ __global__ void ray_gen_kernel(ucnerf_ray_gen_params p) {
         p.pix[i] = y;
         p.pix[p.n + i] = x;
     }
+}
+
+__global__ void ray_gen_kernel(ucnerf_ray_gen_params p) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    ray_gen_one(p, i);
 }
 
 // ------------------------------------------------------------------------------------------- a2
@@ -142,9 +146,7 @@ __device__ __forceinline__ float z_at(float near, float far, int i, int S, int l
     return lindisp ? 1.f / (1.f / near * (1.f - t) + 1.f / far * t) : near * (1.f - t) + far * t;
 }
 
-__global__ void sample_stratified_kernel(ucnerf_sample_stratified_params p) {
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)p.n * p.S) return;
+__device__ __forceinline__ void sample_stratified_one(const ucnerf_sample_stratified_params& p, long long idx) {
     int r = (int)(idx / p.S), s = (int)(idx % p.S);
     const float* ray = p.rays ? p.rays + 8 * (size_t)r : nullptr;
     const float near = ray ? ray[6] : p.near, far = ray ? ray[7] : p.far;
@@ -162,6 +164,21 @@ __global__ void sample_stratified_kernel(ucnerf_sample_stratified_params p) {
         p.pts[3 * idx + 1] = ray[1] + ray[4] * z;
         p.pts[3 * idx + 2] = ray[2] + ray[5] * z;
     }
+}
+
+__global__ void sample_stratified_kernel(ucnerf_sample_stratified_params p) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)p.n * p.S) return;
+    sample_stratified_one(p, idx);
+}
+
+// rays and their depths from ONE launch (the head of the hierarchical step: two ~5 us launches were mostly launch latency):
+// thread (ray, sample) writes its depth; the thread of sample 0 also generates the ray
+__global__ void ray_gen_sample_kernel(ucnerf_ray_gen_params rg, ucnerf_sample_stratified_params ss) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)ss.n * ss.S) return;
+    sample_stratified_one(ss, idx);
+    if (idx % ss.S == 0) ray_gen_one(rg, (int)(idx / ss.S));
 }
 
 // Live cascade sampler: one 64-thread block per ray; the S values are sorted in LDS (bitonic, padded to a
@@ -335,6 +352,20 @@ int ucnerf_ray_gen(const ucnerf_ray_gen_params* p, void* stream) {
     if (p->n == 0) return UCNERF_OK;
     hipLaunchKernelGGL(ray_gen_kernel, dim3(cdiv(p->n, 256)), dim3(256), 0, (hipStream_t)stream, *p);
     return check_launch("ray_gen");
+}
+
+int ucnerf_ray_gen_sample(const ucnerf_ray_gen_params* rg, const ucnerf_sample_stratified_params* ss, void* stream) {
+    UCNERF_REQUIRE(rg && ss, "ray_gen_sample: null params");
+    UCNERF_REQUIRE(rg->n == ss->n && rg->n >= 0, "ray_gen_sample: %d rays but depths for %d", rg->n, ss->n);
+    if (rg->n == 0) return UCNERF_OK;
+    UCNERF_REQUIRE(rg->rays_d && ss->z && ss->S >= 1, "ray_gen_sample: null rays_d / z or S < 1");
+    UCNERF_REQUIRE((rg->xs == nullptr) == (rg->ys == nullptr), "ray_gen_sample: xs and ys must both be given or both NULL");
+    UCNERF_REQUIRE(rg->xs || (rg->W > 0 && rg->H > 0 && rg->grid_start >= 0 && (long long)rg->grid_start + rg->n <= (long long)rg->H * rg->W),
+                   "ray_gen_sample: grid range outside the image");
+    UCNERF_REQUIRE(!ss->rays && !ss->pts, "ray_gen_sample: depths use the scalar near / far form (rays = pts = NULL)");
+    UCNERF_REQUIRE(!(ss->perturb > 0.f) || ss->noise, "ray_gen_sample: perturb > 0 needs noise draws");
+    hipLaunchKernelGGL(ray_gen_sample_kernel, dim3(cdiv((long long)ss->n * ss->S, 256)), dim3(256), 0, (hipStream_t)stream, *rg, *ss);
+    return check_launch("ray_gen_sample");
 }
 
 int ucnerf_ndc_rays(const ucnerf_ndc_rays_params* p, void* stream) {

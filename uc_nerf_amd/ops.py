@@ -80,6 +80,41 @@ def ray_gen(K, c2w, xs=None, ys=None, H=0, W=0, grid_start=0, n=None, opengl=Fal
     return (rays_d, rays_o, pix) if w2c_dir is None else (rays_d, rays_o, pix, angle)
 
 
+class RaySampler:
+    """ray_gen(xs, ys) + sample_stratified(n, S, near, far) from ONE launch, camera matrices bound once (they travel by value in
+    the parameter structs: filling them per call costs more host time than the launch).  Call -> (rays_d [n,3], angle [n,3] or
+    None, z [n,S])."""
+
+    def __init__(self, K, c2w, S, near, far, w2c_dir=None, lindisp=False):
+        self.rg, self.ss = L.RayGenParams(), L.SampleStratifiedParams()
+        _mat(self.rg.K, K, 3, 3)
+        _mat(self.rg.c2w, c2w, 3, 4)
+        self.has_dir = w2c_dir is not None
+        if self.has_dir:
+            _mat(self.rg.w2c_dir, w2c_dir, 3, 4)
+        self.ss.S, self.ss.lindisp, self.ss.near, self.ss.far = int(S), int(lindisp), float(near), float(far)
+
+    def __call__(self, xs, ys, perturb=0.0, noise=None):
+        xs, ys = _f32(xs, "xs"), _f32(ys, "ys")
+        n, device = xs.numel(), xs.device
+        rg, ss = self.rg, self.ss
+        rays_d = torch.empty(n, 3, device=device)
+        angle = torch.empty(n, 3, device=device) if self.has_dir else None
+        z = torch.empty(n, ss.S, device=device)
+        rg.n, rg.xs, rg.ys, rg.rays_d, rg.angle = n, _ptr(xs), _ptr(ys), _ptr(rays_d), _ptr(angle)
+        ss.n, ss.perturb, ss.z = n, float(perturb), _ptr(z)
+        if perturb > 0:
+            noise = _f32(noise if noise is not None else torch.rand(n, ss.S, device=device), "noise")
+        ss.noise = _ptr(noise if perturb > 0 else None)
+        with torch.cuda.device(device):
+            L.check(L.lib().ucnerf_ray_gen_sample(C.addressof(rg), C.addressof(ss), _stream()), "ucnerf_ray_gen_sample")
+        return rays_d, angle, z
+
+
+def ray_gen_sample(K, c2w, xs, ys, S, near, far, perturb=0.0, noise=None, lindisp=False, w2c_dir=None):
+    return RaySampler(K, c2w, S, near, far, w2c_dir, lindisp)(xs, ys, perturb, noise)
+
+
 def ndc_rays(H, W, focal_x, focal_y, near, rays_o, rays_d, variant):
     rays_o, rays_d = _f32(rays_o.reshape(-1, 3)), _f32(rays_d.reshape(-1, 3))
     p = L.NdcRaysParams()

@@ -1,8 +1,8 @@
 """The 64 coarse + 128 fine hierarchical renderer composed from the library's entry points
 (ray_marcher -> render -> sample_pdf on mid-points with w[1:-1] -> sorted merge -> render).
 
-Six library calls per batch, all on the caller's stream:
-  ray_gen -> sample_stratified -> render_fused_fwd (coarse) -> sample_pdf(+merge) -> render_fused_fwd (fine)
+Five library calls per batch (+ the source repack when asked), all on the caller's stream:
+  ray_gen_sample (rays + coarse depths) -> render_fused_fwd (coarse) -> sample_pdf(+merge) -> render_fused_fwd (fine)
 """
 import torch
 
@@ -39,6 +39,7 @@ class CoarseFineRenderer:
         self.K_host, self.c2w_host = scene["K"].detach().cpu(), scene["c2w"].detach().cpu()
         self.w2c_dir_host = w2c_ref.detach().cpu()
         self.near_host, self.far_host = float(scene["near"]), float(scene["far"])
+        self.sampler = ops.RaySampler(self.K_host, self.c2w_host, n_coarse, self.near_host, self.far_host, self.w2c_dir_host)
 
     def set_params(self, flat_params):
         self.wstream.copy_(self.pw.pack(flat_params))
@@ -55,10 +56,7 @@ class CoarseFineRenderer:
         if repack:
             self.pass_.repack_sources()
         # rays and their view-direction feature from one launch; both passes take the feature as an input
-        rays_d, _, _, angle = ops.ray_gen(self.K_host, self.c2w_host, xs=xs, ys=ys, w2c_dir=self.w2c_dir_host)
-        n = rays_d.shape[0]
-        z_c, _ = ops.sample_stratified(None, self.n_coarse, perturb=perturb, noise=noise, n=n, near=self.near_host,
-                                       far=self.far_host, device=self.dev)
+        rays_d, angle, z_c = self.sampler(xs, ys, perturb, noise)
         ev = [(a.h, b.h) for a, b in events] if events else (None, None)
         coarse = self.pass_(rays_d, z_c, want=("weights",), events=ev[0], keep=("raw",) if reuse_coarse else (), dir_feat=angle)
         hs = ops.sample_pdf(None, coarse["weights"], self.u_det if u is None else u, z_merge=z_c, want_inds=False,
