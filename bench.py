@@ -202,6 +202,13 @@ def bench_dropin(ctx, scene, sd, steps=40, warmup=10):
 
     dt = ctx.timed(train_step, steps, warmup)
     assert torch.isfinite(train_step()).all()
+    uc_nerf_amd.set_training_precision("bf16x3")
+    try:
+        dt_b = ctx.timed(train_step, steps, warmup)
+    finally:
+        uc_nerf_amd.set_training_precision("f32")
+    out["dropin_train_bf16x3_forward"] = {"ms_per_step": dt_b * 1e3, "value": 2000 / dt_b, "unit": "rays/s",
+                                          "note": "the same step with the opt-in split-bf16 training forward (set_training_precision('bf16x3'))"}
     out["dropin_train"] = {"ms_per_step": dt * 1e3, "value": 2000 / dt, "unit": "rays/s", "rays": 2000, "samples_per_ray": 90, "dtype": "f32",
                            "note": "rendering() forward (activations kept) + img/depth loss + backward into MLP parameters, cascade volumes, "
                                    "img_feats and confidence + Adam step; the weight stream is repacked once per step"}
@@ -398,11 +405,11 @@ def main():
                     "note": "single pass on precomputed [4096,128,97] features: PE + MLP + composite (no gather, no sampling)"}
         extra["micro_4096x128_precomputed_feats"] = guarded(micro)
 
-        def fused_train():
-            """A training-style step of the library's fused pass: source repack + forward + full backward (parameters, volumes,
-            image features, confidence), 1024 rays x 128 depths, exact-f32 path."""
+        def fused_train(fwd_precision="f32"):
+            """A training-style step of the library's fused pass: source repack + forward (activations kept) + full backward
+            (parameters, volumes, image features, confidence), 1024 rays x 128 depths; forward in exact f32 or split-bf16."""
             n_t, s_t = min(1024, int(xs.shape[0])), 128
-            rt = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, precision="f32")
+            rt = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, precision=fwd_precision)
             flat_t = flat_params_of(sd).to(dev)
             rd_t, _, _ = ops.ray_gen(rt.K_host, rt.c2w_host, xs=xs[:n_t], ys=ys[:n_t])
             z_t, _ = ops.sample_stratified(None, s_t, n=n_t, near=rt.near_host, far=rt.far_host, device=dev)
@@ -414,10 +421,12 @@ def main():
                 return rt.pass_.backward(rd_t, z_t, kept, g_rgb, g_depth, flat_t)
             dt4 = ctx.timed(train_step, 30, 5)
             assert all(torch.isfinite(t).all() for t in train_step() if t is not None)
-            return {"ms_per_step": dt4 * 1e3, "value": n_t / dt4, "unit": "rays/s", "rays": n_t, "samples_per_ray": s_t, "dtype": "f32",
+            return {"ms_per_step": dt4 * 1e3, "value": n_t / dt4, "unit": "rays/s", "rays": n_t, "samples_per_ray": s_t,
+                    "dtype": "f32" if fwd_precision == "f32" else "forward bf16x3 (activations kept in f32), backward f32 / bf16x3 GEMMs",
                     "note": "NOT the headline: source repack + forward + full backward of one fused render pass on one GPU "
                             "(no optimizer, no collective)"}
         extra["train_step"] = guarded(fused_train)
+        extra["train_step_bf16x3_forward"] = guarded(lambda: fused_train("bf16x3"))
 
         if world == 1:
             extra.update(guarded(lambda: bench_dropin(ctx, scene, sd), "dropin"))

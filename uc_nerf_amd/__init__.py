@@ -17,6 +17,12 @@ def set_inference_precision(precision):
     dropin.set_inference_precision(precision)
 
 
+def set_training_precision(precision):
+    """MLP arithmetic of the training forward of the `rendering()` drop-in: "f32" (default) or "bf16x3" (dropin.py)."""
+    from . import dropin
+    dropin.set_training_precision(precision)
+
+
 def install_dropin():
     """Registers this package's mirrors under the reference's module names (`network.renderer`,
     `network.models`, `utils.utils`, `utils.run_nerf_helpers`, `data.ray_utils`) so that the reference's

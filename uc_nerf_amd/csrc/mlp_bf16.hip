@@ -263,9 +263,28 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); retur
 // for, with their operands kept live meanwhile.  An empty volatile asm on the result pins the arithmetic in place.
 template <class T> __device__ __forceinline__ void pin(T& v) { asm volatile("" : "+v"(v)); }
 
-// fragment s (0/1) of an accumulator tile: MODE 0 plain, 1 times m, 2 relu(times m)   (two values per v_pk_mul_f32)
-template <int MODE>
-__device__ __forceinline__ Frag frag_of(const f32x16& a, const f32x16& m, int s) {
+// Training forward (SAVE): the activation sets the backward reads (MlpSaved, mlp_layout.h), row-major [m,128].  A lane owns 64 of its
+// sample's 128 values per set: register group (nt, q = reg / 4) of lane-half h sits at floats 32 nt + 8 q + 4 h of the row.
+__device__ __forceinline__ void save8(float* row, int nt, int s, const float (&t)[8]) {       // fragment s of row-tile nt
+    // (plain stores: the eight 16-byte pieces of a 128-byte line leave this wave hundreds of cycles apart -- between MFMA groups --
+    //  and have to meet in L2; as streaming stores each piece went to memory on its own)
+    *reinterpret_cast<f32x4*>(row + 32 * nt + 16 * s) = (f32x4){t[0], t[1], t[2], t[3]};
+    *reinterpret_cast<f32x4*>(row + 32 * nt + 16 * s + 8) = (f32x4){t[4], t[5], t[6], t[7]};
+}
+template <bool RELU>
+__device__ __forceinline__ void save_tile(float* row, int nt, const f32x16& x) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 v = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+        if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<f32x4*>(row + 32 * nt + 8 * q) = v;
+    }
+}
+
+// fragment s (0/1) of an accumulator tile: MODE 0 plain, 1 times m, 2 relu(times m)   (two values per v_pk_mul_f32);
+// SV: the eight fp32 values also go to `srow` (this lane's row of an activation set, NULL past the last sample) as row-tile nt
+template <int MODE, bool SV = false>
+__device__ __forceinline__ Frag frag_of(const f32x16& a, const f32x16& m, int s, float* srow = nullptr, int nt = 0) {
 #if UCNERF_BF16_EXP & 128      // timing experiment: no epilogue arithmetic at all (wrong results)
     Frag e;
     e.hi = __builtin_bit_cast(bf16x8, (f32x4){a[8 * s], a[8 * s + 1], a[8 * s + 2], a[8 * s + 3]});
@@ -285,6 +304,7 @@ __device__ __forceinline__ Frag frag_of(const f32x16& a, const f32x16& m, int s)
         t[j] = MODE == 2 ? fmaxf(v.x, 0.f) : v.x;
         t[j + 1] = MODE == 2 ? fmaxf(v.y, 0.f) : v.y;
     }
+    if (SV && srow) save8(srow, nt, s, t);
     Frag f = split8(t);
     pin(f.hi); pin(f.lo);
     return f;
@@ -471,11 +491,11 @@ __device__ __forceinline__ void encode16(const float (&x)[3], int h, float (&pe)
     for (int q = 2 * half + 2; q < KS; ++q) pe[q] = 0.f;
 }
 
-template <bool TILED, int NSRC, int TERMS>       // TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only)
+template <bool TILED, int NSRC, int TERMS, bool SAVE>       // TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only); SAVE: training forward
 #ifndef UCNERF_BF16_WPS
 #define UCNERF_BF16_WPS 2      // waves per SIMD: 2 -> 256 VGPRs per wave, 1 -> 512
 #endif
-__global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(ucnerf_mlp_params p, BGeom g, int n_tiles) {
+__global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(ucnerf_mlp_params p, BGeom g, int n_tiles, MlpSaved sv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // ONE shared object: [ring][constants][pe stash]
     char* ring = smem;
     float* cst = reinterpret_cast<float*>(smem + NBUF * SLOT_BYTES);
@@ -568,6 +588,12 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
 #endif
     for (int round = 0; round < n_rounds; ++round) {                          // block-uniform trip count: every wave joins every barrier
         const int tile = round * tiles_per_round + blockIdx.x * BW + wave;
+        // SAVE: this lane's row of an activation set (re-derived at every use: nothing tile-long is kept in a register)
+        auto srow = [&](float* base) -> float* {
+            const int l_ = opaque(lane), s_ = tile * 32 + (l_ & 31);
+            return s_ < p.m ? base + (size_t)s_ * 128 + 4 * (l_ >> 5) : nullptr;
+        };
+        const size_t hstride = SAVE ? (size_t)(sv.h[1] - sv.h[0]) : 0;      // the six trunk sets are carved back to back
         // (few scalars are carried through the trunk -- every VGPR there is spoken for: sample index, feature base
         //  and view direction are re-derived / loaded where they are needed)
         DIAG_STAMP(0)
@@ -636,6 +662,10 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                 }
         }
         DIAG_STAMP(2)
+        if (SAVE) {
+            float* r_ = srow(sv.bd);
+            if (r_) { save_tile<false>(r_, 0, bd[0]); save_tile<false>(r_, 1, bd[1]); save_tile<false>(r_, 2, bd[2]); save_tile<false>(r_, 3, bd[3]); }
+        }
 
         // ---- layer 0 (pair-split) on the point encoding
         {
@@ -650,7 +680,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                 const Frag b = pf;
                 HS(q & 1, b, acc[2], acc[3],
                    if (q < 3) pf = stash[(q + 1) * 64];
-                   X[q] = frag_of<2>(acc[q >> 1], bd[q >> 1], q & 1);
+                   X[q] = frag_of<2, SAVE>(acc[q >> 1], bd[q >> 1], q & 1, SAVE ? srow(sv.h[0]) : nullptr, q >> 1);
                    if (q == 3) init_bias_pair(cst, SEC_L0 + 1, h, 0, acc));
             }
         }
@@ -659,15 +689,17 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         // ---- layers 1..4 (pair-split, fragments ping-pong between X and Y).  In: in[0..3] + acc[2], acc[3] of the
         // previous layer (their epilogue -> in[4..7] runs under phase A); out: out[0..3] + acc[2], acc[3].
         auto layer128 = [&](Frag (&in)[8], Frag (&out)[8], int sec) {
+            float* const h_prev = SAVE ? sv.h[0] + (size_t)(sec - SEC_L0 - 1) * hstride : nullptr;     // h of layer sec - SEC_L0 - 1 (row tiles 2, 3)
+            float* const h_this = SAVE ? h_prev + hstride : nullptr;                                   // h of this layer (row tiles 0, 1)
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 HS(q & 1, in[q], acc[0], acc[1],
-                   if (q < 4) in[4 + q] = frag_of<2>(acc[2 + (q >> 1)], bd[2 + (q >> 1)], q & 1);
+                   if (q < 4) in[4 + q] = frag_of<2, SAVE>(acc[2 + (q >> 1)], bd[2 + (q >> 1)], q & 1, SAVE ? srow(h_prev) : nullptr, 2 + (q >> 1));
                    if (q == 4) init_bias_pair(cst, sec, h, 1, acc));
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 HS(q & 1, in[q], acc[2], acc[3],
-                   if (!(q & 1)) out[q >> 1] = frag_of<2>(acc[q >> 2], bd[q >> 2], (q >> 1) & 1);
+                   if (!(q & 1)) out[q >> 1] = frag_of<2, SAVE>(acc[q >> 2], bd[q >> 2], (q >> 1) & 1, SAVE ? srow(h_this) : nullptr, q >> 2);
                    if (q == 7) init_bias_pair(cst, sec + 1, h, 0, acc));
         };
 #pragma unroll 1
@@ -691,7 +723,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             for (int q = 0; q < 12; ++q) {                                    // phase A
                 const Frag b = q < 4 ? X[q] : (q < 8 ? pf : X[q - 4]);
                 HS(q & 1, b, acc[0], acc[1],
-                   if (q < 4) X[4 + q] = frag_of<2>(acc[2 + (q >> 1)], bd[2 + (q >> 1)], q & 1);
+                   if (q < 4) X[4 + q] = frag_of<2, SAVE>(acc[2 + (q >> 1)], bd[2 + (q >> 1)], q & 1, SAVE ? srow(sv.h[4]) : nullptr, 2 + (q >> 1));
                    if (q >= 3 && q < 7) pf = stash[(q - 3) * 64];
                    if (q == 4) init_bias_pair(cst, SEC_L0 + 5, h, 1, acc));
             }
@@ -741,6 +773,10 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = fmaxf(acc[nt][r] * bd[nt][r], 0.f);
         DIAG_STAMP(7)
+        if (SAVE) {
+            float* r_ = srow(sv.h[5]);
+            if (r_) { save_tile<false>(r_, 0, acc[0]); save_tile<false>(r_, 1, acc[1]); save_tile<false>(r_, 2, acc[2]); save_tile<false>(r_, 3, acc[3]); }
+        }
 
         // ---- confidence-bias net (step-major) -> bd; base heads of row tiles 0,1 underneath
         HeadAcc hbase = {{0.f, 0.f}, {0.f, 0.f}};
@@ -763,6 +799,10 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         }
         if (kc16 < 2) head_part(hbase, hb, h, acc[1], 1, 0, 16, ident);        // (one-step bias net: the rest is exposed)
         DIAG_STAMP(8)
+        if (SAVE) {
+            float* r_ = srow(sv.bc);
+            if (r_) { save_tile<false>(r_, 0, bd[0]); save_tile<false>(r_, 1, bd[1]); save_tile<false>(r_, 2, bd[2]); save_tile<false>(r_, 3, bd[3]); }
+        }
         // g = h5 * b_c: fragments of row tiles 0,1 now, of 2,3 under feature_linear's phase A
 #pragma unroll
         for (int q = 0; q < 4; ++q) X[q] = frag_of<1>(acc[q >> 1], bd[q >> 1], q & 1);
@@ -783,7 +823,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             HS(q & 1, X[q], acc[2], acc[3],
-               if (!(q & 1)) Y[q >> 1] = frag_of<0>(acc[q >> 2], acc[q >> 2], (q >> 1) & 1);
+               if (!(q & 1)) Y[q >> 1] = frag_of<0, SAVE>(acc[q >> 2], acc[q >> 2], (q >> 1) & 1, SAVE ? srow(sv.ft) : nullptr, q >> 2);
                if (q & 1) {                                                    // direction encoding: 6 arguments, two per odd half-step
                    if (q < 7) {
                        encode_sincos(dt, h, q - 1, &pd[q - 1], &pd[6 + q - 1]);
@@ -802,7 +842,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         for (int q = 0; q < 10; ++q) {
             const Frag b = q < 8 ? Y[q] : D[q - 8];
             HS(q & 1, b, acc[0], acc[1],
-               if (q < 4) Y[4 + q] = frag_of<0>(acc[2 + (q >> 1)], acc[2 + (q >> 1)], q & 1);
+               if (q < 4) Y[4 + q] = frag_of<0, SAVE>(acc[2 + (q >> 1)], acc[2 + (q >> 1)], q & 1, SAVE ? srow(sv.ft) : nullptr, 2 + (q >> 1));
                if (q == 4) init_bias_pair(cst, SEC_VC, h, 1, acc);
                if (q == 5 || q == 6) {
                    float t[8];
@@ -817,11 +857,16 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         for (int q = 0; q < 10; ++q) {
             const Frag b = q < 8 ? Y[q] : D[q - 8];
             HS(q & 1, b, acc[2], acc[3],
-               if (q < 4) head_part(hadapt, ha, h, acc[q >> 1], q >> 1, (q & 1) * 8, 8, relu));
+               if (q < 4) head_part(hadapt, ha, h, acc[q >> 1], q >> 1, (q & 1) * 8, 8, relu);
+               if (SAVE && (q == 4 || q == 5)) { float* r_ = srow(sv.vc); if (r_) save_tile<true>(r_, q - 4, acc[q - 4]); });
         }
         DIAG_STAMP(11)
         __builtin_amdgcn_s_setprio(UCNERF_BF16_PRIO_VALU);
         fetch(tile + tiles_per_round);                     // next tile's inputs (clamped past the end: harmless)
+        if (SAVE) {
+            float* r_ = srow(sv.vc);
+            if (r_) { save_tile<true>(r_, 2, acc[2]); save_tile<true>(r_, 3, acc[3]); }
+        }
         // ---- adapt heads of row tiles 2,3, uncertainty blend
         head_part(hadapt, ha, h, acc[2], 2, 0, 16, relu);
         head_part(hadapt, ha, h, acc[3], 3, 0, 16, relu);
@@ -844,11 +889,8 @@ constexpr size_t bf16_smem_bytes() {
     return (size_t)NBUF * SLOT_BYTES + ((CONST_FLOATS * 4 + 15) & ~15) + (size_t)BW * KS16_PE_PTS * 64 * sizeof(Frag) + (size_t)BW * 64 * sizeof(float);
 }
 
-#if UCNERF_BF16_BUILD_TERMS == 3
-int launch_mlp_fwd_bf16x3(const ucnerf_mlp_params* p, hipStream_t st) {
-#else
-int launch_mlp_fwd_bf16_plain(const ucnerf_mlp_params* p, hipStream_t st) {
-#endif
+// `save` (TERMS = 3 only): the training forward -- the activation sets of MlpSaved are written for ucnerf_mlp_bwd (saved_valid = 1)
+static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st) {
     UCNERF_REQUIRE(p, "mlp_fwd: null params");
     if (p->m == 0) return UCNERF_OK;
     UCNERF_REQUIRE(p->pts && p->dirs && p->feats && p->wstream && p->raw, "mlp_fwd: null pointer");
@@ -878,19 +920,45 @@ int launch_mlp_fwd_bf16_plain(const ucnerf_mlp_params* p, hipStream_t st) {
     dim3 grid(blocks), block(64 * BW);
     const bool tiled = p->feats_tiled != 0;
     constexpr int K = UCNERF_BF16_BUILD_TERMS;
+    MlpSaved sv;
+    memset(&sv, 0, sizeof(sv));
 #define UCNERF_BF16_FOR_ALL(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#if UCNERF_BF16_BUILD_TERMS == 3
+    if (save) {
+        UCNERF_REQUIRE(!tiled, "mlp_fwd_train: features must be row-major [m,F]");
+        sv = *save;
+#define X(N)                                                                                                                   \
+        if (B.v == N) {                                                                                                        \
+            const void* fn = (const void*)mlp_fwd_bf16_kernel<false, N, 3, true>;                                              \
+            if (int rc = ensure_dynamic_lds(fn, (int)smem, "mlp_fwd_train (bf16x3)")) return rc;                              \
+            hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, N, 3, true>), grid, block, smem, st, *p, g, n_tiles, sv);           \
+        }
+        UCNERF_BF16_FOR_ALL(X)
+#undef X
+        return check_launch("mlp_fwd_train (bf16x3)");
+    }
+#else
+    UCNERF_REQUIRE(!save, "mlp_fwd_train: plain bf16 has no training forward");
+#endif
 #define X(N)                                                                                                                   \
     if (B.v == N) {                                                                                                            \
-        const void* fn = tiled ? (const void*)mlp_fwd_bf16_kernel<true, N, K> : (const void*)mlp_fwd_bf16_kernel<false, N, K>; \
+        const void* fn = tiled ? (const void*)mlp_fwd_bf16_kernel<true, N, K, false> : (const void*)mlp_fwd_bf16_kernel<false, N, K, false>; \
         if (int rc = ensure_dynamic_lds(fn, (int)smem, "mlp_fwd (bf16)")) return rc;                                          \
-        if (tiled) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, K>), grid, block, smem, st, *p, g, n_tiles);               \
-        else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, N, K>), grid, block, smem, st, *p, g, n_tiles);                    \
+        if (tiled) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, K, false>), grid, block, smem, st, *p, g, n_tiles, sv);    \
+        else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, N, K, false>), grid, block, smem, st, *p, g, n_tiles, sv);         \
     }
     UCNERF_BF16_FOR_ALL(X)
 #undef X
 #undef UCNERF_BF16_FOR_ALL
     return check_launch("mlp_fwd_bf16");
 }
+
+#if UCNERF_BF16_BUILD_TERMS == 3
+int launch_mlp_fwd_bf16x3(const ucnerf_mlp_params* p, hipStream_t st) { return launch_bf16(p, nullptr, st); }
+int launch_mlp_fwd_bf16x3_save(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st) { return launch_bf16(p, save, st); }
+#else
+int launch_mlp_fwd_bf16_plain(const ucnerf_mlp_params* p, hipStream_t st) { return launch_bf16(p, nullptr, st); }
+#endif
 
 #if UCNERF_BF16_BUILD_TERMS == 3
 int64_t bf16_index_count(const ucnerf_mlp_config* cfg) {

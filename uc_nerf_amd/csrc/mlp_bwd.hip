@@ -19,6 +19,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st);
+int launch_mlp_fwd_bf16x3_save(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st);      // mlp_bf16.hip
 
 // 4 consecutive parameters (parameter tensors are only 4-byte aligned inside the flat vector)
 __device__ __forceinline__ f32x4 ld4(const float* p) { return f32x4{p[0], p[1], p[2], p[3]}; }
@@ -666,13 +667,14 @@ int64_t ucnerf_mlp_bwd_workspace_floats(const ucnerf_mlp_config* cfg, int32_t m)
 int ucnerf_mlp_fwd_train(const ucnerf_mlp_params* p, float* bwd_workspace, void* stream) {
     UCNERF_REQUIRE(p && bwd_workspace, "mlp_fwd_train: null pointer");
     if (p->m <= 0) return UCNERF_OK;
-    UCNERF_REQUIRE(p->cfg.precision == 0, "mlp_fwd_train: the training forward runs in f32 precision");
+    UCNERF_REQUIRE(p->cfg.precision == 0 || p->cfg.precision == 1, "mlp_fwd_train: the training forward runs in f32 or bf16x3 precision");
     UCNERF_REQUIRE(!p->feats_tiled, "mlp_fwd_train: features must be row-major [m,F]");
     UCNERF_REQUIRE(((uintptr_t)bwd_workspace & 15) == 0, "mlp_fwd_train: workspace must be 16-byte aligned");
     BwdWork w;
     carve_bwd(bwd_workspace, p->m, p->dirs_per_sample ? p->m : p->m / (p->S > 0 ? p->S : 1), &w);
     hipStream_t st = (hipStream_t)stream;
-    RUN(launch_mlp_fwd(p, &w.sv, st));
+    if (p->cfg.precision == 1) { RUN(launch_mlp_fwd_bf16x3_save(p, &w.sv, st)); }      // split-bf16 matrix cores, activations kept in fp32
+    else RUN(launch_mlp_fwd(p, &w.sv, st));
     // the backward reads the forward's output from its own slot
     if (hipMemcpyAsync(w.raw, p->raw, (size_t)p->m * 4 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return fail(UCNERF_EHIP, "mlp_fwd_train: copy failed");
@@ -704,7 +706,9 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     const int ew_blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
 
     // 0. forward with the activations kept; encodings as explicit matrices for the weight-gradient GEMMs
-    UCNERF_REQUIRE(f.cfg.precision == 0, "mlp_bwd: the backward runs in f32 precision (pack the weights with precision 0)");
+    UCNERF_REQUIRE(f.cfg.precision == 0 || (f.cfg.precision == 1 && bp->saved_valid),
+                   "mlp_bwd: without the activations of ucnerf_mlp_fwd_train (saved_valid) the backward re-runs the forward itself, in f32 "
+                   "precision only (pack the weights with precision 0)");
     if (!bp->saved_valid) {
         ucnerf_mlp_params fw = f;
         fw.raw = w.raw;

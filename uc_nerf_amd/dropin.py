@@ -24,6 +24,7 @@ import torch
 from . import ops
 
 _INFERENCE_PRECISION = "f32"
+_TRAINING_PRECISION = "f32"         # arithmetic of the training FORWARD (activations are kept in fp32 either way)
 _MAX_FEATURE_BYTES = (1 << 31) - (1 << 20)       # the MLP kernels address a pass's feature buffer with 32-bit byte offsets
 
 
@@ -34,6 +35,17 @@ def set_inference_precision(precision):
     if precision not in ops.PackedWeights.PRECISIONS:
         raise ValueError("uc_nerf_amd: unknown precision %r" % (precision,))
     _INFERENCE_PRECISION = precision
+
+
+def set_training_precision(precision):
+    """MLP arithmetic of the forward of `rendering()` under autograd: "f32" (default: exact fp32 MFMA; gradients within 2e-4 of
+    the reference's, element by element) or "bf16x3" (split-bf16 matrix cores: the forward launch takes about half the time;
+    outputs and kept activations within ~1e-5 of the exact ones -- enough to put a pre-activation that lies within 1e-5 of zero
+    on the other side of its relu, so gradients match in direction and norm (cosine > 0.9995), not element by element)."""
+    global _TRAINING_PRECISION
+    if precision not in ("f32", "bf16x3"):
+        raise ValueError("uc_nerf_amd: training forward precision must be 'f32' or 'bf16x3', got %r" % (precision,))
+    _TRAINING_PRECISION = precision
 
 
 def inference_precision(args=None):
@@ -124,9 +136,10 @@ class _FusedRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sess, layout, white_bkgd, coords, z, rays_dir, angle, imgs, w2cs, intrinsics, vol1, vol2, vol3, conf, img_feat, *params):
         src = sess.sources([vol1, vol2, vol3], conf, imgs, img_feat, w2cs, intrinsics)
-        rp, flat = sess.render_pass("f32", layout, src, white_bkgd)
+        rp, flat = sess.render_pass(_TRAINING_PRECISION, layout, src, white_bkgd)
         out = rp(rays_dir, z, want=(), keep=("raw", "feats"), dir_feat=angle, coords=coords)
         ctx.sess, ctx.rp, ctx.src, ctx.pw, ctx.ws, ctx.flat, ctx.white_bkgd = sess, rp, src, rp.pw, rp.wstream, flat, white_bkgd
+        ctx.layout = layout
         ctx.coords, ctx.kept = coords, {"raw": out["raw"], "feats": out["feats"]}
         ctx.geom = (z, rays_dir, angle)
         ctx.shapes = tuple(t.shape for t in (vol1, vol2, vol3, conf, img_feat))
@@ -145,8 +158,12 @@ class _FusedRender(torch.autograd.Function):
             g_rgb = torch.zeros(z.shape[0], 3, device=z.device)
         need = tuple(ctx.needs_input_grad[10:15])                            # vol1, vol2, vol3, conf, img_feat
         need = (need[0], need[1], need[2], need[3], need[4])
+        f32w = None
+        if rp.pw.cfg.precision != 0 and getattr(rp, "_saved_for", None) != (z.shape[0], z.shape[1], ctx.kept["raw"].data_ptr()):
+            _, pw32, ws32 = sess.packed("f32", ctx.layout)       # another forward overwrote the kept activations: recompute them exactly
+            f32w = (pw32, ws32)
         g_flat, gv1, gv2, gv3, gc, gi = rp.backward(rays_dir, z, ctx.kept, g_rgb.contiguous(), g_depth, ctx.flat, need=need,
-                                                    coords=ctx.coords, dir_feat=angle)
+                                                    coords=ctx.coords, dir_feat=angle, f32_weights=f32w)
         grads = [g.reshape(s) if g is not None else None for g, s in zip((gv1, gv2, gv3, gc, gi), ctx.shapes)]
         g_params = []
         for piece, p, has, req in zip(torch.split(g_flat, sess.sizes), sess.params, sess.grad_mask, ctx.needs_input_grad[15:]):

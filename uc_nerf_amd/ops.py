@@ -888,9 +888,9 @@ class RenderPass:
         p.train_workspace = None
         p.dir_feat = _ptr(dir_feat)
         self._saved_for = None
-        if "raw" in keep and "feats" in keep and self.pw.cfg.precision == 0:
-            # training forward: keep the MLP activations in the backward's workspace so that backward() need not
-            # repeat the network forward
+        if "raw" in keep and "feats" in keep and self.pw.cfg.precision in (0, 1):
+            # training forward (exact f32 or split-bf16): keep the MLP activations in the backward's workspace so that
+            # backward() need not repeat the network forward
             need_b = L.lib().ucnerf_render_bwd_workspace_floats(n, S, self.src.V)
             if getattr(self, "_bwd_ws", None) is None or self._bwd_ws.numel() < need_b:
                 self._bwd_ws = torch.empty(need_b, device=dev)
@@ -900,9 +900,11 @@ class RenderPass:
         return out
 
     def backward(self, rays_d, z, kept, g_rgb, g_depth, flat, near_far=None, need=(True, True, True, True, True), coords=None,
-                 dir_feat=None):
+                 dir_feat=None, f32_weights=None):
         """Backward of the last-style forward call: `kept` = its outputs with keep=("raw", "feats").
-        Returns (g_flat, g_vol1, g_vol2, g_vol3, g_conf, g_img_feat)."""
+        Returns (g_flat, g_vol1, g_vol2, g_vol3, g_conf, g_img_feat).  A pass bound to bf16x3 weights runs its backward from
+        the activations the training forward kept; should another forward have overwritten them, the network forward is
+        repeated in f32 and needs `f32_weights` = (PackedWeights, stream) packed from the same parameters."""
         rays_d, z, flat, g_rgb = _f32(rays_d), _f32(z), _f32(flat), _f32(g_rgb)
         n, S = z.shape
         dev = z.device
@@ -921,6 +923,11 @@ class RenderPass:
         saved = getattr(self, "_saved_for", None) == (n, S, kept["raw"].data_ptr())
         ws = self._bwd_ws if saved else torch.empty(L.lib().ucnerf_render_bwd_workspace_floats(n, S, self.src.V), device=dev)
         bp.saved_valid = int(saved)
+        if not saved and self.pw.cfg.precision != 0:
+            if f32_weights is None:
+                raise RuntimeError("uc_nerf_amd.RenderPass.backward: the activations of this bf16x3 training forward were overwritten "
+                                   "by a later forward; pass f32_weights=(PackedWeights, stream) to recompute them")
+            p.cfg, p.wstream = f32_weights[0].cfg, _ptr(f32_weights[1])
         self._saved_for = None
         g_flat = torch.zeros(self.pw.n_params, device=dev)
         gv = [torch.zeros_like(v) if need[k] else None for k, v in enumerate(self.src.vols)]
