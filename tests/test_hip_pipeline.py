@@ -116,9 +116,16 @@ def test_coarse_fine_pipeline_vs_reference_golden(sd_v7):
     close(fine["rgb"][ok], g["f_rgb"][ok], 1e-4); close(fine["depth"][ok], g["f_depth"][ok], 1e-4)       # absolute, depths in [1, 4]
     close(fine["acc"][ok], g["f_acc"][ok], 1e-4); close(fine["var"][ok], g["f_var"][ok], 1e-5, 1e-3)
     close(fine["weights"][ok], g["f_weights"][ok], 2e-5, 1e-3)
-    # free-running end to end: a flipped searchsorted bin moves single samples on few rays
-    err = (out["rgb"].cpu() - g["f_rgb"])[ok].abs().max(-1)[0]
-    assert (err < 1e-4).float().mean() > 0.9 and err.median() < 1e-5
+    # free-running end to end: coarse weights carry fp32 noise, so on a few rays a draw lands in the neighbouring bin of the cdf and
+    # one fine depth moves.  Every ray over 1e-4 must be such a ray (its fine depths differ from the reference's), the others are
+    # within the bar, and the moved ones stay bounded.
+    err = (out["rgb"].cpu() - g["f_rgb"]).abs().max(-1)[0]
+    moved = ((out["z_fine"].cpu() - g["z_fine"]).abs() > 1e-6).any(-1)
+    assert not ((err > 1e-4) & ~moved & ok).any()
+    assert (err[ok] < 1e-4).float().mean() > 0.9 and err[ok].median() < 1e-5
+    assert err[ok].max() < 0.1, err[ok].max()                      # a moved sample changes a ray by what one of its 192 samples carries
+    print("\n[parity] G11 free-running: %d of %d rays with a moved fine depth, %d over 1e-4, max |d rgb| %.2e"
+          % (int((moved & ok).sum()), int(ok.sum()), int(((err > 1e-4) & ok).sum()), err[ok].max().item()))
 
 
 def test_full_size_properties_4096_rays():
