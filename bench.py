@@ -381,7 +381,8 @@ def main():
                                      "max_abs_rgb_vs_f32": (op["rgb"] - ref["rgb"]).abs().max().item(),
                                      "note": "NOT the headline and NOT within the 1e-4 parity bar: one bf16 MFMA per product (precision='bf16')"}
             return res
-        extra.update(guarded(other_precisions, "other_precisions"))
+        if world == 1:        # (N > 1: the scaling series needs `value`; the single-GPU fields are not repeated on every rank)
+            extra.update(guarded(other_precisions, "other_precisions"))
 
         def micro():
             """SURVEY.md 8(d) secondary micro-bench (north_star's literal '4096-ray x 128-sample'): single pass, S = 128,
@@ -404,7 +405,8 @@ def main():
             return {"value": n * world / dtm, "unit": "rays/s", "ms_per_step": dtm * 1e3, "rays": n, "samples_per_ray": S, "precision": args.precision,
                     "tflops_algorithmic": n * S * FLOP_PER_SAMPLE / dtm / 1e12,
                     "note": "single pass on precomputed [4096,128,97] features: PE + MLP + composite (no gather, no sampling)"}
-        extra["micro_4096x128_precomputed_feats"] = guarded(micro)
+        if world == 1:
+            extra["micro_4096x128_precomputed_feats"] = guarded(micro)
 
         def fused_train(fwd_precision="f32"):
             """A training-style step of the library's fused pass: source repack + forward (activations kept) + full backward
@@ -426,8 +428,9 @@ def main():
                     "dtype": "f32" if fwd_precision == "f32" else "forward bf16x3 (activations kept in f32), backward f32 / bf16x3 GEMMs",
                     "note": "NOT the headline: source repack + forward + full backward of one fused render pass on one GPU "
                             "(no optimizer, no collective)"}
-        extra["train_step"] = guarded(fused_train)
-        extra["train_step_bf16x3_forward"] = guarded(lambda: fused_train("bf16x3"))
+        if world == 1:
+            extra["train_step"] = guarded(fused_train)
+            extra["train_step_bf16x3_forward"] = guarded(lambda: fused_train("bf16x3"))
 
         if world == 1:
             extra.update(guarded(lambda: bench_dropin(ctx, scene, sd), "dropin"))
