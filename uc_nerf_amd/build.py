@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "libucnerf_hip.so")
 SOURCES = ["rays.hip", "gather.hip", "gather_cl.hip", "mlp.hip", "mlp_bf16.hip", "mlp_bwd.hip", "composite.hip", "sample_pdf.hip", "render.hip", "mvs.hip"]
 # (source, object name, extra flags): translation units built more than once with different switches
 VARIANTS = [("mlp_bf16.hip", "mlp_bf16_plain.o", ["-DUCNERF_BF16_BUILD_TERMS=1"])]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mlp_layout.h"), os.path.join(CSRC, "sincos_cw.h"),
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mlp_layout.h"), os.path.join(CSRC, "sincos_cw.h"), os.path.join(CSRC, "gather_cl_device.h"),
            os.path.join(HERE, "..", "include", "ucnerf_hip.h")]
 # -ffp-contract=off: the sample_pdf / sampling kernels reproduce torch-CPU roundings (separate mul and add)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
