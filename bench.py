@@ -265,7 +265,7 @@ def main():
     ap.add_argument("--no-reuse", "--headline-only", dest="no_reuse", action="store_true",
                     help="skip the secondary measurements: profiling runs")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (no per-kernel HIP events)")
-    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default="bf16x3",
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16", "bf16x3_fused"], default="bf16x3",
                     help="MLP arithmetic: exact fp32 MFMA; split-bf16 (3 bf16 MFMAs per product, fp32 accumulate, within the "
                          "1e-4 parity bar); plain bf16 (1 MFMA per product, NOT within the parity bar: PSNR reported)")
     args = ap.parse_args()
@@ -477,7 +477,7 @@ def main():
             # achieved / frac count ALGORITHMIC flops (one multiply-accumulate per weight and sample) against the dense bf16
             # peak; the split evaluation executes three bf16 MFMA products per algorithmic one (fp32-grade accuracy), so the
             # matrix pipe itself runs at `executed` TFLOP/s
-            terms = 3 if args.precision == "bf16x3" else 1
+            terms = 3 if args.precision in ("bf16x3", "bf16x3_fused") else 1
             ex = achieved * BF16X3_EXECUTED_FLOP_PER_SAMPLE / 3 * terms / FLOP_PER_SAMPLE
             roof.update(executed=ex, executed_frac=ex / peak,
                         note="bf16x3: 3 bf16 MFMAs per algorithmic MAC; algorithmic ceiling = peak/3.003 = 832 TFLOP/s"
@@ -488,6 +488,7 @@ def main():
             "warmup": args.warmup, "clock_settle_steps": settle, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 via split-bf16 (bf16x3) MFMA, f32 accumulate",
+                      "bf16x3_fused": "f32 via split-bf16 (bf16x3) MFMA, f32 accumulate",
                       "bf16": "bf16 operands, f32 accumulate"}[args.precision], "data": "synthetic",
             "config": {"workload": "configs[1] shapes: %d rays/GPU x (%d coarse + %d fine -> %d merged) samples, V=7 views "
                                    "256x320, cascade volumes 48x64x80/32x128x160/8x256x320, UCNeRF D=6 W=128 random init"

@@ -610,8 +610,8 @@ int64_t ucnerf_mlp_param_count(const ucnerf_mlp_config* cfg) {
 int64_t ucnerf_mlp_stream_count(const ucnerf_mlp_config* cfg) {
     MlpLayout L;
     if (!cfg || !mlp_layout(cfg->n_src, &L)) return fail(UCNERF_EINVAL, "mlp: n_src must be in 1..8");
-    if (cfg->precision == 1 || cfg->precision == 2) return bf16_stream_floats(cfg);
-    if (cfg->precision != 0) return fail(UCNERF_EINVAL, "mlp: precision %d (0 = f32, 1 = bf16x3, 2 = bf16)", cfg->precision);
+    if (cfg->precision >= 1 && cfg->precision <= 3) return bf16_stream_floats(cfg);
+    if (cfg->precision != 0) return fail(UCNERF_EINVAL, "mlp: precision %d (0 = f32, 1 = bf16x3, 2 = bf16, 3 = bf16x3 with the gather fused)", cfg->precision);
     return L.total;
 }
 
@@ -624,7 +624,7 @@ int64_t ucnerf_mlp_index_count(const ucnerf_mlp_config* cfg) {
 int ucnerf_mlp_pack_index(const ucnerf_mlp_config* cfg, int32_t* idx_host) {
     UCNERF_REQUIRE(cfg && idx_host, "mlp_pack_index: null pointer");
     UCNERF_REQUIRE(cfg->pe_layout == 0 || cfg->pe_layout == 1, "mlp_pack_index: pe_layout %d", cfg->pe_layout);
-    UCNERF_REQUIRE(cfg->precision >= 0 && cfg->precision <= 2, "mlp_pack_index: precision %d", cfg->precision);
+    UCNERF_REQUIRE(cfg->precision >= 0 && cfg->precision <= 3, "mlp_pack_index: precision %d", cfg->precision);
     if (cfg->precision == 0) {
         UCNERF_REQUIRE(build_pack_index(cfg, idx_host) == 0, "mlp_pack_index: n_src %d outside 1..8", cfg->n_src);
         return UCNERF_OK;
@@ -656,7 +656,7 @@ int ucnerf_mlp_unpack_grad(const float* g, const int32_t* idx, float* gflat, int
 }
 
 int ucnerf_mlp_fwd(const ucnerf_mlp_params* p, void* stream) {
-    if (p && p->cfg.precision == 1) return launch_mlp_fwd_bf16x3(p, (hipStream_t)stream);
+    if (p && (p->cfg.precision == 1 || p->cfg.precision == 3)) return launch_mlp_fwd_bf16x3(p, (hipStream_t)stream);      // (3: refused there with the reason)
     if (p && p->cfg.precision == 2) return launch_mlp_fwd_bf16_plain(p, (hipStream_t)stream);
     return launch_mlp_fwd(p, nullptr, (hipStream_t)stream);
 }

@@ -30,6 +30,7 @@
 #include "common.h"
 #include "mlp_layout.h"
 #include "sincos_cw.h"
+#include "gather_cl_device.h"
 
 // the LDS-DMA asm below names m0 as a clobber on purpose (it loads the LDS base into it)
 #pragma clang diagnostic ignored "-Winline-asm"
@@ -142,10 +143,31 @@ int build_pack_index_bf16(const ucnerf_mlp_config* cfg, int32_t* idx) {
                 col[hh][j] = c < 0 ? -1 : base + c;
             }
     };
+    // precision 3 (the gather runs inside the kernel, fused_operands below): the two bias nets take their operands in the order the
+    // lane halves produce them -- bd: [stage 1 | stage 2], [stage 3 ch 0..3, view 0 | ch 4..7, view 1], then two views per half and
+    // step (even views in half 0, odd views in half 1); bc: the image features of view 2q + hh in step q
+    const bool fused = cfg->precision == 3;
+    auto bd_fused = [&](int q, int (&col)[2][8]) {
+        for (int hh = 0; hh < 2; ++hh)
+            for (int j = 0; j < 8; ++j) {
+                int c = -1;
+                if (q == 0) c = 8 * hh + j;
+                else if (q == 1 && j < 4) c = 16 + 4 * hh + j;
+                else {
+                    const int pair = q == 1 ? 0 : 1 + 2 * (q - 2) + (j >> 2), view = 2 * pair + hh;
+                    if (view < v) c = 24 + 4 * view + (j & 3);
+                }
+                col[hh][j] = c;
+            }
+    };
+    auto bc_fused = [&](int q, int (&col)[2][8]) {
+        for (int hh = 0; hh < 2; ++hh)
+            for (int j = 0; j < 8; ++j) col[hh][j] = 2 * q + hh < v ? 8 * (2 * q + hh) + j : -1;
+    };
     int col[2][8];
     {   // bd, step-major
         const auto rb = rows(L.p_bdw, 24 + 4 * v);
-        for (int q = 0; q < B.kd16; ++q) { nat(q, 24 + 4 * v, col); put_half(rb, col, 0); put_half(rb, col, 1); }
+        for (int q = 0; q < B.kd16; ++q) { if (fused) bd_fused(q, col); else nat(q, 24 + 4 * v, col); put_half(rb, col, 0); put_half(rb, col, 1); }
     }
     {   // L0
         const auto rb = rows(L.p_lw[0], MLP_PE_PTS);
@@ -165,7 +187,7 @@ int build_pack_index_bf16(const ucnerf_mlp_config* cfg, int32_t* idx) {
     }
     {   // bc, step-major
         const auto rb = rows(L.p_bcw, 8 * v);
-        for (int q = 0; q < B.kc16; ++q) { nat(q, 8 * v, col); put_half(rb, col, 0); put_half(rb, col, 1); }
+        for (int q = 0; q < B.kc16; ++q) { if (fused) bc_fused(q, col); else nat(q, 8 * v, col); put_half(rb, col, 0); put_half(rb, col, 1); }
     }
     {   // feature_linear
         const auto rb = rows(L.p_fw, W);
@@ -491,11 +513,38 @@ __device__ __forceinline__ void encode16(const float (&x)[3], int h, float (&pe)
     for (int q = 2 * half + 2; q < KS; ++q) pe[q] = 0.f;
 }
 
-template <bool TILED, int NSRC, int TERMS, bool SAVE>       // TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only); SAVE: training forward
+// Row f1 (FUSED): the feature gather runs inside this kernel.  A lane (sample j, half hh) works out its own operands of the two bias
+// nets straight from the channel-last sources -- nothing per sample is read but z, nothing is written but raw:
+//   stage-1 volume (hh = 0) / stage-2 volume (hh = 1): all eight channels            -> bd step 0
+//   stage-3 volume: channels 4hh .. 4hh+3 of all eight corners                       -> bd step 1, elements 0..3
+//   source view 2p + hh of pair p: colour + mask -> bd (elements 4..7 of step 1, then two pairs per step), image features -> bc step p
+//   reference projection, confidence: both halves (same values)
+// Arithmetic and accumulation order per feature are gather_cl.hip's (bit-identical features); the weight stream is packed in this
+// operand order (precision 3, build_pack_index_bf16).
+struct FusedGather {
+    int S, V, H, W;
+    int vol_d[3], vol_h[3], vol_w[3];
+    unsigned vol_off[3], img_off, view_bytes;      // byte offsets inside the channel-last buffer (all of it < 4 GB)
+    const char* cl;
+    const float* conf;
+    const float* rays_o;
+    const float* rays_d;
+    const float* z;
+    const float* near_far;
+    float near, far;
+    float w2c_ref[12], K_ref[9];
+    const float* w2cs;
+    const float* Ks;
+    unsigned div_m, div_sh;
+};
+[[maybe_unused]] constexpr int FUSED_MAX_V = 6;    // the operand stash of the confidence-bias net has to fit beside ring, constants and encoding stash (160 KB of LDS)
+constexpr int VIEW_TAB = 24;      // floats per source view in the LDS table: w2c (12), K (9), pad
+
+template <bool TILED, int NSRC, int TERMS, bool SAVE, bool FUSED = false>       // TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only); SAVE: training forward
 #ifndef UCNERF_BF16_WPS
 #define UCNERF_BF16_WPS 2      // waves per SIMD: 2 -> 256 VGPRs per wave, 1 -> 512
 #endif
-__global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(ucnerf_mlp_params p, BGeom g, int n_tiles, MlpSaved sv) {
+__global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(ucnerf_mlp_params p, BGeom g, int n_tiles, MlpSaved sv, FusedGather fg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // ONE shared object: [ring][constants][pe stash]
     char* ring = smem;
     float* cst = reinterpret_cast<float*>(smem + NBUF * SLOT_BYTES);
@@ -516,6 +565,16 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     const float* ha = hb + 516;
     Frag* stash = stash_all + (size_t)wave * (KS16_PE_PTS * 64) + lane;        // step q at stash[q * 64]
     float* ustash_w = reinterpret_cast<float*>(stash_all + (size_t)BW * KS16_PE_PTS * 64) + wave * 64;          // per-sample scalar parked across the tile
+    // FUSED: [view table][operands of the confidence-bias net, gathered one tile ahead: step q of this lane at bcst[(q * 64) * 8]]
+    float* vtab = reinterpret_cast<float*>(stash_all + (size_t)BW * KS16_PE_PTS * 64) + BW * 64;
+    float* bcst = vtab + 8 * VIEW_TAB + ((size_t)wave * KC_S * 64 + lane) * 8;
+    if (FUSED) {
+        for (int i = threadIdx.x; i < fg.V * VIEW_TAB; i += 64 * BW) {
+            const int vi = i / VIEW_TAB, e = i % VIEW_TAB;
+            vtab[i] = e < 12 ? fg.w2cs[12 * vi + e] : e < 21 ? fg.Ks[9 * vi + e - 12] : 0.f;
+        }
+        __syncthreads();
+    }
 
     Pipe P;
     P.gsrc = ws + wave * (DMA_PER_SLOT * 1024) + lane * 16;
@@ -579,7 +638,134 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         npx[0] = prow[0]; npx[1] = prow[1]; npx[2] = prow[2];
 #endif
     };
-    fetch(blockIdx.x * BW + wave);
+    // FUSED: the same values, gathered from the sources (see FusedGather)
+    // Latency, not bytes, is what the in-kernel gather has to hide with eight waves per CU (the stand-alone kernel runs 28): footprints of
+    // every unit first, then the corner loads back to back -- volumes, confidence, view pair 0; the next pair's as soon as a volume's
+    // registers are free again -- each consumed in issue order, so that a tile pays about one memory round trip instead of one per unit.
+    struct VolFp { unsigned o[4], dx; float w[4], wx0, wx1; };
+    struct ImgFp { unsigned p00, p10, dx; float w00, w01, w10, w11, mask; };
+    auto gather = [&](int tile) {
+        const unsigned s = (unsigned)sample_of(tile);
+        const unsigned r = fg.S == 1 ? s : (__umulhi(s, fg.div_m) >> fg.div_sh);
+        const float z = fg.z[s];
+        const float* rd = fg.rays_d + 3 * (size_t)r;
+        const float x = fg.rays_o[0] + z * rd[0], y = fg.rays_o[1] + z * rd[1], w = fg.rays_o[2] + z * rd[2];
+        const int hl = opaque(h);
+        float u, v, qz;
+        {
+            float qx, qy;
+            project_cl(fg.w2c_ref, fg.K_ref, x, y, w, &qx, &qy, &qz);
+            u = (qx / qz + 0.0f) / (float)(fg.W - 1); v = (qy / qz + 0.0f) / (float)(fg.H - 1);
+        }
+        npx[0] = u; npx[1] = v; npx[2] = (qz - fg.near) / (fg.far - fg.near);
+        // ---- footprints.  Volumes: `unit` is this lane's (hl in the first sweep, 2 in the second), `c0` the first byte of its channels
+        auto vol_fp = [&](int unit, unsigned c0) {
+            float nk = fg.near, fk = fg.far;
+            if (fg.near_far) { nk = fg.near_far[6 * (size_t)r + 2 * unit]; fk = fg.near_far[6 * (size_t)r + 2 * unit + 1]; }
+            const float zn = (qz - nk) / (fk - nk);
+            const int D = fg.vol_d[unit], hh = fg.vol_h[unit], ww = fg.vol_w[unit];
+            const LerpCl ax = axis_cl(u * 2.f - 1.0f, ww, false), ay = axis_cl(v * 2.f - 1.0f, hh, false), az = axis_cl(zn * 2.f - 1.0f, D, false);
+            const unsigned vb = fg.vol_off[unit] + c0;
+            VolFp f;
+            f.o[0] = vb + (unsigned)((az.i0 * hh + ay.i0) * ww + ax.i0) * 32u; f.o[1] = vb + (unsigned)((az.i0 * hh + ay.i1) * ww + ax.i0) * 32u;
+            f.o[2] = vb + (unsigned)((az.i1 * hh + ay.i0) * ww + ax.i0) * 32u; f.o[3] = vb + (unsigned)((az.i1 * hh + ay.i1) * ww + ax.i0) * 32u;
+            f.dx = (unsigned)(ax.i1 - ax.i0) * 32u;
+            f.w[0] = az.w0 * ay.w0; f.w[1] = az.w0 * ay.w1; f.w[2] = az.w1 * ay.w0; f.w[3] = az.w1 * ay.w1;
+            f.wx0 = ax.w0; f.wx1 = ax.w1;
+            return f;
+        };
+        const VolFp fa = vol_fp(hl, 0u), fb3 = vol_fp(2, 16u * hl);
+        unsigned co[4]; float cw[4];
+        {   // confidence
+            const LerpCl ax = axis_cl(u * 2.f - 1.0f, fg.W, false), ay = axis_cl(v * 2.f - 1.0f, fg.H, false);
+            co[0] = (unsigned)(ay.i0 * fg.W + ax.i0); co[1] = (unsigned)(ay.i0 * fg.W + ax.i1);
+            co[2] = (unsigned)(ay.i1 * fg.W + ax.i0); co[3] = (unsigned)(ay.i1 * fg.W + ax.i1);
+            cw[0] = ay.w0 * ax.w0; cw[1] = ay.w0 * ax.w1; cw[2] = ay.w1 * ax.w0; cw[3] = ay.w1 * ax.w1;
+        }
+        constexpr int NP = (NSRC + 1) / 2;                    // view pairs: this lane's view of pair pr is 2 pr + hl
+        ImgFp fi[NP];
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr) {
+            const int vi = min(2 * pr + hl, NSRC - 1);       // (a half without a view repeats the last one: finite values onto zero weights)
+            const float* mt = vtab + vi * VIEW_TAB;
+            float qx, qy, qv;
+            project_cl(mt, mt + 12, x, y, w, &qx, &qy, &qv);
+            const float gx = (qx / qv + 0.0f) / (float)(fg.W - 1) * 2.0f - 1.0f, gy = (qy / qv + 0.0f) / (float)(fg.H - 1) * 2.0f - 1.0f;
+            const LerpCl ax = axis_cl(gx, fg.W, true), ay = axis_cl(gy, fg.H, true);
+            const unsigned ib = fg.img_off + (unsigned)vi * fg.view_bytes;
+            fi[pr].p00 = ib + (unsigned)(ay.i0 * fg.W + ax.i0) * 48u; fi[pr].p10 = ib + (unsigned)(ay.i1 * fg.W + ax.i0) * 48u;
+            fi[pr].dx = (unsigned)(ax.i1 - ax.i0) * 48u;
+            fi[pr].w00 = ay.w0 * ax.w0; fi[pr].w01 = ay.w0 * ax.w1; fi[pr].w10 = ay.w1 * ax.w0; fi[pr].w11 = ay.w1 * ax.w1;
+            fi[pr].mask = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.f : 0.f;
+        }
+        SB0;
+        // ---- loads, group 1
+        float4 va[16], vb3[8], vi_[NP][12];
+        float cv[4];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {                         // corner c = (z, y, x): the accumulation order of gather_cl.hip
+            const unsigned o = fa.o[c >> 1] + ((c & 1) ? fa.dx : 0u);
+            va[2 * c] = ld16(fg.cl, o); va[2 * c + 1] = ld16(fg.cl, o + 16u);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) vb3[c] = ld16(fg.cl, fb3.o[c >> 1] + ((c & 1) ? fb3.dx : 0u));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cv[c] = fg.conf[co[c]];
+        auto img_loads = [&](int pr) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                     // (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+                const unsigned o = ((c & 2) ? fi[pr].p10 : fi[pr].p00) + ((c & 1) ? fi[pr].dx : 0u);
+                vi_[pr][3 * c] = ld16(fg.cl, o); vi_[pr][3 * c + 1] = ld16(fg.cl, o + 16u); vi_[pr][3 * c + 2] = ld16(fg.cl, o + 32u);
+            }
+        };
+        img_loads(0);
+        SB0;
+        // ---- volumes + confidence
+#pragma unroll
+        for (int q = 2; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) nfs[q][e] = 0.f;          // (slots no view fills meet zero weights)
+        {
+            gf2 lo[2] = {{0, 0}, {0, 0}}, hi[2] = {{0, 0}, {0, 0}};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { const float w__ = fa.w[c >> 1] * ((c & 1) ? fa.wx1 : fa.wx0); FMA4(lo, va[2 * c], w__) FMA4(hi, va[2 * c + 1], w__) }
+            nfs[0][0] = lo[0].x; nfs[0][1] = lo[0].y; nfs[0][2] = lo[1].x; nfs[0][3] = lo[1].y;
+            nfs[0][4] = hi[0].x; nfs[0][5] = hi[0].y; nfs[0][6] = hi[1].x; nfs[0][7] = hi[1].y;
+        }
+        SB0;
+        if (NP > 1) img_loads(1);                             // (into the registers the first volume has just left)
+        SB0;
+        {
+            gf2 lo[2] = {{0, 0}, {0, 0}};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { const float w__ = fb3.w[c >> 1] * ((c & 1) ? fb3.wx1 : fb3.wx0); FMA4(lo, vb3[c], w__) }
+            nfs[1][0] = lo[0].x; nfs[1][1] = lo[0].y; nfs[1][2] = lo[1].x; nfs[1][3] = lo[1].y;
+        }
+        {
+            float acc = cv[0] * cw[0];
+            acc += cv[1] * cw[1];
+            acc += cv[2] * cw[2];
+            acc += cv[3] * cw[3];
+            nconf = acc;
+        }
+        SB0;
+        if (NP > 2) img_loads(2);
+        SB0;
+        // ---- source views
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr) {
+            gf2 c0[2] = {{0, 0}, {0, 0}}, c1[2] = {{0, 0}, {0, 0}}, c2[2] = {{0, 0}, {0, 0}};      // (r g b f0) (f1..f4) (f5 f6 f7 -)
+            const float wt[4] = {fi[pr].w00, fi[pr].w01, fi[pr].w10, fi[pr].w11};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { FMA4(c0, vi_[pr][3 * c], wt[c]) FMA4(c1, vi_[pr][3 * c + 1], wt[c]) FMA4(c2, vi_[pr][3 * c + 2], wt[c]) }
+            float* col = pr == 0 ? &nfs[1][4] : &nfs[2 + (pr - 1) / 2][4 * ((pr - 1) & 1)];
+            col[0] = c0[0].x; col[1] = c0[0].y; col[2] = c0[1].x; col[3] = fi[pr].mask;
+            f32x4* dst = reinterpret_cast<f32x4*>(bcst + (size_t)pr * 64 * 8);
+            dst[0] = (f32x4){c0[1].y, c1[0].x, c1[0].y, c1[1].x};
+            dst[1] = (f32x4){c1[1].y, c2[0].x, c2[0].y, c2[1].x};
+        }
+    };
+    if (FUSED) gather(blockIdx.x * BW + wave); else fetch(blockIdx.x * BW + wave);
 
 #ifdef UCNERF_MLP_DIAG
 #define DIAG_STAMP(K) { SB0; if (g.diag && lane == 0 && round == 5) g.diag[(size_t)(blockIdx.x * BW + wave) * 16 + (K)] = __builtin_readcyclecounter(); SB0; }
@@ -738,6 +924,15 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                        pin(acc[q]);
                    }
                    if (q == 8) {                                              // operands of the confidence-bias net
+                       if (FUSED) {
+                           _Pragma("unroll")
+                           for (int qq = 0; qq < 4; ++qq) {
+                               const f32x4* src_ = reinterpret_cast<const f32x4*>(bcst + (size_t)(qq < kc16 ? qq : 0) * 64 * 8);
+                               const f32x4 a_ = src_[0], b_ = src_[1];
+                               fsec[qq][0] = a_.x; fsec[qq][1] = a_.y; fsec[qq][2] = a_.z; fsec[qq][3] = a_.w;
+                               fsec[qq][4] = b_.x; fsec[qq][5] = b_.y; fsec[qq][6] = b_.z; fsec[qq][7] = b_.w;
+                           }
+                       } else {
                        _Pragma("unroll")
                        for (int qq = 0; qq < 4; ++qq)
                            _Pragma("unroll")
@@ -760,6 +955,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                                fsec[qq][e] = qq >= kc16 ? 0.f : TILED ? __builtin_nontemporal_load(src_) : *src_;
 #endif
                            }
+                       }
                        int ray = s_here;
                        if (!p.dirs_per_sample) { int S = p.S; asm volatile("" : "+s"(S)); ray = s_here / S; }   // (opaque: no reciprocal hoisted into a loop-long VGPR)
                        const float* drow = p.dirs + (size_t)ray * 3;
@@ -862,7 +1058,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         }
         DIAG_STAMP(11)
         __builtin_amdgcn_s_setprio(UCNERF_BF16_PRIO_VALU);
-        fetch(tile + tiles_per_round);                     // next tile's inputs (clamped past the end: harmless)
+        if (!FUSED) fetch(tile + tiles_per_round);         // next tile's inputs (clamped past the end: harmless)
         if (SAVE) {
             float* r_ = srow(sv.vc);
             if (r_) { save_tile<true>(r_, 2, acc[2]); save_tile<true>(r_, 3, acc[3]); }
@@ -881,6 +1077,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         out.w = fmaxf(adapt.w * omu + base.w * u, 0.f);
         if (h == 0 && s_raw < p.m) reinterpret_cast<f32x4*>(p.raw)[s_raw] = out;
         DIAG_STAMP(13)
+        if (FUSED) gather(tile + tiles_per_round);         // (after the heads: its loads in flight want the registers)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
 }
@@ -889,11 +1086,15 @@ constexpr size_t bf16_smem_bytes() {
     return (size_t)NBUF * SLOT_BYTES + ((CONST_FLOATS * 4 + 15) & ~15) + (size_t)BW * KS16_PE_PTS * 64 * sizeof(Frag) + (size_t)BW * 64 * sizeof(float);
 }
 
+constexpr size_t bf16_smem_bytes_fused(int v) { return bf16_smem_bytes() + 8 * VIEW_TAB * sizeof(float) + (size_t)BW * ((8 * v + 15) / 16) * 64 * 8 * sizeof(float); }
+
 // `save` (TERMS = 3 only): the training forward -- the activation sets of MlpSaved are written for ucnerf_mlp_bwd (saved_valid = 1)
-static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st) {
+static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st, const FusedGather* fuse = nullptr) {
     UCNERF_REQUIRE(p, "mlp_fwd: null params");
     if (p->m == 0) return UCNERF_OK;
-    UCNERF_REQUIRE(p->pts && p->dirs && p->feats && p->wstream && p->raw, "mlp_fwd: null pointer");
+    UCNERF_REQUIRE(p->dirs && p->wstream && p->raw && (fuse || (p->pts && p->feats)), "mlp_fwd: null pointer");
+    UCNERF_REQUIRE((p->cfg.precision == 3) == (fuse != nullptr), "mlp_fwd: a weight stream packed with precision 3 serves the render pass with the gather "
+                   "fused into the MLP kernel and nothing else (ucnerf_render_fused_fwd)");
     UCNERF_REQUIRE(!p->encoded && !p->pts_stride && !p->dirs_stride, "mlp_fwd (bf16x3): encoded / strided inputs are only available in f32 precision");
     UCNERF_REQUIRE(p->dirs_per_sample || p->S > 0, "mlp_fwd: S must be > 0 when dirs are per ray");
     UCNERF_REQUIRE(((uintptr_t)p->wstream & 15) == 0 && ((uintptr_t)p->raw & 15) == 0, "mlp_fwd: wstream/raw must be 16-byte aligned");
@@ -922,8 +1123,24 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
     constexpr int K = UCNERF_BF16_BUILD_TERMS;
     MlpSaved sv;
     memset(&sv, 0, sizeof(sv));
+    FusedGather fg;
+    memset(&fg, 0, sizeof(fg));
 #define UCNERF_BF16_FOR_ALL(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #if UCNERF_BF16_BUILD_TERMS == 3
+    if (fuse) {
+        UCNERF_REQUIRE(!save && B.v <= FUSED_MAX_V, "mlp_fwd (gather fused): inference forward, n_src <= %d", FUSED_MAX_V);
+        fg = *fuse;
+        const size_t smem_f = bf16_smem_bytes_fused(B.v);
+#define X(N)                                                                                                                   \
+        if (B.v == N) {                                                                                                        \
+            const void* fn = (const void*)mlp_fwd_bf16_kernel<true, N, 3, false, true>;                                        \
+            if (int rc = ensure_dynamic_lds(fn, (int)smem_f, "mlp_fwd (bf16x3, gather fused)")) return rc;                    \
+            hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, 3, false, true>), grid, block, smem_f, st, *p, g, n_tiles, sv, fg); \
+        }
+        X(1) X(2) X(3) X(4) X(5) X(6)
+#undef X
+        return check_launch("mlp_fwd (bf16x3, gather fused)");
+    }
     if (save) {
         UCNERF_REQUIRE(!tiled, "mlp_fwd_train: features must be row-major [m,F]");
         sv = *save;
@@ -931,7 +1148,7 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
         if (B.v == N) {                                                                                                        \
             const void* fn = (const void*)mlp_fwd_bf16_kernel<false, N, 3, true>;                                              \
             if (int rc = ensure_dynamic_lds(fn, (int)smem, "mlp_fwd_train (bf16x3)")) return rc;                              \
-            hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, N, 3, true>), grid, block, smem, st, *p, g, n_tiles, sv);           \
+            hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, N, 3, true>), grid, block, smem, st, *p, g, n_tiles, sv, fg);           \
         }
         UCNERF_BF16_FOR_ALL(X)
 #undef X
@@ -944,8 +1161,8 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
     if (B.v == N) {                                                                                                            \
         const void* fn = tiled ? (const void*)mlp_fwd_bf16_kernel<true, N, K, false> : (const void*)mlp_fwd_bf16_kernel<false, N, K, false>; \
         if (int rc = ensure_dynamic_lds(fn, (int)smem, "mlp_fwd (bf16)")) return rc;                                          \
-        if (tiled) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, K, false>), grid, block, smem, st, *p, g, n_tiles, sv);    \
-        else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, N, K, false>), grid, block, smem, st, *p, g, n_tiles, sv);         \
+        if (tiled) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, K, false>), grid, block, smem, st, *p, g, n_tiles, sv, fg);    \
+        else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, N, K, false>), grid, block, smem, st, *p, g, n_tiles, sv, fg);         \
     }
     UCNERF_BF16_FOR_ALL(X)
 #undef X
@@ -956,6 +1173,41 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
 #if UCNERF_BF16_BUILD_TERMS == 3
 int launch_mlp_fwd_bf16x3(const ucnerf_mlp_params* p, hipStream_t st) { return launch_bf16(p, nullptr, st); }
 int launch_mlp_fwd_bf16x3_save(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st) { return launch_bf16(p, save, st); }
+
+// called by render.hip: gather + PE + MLP of one pass in ONE launch (row f1), from the channel-last sources and (ray, depth)
+int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* repacked, const float* dirs, float* raw, hipStream_t st) {
+    const long long M = (long long)rp->n * rp->S;
+    UCNERF_REQUIRE(M < (1ll << 31), "render (gather fused): %lld samples in one pass (limit 2^31 - 1)", M);
+    ucnerf_mlp_params m;
+    memset(&m, 0, sizeof(m));
+    m.cfg = rp->cfg; m.m = (int)M; m.S = rp->S; m.max_blocks = rp->max_blocks; m.dirs = dirs; m.wstream = rp->wstream; m.raw = raw;
+    FusedGather f;
+    memset(&f, 0, sizeof(f));
+    f.S = rp->S; f.V = rp->cfg.n_src; f.H = rp->H; f.W = rp->W;
+    unsigned long long off = 0;
+    for (int k = 0; k < 3; ++k) {
+        f.vol_d[k] = rp->vol_d[k]; f.vol_h[k] = rp->vol_h[k]; f.vol_w[k] = rp->vol_w[k];
+        f.vol_off[k] = (unsigned)off;
+        off += 32ull * rp->vol_d[k] * rp->vol_h[k] * rp->vol_w[k];
+    }
+    f.img_off = (unsigned)off;
+    f.view_bytes = (unsigned)(48ull * rp->H * rp->W);
+    off += (unsigned long long)f.view_bytes * f.V;
+    UCNERF_REQUIRE(off < (1ull << 32), "render (gather fused): %llu bytes of channel-last sources (limit 4 GB)", off);
+    f.cl = reinterpret_cast<const char*>(repacked);
+    f.conf = rp->conf; f.rays_o = rp->rays_o; f.rays_d = rp->rays_d; f.z = rp->z; f.near_far = rp->near_far;
+    f.near = rp->near; f.far = rp->far;
+    memcpy(f.w2c_ref, rp->w2c_ref, sizeof(f.w2c_ref));
+    memcpy(f.K_ref, rp->K_ref, sizeof(f.K_ref));
+    f.w2cs = rp->w2cs; f.Ks = rp->intrinsics;
+    {   // magic for idx / S (gather_cl.hip)
+        unsigned l = 1;
+        while ((1u << l) < (unsigned)rp->S) ++l;
+        f.div_m = (unsigned)((((unsigned long long)1 << (31 + l)) + (unsigned)rp->S - 1) / (unsigned)rp->S);
+        f.div_sh = l - 1;
+    }
+    return launch_bf16(&m, nullptr, st, &f);
+}
 #else
 int launch_mlp_fwd_bf16_plain(const ucnerf_mlp_params* p, hipStream_t st) { return launch_bf16(p, nullptr, st); }
 #endif

@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(256) render_points_kernel(PointsArgs a) {
 }
 
 int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float* feats, int tiled, float* ndc, hipStream_t st);
+int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* repacked, const float* dirs, float* raw, hipStream_t st);   // mlp_bf16.hip
 
 struct Workspace {
     float *pts, *ndc1, *ndc2, *ndc3, *ndc, *angle, *feats, *raw;
@@ -129,7 +130,17 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
     int rc;
     const bool keep_feats = p->feats != nullptr;        // caller wants row-major features (for the backward)
     ucnerf_feat_gather_params g;
-    if (p->sources_cl) {                                // fast path: channel-last sources, coordinates derived in-kernel
+    float* raw_fused = nullptr;
+    if (p->cfg.precision == 3) {                        // row f1: gather + PE + MLP in one launch, no feature buffer at all
+        UCNERF_REQUIRE(p->sources_cl && !keep_feats && !coords_given(p) && !p->u_sampled && !p->train_workspace,
+                       "render_fused_fwd: precision 3 (gather fused into the MLP kernel) needs the channel-last sources and derives its "
+                       "coordinates from (ray, depth); it keeps no features and returns no per-sample uncertainty");
+        if (!p->dir_feat && (rc = launch_dirs(p, st, w))) return rc;
+        raw_fused = p->raw ? p->raw : w->raw;
+        if (p->ev_mlp_start && (rc = ucnerf_event_record(p->ev_mlp_start, st))) return rc;
+        if ((rc = launch_mlp_fwd_bf16x3_gather(p, p->sources_cl, p->dir_feat ? p->dir_feat : w->angle, raw_fused, st))) return rc;
+        if (p->ev_mlp_stop && (rc = ucnerf_event_record(p->ev_mlp_stop, st))) return rc;
+    } else if (p->sources_cl) {                                // fast path: channel-last sources, coordinates derived in-kernel
         g.out_tiled = keep_feats ? 0 : 1;
         g.feats = keep_feats ? p->feats : w->feats;
         if ((rc = launch_gather_cl(p, p->sources_cl, g.feats, g.out_tiled, w->ndc, st))) return rc;
@@ -141,18 +152,22 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
         g.u_out = p->u_sampled;
         if ((rc = ucnerf_feat_gather_fwd(&g, st))) return rc;
     }
-    if (!p->dir_feat && (rc = launch_dirs(p, st, w))) return rc;
     ucnerf_mlp_params m;
-    mlp_args(p, w, g.feats, g.out_tiled, p->raw ? p->raw : w->raw, &m);
-    if (p->dir_feat) m.dirs = p->dir_feat;
-    if (p->ev_mlp_start && (rc = ucnerf_event_record(p->ev_mlp_start, st))) return rc;
-    if (p->train_workspace && keep_feats && p->raw) {    // training forward: activations go straight into the backward's workspace
-        Workspace wb;
-        float *g_raw, *g_feats, *mlp_ws;
-        carve_bwd_render(p->train_workspace, p->n, p->S, V, &wb, &g_raw, &g_feats, &mlp_ws);
-        if ((rc = ucnerf_mlp_fwd_train(&m, mlp_ws, st))) return rc;
-    } else if ((rc = ucnerf_mlp_fwd(&m, st))) return rc;
-    if (p->ev_mlp_stop && (rc = ucnerf_event_record(p->ev_mlp_stop, st))) return rc;
+    memset(&m, 0, sizeof(m));
+    m.raw = raw_fused;
+    if (!raw_fused) {
+        if (!p->dir_feat && (rc = launch_dirs(p, st, w))) return rc;
+        mlp_args(p, w, g.feats, g.out_tiled, p->raw ? p->raw : w->raw, &m);
+        if (p->dir_feat) m.dirs = p->dir_feat;
+        if (p->ev_mlp_start && (rc = ucnerf_event_record(p->ev_mlp_start, st))) return rc;
+        if (p->train_workspace && keep_feats && p->raw) {    // training forward: activations go straight into the backward's workspace
+            Workspace wb;
+            float *g_raw, *g_feats, *mlp_ws;
+            carve_bwd_render(p->train_workspace, p->n, p->S, V, &wb, &g_raw, &g_feats, &mlp_ws);
+            if ((rc = ucnerf_mlp_fwd_train(&m, mlp_ws, st))) return rc;
+        } else if ((rc = ucnerf_mlp_fwd(&m, st))) return rc;
+        if (p->ev_mlp_stop && (rc = ucnerf_event_record(p->ev_mlp_stop, st))) return rc;
+    }
 
     ucnerf_composite_params c;
     memset(&c, 0, sizeof(c));
