@@ -565,9 +565,9 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     const float* ha = hb + 516;
     Frag* stash = stash_all + (size_t)wave * (KS16_PE_PTS * 64) + lane;        // step q at stash[q * 64]
     float* ustash_w = reinterpret_cast<float*>(stash_all + (size_t)BW * KS16_PE_PTS * 64) + wave * 64;          // per-sample scalar parked across the tile
-    // FUSED: [view table][operands of the confidence-bias net, gathered one tile ahead: step q of this lane at bcst[(q * 64) * 8]]
+    // FUSED: [view table][operands of the confidence-bias net, gathered one tile ahead: step q of this lane at bcst_of(q)]
     float* vtab = reinterpret_cast<float*>(stash_all + (size_t)BW * KS16_PE_PTS * 64) + BW * 64;
-    float* bcst = vtab + 8 * VIEW_TAB + ((size_t)wave * KC_S * 64 + lane) * 8;
+    auto bcst_of = [&](int q) { return vtab + 8 * VIEW_TAB + ((size_t)(wave * KC_S + q) * 64 + opaque(lane)) * 8; };      // (re-derived at each use: not a loop-long register)
     if (FUSED) {
         for (int i = threadIdx.x; i < fg.V * VIEW_TAB; i += 64 * BW) {
             const int vi = i / VIEW_TAB, e = i % VIEW_TAB;
@@ -639,17 +639,43 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
 #endif
     };
     // FUSED: the same values, gathered from the sources (see FusedGather)
-    // Latency, not bytes, is what the in-kernel gather has to hide with eight waves per CU (the stand-alone kernel runs 28): footprints of
-    // every unit first, then the corner loads back to back -- volumes, confidence, view pair 0; the next pair's as soon as a volume's
-    // registers are free again -- each consumed in issue order, so that a tile pays about one memory round trip instead of one per unit.
+    // The in-kernel gather runs with eight waves per CU (the stand-alone kernel has 28) and all of them reach it together, so it is
+    // staged: g_pre (z, ray, depth range of the next tile: issued under the last GEMM phase), g_foot (footprints of every unit),
+    // g_issue_first (corner loads of the volumes + confidence, back to back), then -- while those are in flight -- the current tile's
+    // heads and the next tile's point encoding, and g_finish: consume in issue order, the next view pair's loads going out as soon as
+    // a volume's registers are free again.
     struct VolFp { unsigned o[4], dx; float w[4], wx0, wx1; };
     struct ImgFp { unsigned p00, p10, dx; float w00, w01, w10, w11, mask; };
-    auto gather = [&](int tile) {
+    constexpr int NP = NSRC > 0 ? (NSRC + 1) / 2 : 1;     // view pairs: this lane's view of pair pr is 2 pr + hl
+    float gz = 0.f, grd[3] = {0.f, 0.f, 0.f}, gnf[4] = {0.f, 0.f, 0.f, 0.f};
+    VolFp fa, fb3;
+    unsigned co[4];
+    float cw[4];
+    ImgFp fi[NP];
+    float4 va[16], vb3[8], vi_[NP][12];
+    float cv[4];
+    auto g_pre = [&](int tile) {
         const unsigned s = (unsigned)sample_of(tile);
         const unsigned r = fg.S == 1 ? s : (__umulhi(s, fg.div_m) >> fg.div_sh);
-        const float z = fg.z[s];
+        gz = fg.z[s];
         const float* rd = fg.rays_d + 3 * (size_t)r;
-        const float x = fg.rays_o[0] + z * rd[0], y = fg.rays_o[1] + z * rd[1], w = fg.rays_o[2] + z * rd[2];
+        grd[0] = rd[0]; grd[1] = rd[1]; grd[2] = rd[2];
+        const int hl = opaque(h);
+        gnf[0] = gnf[2] = fg.near; gnf[1] = gnf[3] = fg.far;
+        if (fg.near_far) {                                    // this lane's first volume (stage 1 + hl), then stage 3
+            const float* nf = fg.near_far + 6 * (size_t)r;
+            gnf[0] = nf[2 * hl]; gnf[1] = nf[2 * hl + 1]; gnf[2] = nf[4]; gnf[3] = nf[5];
+        }
+    };
+    auto img_loads = [&](int pr) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                         // (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+            const unsigned o = ((c & 2) ? fi[pr].p10 : fi[pr].p00) + ((c & 1) ? fi[pr].dx : 0u);
+            vi_[pr][3 * c] = ld16(fg.cl, o); vi_[pr][3 * c + 1] = ld16(fg.cl, o + 16u); vi_[pr][3 * c + 2] = ld16(fg.cl, o + 32u);
+        }
+    };
+    auto g_foot = [&]() {
+        const float x = fg.rays_o[0] + gz * grd[0], y = fg.rays_o[1] + gz * grd[1], w = fg.rays_o[2] + gz * grd[2];
         const int hl = opaque(h);
         float u, v, qz;
         {
@@ -658,10 +684,8 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             u = (qx / qz + 0.0f) / (float)(fg.W - 1); v = (qy / qz + 0.0f) / (float)(fg.H - 1);
         }
         npx[0] = u; npx[1] = v; npx[2] = (qz - fg.near) / (fg.far - fg.near);
-        // ---- footprints.  Volumes: `unit` is this lane's (hl in the first sweep, 2 in the second), `c0` the first byte of its channels
-        auto vol_fp = [&](int unit, unsigned c0) {
-            float nk = fg.near, fk = fg.far;
-            if (fg.near_far) { nk = fg.near_far[6 * (size_t)r + 2 * unit]; fk = fg.near_far[6 * (size_t)r + 2 * unit + 1]; }
+        // volumes: `unit` is this lane's (hl in the first sweep, 2 in the second), `c0` the first byte of its channels in a voxel
+        auto vol_fp = [&](int unit, unsigned c0, float nk, float fk) {
             const float zn = (qz - nk) / (fk - nk);
             const int D = fg.vol_d[unit], hh = fg.vol_h[unit], ww = fg.vol_w[unit];
             const LerpCl ax = axis_cl(u * 2.f - 1.0f, ww, false), ay = axis_cl(v * 2.f - 1.0f, hh, false), az = axis_cl(zn * 2.f - 1.0f, D, false);
@@ -674,16 +698,14 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             f.wx0 = ax.w0; f.wx1 = ax.w1;
             return f;
         };
-        const VolFp fa = vol_fp(hl, 0u), fb3 = vol_fp(2, 16u * hl);
-        unsigned co[4]; float cw[4];
+        fa = vol_fp(hl, 0u, gnf[0], gnf[1]);
+        fb3 = vol_fp(2, 16u * hl, gnf[2], gnf[3]);
         {   // confidence
             const LerpCl ax = axis_cl(u * 2.f - 1.0f, fg.W, false), ay = axis_cl(v * 2.f - 1.0f, fg.H, false);
             co[0] = (unsigned)(ay.i0 * fg.W + ax.i0); co[1] = (unsigned)(ay.i0 * fg.W + ax.i1);
             co[2] = (unsigned)(ay.i1 * fg.W + ax.i0); co[3] = (unsigned)(ay.i1 * fg.W + ax.i1);
             cw[0] = ay.w0 * ax.w0; cw[1] = ay.w0 * ax.w1; cw[2] = ay.w1 * ax.w0; cw[3] = ay.w1 * ax.w1;
         }
-        constexpr int NP = (NSRC + 1) / 2;                    // view pairs: this lane's view of pair pr is 2 pr + hl
-        ImgFp fi[NP];
 #pragma unroll
         for (int pr = 0; pr < NP; ++pr) {
             const int vi = min(2 * pr + hl, NSRC - 1);       // (a half without a view repeats the last one: finite values onto zero weights)
@@ -698,10 +720,9 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             fi[pr].w00 = ay.w0 * ax.w0; fi[pr].w01 = ay.w0 * ax.w1; fi[pr].w10 = ay.w1 * ax.w0; fi[pr].w11 = ay.w1 * ax.w1;
             fi[pr].mask = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.f : 0.f;
         }
+    };
+    auto g_issue_first = [&]() {
         SB0;
-        // ---- loads, group 1
-        float4 va[16], vb3[8], vi_[NP][12];
-        float cv[4];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {                         // corner c = (z, y, x): the accumulation order of gather_cl.hip
             const unsigned o = fa.o[c >> 1] + ((c & 1) ? fa.dx : 0u);
@@ -711,16 +732,12 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         for (int c = 0; c < 8; ++c) vb3[c] = ld16(fg.cl, fb3.o[c >> 1] + ((c & 1) ? fb3.dx : 0u));
 #pragma unroll
         for (int c = 0; c < 4; ++c) cv[c] = fg.conf[co[c]];
-        auto img_loads = [&](int pr) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {                     // (y0,x0) (y0,x1) (y1,x0) (y1,x1)
-                const unsigned o = ((c & 2) ? fi[pr].p10 : fi[pr].p00) + ((c & 1) ? fi[pr].dx : 0u);
-                vi_[pr][3 * c] = ld16(fg.cl, o); vi_[pr][3 * c + 1] = ld16(fg.cl, o + 16u); vi_[pr][3 * c + 2] = ld16(fg.cl, o + 32u);
-            }
-        };
+        SB0;
+    };
+    auto g_finish = [&]() {
+        SB0;
         img_loads(0);
         SB0;
-        // ---- volumes + confidence
 #pragma unroll
         for (int q = 2; q < 4; ++q)
 #pragma unroll
@@ -751,7 +768,6 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         SB0;
         if (NP > 2) img_loads(2);
         SB0;
-        // ---- source views
 #pragma unroll
         for (int pr = 0; pr < NP; ++pr) {
             gf2 c0[2] = {{0, 0}, {0, 0}}, c1[2] = {{0, 0}, {0, 0}}, c2[2] = {{0, 0}, {0, 0}};      // (r g b f0) (f1..f4) (f5 f6 f7 -)
@@ -760,12 +776,32 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             for (int c = 0; c < 4; ++c) { FMA4(c0, vi_[pr][3 * c], wt[c]) FMA4(c1, vi_[pr][3 * c + 1], wt[c]) FMA4(c2, vi_[pr][3 * c + 2], wt[c]) }
             float* col = pr == 0 ? &nfs[1][4] : &nfs[2 + (pr - 1) / 2][4 * ((pr - 1) & 1)];
             col[0] = c0[0].x; col[1] = c0[0].y; col[2] = c0[1].x; col[3] = fi[pr].mask;
-            f32x4* dst = reinterpret_cast<f32x4*>(bcst + (size_t)pr * 64 * 8);
+            f32x4* dst = reinterpret_cast<f32x4*>(bcst_of(pr));
             dst[0] = (f32x4){c0[1].y, c1[0].x, c1[0].y, c1[1].x};
             dst[1] = (f32x4){c1[1].y, c2[0].x, c2[0].y, c2[1].x};
         }
     };
-    if (FUSED) gather(blockIdx.x * BW + wave); else fetch(blockIdx.x * BW + wave);
+    // point encoding -> fragments in LDS (layer 0 and the skip connection read them from there)
+    auto encode_point = [&]() {
+        const float px[3] = {npx[0], npx[1], npx[2]};
+        float pe[KS_PE_PTS];
+        encode16<10, KS_PE_PTS>(px, opaque(h), pe);
+#pragma unroll
+        for (int q = 0; q < KS16_PE_PTS; ++q) {
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = pe[8 * q + e];
+            stash[q * 64] = split8(t);
+        }
+    };
+    if (FUSED) {
+        g_pre(blockIdx.x * BW + wave);
+        g_foot();
+        g_issue_first();
+        encode_point();
+        g_finish();
+    } else
+    fetch(blockIdx.x * BW + wave);
 
 #ifdef UCNERF_MLP_DIAG
 #define DIAG_STAMP(K) { SB0; if (g.diag && lane == 0 && round == 5) g.diag[(size_t)(blockIdx.x * BW + wave) * 16 + (K)] = __builtin_readcyclecounter(); SB0; }
@@ -797,8 +833,8 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         DIAG_STAMP(4)
 #endif
 
-        // ---- point encoding -> fragments in LDS (layer 0 and the skip connection read them from there)
-        {
+        // ---- point encoding -> fragments in LDS (layer 0 and the skip connection read them from there); FUSED: done at the previous tail
+        if (!FUSED) {
             const float px[3] = {npx[0], npx[1], npx[2]};
             float pe[KS_PE_PTS];
 #if UCNERF_BF16_EXP & 512       // timing experiment: no point encoding arithmetic (wrong results) -- what moving it out of the kernel could buy
@@ -927,7 +963,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                        if (FUSED) {
                            _Pragma("unroll")
                            for (int qq = 0; qq < 4; ++qq) {
-                               const f32x4* src_ = reinterpret_cast<const f32x4*>(bcst + (size_t)(qq < kc16 ? qq : 0) * 64 * 8);
+                               const f32x4* src_ = reinterpret_cast<const f32x4*>(bcst_of(qq < kc16 ? qq : 0));
                                const f32x4 a_ = src_[0], b_ = src_[1];
                                fsec[qq][0] = a_.x; fsec[qq][1] = a_.y; fsec[qq][2] = a_.z; fsec[qq][3] = a_.w;
                                fsec[qq][4] = b_.x; fsec[qq][5] = b_.y; fsec[qq][6] = b_.z; fsec[qq][7] = b_.w;
@@ -1022,8 +1058,9 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                if (!(q & 1)) Y[q >> 1] = frag_of<0, SAVE>(acc[q >> 2], acc[q >> 2], (q >> 1) & 1, SAVE ? srow(sv.ft) : nullptr, q >> 2);
                if (q & 1) {                                                    // direction encoding: 6 arguments, two per odd half-step
                    if (q < 7) {
-                       encode_sincos(dt, h, q - 1, &pd[q - 1], &pd[6 + q - 1]);
-                       encode_sincos(dt, h, q, &pd[q], &pd[6 + q]);
+                       const int hq_ = FUSED ? opaque(h) : h;           // (FUSED: keeps the per-lane frequency selects out of loop-long registers)
+                       encode_sincos(dt, hq_, q - 1, &pd[q - 1], &pd[6 + q - 1]);
+                       encode_sincos(dt, hq_, q, &pd[q], &pd[6 + q]);
                        pin(pd[q - 1]); pin(pd[q]); pin(pd[5 + q]); pin(pd[6 + q]);
                    } else init_bias_pair(cst, SEC_VC, h, 0, acc);
                });
@@ -1054,6 +1091,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             const Frag b = q < 8 ? Y[q] : D[q - 8];
             HS(q & 1, b, acc[2], acc[3],
                if (q < 4) head_part(hadapt, ha, h, acc[q >> 1], q >> 1, (q & 1) * 8, 8, relu);
+               if (FUSED && q == 9) g_pre(tile + tiles_per_round);              // (after the tile's last advance(): its counted wait would sit on these loads too; clamped past the end: harmless)
                if (SAVE && (q == 4 || q == 5)) { float* r_ = srow(sv.vc); if (r_) save_tile<true>(r_, q - 4, acc[q - 4]); });
         }
         DIAG_STAMP(11)
@@ -1077,7 +1115,11 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         out.w = fmaxf(adapt.w * omu + base.w * u, 0.f);
         if (h == 0 && s_raw < p.m) reinterpret_cast<f32x4*>(p.raw)[s_raw] = out;
         DIAG_STAMP(13)
-        if (FUSED) gather(tile + tiles_per_round);         // (after the heads: its loads in flight want the registers)
+        if (FUSED) {                                       // next tile's gather; its point encoding runs while the first loads are in flight
+            g_foot(); g_issue_first();
+            encode_point(); g_finish();
+            cur = read_half(P.buf, lane, 0);               // the fragments the last half-step left in `cur`, read again: sixteen registers the gather can use
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
 }
