@@ -265,9 +265,10 @@ def main():
     ap.add_argument("--no-reuse", "--headline-only", dest="no_reuse", action="store_true",
                     help="skip the secondary measurements: profiling runs")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (no per-kernel HIP events)")
-    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16", "bf16x3_fused"], default="bf16x3",
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16", "bf16x3_fused"], default="bf16x3_fused",
                     help="MLP arithmetic: exact fp32 MFMA; split-bf16 (3 bf16 MFMAs per product, fp32 accumulate, within the "
-                         "1e-4 parity bar); plain bf16 (1 MFMA per product, NOT within the parity bar: PSNR reported)")
+                         "1e-4 parity bar); plain bf16 (1 MFMA per product, NOT within the parity bar: PSNR reported); bf16x3_fused (default): "
+                         "split-bf16 with the feature gather inside the MLP kernel -- one launch per pass, no feature buffer")
     args = ap.parse_args()
     ctx = Ctx(args)
     rank, world, dev = ctx.rank, ctx.world, ctx.dev
@@ -370,7 +371,7 @@ def main():
                                     "roofline": {"bound": "mfma", "kernel": "mlp_fwd_kernel", "achieved": ach32, "peak": PEAK_F32_MFMA_TFLOPS,
                                                  "unit": "TFLOP/s", "frac": ach32 / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": ms32 / 80},
                                     "note": "NOT the headline: precision='f32' (v_mfma_f32_32x32x2_f32, exact fp32 products)"}
-            if args.precision == "bf16x3":       # plain-bf16 operands (the dtype configs[1] names): NOT within the 1e-4 parity bar
+            if args.precision in ("bf16x3", "bf16x3_fused"):       # plain-bf16 operands (the dtype configs[1] names): NOT within the 1e-4 parity bar
                 rp = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, max_blocks=args.max_blocks, precision="bf16")
                 dt3 = ctx.timed(lambda: rp.render(xs, ys, perturb=1.0, noise=noise), args.steps, args.warmup)
                 op = rp.render(xs, ys, perturb=1.0, noise=noise)
@@ -381,8 +382,37 @@ def main():
                                      "max_abs_rgb_vs_f32": (op["rgb"] - ref["rgb"]).abs().max().item(),
                                      "note": "NOT the headline and NOT within the 1e-4 parity bar: one bf16 MFMA per product (precision='bf16')"}
             return res
+        def other_route():
+            """Row f1: the same step on the other route -- the gather inside the MLP kernel (one launch per pass, the default) against
+            the two-kernel pass (gather -> feature buffer -> MLP)."""
+            fused_is_headline = args.precision == "bf16x3_fused"
+            prec = "bf16x3" if fused_is_headline else "bf16x3_fused"
+            rf = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, max_blocks=args.max_blocks, precision=prec)
+            evf = [[(ops.Event(), ops.Event()), (ops.Event(), ops.Event())] for _ in range(args.steps)]
+            kf = [-args.warmup]
+
+            def stepf():
+                rf.render(xs, ys, perturb=1.0, noise=noise, events=evf[kf[0]] if kf[0] >= 0 else None)
+                kf[0] += 1
+            dtf = ctx.timed(stepf, args.steps, args.warmup)
+            msf = sum(a.elapsed_ms(b) for st in evf for a, b in st)
+            achf = samples_per_step * args.steps * FLOP_PER_SAMPLE / (msf * 1e-3) / 1e12
+            of = rf.render(xs, ys, perturb=1.0, noise=noise)
+            same = (of["z_fine"] - out["z_fine"]).abs().amax(-1) < 1e-4
+            exf = achf * BF16X3_EXECUTED_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE
+            return {"value": global_rays / dtf, "unit": "rays/s", "ms_per_step": dtf * 1e3, "precision": prec,
+                    "roofline": {"bound": "mfma", "kernel": "mlp_fwd_bf16_kernel" + ("" if fused_is_headline else " (gather fused)"),
+                                 "achieved": achf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achf / PEAK_BF16_MFMA_TFLOPS,
+                                 "executed": exf, "executed_frac": exf / PEAK_BF16_MFMA_TFLOPS, "avg_launch_ms": msf / (2 * args.steps)},
+                    "max_abs_rgb_vs_headline_on_rays_with_equal_depths": (of["rgb"] - out["rgb"]).abs().amax(-1)[same].max().item(),
+                    "rays_with_equal_fine_depths": same.float().mean().item(),
+                    "note": ("NOT the headline: the two-kernel pass (feat_gather_cl -> tiled feature buffer -> mlp_fwd_bf16); its MLP launch does "
+                             "no gather, so its roofline fraction is the kernel-only figure" if fused_is_headline else
+                             "NOT the headline: the gather inside the MLP kernel; `achieved` counts the MLP's algorithmic flops only")}
         if world == 1:        # (N > 1: the scaling series needs `value`; the single-GPU fields are not repeated on every rank)
             extra.update(guarded(other_precisions, "other_precisions"))
+            if args.precision in ("bf16x3", "bf16x3_fused"):
+                extra["two_kernel_pass" if args.precision == "bf16x3_fused" else "gather_fused"] = guarded(other_route)
 
         def micro():
             """SURVEY.md 8(d) secondary micro-bench (north_star's literal '4096-ray x 128-sample'): single pass, S = 128,
@@ -396,6 +426,9 @@ def main():
             dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
             z = torch.sort(1 + 3 * torch.rand(n, S, generator=g), -1)[0].to(dev)
             pw, ws = renderer.pw, renderer.wstream
+            if args.precision == "bf16x3_fused":          # precomputed features: the stand-alone MLP entry, a stream in the two-kernel operand order
+                pw = ops.PackedWeights.get(pw.cfg.n_src, 0, dev, "bf16x3")
+                ws = pw.pack(flat_params_of(sd).to(dev))
 
             def step():
                 raw = ops.mlp_fwd(pw, ws, pts, dirs, feats, S)
@@ -461,7 +494,8 @@ def main():
     # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, scripts/pmc_mlp.sh), which
     # cannot run inside this process: the figure is READ BACK from the committed profile and labelled as such
     traffic, traffic_source = None, None
-    for name in (("r02_mlp_bf16_hbm_traffic.json", "r01_mlp_bf16_hbm_traffic.json") if bf16 else ("r02_mlp_fwd_hbm_traffic.json", "r01_mlp_fwd_hbm_traffic.json")):
+    for name in (("r02_mlp_bf16_fused_hbm_traffic.json",) if args.precision == "bf16x3_fused" else
+                 ("r02_mlp_bf16_hbm_traffic.json", "r01_mlp_bf16_hbm_traffic.json") if bf16 else ("r02_mlp_fwd_hbm_traffic.json", "r01_mlp_fwd_hbm_traffic.json")):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):
             with open(tpath) as f:
@@ -470,7 +504,8 @@ def main():
             break
 
     if rank == 0:
-        roof = {"bound": "mfma", "kernel": "mlp_fwd_bf16_kernel" if bf16 else "mlp_fwd_kernel", "achieved": achieved,
+        roof = {"bound": "mfma", "kernel": ("mlp_fwd_bf16_kernel (FUSED instantiation: feature gather + encoding + MLP)" if args.precision == "bf16x3_fused"
+                                            else "mlp_fwd_bf16_kernel" if bf16 else "mlp_fwd_kernel"), "achieved": achieved,
                 "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": mlp_ms / launches, "flop_per_launch_avg": samples_per_step * FLOP_PER_SAMPLE / 2}
         if bf16:
@@ -480,7 +515,10 @@ def main():
             terms = 3 if args.precision in ("bf16x3", "bf16x3_fused") else 1
             ex = achieved * BF16X3_EXECUTED_FLOP_PER_SAMPLE / 3 * terms / FLOP_PER_SAMPLE
             roof.update(executed=ex, executed_frac=ex / peak,
-                        note="bf16x3: 3 bf16 MFMAs per algorithmic MAC; algorithmic ceiling = peak/3.003 = 832 TFLOP/s"
+                        note=("bf16x3: 3 bf16 MFMAs per algorithmic MAC; algorithmic ceiling = peak/3.003 = 832 TFLOP/s"
+                              + ("; this launch also does the pass's feature gather (no separate gather kernel, no feature buffer): `achieved` "
+                                 "counts the MLP's flops only -- the kernel-only figure is two_kernel_pass.roofline"
+                                 if args.precision == "bf16x3_fused" else ""))
                         if terms == 3 else "plain bf16: NOT within the 1e-4 parity bar, see parity_vs_f32")
         line = {
             "metric": "rendered rays/sec (coarse+fine, 64+128 samples)",
@@ -488,7 +526,7 @@ def main():
             "warmup": args.warmup, "clock_settle_steps": settle, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 via split-bf16 (bf16x3) MFMA, f32 accumulate",
-                      "bf16x3_fused": "f32 via split-bf16 (bf16x3) MFMA, f32 accumulate",
+                      "bf16x3_fused": "f32 via split-bf16 (bf16x3) MFMA, f32 accumulate (feature gather fused into the MLP kernel)",
                       "bf16": "bf16 operands, f32 accumulate"}[args.precision], "data": "synthetic",
             "config": {"workload": "configs[1] shapes: %d rays/GPU x (%d coarse + %d fine -> %d merged) samples, V=7 views "
                                    "256x320, cascade volumes 48x64x80/32x128x160/8x256x320, UCNeRF D=6 W=128 random init"
