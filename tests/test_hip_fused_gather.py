@@ -160,3 +160,31 @@ def test_gather_fused_pipeline_at_the_headline_shape():
     fa = a.pass_(two["rays_d"], two["z_fine"])
     fb = b.pass_(two["rays_d"], two["z_fine"])
     close(fb["rgb"], fa["rgb"], 1e-5); close(fb["depth"], fa["depth"], 2e-5)
+
+
+@pytest.mark.gpu
+def test_small_passes_take_the_two_kernel_route():
+    """Below fused_min_samples a 'bf16x3_fused' renderer serves the pass with the two-kernel route (same parameters, second stream):
+    bit-identical to a 'bf16x3' renderer; fused_min_rounds=0 forces the fused kernel."""
+    from uc_nerf_amd.pipeline import CoarseFineRenderer, flat_params_of
+    from uc_nerf_amd.synthetic import init_ucnerf_state_dict, random_pixels
+    scene = _scene(6)
+    sd = init_ucnerf_state_dict(seed=5, sigma_scale=0.1, sigma_bias=0.02)
+    flat = flat_params_of(sd).to(DEV)
+    xs, ys = random_pixels(64, 32, 40, seed=1)
+    two = CoarseFineRenderer(to_dev(scene), flat, 64, 128, precision="bf16x3").render(xs.to(DEV), ys.to(DEV))
+    auto = CoarseFineRenderer(to_dev(scene), flat, 64, 128, precision="bf16x3_fused")
+    assert auto.fused_min_samples == 4 * torch.cuda.get_device_properties(0).multi_processor_count * 256
+    a = auto.render(xs.to(DEV), ys.to(DEV))
+    assert torch.equal(a["rgb"], two["rgb"]) and torch.equal(a["depth"], two["depth"])
+    forced = CoarseFineRenderer(to_dev(scene), flat, 64, 128, precision="bf16x3_fused", fused_min_rounds=0)
+    assert forced.pass_small is None
+    f = forced.render(xs.to(DEV), ys.to(DEV))
+    same = (f["z_fine"] - two["z_fine"]).abs().amax(-1) < 1e-4
+    assert ((f["rgb"] - two["rgb"]).abs().amax(-1)[same] < 2e-5).float().mean().item() > 0.9       # (border rows: in-mask knife edges)
+    # new parameters reach both streams
+    sd2 = init_ucnerf_state_dict(seed=6, sigma_scale=0.1, sigma_bias=0.02)
+    auto.set_params(flat_params_of(sd2).to(DEV))
+    b = auto.render(xs.to(DEV), ys.to(DEV))
+    two2 = CoarseFineRenderer(to_dev(scene), flat_params_of(sd2).to(DEV), 64, 128, precision="bf16x3").render(xs.to(DEV), ys.to(DEV))
+    assert torch.equal(b["rgb"], two2["rgb"])

@@ -20,19 +20,31 @@ class CoarseFineRenderer:
     confidence [H,W]; tensors already on the device.  flat_params: the MLP's flat parameter vector (device)."""
 
     def __init__(self, scene, flat_params, n_coarse=64, n_fine=128, white_bkgd=False, pe_layout=0, max_blocks=0,
-                 precision="f32"):
+                 precision="f32", fused_min_rounds=4):
         dev = scene["confidence"].device
         self.scene, self.dev = scene, dev
         self.n_coarse, self.n_fine, self.white_bkgd = n_coarse, n_fine, white_bkgd
         self.src = ops.GatherSources(scene["vols"], scene["confidence"], scene["imgs"], scene["img_feat"],
                                      scene["w2cs"][1:], scene["intrinsics"][1:])
         self.precision = precision          # "f32": exact fp32 MFMA; "bf16x3": split-bf16 matrix cores (inference, within the
-                                            # parity bar); "bf16": plain bf16 operands (inference, ~3e-3 render error)
+                                            # parity bar); "bf16": plain bf16 operands (inference, ~3e-3 render error);
+                                            # "bf16x3_fused": bf16x3 with the feature gather inside the MLP kernel (one launch per pass)
         self.pw = ops.PackedWeights.get(self.src.V, pe_layout, dev, precision)
         self.wstream = self.pw.pack(flat_params)
         w2c_ref = scene["w2cs"][0]
         self.pass_ = ops.RenderPass(self.src, self.pw, self.wstream, scene["c2w"][:3, 3].to(dev), w2c_ref,
                                     scene["intrinsics"][0], w2c_ref, scene["near"], scene["far"], white_bkgd, max_blocks)
+        # The gather-fused kernel pays per launch (a serial first gather) and per tile (eight waves per CU hide its loads, the stand-alone
+        # gather has 28): it wins from about four tiles per wave on (measured crossover: 2048 rays x 64 + 128, scripts/ab_rays.sh).  Smaller
+        # passes -- the per-GPU shard of a strongly-scaled batch -- take the two-kernel route with a second stream of the same parameters.
+        self.pass_small, self.fused_min_samples = None, 0
+        if precision == "bf16x3_fused" and fused_min_rounds > 0:
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
+            self.fused_min_samples = int(fused_min_rounds) * cus * 8 * 32
+            self.pw_small = ops.PackedWeights.get(self.src.V, pe_layout, dev, "bf16x3")
+            self.wstream_small = self.pw_small.pack(flat_params)
+            self.pass_small = ops.RenderPass(self.src, self.pw_small, self.wstream_small, scene["c2w"][:3, 3].to(dev), w2c_ref,
+                                             scene["intrinsics"][0], w2c_ref, scene["near"], scene["far"], white_bkgd, max_blocks)
         self.u_det = torch.linspace(0., 1., n_fine, device=dev)
         # camera matrices and depth range travel BY VALUE in the ABI structs: keep host copies so that a render call
         # never reads device memory back (a read-back would drain the stream once per batch)
@@ -43,6 +55,16 @@ class CoarseFineRenderer:
 
     def set_params(self, flat_params):
         self.wstream.copy_(self.pw.pack(flat_params))
+        if self.pass_small is not None:
+            self.wstream_small.copy_(self.pw_small.pack(flat_params))
+
+    def _pass_for(self, n_samples):
+        """The render pass serving a pass of `n_samples` samples (see fused_min_samples)."""
+        if self.pass_small is not None and n_samples < self.fused_min_samples:
+            if self.pass_.use_cl and not self.pass_small.use_cl:
+                self.pass_small.repack_sources(force=False)      # (the channel-last copies belong to the shared sources object)
+            return self.pass_small
+        return self.pass_
 
     def render(self, xs, ys, perturb=0.0, noise=None, u=None, events=None, repack=True, reuse_coarse=False):
         """xs, ys: pixel coordinates [n] (device, float32).  events: optional [(start, stop), (start, stop)]
@@ -58,15 +80,16 @@ class CoarseFineRenderer:
         # rays and their view-direction feature from one launch; both passes take the feature as an input
         rays_d, angle, z_c = self.sampler(xs, ys, perturb, noise)
         ev = [(a.h, b.h) for a, b in events] if events else (None, None)
-        coarse = self.pass_(rays_d, z_c, want=("weights",), events=ev[0], keep=("raw",) if reuse_coarse else (), dir_feat=angle)
+        n = int(xs.shape[0])
+        coarse = self._pass_for(n * self.n_coarse)(rays_d, z_c, want=("weights",), events=ev[0], keep=("raw",) if reuse_coarse else (), dir_feat=angle)
         hs = ops.sample_pdf(None, coarse["weights"], self.u_det if u is None else u, z_merge=z_c, want_inds=False,
                             from_coarse=True, want_rank=reuse_coarse)
         if reuse_coarse:
-            new = self.pass_(rays_d, hs["samples"], want=(), events=ev[1], keep=("raw",), dir_feat=angle)
+            new = self._pass_for(n * self.n_fine)(rays_d, hs["samples"], want=(), events=ev[1], keep=("raw",), dir_feat=angle)
             raw = ops.merge_rows(new["raw"], coarse["raw"], hs["merge_rank"])      # cat(samples, z_coarse) order
             out = ops.composite_fwd(raw, hs["z_sorted"], 0, self.white_bkgd)
         else:
-            out = self.pass_(rays_d, hs["z_sorted"], want=("acc", "weights", "var"), events=ev[1], dir_feat=angle)
+            out = self._pass_for(n * (self.n_coarse + self.n_fine))(rays_d, hs["z_sorted"], want=("acc", "weights", "var"), events=ev[1], dir_feat=angle)
         out.update(z_coarse=z_c, z_fine=hs["z_sorted"], z_samples=hs["samples"], coarse=coarse, rays_d=rays_d)
         return out
 
