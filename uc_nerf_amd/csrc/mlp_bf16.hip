@@ -794,14 +794,8 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             stash[q * 64] = split8(t);
         }
     };
-    if (FUSED) {
-        g_pre(blockIdx.x * BW + wave);
-        g_foot();
-        g_issue_first();
-        encode_point();
-        g_finish();
-    } else
-    fetch(blockIdx.x * BW + wave);
+    if (FUSED) g_pre(blockIdx.x * BW + wave);              // (the gather itself opens every iteration of the tile loop)
+    else fetch(blockIdx.x * BW + wave);
 
 #ifdef UCNERF_MLP_DIAG
 #define DIAG_STAMP(K) { SB0; if (g.diag && lane == 0 && round == 5) g.diag[(size_t)(blockIdx.x * BW + wave) * 16 + (K)] = __builtin_readcyclecounter(); SB0; }
@@ -810,6 +804,13 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
 #endif
     for (int round = 0; round < n_rounds; ++round) {                          // block-uniform trip count: every wave joins every barrier
         const int tile = round * tiles_per_round + blockIdx.x * BW + wave;
+        if (FUSED) {
+            // this tile's gather (its depth / ray / depth range came in under the previous tile's last GEMM phase); the point encoding
+            // runs while the first loads are in flight.  ONE copy of this code: as a prologue before the loop it spilled 208 bytes per lane
+            g_foot(); g_issue_first();
+            encode_point(); g_finish();
+            cur = read_half(P.buf, lane, 0);               // the fragments the last half-step left in `cur`, read again: sixteen registers the gather can use
+        }
         // SAVE: this lane's row of an activation set (re-derived at every use: nothing tile-long is kept in a register)
         auto srow = [&](float* base) -> float* {
             const int l_ = opaque(lane), s_ = tile * 32 + (l_ & 31);
@@ -1115,11 +1116,6 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         out.w = fmaxf(adapt.w * omu + base.w * u, 0.f);
         if (h == 0 && s_raw < p.m) reinterpret_cast<f32x4*>(p.raw)[s_raw] = out;
         DIAG_STAMP(13)
-        if (FUSED) {                                       // next tile's gather; its point encoding runs while the first loads are in flight
-            g_foot(); g_issue_first();
-            encode_point(); g_finish();
-            cur = read_half(P.buf, lane, 0);               // the fragments the last half-step left in `cur`, read again: sixteen registers the gather can use
-        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
 }
