@@ -262,6 +262,8 @@ def main():
     ap.add_argument("--mode", choices=["render", "train"], default="render")
     ap.add_argument("--cpu-rays", type=int, default=512, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--max-blocks", type=int, default=0)
+    ap.add_argument("--fused-min-rounds", type=int, default=0,
+                    help="bf16x3_fused: passes with fewer tiles per wave than this take the two-kernel route (0: always the fused kernel)")
     ap.add_argument("--no-reuse", "--headline-only", dest="no_reuse", action="store_true",
                     help="skip the secondary measurements: profiling runs")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (no per-kernel HIP events)")
@@ -299,7 +301,7 @@ def main():
     rays = args.rays if args.scaling == "weak" else max(1, args.rays // world)           # per rank
     global_rays = rays * world
     renderer = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, max_blocks=args.max_blocks,
-                                  precision=args.precision)
+                                  precision=args.precision, fused_min_rounds=args.fused_min_rounds)
     # this rank's shard of the global batch: contiguous block split
     xs_all, ys_all = random_pixels(global_rays, scene_cpu["H"], scene_cpu["W"], seed=0)
     xs = xs_all[rank * rays:(rank + 1) * rays].to(dev)

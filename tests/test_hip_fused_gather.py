@@ -164,8 +164,8 @@ def test_gather_fused_pipeline_at_the_headline_shape():
 
 @pytest.mark.gpu
 def test_small_passes_take_the_two_kernel_route():
-    """Below fused_min_samples a 'bf16x3_fused' renderer serves the pass with the two-kernel route (same parameters, second stream):
-    bit-identical to a 'bf16x3' renderer; fused_min_rounds=0 forces the fused kernel."""
+    """With fused_min_rounds > 0 a 'bf16x3_fused' renderer serves passes below that many tiles per wave with the two-kernel route (same
+    parameters, second stream): bit-identical to a 'bf16x3' renderer; the default (0) is the fused kernel at every size."""
     from uc_nerf_amd.pipeline import CoarseFineRenderer, flat_params_of
     from uc_nerf_amd.synthetic import init_ucnerf_state_dict, random_pixels
     scene = _scene(6)
@@ -173,11 +173,11 @@ def test_small_passes_take_the_two_kernel_route():
     flat = flat_params_of(sd).to(DEV)
     xs, ys = random_pixels(64, 32, 40, seed=1)
     two = CoarseFineRenderer(to_dev(scene), flat, 64, 128, precision="bf16x3").render(xs.to(DEV), ys.to(DEV))
-    auto = CoarseFineRenderer(to_dev(scene), flat, 64, 128, precision="bf16x3_fused")
+    auto = CoarseFineRenderer(to_dev(scene), flat, 64, 128, precision="bf16x3_fused", fused_min_rounds=4)
     assert auto.fused_min_samples == 4 * torch.cuda.get_device_properties(0).multi_processor_count * 256
     a = auto.render(xs.to(DEV), ys.to(DEV))
     assert torch.equal(a["rgb"], two["rgb"]) and torch.equal(a["depth"], two["depth"])
-    forced = CoarseFineRenderer(to_dev(scene), flat, 64, 128, precision="bf16x3_fused", fused_min_rounds=0)
+    forced = CoarseFineRenderer(to_dev(scene), flat, 64, 128, precision="bf16x3_fused")
     assert forced.pass_small is None
     f = forced.render(xs.to(DEV), ys.to(DEV))
     same = (f["z_fine"] - two["z_fine"]).abs().amax(-1) < 1e-4

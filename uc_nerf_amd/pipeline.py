@@ -20,7 +20,7 @@ class CoarseFineRenderer:
     confidence [H,W]; tensors already on the device.  flat_params: the MLP's flat parameter vector (device)."""
 
     def __init__(self, scene, flat_params, n_coarse=64, n_fine=128, white_bkgd=False, pe_layout=0, max_blocks=0,
-                 precision="f32", fused_min_rounds=4):
+                 precision="f32", fused_min_rounds=0):
         dev = scene["confidence"].device
         self.scene, self.dev = scene, dev
         self.n_coarse, self.n_fine, self.white_bkgd = n_coarse, n_fine, white_bkgd
@@ -34,9 +34,9 @@ class CoarseFineRenderer:
         w2c_ref = scene["w2cs"][0]
         self.pass_ = ops.RenderPass(self.src, self.pw, self.wstream, scene["c2w"][:3, 3].to(dev), w2c_ref,
                                     scene["intrinsics"][0], w2c_ref, scene["near"], scene["far"], white_bkgd, max_blocks)
-        # The gather-fused kernel pays per launch (a serial first gather) and per tile (eight waves per CU hide its loads, the stand-alone
-        # gather has 28): it wins from about four tiles per wave on (measured crossover: 2048 rays x 64 + 128, scripts/ab_rays.sh).  Smaller
-        # passes -- the per-GPU shard of a strongly-scaled batch -- take the two-kernel route with a second stream of the same parameters.
+        # fused_min_rounds > 0: passes with fewer tiles per wave than that take the two-kernel route (a second stream of the same
+        # parameters).  Measured (scripts/ab_rounds.sh, 512 .. 2048 rays x 64 + 128): the fused kernel wins or ties at every size,
+        # so the default is 0 -- always fused; the option stays for devices / shapes where a launch-bound shard might prefer otherwise.
         self.pass_small, self.fused_min_samples = None, 0
         if precision == "bf16x3_fused" and fused_min_rounds > 0:
             cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
