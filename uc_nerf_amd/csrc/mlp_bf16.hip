@@ -281,6 +281,7 @@ __device__ __forceinline__ Frag split8(const float (&x)[8]) {
 // (The constants never change, so the compiler would hoist these LDS loads out of the tile loop and then spill what it
 //  hoisted: the lane offset is laundered through an empty asm to keep every load where it is written.)
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ int sopaque(int v) { asm volatile("" : "+s"(v)); return v; }      // the same for a wave-uniform value (kept in a scalar register)
 // Results that are only needed much later would be sunk towards their use -- out of the MFMA shadow they were written
 // for, with their operands kept live meanwhile.  An empty volatile asm on the result pins the arithmetic in place.
 template <class T> __device__ __forceinline__ void pin(T& v) { asm volatile("" : "+v"(v)); }
@@ -675,19 +676,21 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         }
     };
     auto g_foot = [&]() {
+        const int gW = sopaque(fg.W), gH = sopaque(fg.H);
         const float x = fg.rays_o[0] + gz * grd[0], y = fg.rays_o[1] + gz * grd[1], w = fg.rays_o[2] + gz * grd[2];
         const int hl = opaque(h);
         float u, v, qz;
         {
             float qx, qy;
             project_cl(fg.w2c_ref, fg.K_ref, x, y, w, &qx, &qy, &qz);
-            u = (qx / qz + 0.0f) / (float)(fg.W - 1); v = (qy / qz + 0.0f) / (float)(fg.H - 1);
+            u = (qx / qz + 0.0f) / (float)(gW - 1); v = (qy / qz + 0.0f) / (float)(gH - 1);
         }
         npx[0] = u; npx[1] = v; npx[2] = (qz - fg.near) / (fg.far - fg.near);
         // volumes: `unit` is this lane's (hl in the first sweep, 2 in the second), `c0` the first byte of its channels in a voxel
         auto vol_fp = [&](int unit, unsigned c0, float nk, float fk) {
             const float zn = (qz - nk) / (fk - nk);
-            const int D = fg.vol_d[unit], hh = fg.vol_h[unit], ww = fg.vol_w[unit];
+            // (wave-uniform sizes pass through an empty asm: their float forms are otherwise hoisted out of the tile loop into vector registers and spilled)
+            const int D = unit == 2 ? sopaque(fg.vol_d[2]) : fg.vol_d[unit], hh = unit == 2 ? sopaque(fg.vol_h[2]) : fg.vol_h[unit], ww = unit == 2 ? sopaque(fg.vol_w[2]) : fg.vol_w[unit];
             const LerpCl ax = axis_cl(u * 2.f - 1.0f, ww, false), ay = axis_cl(v * 2.f - 1.0f, hh, false), az = axis_cl(zn * 2.f - 1.0f, D, false);
             const unsigned vb = fg.vol_off[unit] + c0;
             VolFp f;
@@ -701,9 +704,9 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         fa = vol_fp(hl, 0u, gnf[0], gnf[1]);
         fb3 = vol_fp(2, 16u * hl, gnf[2], gnf[3]);
         {   // confidence
-            const LerpCl ax = axis_cl(u * 2.f - 1.0f, fg.W, false), ay = axis_cl(v * 2.f - 1.0f, fg.H, false);
-            co[0] = (unsigned)(ay.i0 * fg.W + ax.i0); co[1] = (unsigned)(ay.i0 * fg.W + ax.i1);
-            co[2] = (unsigned)(ay.i1 * fg.W + ax.i0); co[3] = (unsigned)(ay.i1 * fg.W + ax.i1);
+            const LerpCl ax = axis_cl(u * 2.f - 1.0f, gW, false), ay = axis_cl(v * 2.f - 1.0f, gH, false);
+            co[0] = (unsigned)(ay.i0 * gW + ax.i0); co[1] = (unsigned)(ay.i0 * gW + ax.i1);
+            co[2] = (unsigned)(ay.i1 * gW + ax.i0); co[3] = (unsigned)(ay.i1 * gW + ax.i1);
             cw[0] = ay.w0 * ax.w0; cw[1] = ay.w0 * ax.w1; cw[2] = ay.w1 * ax.w0; cw[3] = ay.w1 * ax.w1;
         }
 #pragma unroll
@@ -712,10 +715,10 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             const float* mt = vtab + vi * VIEW_TAB;
             float qx, qy, qv;
             project_cl(mt, mt + 12, x, y, w, &qx, &qy, &qv);
-            const float gx = (qx / qv + 0.0f) / (float)(fg.W - 1) * 2.0f - 1.0f, gy = (qy / qv + 0.0f) / (float)(fg.H - 1) * 2.0f - 1.0f;
-            const LerpCl ax = axis_cl(gx, fg.W, true), ay = axis_cl(gy, fg.H, true);
+            const float gx = (qx / qv + 0.0f) / (float)(gW - 1) * 2.0f - 1.0f, gy = (qy / qv + 0.0f) / (float)(gH - 1) * 2.0f - 1.0f;
+            const LerpCl ax = axis_cl(gx, gW, true), ay = axis_cl(gy, gH, true);
             const unsigned ib = fg.img_off + (unsigned)vi * fg.view_bytes;
-            fi[pr].p00 = ib + (unsigned)(ay.i0 * fg.W + ax.i0) * 48u; fi[pr].p10 = ib + (unsigned)(ay.i1 * fg.W + ax.i0) * 48u;
+            fi[pr].p00 = ib + (unsigned)(ay.i0 * gW + ax.i0) * 48u; fi[pr].p10 = ib + (unsigned)(ay.i1 * gW + ax.i0) * 48u;
             fi[pr].dx = (unsigned)(ax.i1 - ax.i0) * 48u;
             fi[pr].w00 = ay.w0 * ax.w0; fi[pr].w01 = ay.w0 * ax.w1; fi[pr].w10 = ay.w1 * ax.w0; fi[pr].w11 = ay.w1 * ax.w1;
             fi[pr].mask = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.f : 0.f;
