@@ -2,6 +2,7 @@
 import collections
 import csv
 import glob
+import os
 import json
 import sys
 
@@ -13,7 +14,7 @@ for name in ("sq1", "sq2", "fetch", "write", "grbm", "tcc"):
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     dur = {}
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):        # (the newest pass when earlier ones share the directory)
         agg[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
         dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     ds = sorted(agg, key=int)
