@@ -230,7 +230,11 @@ typedef struct {
                                 stay within 1e-5 of fp64 (the parity bar is 1e-4), ~2.9x the f32 throughput.
                              2: bf16 -- the hi*hi term only (plain bf16 operands, fp32 accumulate; same packed stream as 1):
                                 inference forward only, NOT within the 1e-4 parity bar (rendered error ~3e-3, > 50 dB PSNR
-                                against the f32 render); offered because the reference configuration names bf16. */
+                                against the f32 render); offered because the reference configuration names bf16.
+                             3: bf16x3 with the feature gather INSIDE the MLP kernel: the stream is packed in the
+                                order that kernel's lane halves produce the bias nets' operands and serves ucnerf_render_fused_fwd
+                                only (n_src <= 6, channel-last sources, coordinates derived from (ray, depth), no kept features, no
+                                per-sample uncertainty); ucnerf_mlp_fwd refuses it.  Same arithmetic as 1. */
 } ucnerf_mlp_config;
 
 /* Sizes: floats in the flat parameter vector, floats (4-byte units) of the packed stream, int32 entries of the pack
@@ -447,7 +451,8 @@ typedef struct {
     const float* wstream;
     const float* sources_cl;   /* optional: channel-last copies of the sources (ucnerf_gather_repack).  When given and
                                   `feats` is NULL, the pass uses the fast gather that reads them and derives the
-                                  sample coordinates itself; vol/imgs/img_feat are then not touched */
+                                  sample coordinates itself; vol/imgs/img_feat are then not touched.  REQUIRED when
+                                  cfg.precision == 3 (the gather then runs inside the MLP kernel: no feature buffer) */
     /* workspace: ucnerf_render_workspace_floats(n, S, V) floats */
     float* workspace;
     /* outputs */
