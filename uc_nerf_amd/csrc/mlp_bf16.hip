@@ -592,7 +592,8 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
 
     // Inputs of a tile are fetched one tile ahead (under the previous tile's head / blend arithmetic, when few registers
     // are live): operands of the depth-bias net (element e of step q = feature 16q + 8h + e; columns past a section's
-    // width meet zero weights, so their index is only clamped into the row -- no branch), confidence, point.
+    // width meet zero weights, so where the upper half's column would leave the row BOTH halves read the lower half's --
+    // a constant offset again: the per-lane clamp it replaces cost the odd view counts 64-80 bytes of scratch), confidence, point.
     float nfs[4][8], nconf, npx[3];
     // (j and the parked-scalar address are re-derived from `lane` at each use: as loop-long values they get spilled)
     auto sample_of = [&](int tile) { const int s_raw = tile * 32 + (opaque(lane) & 31); return s_raw < p.m ? s_raw : p.m - 1; };
@@ -614,7 +615,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                 const int c = 16 * q + e;                  // feature c + 8h
                 // (tiled layout: streaming loads -- every 128-byte line is consumed by one load; kept out of the L2 they leave the
                 //  gather's sources there.  Row-major rows are read four bytes at a time and need the cache.)
-                const float* src_ = (NSRC && c + 8 < F) ? &fh[c * fstride] : &fb[(size_t)min(c + 8 * h, F - 1) * fstride];
+                const float* src_ = (NSRC && c + 8 < F) ? &fh[c * fstride] : &fb[(size_t)min(c, F - 1) * fstride];
 #if UCNERF_BF16_EXP & 1024
                 { float z_ = 0.f; asm volatile("" : "+v"(z_)); nfs[q][e] = z_; }      // (opaque zero: keeps the split arithmetic)
                 (void)src_;
@@ -978,7 +979,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                            _Pragma("unroll")
                            for (int e = 0; e < 8; ++e) {
                                const int c = f_img + 16 * qq + e;
-                               const float* src_ = (NSRC && c + 8 < F) ? &fhb[c * fstride] : &fb[(size_t)min(c + 8 * h, F - 1) * fstride];
+                               const float* src_ = (NSRC && c + 8 < F) ? &fhb[c * fstride] : &fb[(size_t)min(c, F - 1) * fstride];
 #if UCNERF_BF16_EXP & 1024
                                { float z_ = 0.f; asm volatile("" : "+v"(z_)); fsec[qq][e] = z_; }
                                (void)src_;
