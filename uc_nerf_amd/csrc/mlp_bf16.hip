@@ -74,6 +74,12 @@ __device__ __forceinline__ float sc_fma(float a, float b, float c) { float r = _
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define SB0 __builtin_amdgcn_sched_barrier(0)
 
+#ifndef UCNERF_FUSED_FOOT_UNDER_GEMM
+#define UCNERF_FUSED_FOOT_UNDER_GEMM 0    // gather-fused kernel: 1 = the NEXT tile's footprints (projection, corner offsets and weights of every unit: ~500 vector
+                                         //   instructions, no loads) are computed in otherwise empty fills of the last GEMM phase, beside the MFMAs; 0 = at the top of
+                                         //   the tile loop with the rest of the gather.  Measured: 1 is SLOWER (step 0.857 against 0.845-0.847 ms, same box) -- beside
+                                         //   the MFMAs of a power-limited kernel the instructions cost at least what they cost alone (profiles/r02_mlp_bf16_experiments.md)
+#endif
 #ifndef UCNERF_BF16_BW
 #define UCNERF_BF16_BW 8       // 8: one 512-thread block per CU, all eight waves share ONE weight ring -- half the LDS-DMA traffic and DMA issues
                                //    per tile of two 4-wave blocks; measured -3.3 % on the launch (profiles/r02_mlp_bf16_experiments.md)
@@ -281,7 +287,9 @@ __device__ __forceinline__ Frag split8(const float (&x)[8]) {
 // (The constants never change, so the compiler would hoist these LDS loads out of the tile loop and then spill what it
 //  hoisted: the lane offset is laundered through an empty asm to keep every load where it is written.)
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
-__device__ __forceinline__ int sopaque(int v) { asm volatile("" : "+s"(v)); return v; }      // the same for a wave-uniform value (kept in a scalar register)
+// the same for a wave-uniform value (kept in a scalar register); `on` = 0: identity (inside a GEMM phase's fill the asm form does not select:
+// "illegal VGPR to SGPR copy")
+__device__ __forceinline__ int sopaque(int v, bool on = true) { if (on) asm volatile("" : "+s"(v)); return v; }
 // Results that are only needed much later would be sunk towards their use -- out of the MFMA shadow they were written
 // for, with their operands kept live meanwhile.  An empty volatile asm on the result pins the arithmetic in place.
 template <class T> __device__ __forceinline__ void pin(T& v) { asm volatile("" : "+v"(v)); }
@@ -649,7 +657,12 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     struct VolFp { unsigned o[4], dx; float w[4], wx0, wx1; };
     struct ImgFp { unsigned p00, p10, dx; float w00, w01, w10, w11, mask; };
     constexpr int NP = NSRC > 0 ? (NSRC + 1) / 2 : 1;     // view pairs: this lane's view of pair pr is 2 pr + hl
-    float gz = 0.f, grd[3] = {0.f, 0.f, 0.f}, gnf[4] = {0.f, 0.f, 0.f, 0.f};
+    float gz = 0.f, grd[3] = {0.f, 0.f, 0.f}, gnf[4] = {0.f, 0.f, 0.f, 0.f}, gqz = 0.f;
+    float ro[3] = {0.f, 0.f, 0.f};                           // ray origin, read ONCE into scalar registers (a load inside a GEMM phase would bring a compiler-counted wait with it)
+    if (FUSED) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ro[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fg.rays_o[i])));
+    }
     VolFp fa, fb3;
     unsigned co[4];
     float cw[4];
@@ -676,22 +689,27 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             vi_[pr][3 * c] = ld16(fg.cl, o); vi_[pr][3 * c + 1] = ld16(fg.cl, o + 16u); vi_[pr][3 * c + 2] = ld16(fg.cl, o + 32u);
         }
     };
-    auto g_foot = [&]() {
-        const int gW = sopaque(fg.W), gH = sopaque(fg.H);
-        const float x = fg.rays_o[0] + gz * grd[0], y = fg.rays_o[1] + gz * grd[1], w = fg.rays_o[2] + gz * grd[2];
+    // footprints of the gather, in parts (so that they can be spread over several fills): 0 reference projection (+ the point the
+    // encoding takes), 1 this lane's first volume, 2 stage-3 volume + confidence, 3 + pr view pair pr
+    auto g_part = [&](int part) {
+        constexpr bool so_ = !UCNERF_FUSED_FOOT_UNDER_GEMM;
+        const int gW = sopaque(fg.W, so_), gH = sopaque(fg.H, so_);
+        const float x = ro[0] + gz * grd[0], y = ro[1] + gz * grd[1], w = ro[2] + gz * grd[2];
         const int hl = opaque(h);
-        float u, v, qz;
-        {
-            float qx, qy;
+        if (part == 0) {
+            float qx, qy, qz;
             project_cl(fg.w2c_ref, fg.K_ref, x, y, w, &qx, &qy, &qz);
-            u = (qx / qz + 0.0f) / (float)(gW - 1); v = (qy / qz + 0.0f) / (float)(gH - 1);
+            npx[0] = (qx / qz + 0.0f) / (float)(gW - 1); npx[1] = (qy / qz + 0.0f) / (float)(gH - 1);
+            npx[2] = (qz - fg.near) / (fg.far - fg.near);
+            gqz = qz;
+            return;
         }
-        npx[0] = u; npx[1] = v; npx[2] = (qz - fg.near) / (fg.far - fg.near);
+        const float u = npx[0], v = npx[1], qz = gqz;
         // volumes: `unit` is this lane's (hl in the first sweep, 2 in the second), `c0` the first byte of its channels in a voxel
         auto vol_fp = [&](int unit, unsigned c0, float nk, float fk) {
             const float zn = (qz - nk) / (fk - nk);
             // (wave-uniform sizes pass through an empty asm: their float forms are otherwise hoisted out of the tile loop into vector registers and spilled)
-            const int D = unit == 2 ? sopaque(fg.vol_d[2]) : fg.vol_d[unit], hh = unit == 2 ? sopaque(fg.vol_h[2]) : fg.vol_h[unit], ww = unit == 2 ? sopaque(fg.vol_w[2]) : fg.vol_w[unit];
+            const int D = unit == 2 ? sopaque(fg.vol_d[2], so_) : fg.vol_d[unit], hh = unit == 2 ? sopaque(fg.vol_h[2], so_) : fg.vol_h[unit], ww = unit == 2 ? sopaque(fg.vol_w[2], so_) : fg.vol_w[unit];
             const LerpCl ax = axis_cl(u * 2.f - 1.0f, ww, false), ay = axis_cl(v * 2.f - 1.0f, hh, false), az = axis_cl(zn * 2.f - 1.0f, D, false);
             const unsigned vb = fg.vol_off[unit] + c0;
             VolFp f;
@@ -702,16 +720,17 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             f.wx0 = ax.w0; f.wx1 = ax.w1;
             return f;
         };
-        fa = vol_fp(hl, 0u, gnf[0], gnf[1]);
-        fb3 = vol_fp(2, 16u * hl, gnf[2], gnf[3]);
-        {   // confidence
-            const LerpCl ax = axis_cl(u * 2.f - 1.0f, gW, false), ay = axis_cl(v * 2.f - 1.0f, gH, false);
+        if (part == 1) { fa = vol_fp(hl, 0u, gnf[0], gnf[1]); return; }
+        if (part == 2) {
+            fb3 = vol_fp(2, 16u * hl, gnf[2], gnf[3]);
+            const LerpCl ax = axis_cl(u * 2.f - 1.0f, gW, false), ay = axis_cl(v * 2.f - 1.0f, gH, false);      // confidence
             co[0] = (unsigned)(ay.i0 * gW + ax.i0); co[1] = (unsigned)(ay.i0 * gW + ax.i1);
             co[2] = (unsigned)(ay.i1 * gW + ax.i0); co[3] = (unsigned)(ay.i1 * gW + ax.i1);
             cw[0] = ay.w0 * ax.w0; cw[1] = ay.w0 * ax.w1; cw[2] = ay.w1 * ax.w0; cw[3] = ay.w1 * ax.w1;
+            return;
         }
-#pragma unroll
-        for (int pr = 0; pr < NP; ++pr) {
+        const int pr = part - 3;
+        if (pr < NP) {
             const int vi = min(2 * pr + hl, NSRC - 1);       // (a half without a view repeats the last one: finite values onto zero weights)
             const float* mt = vtab + vi * VIEW_TAB;
             float qx, qy, qv;
@@ -724,6 +743,10 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             fi[pr].w00 = ay.w0 * ax.w0; fi[pr].w01 = ay.w0 * ax.w1; fi[pr].w10 = ay.w1 * ax.w0; fi[pr].w11 = ay.w1 * ax.w1;
             fi[pr].mask = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.f : 0.f;
         }
+    };
+    auto g_foot = [&]() {
+#pragma unroll
+        for (int part = 0; part < 3 + NP; ++part) g_part(part);
     };
     auto g_issue_first = [&]() {
         SB0;
@@ -798,8 +821,10 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             stash[q * 64] = split8(t);
         }
     };
-    if (FUSED) g_pre(blockIdx.x * BW + wave);              // (the gather itself opens every iteration of the tile loop)
-    else fetch(blockIdx.x * BW + wave);
+    if (FUSED) {                                            // (the gather itself opens every iteration of the tile loop)
+        g_pre(blockIdx.x * BW + wave);
+        if (UCNERF_FUSED_FOOT_UNDER_GEMM) g_foot();
+    } else fetch(blockIdx.x * BW + wave);
 
 #ifdef UCNERF_MLP_DIAG
 #define DIAG_STAMP(K) { SB0; if (g.diag && lane == 0 && round == 5) g.diag[(size_t)(blockIdx.x * BW + wave) * 16 + (K)] = __builtin_readcyclecounter(); SB0; }
@@ -811,7 +836,8 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         if (FUSED) {
             // this tile's gather (its depth / ray / depth range came in under the previous tile's last GEMM phase); the point encoding
             // runs while the first loads are in flight.  ONE copy of this code: as a prologue before the loop it spilled 208 bytes per lane
-            g_foot(); g_issue_first();
+            if (!UCNERF_FUSED_FOOT_UNDER_GEMM) g_foot();
+            g_issue_first();
             encode_point(); g_finish();
             cur = read_half(P.buf, lane, 0);               // the fragments the last half-step left in `cur`, read again: sixteen registers the gather can use
         }
@@ -1001,6 +1027,11 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                        if (!p.dirs_per_sample) { int S = p.S; asm volatile("" : "+s"(S)); ray = s_here / S; }   // (opaque: no reciprocal hoisted into a loop-long VGPR)
                        const float* drow = p.dirs + (size_t)ray * 3;
                        dv[0] = drow[0]; dv[1] = drow[1]; dv[2] = drow[2];
+                       if (FUSED && UCNERF_FUSED_FOOT_UNDER_GEMM) g_pre(tile + tiles_per_round);      // depth, ray, depth range of the NEXT tile's sample (clamped past the end: harmless)
+                   }
+                   if (FUSED && UCNERF_FUSED_FOOT_UNDER_GEMM && q == 10) {     // every plain load of the tile is waited for HERE, in one place
+                       pin(dv[0]); pin(dv[1]); pin(dv[2]);
+                       pin(gz); pin(grd[0]); pin(grd[1]); pin(grd[2]); pin(gnf[0]); pin(gnf[1]); pin(gnf[2]); pin(gnf[3]);
                    });
             }
         }
@@ -1087,7 +1118,9 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                    _Pragma("unroll")
                    for (int e = 0; e < 8; ++e) t[e] = pd[8 * (q - 5) + e];
                    D[q - 5] = split8(t); pin(D[q - 5].hi); pin(D[q - 5].lo);
-               });
+               }
+               if (FUSED && UCNERF_FUSED_FOOT_UNDER_GEMM && q >= 7) g_part(q - 7);          // next tile: reference projection, the two volumes + confidence
+               );
         }
         HeadAcc hadapt = {{0.f, 0.f}, {0.f, 0.f}};
         auto relu = [](float v) { return fmaxf(v, 0.f); };
@@ -1096,7 +1129,8 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             const Frag b = q < 8 ? Y[q] : D[q - 8];
             HS(q & 1, b, acc[2], acc[3],
                if (q < 4) head_part(hadapt, ha, h, acc[q >> 1], q >> 1, (q & 1) * 8, 8, relu);
-               if (FUSED && q == 9) g_pre(tile + tiles_per_round);              // (after the tile's last advance(): its counted wait would sit on these loads too; clamped past the end: harmless)
+               if (FUSED && UCNERF_FUSED_FOOT_UNDER_GEMM && q >= 4 && q - 4 < NP) g_part(3 + q - 4);      // ... its view pairs
+               if (FUSED && !UCNERF_FUSED_FOOT_UNDER_GEMM && q == 9) g_pre(tile + tiles_per_round);              // (after the tile's last advance(): its counted wait would sit on these loads too; clamped past the end: harmless)
                if (SAVE && (q == 4 || q == 5)) { float* r_ = srow(sv.vc); if (r_) save_tile<true>(r_, q - 4, acc[q - 4]); });
         }
         DIAG_STAMP(11)
