@@ -188,3 +188,44 @@ def test_small_passes_take_the_two_kernel_route():
     b = auto.render(xs.to(DEV), ys.to(DEV))
     two2 = CoarseFineRenderer(to_dev(scene), flat_params_of(sd2).to(DEV), 64, 128, precision="bf16x3").render(xs.to(DEV), ys.to(DEV))
     assert torch.equal(b["rgb"], two2["rgb"])
+
+
+@pytest.mark.gpu
+def test_gather_fused_pass_on_randomised_shapes():
+    """Seeded sweep over view counts, ray / sample counts (ragged tiles, more tiles than the grid holds with max_blocks = 1), depth ranges
+    and background: the fused pass against the two-kernel pass on the same inputs."""
+    from uc_nerf_amd import ops
+    from uc_nerf_amd.pipeline import flat_params_of
+    from uc_nerf_amd.synthetic import init_ucnerf_state_dict
+    rng = np.random.default_rng(7)
+    for case in range(14):
+        V = int(rng.integers(1, 7))
+        N, S = int(rng.integers(1, 80)), int(rng.integers(1, 130))
+        ranges, white, max_blocks = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), int(rng.choice([0, 0, 1, 3]))
+        scene = _scene(V, seed=20 + case)
+        g = torch.Generator().manual_seed(1000 + case)
+        sd = init_ucnerf_state_dict(seed=case, n_src=V, sigma_scale=0.1, sigma_bias=0.02)
+        xs, ys = 39 * torch.rand(N, generator=g), 1 + 29 * torch.rand(N, generator=g)      # (off the border rows: no in-mask knife edges)
+        _, rays_d, _ = O.get_rays_mvs_pixels(xs, ys, scene["K"], scene["c2w"])
+        z = torch.sort(1.0 + 3.0 * torch.rand(N, S, generator=g), -1)[0]
+        nf = None
+        if ranges:
+            lo = 0.8 + 0.4 * torch.rand(N, 3, generator=g)
+            nf = torch.stack([lo[:, 0], lo[:, 0] + 3, lo[:, 1], lo[:, 1] + 2.5, lo[:, 2], lo[:, 2] + 3.5], -1).to(DEV)
+        sc = to_dev(scene)
+        src = ops.GatherSources(sc["vols"], sc["confidence"], sc["imgs"], sc["img_feat"], sc["w2cs"][1:], sc["intrinsics"][1:])
+        flat = flat_params_of(sd).to(DEV)
+        outs = {}
+        for prec in ("bf16x3", "bf16x3_fused"):
+            pw = ops.PackedWeights.get(src.V, 0, torch.device(DEV), prec)
+            rp = ops.RenderPass(src, pw, pw.pack(flat), sc["c2w"][:3, 3], sc["w2cs"][0], sc["intrinsics"][0], sc["w2cs"][0],
+                                scene["near"], scene["far"], white_bkgd=white, max_blocks=max_blocks)
+            rp.repack_sources()
+            outs[prec] = rp(rays_d.to(DEV), z.to(DEV), near_far=nf, keep=("raw",))
+        one, two = outs["bf16x3_fused"], outs["bf16x3"]
+        what = "case %d: V=%d N=%d S=%d ranges=%s white=%s max_blocks=%d" % (case, V, N, S, ranges, white, max_blocks)
+        scale = max(1.0, two["raw"][..., 3].abs().max().item())
+        assert torch.isfinite(one["raw"]).all(), what
+        assert (one["raw"] - two["raw"]).abs().max().item() < 3e-5 * scale, what
+        assert (one["rgb"] - two["rgb"]).abs().max().item() < 2e-5 and (one["depth"] - two["depth"]).abs().max().item() < 3e-5, what
+        assert (one["weights"] - two["weights"]).abs().max().item() < 2e-5, what
