@@ -27,6 +27,8 @@
 //     eight tiles.  (Round 1 ran two 4-wave blocks per CU so that the two waves of a SIMD never met at a barrier; measured in
 //     round 2: the chip is power-limited under this kernel -- one wave per SIMD renders 93 % of what two do -- so what pays is
 //     less data movement per tile, not more overlap.)
+//   * FUSED instantiation: the tile loop opens with the tile's feature gather -- the operands of the
+//     two bias nets come straight from the channel-last sources instead of a feature buffer written by feat_gather_cl_kernel.
 #include "common.h"
 #include "mlp_layout.h"
 #include "sincos_cw.h"
@@ -650,10 +652,10 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     };
     // FUSED: the same values, gathered from the sources (see FusedGather)
     // The in-kernel gather runs with eight waves per CU (the stand-alone kernel has 28) and all of them reach it together, so it is
-    // staged: g_pre (z, ray, depth range of the next tile: issued under the last GEMM phase), g_foot (footprints of every unit),
-    // g_issue_first (corner loads of the volumes + confidence, back to back), then -- while those are in flight -- the current tile's
-    // heads and the next tile's point encoding, and g_finish: consume in issue order, the next view pair's loads going out as soon as
-    // a volume's registers are free again.
+    // staged: g_pre (depth, ray, depth range of the NEXT tile's sample: plain loads in the last fill of the last GEMM phase, after the
+    // tile's last advance()); then, opening the next iteration of the tile loop: g_foot (footprints of every unit), g_issue_first (corner
+    // loads of the volumes + confidence, back to back), the tile's point encoding while those are in flight, and g_finish: consume in
+    // issue order, the next view pair's loads going out as soon as a volume's registers are free again.
     struct VolFp { unsigned o[4], dx; float w[4], wx0, wx1; };
     struct ImgFp { unsigned p00, p10, dx; float w00, w01, w10, w11, mask; };
     constexpr int NP = NSRC > 0 ? (NSRC + 1) / 2 : 1;     // view pairs: this lane's view of pair pr is 2 pr + hl
