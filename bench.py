@@ -496,6 +496,19 @@ def main():
                         "note": "NOT the headline (which repacks the sources in every step): channel-last source copies rebuilt once per "
                                 "%d x %d image = every %d batches" % (scene_cpu["H"], scene_cpu["W"], per_image)}
             extra["constant_sources"] = guarded(constant_sources)
+
+            def hip_graph_replay():
+                """The headline step (source repack included) captured once into a HIP graph and replayed: the same launches without the
+                host's per-launch work (`CoarseFineRenderer.capture`, replay asserted bit-identical to the eager step)."""
+                g = renderer.capture(rays, perturb=1.0)
+                dtg = ctx.timed(lambda: g(xs, ys, noise), args.steps, args.warmup)
+                og = g(xs, ys, noise)
+                ref = renderer.render(xs, ys, perturb=1.0, noise=noise)
+                assert torch.equal(og["rgb"], ref["rgb"]) and torch.equal(og["depth"], ref["depth"])
+                return {"value": global_rays / dtg, "unit": "rays/s", "ms_per_step": dtg * 1e3,
+                        "note": "NOT the headline (which issues its launches eagerly, with HIP events around the MLP launches): one graph replay per step"}
+            if not args.graph:
+                extra["hip_graph_replay"] = guarded(hip_graph_replay)
         else:
             extra["train_dp"] = guarded(lambda: bench_train_dp(ctx, scene, sd, 2000 if args.scaling == "weak" else max(1, 2000 // world)))
 
