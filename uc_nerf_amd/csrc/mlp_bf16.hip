@@ -82,6 +82,9 @@ __device__ __forceinline__ float sc_fma(float a, float b, float c) { float r = _
                                          //   the tile loop with the rest of the gather.  Measured: 1 is SLOWER (step 0.857 against 0.845-0.847 ms, same box) -- beside
                                          //   the MFMAs of a power-limited kernel the instructions cost at least what they cost alone (profiles/r02_mlp_bf16_experiments.md)
 #endif
+#ifndef UCNERF_BF16_IDLE_SKIP
+#define UCNERF_BF16_IDLE_SKIP 1          // a wave whose tile lies past the end only turns the weight ring (0: it computes a clamped tile and discards it)
+#endif
 #ifndef UCNERF_BF16_BW
 #define UCNERF_BF16_BW 8       // 8: one 512-thread block per CU, all eight waves share ONE weight ring -- half the LDS-DMA traffic and DMA issues
                                //    per tile of two 4-wave blocks; measured -3.3 % on the launch (profiles/r02_mlp_bf16_experiments.md)
@@ -597,8 +600,13 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     __builtin_amdgcn_s_barrier();                                                        // ... for every wave
     AF cur = read_half(P.buf, lane, 0);                     // (TERMS 1 reads the unused lo halves once here)
 
+    // Tile of (round, block, wave), WAVE-MAJOR inside a round: a last round that is only partly filled then keeps the same number of waves
+    // busy in every block -- with at most half of it filled, one wave per SIMD, which renders a tile in 0.70 of the time two waves sharing the
+    // SIMD take (58 k against 83 k cycles) -- instead of running some blocks full and leaving others empty.  A wave without a tile only
+    // keeps the weight ring turning (idle_tile below): the 512-ray shard of a strongly-scaled batch is 0.5 + 1.5 such rounds.
     const int tiles_per_round = gridDim.x * BW;
     const int n_rounds = (n_tiles + tiles_per_round - 1) / tiles_per_round;
+    const int tile0 = wave * (int)gridDim.x + (int)blockIdx.x;
 
     // Inputs of a tile are fetched one tile ahead (under the previous tile's head / blend arithmetic, when few registers
     // are live): operands of the depth-bias net (element e of step q = feature 16q + 8h + e; columns past a section's
@@ -824,9 +832,9 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         }
     };
     if (FUSED) {                                            // (the gather itself opens every iteration of the tile loop)
-        g_pre(blockIdx.x * BW + wave);
+        g_pre(tile0);
         if (UCNERF_FUSED_FOOT_UNDER_GEMM) g_foot();
-    } else fetch(blockIdx.x * BW + wave);
+    } else fetch(tile0);
 
 #ifdef UCNERF_MLP_DIAG
 #define DIAG_STAMP(K) { SB0; if (g.diag && lane == 0 && round == 5) g.diag[(size_t)(blockIdx.x * BW + wave) * 16 + (K)] = __builtin_readcyclecounter(); SB0; }
@@ -834,7 +842,14 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
 #define DIAG_STAMP(K)
 #endif
     for (int round = 0; round < n_rounds; ++round) {                          // block-uniform trip count: every wave joins every barrier
-        const int tile = round * tiles_per_round + blockIdx.x * BW + wave;
+        const int tile = round * tiles_per_round + tile0;
+#if UCNERF_BF16_IDLE_SKIP
+        if (tile >= n_tiles) {                               // (wave-uniform; every later tile of this wave is past the end too)
+            for (int i = 0; i < g.slots; ++i) advance(P);    // this wave's DMA pieces and barriers of one tile, nothing else
+            cur = read_half(P.buf, lane, 0);
+            continue;
+        }
+#endif
         if (FUSED) {
             // this tile's gather (its depth / ray / depth range came in under the previous tile's last GEMM phase); the point encoding
             // runs while the first loads are in flight.  ONE copy of this code: as a prologue before the loop it spilled 208 bytes per lane
@@ -1183,6 +1198,8 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
     if (cus <= 0) return fail(UCNERF_EHIP, "mlp_fwd: no device");
     int blocks = cdiv(n_tiles, BW);
     const int cap = p->max_blocks > 0 ? p->max_blocks : UCNERF_BF16_WPS * 4 / BW * cus;      // blocks per CU = waves per SIMD * 4 / BW
+    // fewer tiles than wave slots: rather every CU with one wave per SIMD than half the CUs with two (tiles are dealt wave-major, see the kernel)
+    if (BW == 8 && UCNERF_BF16_IDLE_SKIP && blocks < cap) { const int spread = cdiv(n_tiles, 4); blocks = spread < cap ? spread : cap; }
     if (blocks > cap) blocks = cap;
     BGeom g;
     g.F = B.F; g.kd16 = B.kd16; g.kc16 = B.kc16; g.f_img = 24 + 4 * B.v; g.slots = B.slots;
