@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
     // raw 3-vector of this lane's sample in the first tile; later tiles are prefetched one tile ahead
     float px[3] = {0.f, 0.f, 0.f};
     {
-        const int t0 = blockIdx.x * MLP_WAVES + wave;
+        const int t0 = wave * (int)gridDim.x + (int)blockIdx.x;      // tiles are dealt wave-major (see the tile loop)
         if (!ENC && t0 < n_tiles) {
             const int s0 = t0 * 32 + j < p.m ? t0 * 32 + j : p.m - 1;
             const float* prow = p.pts + (size_t)s0 * g.pts_stride;
@@ -391,7 +391,9 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
 #ifdef UCNERF_MLP_DIAG
     int diag_k = 0;
 #endif
-    for (int tile = blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += n_waves) {
+    // Wave-major inside a round of n_waves tiles: a partly filled last round keeps the same number of waves busy in every block (one per
+    // SIMD while it is at most half full) instead of running some blocks with two waves per SIMD and leaving others empty.
+    for (int tile = wave * (int)gridDim.x + (int)blockIdx.x; tile < n_tiles; tile += n_waves) {
 #ifdef UCNERF_MLP_DIAG
 #define DIAG_STAMP(K) { __builtin_amdgcn_sched_barrier(0); if (g.diag && lane == 0 && diag_k == 5) g.diag[(size_t)(blockIdx.x * MLP_WAVES + wave) * 16 + (K)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
 #else
@@ -549,6 +551,7 @@ int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t
     if (cus <= 0) return fail(UCNERF_EHIP, "mlp_fwd: no device");
     int blocks = cdiv(n_tiles, MLP_WAVES);
     int cap = p->max_blocks > 0 ? p->max_blocks : cus;          // one 8-wave block per CU (two waves per SIMD)
+    if (MLP_WAVES == 8 && blocks < cap) { const int spread = cdiv(n_tiles, 4); blocks = spread < cap ? spread : cap; }      // fewer tiles than wave slots: every CU, one wave per SIMD
     if (blocks > cap) blocks = cap;
     MlpGeom g = geom_of(L);
     g.stream_bytes = (int)(L.total * 4);
