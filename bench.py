@@ -260,7 +260,7 @@ def main():
     ap.add_argument("--fine", type=int, default=128)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--mode", choices=["render", "train"], default="render")
-    ap.add_argument("--cpu-rays", type=int, default=512, help="size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=2048, help="size of the CPU-baseline sample (0 = skip); 2048 rays = five runs of 2-3 s on 16 host threads")
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--fused-min-rounds", type=int, default=0,
                     help="bf16x3_fused: passes with fewer tiles per wave than this take the two-kernel route (0: always the fused kernel)")
