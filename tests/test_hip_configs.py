@@ -209,7 +209,7 @@ def test_hamlyn_view_count_through_the_rendering_mirror():
     close(rgb2, g["rgb_second"], 1e-4); close(d2, g["depth_second"], 1e-4)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3_fused"])
 def test_hamlyn_view_count_coarse_fine_hierarchy(precision):
     """CoarseFineRenderer with 3 source views against the oracle (pinned at V = 4 by G16 and G6 v4)."""
     from uc_nerf_amd.pipeline import CoarseFineRenderer, flat_params_of
@@ -229,7 +229,7 @@ def test_hamlyn_view_count_coarse_fine_hierarchy(precision):
 
 
 # ---------------------------------------------------------------------------------------------- configs[0]
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3_fused"])
 def test_plumbing_config_400x400_image_1024_rays_64_samples(precision):
     """BASELINE configs[0]: 400x400 scene (K = [[500,0,200],[0,500,200],[0,0,1]]), one 1024-ray batch, 64
     stratified samples, single pass: ray_gen -> sample_stratified -> fused pass against the oracle."""
@@ -266,7 +266,7 @@ def test_plumbing_config_400x400_image_1024_rays_64_samples(precision):
 
 
 # ---------------------------------------------------------------------------------------------- configs[1]: the error record
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3_fused"])
 def test_full_batch_errors_against_the_fp32_oracle_with_knife_edge_rays_characterised(precision):
     """4096 rays x (64 + 128) of the bench scene, NO ray excluded, against the fp32 oracle teacher-forced on the device's
     own fine depths.  The synthetic source views are pure x-translations of the target, so pixels of image rows 0 and H-1
@@ -283,8 +283,14 @@ def test_full_batch_errors_against_the_fp32_oracle_with_knife_edge_rays_characte
     xs, ys = random_pixels(n, 256, 320, seed=0)
     r = CoarseFineRenderer(scene_to(scene, torch.device(DEV)), flat_params_of(sd).to(DEV), 64, 128, precision=precision)
     out = r.render(dev(xs), dev(ys))
-    fine = r.pass_(out["rays_d"], out["z_fine"], keep=("feats",))                  # the same pass with its features kept
-    close(fine["rgb"], out["rgb"], 2e-6); close(fine["depth"], out["depth"], 5e-6)
+    if precision == "bf16x3_fused":      # the gather-fused route keeps no features: the in-mask bits are read off the two-kernel gather (same arithmetic)
+        r2 = CoarseFineRenderer(scene_to(scene, torch.device(DEV)), flat_params_of(sd).to(DEV), 64, 128, precision="bf16x3")
+        r2.pass_.repack_sources()
+        fine = r2.pass_(out["rays_d"], out["z_fine"], keep=("feats",))
+        close(fine["rgb"], out["rgb"], 1e-5); close(fine["depth"], out["depth"], 2e-5)
+    else:
+        fine = r.pass_(out["rays_d"], out["z_fine"], keep=("feats",))              # the same pass with its features kept
+        close(fine["rgb"], out["rgb"], 2e-6); close(fine["depth"], out["depth"], 5e-6)
     with torch.no_grad():
         ref = O.render_coarse_fine(sd, scene, xs, ys, 64, 128, z_fine_override=out["z_fine"].cpu())
     V = 6
