@@ -57,7 +57,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define UCNERF_BF16_EXP 0      // timing experiments only (results are wrong): 1 no DMA wait, 2 no barrier, 4 no DMA, 64 no interleave hints, 128 no epilogue arithmetic, 256 half the LDS fragment reads, 512 no point-encoding arithmetic, 1024 no feature / point loads: zeros instead (compare with a launch on all-zero inputs: same values, same power draw), 8192 one more VALU per split value, 2048 every feature load issued TWICE (the second from another tile's rows, weighted 0: same values, same power -- what the loads cost is what the copy adds)
 #endif
 #ifndef UCNERF_BF16_HINT_V
-#define UCNERF_BF16_HINT_V 7   // VALU instructions the scheduler may place after each MFMA of a half-step
+#define UCNERF_BF16_HINT_V 5   // VALU instructions the scheduler may place after each MFMA of a half-step (7 would fill an MFMA's 32 cycles; measured
+                               // over 1..9: 3..6 read 0.5 % faster than 7, 9 is 1.5 % slower -- profiles/r02_logs/r02_hint_v_sweep.log)
 #endif
 #ifndef UCNERF_BF16_PRIO_VALU
 #define UCNERF_BF16_PRIO_VALU 0     // wave priority during the phases without MFMAs (point encoding, tail)
