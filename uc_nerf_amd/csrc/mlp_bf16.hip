@@ -607,7 +607,10 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     // keeps the weight ring turning (idle_tile below): the 512-ray shard of a strongly-scaled batch is 0.5 + 1.5 such rounds.
     const int tiles_per_round = gridDim.x * BW;
     const int n_rounds = (n_tiles + tiles_per_round - 1) / tiles_per_round;
-    const int tile0 = wave * (int)gridDim.x + (int)blockIdx.x;
+#ifndef UCNERF_BF16_WAVE_MAJOR
+#define UCNERF_BF16_WAVE_MAJOR 1
+#endif
+    const int tile0 = UCNERF_BF16_WAVE_MAJOR ? wave * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * BW + wave;
 
     // Inputs of a tile are fetched one tile ahead (under the previous tile's head / blend arithmetic, when few registers
     // are live): operands of the depth-bias net (element e of step q = feature 16q + 8h + e; columns past a section's
