@@ -233,7 +233,7 @@ typedef struct {
                                 against the f32 render); offered because the reference configuration names bf16.
                              3: bf16x3 with the feature gather INSIDE the MLP kernel: the stream is packed in the
                                 order that kernel's lane halves produce the bias nets' operands and serves ucnerf_render_fused_fwd
-                                only (n_src <= 6, channel-last sources, coordinates derived from (ray, depth), no kept features, no
+                                only (channel-last sources, coordinates derived from (ray, depth), no kept features, no
                                 per-sample uncertainty); ucnerf_mlp_fwd refuses it.  Same arithmetic as 1. */
 } ucnerf_mlp_config;
 

@@ -97,6 +97,7 @@ constexpr int HALF_BYTES = 4096;
 #define UCNERF_BF16_NBUF 4
 #endif
 constexpr int NBUF = UCNERF_BF16_NBUF;   // LDS ring slots (power of two); the slot of ring position g is refilled with position g + NBUF
+constexpr int fused_ring_slots(bool fused, int n_src) { return fused && n_src > 6 && NBUF > 2 ? 2 : NBUF; }      // (see the kernel)
 constexpr int DMA_PER_SLOT = SLOT_BYTES / 1024 / BW;      // 1-KB global_load_lds pieces per wave per slot
 constexpr int KS16_PE_PTS = 4, KS16_PE_DIR = 2, KS16_HID = 8;
 
@@ -371,9 +372,10 @@ struct Pipe {
 // The copy is issued from inline asm on purpose: the compiler models a global_load_lds as a FLAT access that may
 // touch both memories and from then on degrades every counted wait of the kernel to vmcnt(0) / lgkmcnt(0), which
 // serialises the fragment prefetch below.  All hazards of the ring are handled explicitly in advance().
+template <int NB = NBUF>
 __device__ __forceinline__ void issue_dma(Pipe& P, int pos) {
     const char* src = P.gsrc + (size_t)P.next_src * SLOT_BYTES;
-    const unsigned dst = P.ring_lds + (pos & (NBUF - 1)) * SLOT_BYTES + P.wave * (DMA_PER_SLOT * 1024);
+    const unsigned dst = P.ring_lds + (pos & (NB - 1)) * SLOT_BYTES + P.wave * (DMA_PER_SLOT * 1024);
 #pragma unroll
     for (int i = 0; i < DMA_PER_SLOT; ++i)
         asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off offset:%2" ::"v"(src), "s"(dst), "n"(i * 1024) : "memory", "m0");   // the offset moves both addresses
@@ -390,18 +392,19 @@ __device__ __forceinline__ AF read_half(const char* buf, int lane, int half) {
 // Waits until the next slot has landed for the whole block, refills the slot just read and moves on to it.
 // The lgkmcnt(0) retires every ds_read of the current slot, so after the barrier no wave still reads it.
 // vmcnt: the DMAs younger than the awaited slot are those of the NBUF - 2 slots after it.
+template <int NB = NBUF>
 __device__ __forceinline__ void advance(Pipe& P) {
 #if !(UCNERF_BF16_EXP & 1)
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NBUF - 2) * DMA_PER_SLOT) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NB - 2) * DMA_PER_SLOT) : "memory");
 #endif
 #if !(UCNERF_BF16_EXP & 2)
     __builtin_amdgcn_s_barrier();
 #endif
 #if !(UCNERF_BF16_EXP & 4)
-    issue_dma(P, P.gpos);                                   // position gpos + NBUF into the slot of position gpos
+    issue_dma<NB>(P, P.gpos);                               // position gpos + NB into the slot of position gpos
 #endif
     ++P.gpos;
-    P.buf = P.ring + (P.gpos & (NBUF - 1)) * SLOT_BYTES;
+    P.buf = P.ring + (P.gpos & (NB - 1)) * SLOT_BYTES;
 }
 
 // scheduling hint for a half-step region: one MFMA, then up to `V` VALU, six times (LDS reads stay with their users)
@@ -419,9 +422,9 @@ __device__ __forceinline__ void interleave_hint() {
 // One half-step: (c0, c1) += A_hi*B_hi + A_hi*B_lo + A_lo*B_hi for one row-tile pair, with `fill()` -- element-wise work
 // that does not depend on these MFMAs -- issued between them.  ODD = second half-step of its ring slot (the next
 // fragments then come from the next slot).  `cur` holds this half-step's A fragments on entry, the next one's on exit.
-template <int TERMS, class F>
+template <int TERMS, int NB = NBUF, class F>
 __device__ __forceinline__ void half_step(const int ODD, Pipe& P, AF& cur, int lane, const Frag& b, f32x16& c0, f32x16& c1, F&& fill) {
-    if (ODD) advance(P);                                   // (a constant once the caller's loop is unrolled)
+    if (ODD) advance<NB>(P);                                   // (a constant once the caller's loop is unrolled)
     AF nxt;
 #if UCNERF_BF16_EXP & 256       // timing experiment: half the fragment reads (lo := hi, wrong results)
     if (false) {}
@@ -442,7 +445,7 @@ __device__ __forceinline__ void half_step(const int ODD, Pipe& P, AF& cur, int l
     SB0;
     cur = nxt;
 }
-#define HS(ODD, B, C0, C1, ...) half_step<TERMS>((ODD), P, cur, lane, (B), (C0), (C1), [&]() { __VA_ARGS__; })
+#define HS(ODD, B, C0, C1, ...) half_step<TERMS, NB>((ODD), P, cur, lane, (B), (C0), (C1), [&]() { __VA_ARGS__; })      // (NB: the kernel's ring depth)
 
 // bias block of section `sec` -> accumulators of one row-tile pair
 __device__ __forceinline__ void init_bias_pair(const float* cst, int sec, int h, int pair, f32x16 (&acc)[4]) {
@@ -552,7 +555,7 @@ struct FusedGather {
     const float* Ks;
     unsigned div_m, div_sh;
 };
-[[maybe_unused]] constexpr int FUSED_MAX_V = 6;    // the operand stash of the confidence-bias net has to fit beside ring, constants and encoding stash (160 KB of LDS)
+[[maybe_unused]] constexpr int FUSED_MAX_V = 8;    // (seven and eight views: with a two-slot weight ring, fused_ring_slots)
 constexpr int VIEW_TAB = 24;      // floats per source view in the LDS table: w2c (12), K (9), pad
 
 template <bool TILED, int NSRC, int TERMS, bool SAVE, bool FUSED = false>       // TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only); SAVE: training forward
@@ -561,9 +564,12 @@ template <bool TILED, int NSRC, int TERMS, bool SAVE, bool FUSED = false>       
 #endif
 __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(ucnerf_mlp_params p, BGeom g, int n_tiles, MlpSaved sv, FusedGather fg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // ONE shared object: [ring][constants][pe stash]
+    // ring depth: the operand stash of seven and eight source views (FUSED) takes the room of two ring slots; a two-slot ring was measured
+    // equal at full grids and 1.3 % slower on half-empty ones (profiles/r02_logs/r02_ring_two_slots.log)
+    constexpr int NB = fused_ring_slots(FUSED, NSRC);
     char* ring = smem;
-    float* cst = reinterpret_cast<float*>(smem + NBUF * SLOT_BYTES);
-    Frag* stash_all = reinterpret_cast<Frag*>(smem + NBUF * SLOT_BYTES + ((CONST_FLOATS * 4 + 15) & ~15));
+    float* cst = reinterpret_cast<float*>(smem + NB * SLOT_BYTES);
+    Frag* stash_all = reinterpret_cast<Frag*>(smem + NB * SLOT_BYTES + ((CONST_FLOATS * 4 + 15) & ~15));
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
     constexpr int KD_S = (24 + 4 * NSRC + 15) / 16, KC_S = (8 * NSRC + 15) / 16;
@@ -596,8 +602,8 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     P.ring = ring; P.ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring; P.buf = ring;
     P.wave = wave; P.gpos = 0; P.next_src = 0; P.slots = g.slots;
 #pragma unroll
-    for (int i = 0; i < NBUF; ++i) issue_dma(P, i);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * DMA_PER_SLOT) : "memory");     // slot 0 has landed ...
+    for (int i = 0; i < NB; ++i) issue_dma<NB>(P, i);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 1) * DMA_PER_SLOT) : "memory");       // slot 0 has landed ...
     __builtin_amdgcn_s_barrier();                                                        // ... for every wave
     AF cur = read_half(P.buf, lane, 0);                     // (TERMS 1 reads the unused lo halves once here)
 
@@ -809,8 +815,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         SB0;
         if (NP > 2) img_loads(2);
         SB0;
-#pragma unroll
-        for (int pr = 0; pr < NP; ++pr) {
+        auto view_consume = [&](int pr) {
             gf2 c0[2] = {{0, 0}, {0, 0}}, c1[2] = {{0, 0}, {0, 0}}, c2[2] = {{0, 0}, {0, 0}};      // (r g b f0) (f1..f4) (f5 f6 f7 -)
             const float wt[4] = {fi[pr].w00, fi[pr].w01, fi[pr].w10, fi[pr].w11};
 #pragma unroll
@@ -820,7 +825,13 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             f32x4* dst = reinterpret_cast<f32x4*>(bcst_of(pr));
             dst[0] = (f32x4){c0[1].y, c1[0].x, c1[0].y, c1[1].x};
             dst[1] = (f32x4){c1[1].y, c2[0].x, c2[0].y, c2[1].x};
-        }
+        };
+        view_consume(0);
+        SB0;
+        if (NP > 3) img_loads(3);                             // (seven and eight views: the fourth pair into the registers the first has just left)
+        SB0;
+#pragma unroll
+        for (int pr = 1; pr < NP; ++pr) view_consume(pr);
     };
     // point encoding -> fragments in LDS (layer 0 and the skip connection read them from there)
     auto encode_point = [&]() {
@@ -849,7 +860,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         const int tile = round * tiles_per_round + tile0;
 #if UCNERF_BF16_IDLE_SKIP
         if (tile >= n_tiles) {                               // (wave-uniform; every later tile of this wave is past the end too)
-            for (int i = 0; i < g.slots; ++i) advance(P);    // this wave's DMA pieces and barriers of one tile, nothing else
+            for (int i = 0; i < g.slots; ++i) advance<NB>(P);      // this wave's DMA pieces and barriers of one tile, nothing else
             cur = read_half(P.buf, lane, 0);
             continue;
         }
@@ -1179,11 +1190,14 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
-constexpr size_t bf16_smem_bytes() {
-    return (size_t)NBUF * SLOT_BYTES + ((CONST_FLOATS * 4 + 15) & ~15) + (size_t)BW * KS16_PE_PTS * 64 * sizeof(Frag) + (size_t)BW * 64 * sizeof(float);
+constexpr size_t bf16_smem_bytes(int ring_slots = NBUF) {
+    return (size_t)ring_slots * SLOT_BYTES + ((CONST_FLOATS * 4 + 15) & ~15) + (size_t)BW * KS16_PE_PTS * 64 * sizeof(Frag) + (size_t)BW * 64 * sizeof(float);
 }
 
-constexpr size_t bf16_smem_bytes_fused(int v) { return bf16_smem_bytes() + 8 * VIEW_TAB * sizeof(float) + (size_t)BW * ((8 * v + 15) / 16) * 64 * 8 * sizeof(float); }
+constexpr size_t bf16_smem_bytes_fused(int v) {
+    return bf16_smem_bytes(fused_ring_slots(true, v)) + 8 * VIEW_TAB * sizeof(float) + (size_t)BW * ((8 * v + 15) / 16) * 64 * 8 * sizeof(float);
+}
+static_assert(bf16_smem_bytes_fused(6) <= 160 * 1024 && bf16_smem_bytes_fused(8) <= 160 * 1024, "the fused kernel's LDS image must fit the CU");
 
 // `save` (TERMS = 3 only): the training forward -- the activation sets of MlpSaved are written for ucnerf_mlp_bwd (saved_valid = 1)
 static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st, const FusedGather* fuse = nullptr) {
@@ -1236,7 +1250,7 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
             if (int rc = ensure_dynamic_lds(fn, (int)smem_f, "mlp_fwd (bf16x3, gather fused)")) return rc;                    \
             hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, 3, false, true>), grid, block, smem_f, st, *p, g, n_tiles, sv, fg); \
         }
-        X(1) X(2) X(3) X(4) X(5) X(6)
+        UCNERF_BF16_FOR_ALL(X)
 #undef X
         return check_launch("mlp_fwd (bf16x3, gather fused)");
     }
