@@ -355,6 +355,9 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
     const int j = lane & 31, h = lane >> 5;
     const float* __restrict__ ws = p.wstream;
     const int n_waves = gridDim.x * MLP_WAVES;
+    // workgroups go to the eight XCDs round-robin: block b counts as logical block (b % 8) * (blocks / 8) + b / 8, so that consecutive tiles
+    // (pieces of one ray) stay behind one XCD's L2
+    const int lblock = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     float* stash = pe_stash[wave];
 
     for (int i = threadIdx.x; i < CONST_FLOATS; i += 64 * MLP_WAVES) cst[i] = ws[g.off_const + i];
@@ -380,7 +383,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
     // raw 3-vector of this lane's sample in the first tile; later tiles are prefetched one tile ahead
     float px[3] = {0.f, 0.f, 0.f};
     {
-        const int t0 = wave * (int)gridDim.x + (int)blockIdx.x;      // tiles are dealt wave-major (see the tile loop)
+        const int t0 = wave * (int)gridDim.x + lblock;               // tiles are dealt wave-major (see the tile loop)
         if (!ENC && t0 < n_tiles) {
             const int s0 = t0 * 32 + j < p.m ? t0 * 32 + j : p.m - 1;
             const float* prow = p.pts + (size_t)s0 * g.pts_stride;
@@ -393,7 +396,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
 #endif
     // Wave-major inside a round of n_waves tiles: a partly filled last round keeps the same number of waves busy in every block (one per
     // SIMD while it is at most half full) instead of running some blocks with two waves per SIMD and leaving others empty.
-    for (int tile = wave * (int)gridDim.x + (int)blockIdx.x; tile < n_tiles; tile += n_waves) {
+    for (int tile = wave * (int)gridDim.x + lblock; tile < n_tiles; tile += n_waves) {
 #ifdef UCNERF_MLP_DIAG
 #define DIAG_STAMP(K) { __builtin_amdgcn_sched_barrier(0); if (g.diag && lane == 0 && diag_k == 5) g.diag[(size_t)(blockIdx.x * MLP_WAVES + wave) * 16 + (K)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
 #else

@@ -616,7 +616,11 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
 #ifndef UCNERF_BF16_WAVE_MAJOR
 #define UCNERF_BF16_WAVE_MAJOR 1
 #endif
-    const int tile0 = UCNERF_BF16_WAVE_MAJOR ? wave * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * BW + wave;
+    // (workgroups go to the eight XCDs round-robin: block b counts as logical block (b % 8) * (blocks / 8) + b / 8, so that consecutive tiles --
+    //  the 32-sample pieces of one ray, which gather from the same corner of the sources -- stay behind one XCD's L2)
+    const int nb_ = (int)gridDim.x, bx_ = (int)blockIdx.x;
+    const int lblock = (nb_ & 7) == 0 ? (bx_ & 7) * (nb_ >> 3) + (bx_ >> 3) : bx_;
+    const int tile0 = UCNERF_BF16_WAVE_MAJOR ? wave * nb_ + lblock : bx_ * BW + wave;
 
     // Inputs of a tile are fetched one tile ahead (under the previous tile's head / blend arithmetic, when few registers
     // are live): operands of the depth-bias net (element e of step q = feature 16q + 8h + e; columns past a section's
