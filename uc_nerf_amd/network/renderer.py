@@ -101,7 +101,7 @@ def rendering(args, pose_ref, rays_pts, rays_ndc, depth_candidates, rays_dir, vo
     extras = tuple(kwargs.get("extras", ()))
     layout = None
     if (hasattr(network_fn, "forward_raw") and isinstance(network_fn, torch.nn.Module) and not args.use_color_volume
-            and None not in (volume_feature, imgs, img_feat, confidence)):
+            and volume_feature is not None and imgs is not None and img_feat is not None and confidence is not None):      # (`None in (tensors)` compares element-wise: 40 us)
         layout = dropin.query_layout(network_query_fn)
     if layout is not None:
         vols = [volume_feature["stage%d" % k]["volume_feature_no_ref"] for k in (1, 2, 3)]

@@ -30,7 +30,8 @@ def _ptr(t):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # (the raw handle of torch's current stream on the current device; torch.cuda.current_stream() builds a Stream object: ~5 us a call)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _mat(dst, src, rows, cols):
@@ -41,8 +42,29 @@ def _mat(dst, src, rows, cols):
             dst[r * cols + c] = float(m[r, c])
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(device):
+    """Context that makes `device` current for the library call inside: nothing at all when it already is (one process per GPU)."""
+    idx = device.index
+    return _NO_SWITCH if idx is None or idx == torch._C._cuda_getDevice() else torch.cuda.device(device)
+
+
 def _launch(name, params, device):
-    with torch.cuda.device(device):
+    idx = device.index if device.index is not None else torch._C._cuda_getDevice()
+    if idx == torch._C._cuda_getDevice():                 # the usual case (one process per GPU): no device switch, no context manager
+        L.call(name, params, torch._C._cuda_getCurrentRawStream(idx))
+        return
+    with _on(device):
         L.call(name, params, _stream())
 
 
@@ -106,7 +128,7 @@ class RaySampler:
         if perturb > 0:
             noise = _f32(noise if noise is not None else torch.rand(n, ss.S, device=device), "noise")
         ss.noise = _ptr(noise if perturb > 0 else None)
-        with torch.cuda.device(device):
+        with _on(device):
             L.check(L.lib().ucnerf_ray_gen_sample(C.addressof(rg), C.addressof(ss), _stream()), "ucnerf_ray_gen_sample")
         return rays_d, angle, z
 
@@ -414,13 +436,13 @@ class PackedWeights:
             raise RuntimeError("uc_nerf_amd: flat parameter vector has %d floats, expected %d"
                                % (flat.numel(), self.n_params))
         out = torch.empty(self.n_stream, device=flat.device)
-        with torch.cuda.device(flat.device):
+        with _on(flat.device):
             L.check(L.lib().ucnerf_mlp_pack(C.addressof(self.cfg), _ptr(flat), _ptr(self.idx), _ptr(out), _stream()), "ucnerf_mlp_pack")
         return out
 
     def unpack_grad(self, g_stream):
         g_flat = torch.zeros(self.n_params, device=g_stream.device)
-        with torch.cuda.device(g_stream.device):
+        with _on(g_stream.device):
             L.check(L.lib().ucnerf_mlp_unpack_grad(_ptr(g_stream), _ptr(self.idx), _ptr(g_flat), self.n_stream, _stream()),
                     "ucnerf_mlp_unpack_grad")
         return g_flat
@@ -832,7 +854,7 @@ class RenderPass:
         if fresh:
             src._cl = torch.empty(n, device=src.device)
         if fresh or force:
-            with torch.cuda.device(src.device):
+            with _on(src.device):
                 L.check(L.lib().ucnerf_gather_repack(C.addressof(self.p), _ptr(src._cl), _stream()), "ucnerf_gather_repack")
         self.p.sources_cl = _ptr(src._cl)
         self.use_cl = True
