@@ -29,9 +29,14 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+# the raw handle of torch's current stream / the current device index: torch.cuda.current_stream() builds a Stream object (~5 us a call);
+# the public calls are the fallback where a torch build lacks the two private ones
+_cur_dev = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+
+
 def _stream():
-    # (the raw handle of torch's current stream on the current device; torch.cuda.current_stream() builds a Stream object: ~5 us a call)
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    return _raw_stream(_cur_dev())
 
 
 def _mat(dst, src, rows, cols):
@@ -56,15 +61,11 @@ _NO_SWITCH = _NoSwitch()
 def _on(device):
     """Context that makes `device` current for the library call inside: nothing at all when it already is (one process per GPU)."""
     idx = device.index
-    return _NO_SWITCH if idx is None or idx == torch._C._cuda_getDevice() else torch.cuda.device(device)
+    return _NO_SWITCH if idx is None or idx == _cur_dev() else torch.cuda.device(device)
 
 
 def _launch(name, params, device):
-    idx = device.index if device.index is not None else torch._C._cuda_getDevice()
-    if idx == torch._C._cuda_getDevice():                 # the usual case (one process per GPU): no device switch, no context manager
-        L.call(name, params, torch._C._cuda_getCurrentRawStream(idx))
-        return
-    with _on(device):
+    with _on(device):                                     # (no switch, no context manager when the device is current: one process per GPU)
         L.call(name, params, _stream())
 
 
