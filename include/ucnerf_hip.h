@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UCNERF_ABI_VERSION 2
+#define UCNERF_ABI_VERSION 3
 
 #define UCNERF_OK 0
 #define UCNERF_EINVAL (-1)   /* bad argument (null pointer, unsupported size/config) */
@@ -37,6 +37,10 @@ int ucnerf_abi_version(void);
 int ucnerf_sizeof(const char* struct_name);
 /* Number of compute units of the current device (grid sizing for persistent kernels); <0 on error. */
 int ucnerf_device_cus(void);
+/* The compile-time switches this binary was built with, as "NAME=value NAME=value ..." (experiment / variant macros of the kernels:
+ * UCNERF_BF16_EXP, UCNERF_TN_EXP, UCNERF_GATHER_EXP, UCNERF_BF16_NO_PK, UCNERF_BF16_BW, UCNERF_BF16_NBUF, ...).  A production build
+ * reports every experiment switch as 0; the host side refuses to load a library that does not (tests/test_abi_host.py). */
+const char* ucnerf_build_flags(void);
 /* HIP timing events for measuring kernels inside a call chain (bench harness): create / record on a stream /
  * elapsed milliseconds between two recorded events (waits for `stop`) / destroy. */
 void* ucnerf_event_create(void);
@@ -270,8 +274,8 @@ typedef struct {
 } ucnerf_mlp_params;
 int ucnerf_mlp_fwd(const ucnerf_mlp_params* p, void* stream);
 
-/* Backward (autograd of network/models.py:138-184): re-runs the forward keeping the per-layer activations, then
- * walks the layers backwards with fp32-MFMA GEMMs.  Produces d(feats) and ACCUMULATES the parameter gradients
+/* Backward (autograd of network/models.py:138-184): re-runs the forward keeping the per-layer activations (unless
+ * saved_valid), then walks the layers backwards (bwd_mode).  Produces d(feats) and ACCUMULATES the parameter gradients
  * into g_flat, a vector laid out exactly like the flat parameter vector (zero it first).  The three parameter
  * sets the reference never uses (pts_bias_confidence_1, feature_linear_1, confi_linear) get no contribution.
  * Positions and view directions receive no gradient (the reference path is non-differentiable there). */
@@ -285,6 +289,9 @@ typedef struct {
     float* workspace;          /* scratch, ucnerf_mlp_bwd_workspace_floats() floats, 16-byte aligned */
     int32_t saved_valid;       /* 1: `workspace` already holds the activations of THIS forward, written by
                                   ucnerf_mlp_fwd_train with the same arguments -- the backward then skips its own forward */
+    int32_t bwd_mode;          /* 0: register-resident gradient chain (ONE kernel walks the network backwards per 32-sample tile, data
+                                  gradients as split-bf16 products on the matrix cores, fp32 accumulate: 2^-16 relative) + one
+                                  weight-gradient GEMM per layer;  1: layer-by-layer exact-fp32 data-gradient GEMMs (round 1/2 path) */
 } ucnerf_mlp_bwd_params;
 int64_t ucnerf_mlp_bwd_workspace_floats(const ucnerf_mlp_config* cfg, int32_t m);
 int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* p, void* stream);
@@ -507,6 +514,7 @@ typedef struct {
     float* gather_scratch;         /* optional: ucnerf_feat_gather_bwd_params.scratch for the gather backward */
     int32_t saved_valid;           /* 1: the forward call was given this `workspace` as fwd.train_workspace (it kept the
                                       MLP activations there), so the backward does not repeat the network forward */
+    int32_t bwd_mode;              /* ucnerf_mlp_bwd_params.bwd_mode */
 } ucnerf_render_bwd_params;
 int64_t ucnerf_render_bwd_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* p, void* stream);

@@ -36,6 +36,22 @@ def test_every_declared_symbol_is_exported_and_bound(L):
     assert L.lib().ucnerf_sizeof(b"nope") == -1
 
 
+# switches that select between CORRECT variants, with the value a production build carries; everything else (…_EXP, …_DIAG_ON, NO_PK, SPLIT_DOT,
+# FOOT_UNDER_GEMM, GATHER_RUN) is an experiment and must read 0
+PRODUCTION_FLAGS = {"UCNERF_BF16_BW": "8", "UCNERF_BF16_NBUF": "4", "UCNERF_BF16_WPS": "2", "UCNERF_BF16_HINT_V": "5", "UCNERF_BF16_IDLE_SKIP": "1",
+                    "UCNERF_BF16_WAVE_MAJOR": "1", "UCNERF_MLP_WAVES": "8", "UCNERF_MLP_PRIO": "3", "UCNERF_MLP_RING": "4", "UCNERF_TN_BF16X3": "1",
+                    "UCNERF_TN_DEPTH2": "2", "UCNERF_GATHER_WAVES": "1"}
+
+
+def test_library_was_built_with_production_switches(L):
+    """ucnerf_build_flags() names every compile-time switch of the kernels: no wrong-result experiment may be live in the shipped binary."""
+    flags = L.lib().ucnerf_build_flags().decode()
+    pairs = re.findall(r"(UCNERF_[A-Z0-9_]+)=(\S+)", flags)
+    assert len(pairs) >= 35 and {"mlp_bf16x3", "mlp_bf16_plain", "mlp_f32", "mlp_bwd", "gather_cl"} <= set(re.findall(r"(\w+):", flags)), flags
+    for name, value in pairs:
+        assert value == PRODUCTION_FLAGS.get(name, "0"), "%s=%s in the shipped library (%s)" % (name, value, flags)
+
+
 def test_argument_validation_reports_instead_of_launching(L):
     lib = L.lib()
     assert lib.ucnerf_ray_gen(None, None) == -1 and b"null params" in lib.ucnerf_last_error()

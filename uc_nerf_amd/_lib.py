@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UCNERF_LIB") or os.path.join(_HERE, "libucnerf_hip.so")   # override: A/B builds
 
-ABI_VERSION = 2    # UCNERF_ABI_VERSION of include/ucnerf_hip.h this binding mirrors
+ABI_VERSION = 3    # UCNERF_ABI_VERSION of include/ucnerf_hip.h this binding mirrors
 
 fp = C.POINTER(C.c_float)
 i32 = C.c_int32
@@ -77,7 +77,7 @@ class MlpParams(C.Structure):
 
 class MlpBwdParams(C.Structure):
     _fields_ = [("fwd", MlpParams), ("g_raw", vp), ("flat_params", vp), ("g_feats", vp), ("g_feat_stride", i32),
-                ("g_flat", vp), ("workspace", vp), ("saved_valid", i32)]
+                ("g_flat", vp), ("workspace", vp), ("saved_valid", i32), ("bwd_mode", i32)]
 
 
 class CompositeParams(C.Structure):
@@ -134,7 +134,7 @@ class RenderParams(C.Structure):
 class RenderBwdParams(C.Structure):
     _fields_ = [("fwd", RenderParams), ("g_rgb", vp), ("g_depth", vp), ("flat_params", vp), ("g_flat", vp),
                 ("g_vol", vp * 3), ("g_conf", vp), ("g_img_feat", vp), ("workspace", vp), ("gather_scratch", vp),
-                ("saved_valid", i32)]
+                ("saved_valid", i32), ("bwd_mode", i32)]
 
 
 STRUCTS = {
@@ -158,6 +158,7 @@ SYMBOLS = {
     "ucnerf_abi_version": (C.c_int, []),
     "ucnerf_sizeof": (C.c_int, [C.c_char_p]),
     "ucnerf_device_cus": (C.c_int, []),
+    "ucnerf_build_flags": (C.c_char_p, []),
     "ucnerf_event_create": (C.c_void_p, []),
     "ucnerf_event_record": (C.c_int, [_P, _P]),
     "ucnerf_event_elapsed_ms": (C.c_int, [_P, _P, _P]),

@@ -36,6 +36,16 @@ struct Mat33 { float m[9]; };
 
 int device_cus();   // of the CURRENT device, cached per device (thread-safe)
 
+// ucnerf_build_flags(): every translation unit with compile-time switches reports them as "NAME=value " (stringified after expansion)
+#define UCNERF_STR2(x) #x
+#define UCNERF_STR(x) UCNERF_STR2(x)
+#define UCNERF_FLAG(NAME) #NAME "=" UCNERF_STR(NAME) " "
+const char* build_flags_mlp_bf16x3();
+const char* build_flags_mlp_bf16_plain();
+const char* build_flags_mlp_bwd();
+const char* build_flags_gather_cl();
+const char* build_flags_mlp_f32();
+
 // Opt-in for more than 64 KB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize).  The attribute belongs to the
 // (device, function) pair, so it is set once per pair -- keyed on hipGetDevice(), under a lock -- and a failure is
 // reported through fail().  Returns UCNERF_OK or UCNERF_EHIP.

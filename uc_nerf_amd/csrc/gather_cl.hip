@@ -351,4 +351,6 @@ int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float
     return check_launch("feat_gather_cl");
 }
 
+const char* build_flags_gather_cl() { return "gather_cl: " UCNERF_FLAG(UCNERF_GATHER_EXP) UCNERF_FLAG(UCNERF_GATHER_RUN) UCNERF_FLAG(UCNERF_GATHER_WAVES); }
+
 }  // namespace ucnerf

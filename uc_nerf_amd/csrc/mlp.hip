@@ -601,6 +601,13 @@ int launch_pack_bf16(const ucnerf_mlp_config* cfg, const float* flat, const int3
 int launch_mlp_fwd_bf16x3(const ucnerf_mlp_params* p, hipStream_t st);      // mlp_bf16.hip built with TERMS = 3
 int launch_mlp_fwd_bf16_plain(const ucnerf_mlp_params* p, hipStream_t st);   // ... and with TERMS = 1
 
+#ifdef UCNERF_MLP_DIAG
+#define UCNERF_MLP_DIAG_ON 1
+#else
+#define UCNERF_MLP_DIAG_ON 0
+#endif
+const char* build_flags_mlp_f32() { return "mlp_f32: " UCNERF_FLAG(UCNERF_MLP_WAVES) UCNERF_FLAG(UCNERF_MLP_PRIO) UCNERF_FLAG(UCNERF_MLP_RING) UCNERF_FLAG(UCNERF_MLP_DIAG_ON); }
+
 }  // namespace ucnerf
 
 using namespace ucnerf;

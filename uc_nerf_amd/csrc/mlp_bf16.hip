@@ -1287,6 +1287,20 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
     return check_launch("mlp_fwd_bf16");
 }
 
+#ifdef UCNERF_MLP_DIAG
+#define UCNERF_MLP_DIAG_ON 1
+#else
+#define UCNERF_MLP_DIAG_ON 0
+#endif
+#define UCNERF_BF16_FLAGS UCNERF_FLAG(UCNERF_BF16_EXP) UCNERF_FLAG(UCNERF_BF16_NO_PK) UCNERF_FLAG(UCNERF_BF16_SPLIT_DOT) UCNERF_FLAG(UCNERF_BF16_BW) \
+    UCNERF_FLAG(UCNERF_BF16_NBUF) UCNERF_FLAG(UCNERF_BF16_WPS) UCNERF_FLAG(UCNERF_BF16_HINT_V) UCNERF_FLAG(UCNERF_BF16_PRIO_VALU) UCNERF_FLAG(UCNERF_BF16_PRIO_GEMM) \
+    UCNERF_FLAG(UCNERF_BF16_IDLE_SKIP) UCNERF_FLAG(UCNERF_BF16_WAVE_MAJOR) UCNERF_FLAG(UCNERF_FUSED_FOOT_UNDER_GEMM) UCNERF_FLAG(UCNERF_GATHER_EXP) UCNERF_FLAG(UCNERF_MLP_DIAG_ON)
+#if UCNERF_BF16_BUILD_TERMS == 3
+const char* build_flags_mlp_bf16x3() { return "mlp_bf16x3: " UCNERF_BF16_FLAGS; }
+#else
+const char* build_flags_mlp_bf16_plain() { return "mlp_bf16_plain: " UCNERF_BF16_FLAGS; }
+#endif
+
 #if UCNERF_BF16_BUILD_TERMS == 3
 int launch_mlp_fwd_bf16x3(const ucnerf_mlp_params* p, hipStream_t st) { return launch_bf16(p, nullptr, st); }
 int launch_mlp_fwd_bf16x3_save(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st) { return launch_bf16(p, save, st); }

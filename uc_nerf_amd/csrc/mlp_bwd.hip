@@ -20,6 +20,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st);
 int launch_mlp_fwd_bf16x3_save(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st);      // mlp_bf16.hip
+// mlp_bwd_chain.hip: the data-gradient half of the backward as one register-resident kernel (bwd_mode 0)
+size_t bwd_chain_stream_floats();
+int launch_pack_bwd(int n_src, const float* flat, float* stream_out, hipStream_t st);
+int launch_mlp_bwd_chain(int n_src, int m, const float* raw, const float* g_raw, const float* feats, int ldf, const MlpSaved* sv, const float* stream,
+                         float* G_vc, float* G_f, float* G_bc, float* gx, float* G_bd, float* const* G_y, float* g_feats, int ldgf, float* g_base,
+                         float* g_adapt, hipStream_t st);
 
 // 4 consecutive parameters (parameter tensors are only 4-byte aligned inside the flat vector)
 __device__ __forceinline__ f32x4 ld4(const float* p) { return f32x4{p[0], p[1], p[2], p[3]}; }
@@ -536,6 +542,84 @@ __global__ void __launch_bounds__(32 * HEAD_SLOTS) head_bwd_kernel(HeadArgs a) {
     }
 }
 
+// Parameter gradients of the four head layers alone (bwd_mode 0: the gradient chain has already written g_base / g_adapt):
+// head_bwd_kernel's register accumulation -- every lane keeps the 4 x 4 products of its four features with the head gradients
+// over its samples, block sums through LDS, one atomic per weight and block.
+struct HeadWArgs {
+    int m;
+    const float* g_base; const float* g_adapt;       // [m,4]
+    const float* h5; const float* vc;                 // [m,128]
+    float *gw_crgb, *gw_a1, *gw_rgb, *gw_a, *gb_crgb, *gb_a1, *gb_rgb, *gb_a;
+};
+__global__ void __launch_bounds__(32 * HEAD_SLOTS) head_wgrad_kernel(HeadWArgs a) {
+    __shared__ float red[HEAD_SLOTS][32][33];
+    __shared__ float redb[HEAD_SLOTS][8];
+    const int slot = threadIdx.x >> 5, c = threadIdx.x & 31;
+    float accb[4][4], acca[4][4], bsum[8];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) accb[o][k] = acca[o][k] = 0.f;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) bsum[o] = 0.f;
+    struct In { f32x4 hv, vv, gb, ga; };
+    auto fetch = [&](int s) {
+        In x;
+        const int sc = s < a.m ? s : a.m - 1;
+        x.hv = reinterpret_cast<const f32x4*>(a.h5 + (size_t)sc * 128)[c];
+        x.vv = reinterpret_cast<const f32x4*>(a.vc + (size_t)sc * 128)[c];
+        x.gb = reinterpret_cast<const f32x4*>(a.g_base)[sc];
+        x.ga = reinterpret_cast<const f32x4*>(a.g_adapt)[sc];
+        return x;
+    };
+    const int stride = gridDim.x * HEAD_SLOTS;
+    In nxt = fetch(blockIdx.x * HEAD_SLOTS + slot);
+    for (int s = blockIdx.x * HEAD_SLOTS + slot; s < a.m; s += stride) {
+        const In cur = nxt;
+        nxt = fetch(s + stride);
+        const float gb4[4] = {cur.gb.x, cur.gb.y, cur.gb.z, cur.gb.w}, ga4[4] = {cur.ga.x, cur.ga.y, cur.ga.z, cur.ga.w};
+        const float hvv[4] = {cur.hv.x, cur.hv.y, cur.hv.z, cur.hv.w}, vvv[4] = {cur.vv.x, cur.vv.y, cur.vv.z, cur.vv.w};
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { accb[o][k] += gb4[o] * hvv[k]; acca[o][k] += ga4[o] * vvv[k]; }
+        if (c == 0) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) { bsum[o] += gb4[o]; bsum[4 + o] += ga4[o]; }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[slot][c][4 * o + k] = accb[o][k]; red[slot][c][16 + 4 * o + k] = acca[o][k]; }
+    if (c == 0) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) redb[slot][o] = bsum[o];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 1024 / (32 * HEAD_SLOTS); ++q) {
+        const int e = threadIdx.x + 32 * HEAD_SLOTS * q;
+        const int cc = e >> 5, i = e & 31, o = (i & 15) >> 2, k = i & 3;
+        float v = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < HEAD_SLOTS; ++sl) v += red[sl][cc][i];
+        float* dst = nullptr;
+        if (i < 16) dst = o < 3 ? a.gw_crgb + o * 128 + 4 * cc + k : a.gw_a1 + 4 * cc + k;
+        else if (cc < 16) { if (o < 3) dst = a.gw_rgb + o * 64 + 4 * cc + k; }
+        else if (o == 3) dst = a.gw_a + 4 * (cc - 16) + k;
+        if (dst) atomicAdd(dst, v);
+    }
+    if (threadIdx.x < 8) {
+        float v = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < HEAD_SLOTS; ++sl) v += redb[sl][threadIdx.x];
+        const int o = threadIdx.x & 3;
+        float* dst = threadIdx.x < 4 ? (o < 3 ? a.gb_crgb + o : a.gb_a1) : (o < 3 ? a.gb_rgb + o : a.gb_a);
+        atomicAdd(dst, v);
+    }
+}
+
 // after feature_linear, down to the trunk's top layer in one pass over the activations (models.py:158-165 and the layer-5
 // relu / modulation backwards):  g_bc = g_g * h5;  g_h5 = g_g * bc + W_basehead^T g_base;  g_pre = g_h5 * [h5 > 0];
 // g_y = g_pre * bd (written over g_g in place);  g_bd = g_pre * (h5 / bd);  also gx = h5 * bc for feature_linear's weights
@@ -581,6 +665,8 @@ __global__ void __launch_bounds__(256) trunk_top_bwd_kernel(TopArgs a) {
 struct BwdWork {
     MlpSaved sv;
     float *pep, *ped, *g1, *g2, *g3, *gbd, *gx, *g_base, *g_adapt, *raw;
+    float* gy[6];           // bwd_mode 0: g_y of the six trunk layers (operands of their weight-gradient GEMMs)
+    float* wstream_bwd;     // bwd_mode 0: transposed weights as split-bf16 fragments + head table (mlp_bwd_chain.hip)
 };
 
 static size_t carve_bwd(float* base, int m, int n_dirs, BwdWork* w) {
@@ -593,6 +679,8 @@ static size_t carve_bwd(float* base, int m, int n_dirs, BwdWork* w) {
     w->pep = take(M * 63); w->ped = take((size_t)n_dirs * 27);
     w->g1 = take(M * 128); w->g2 = take(M * 128); w->g3 = take(M * 128); w->gbd = take(M * 128); w->gx = take(M * 128);
     w->g_base = take(M * 4); w->g_adapt = take(M * 4); w->raw = take(M * 4);
+    for (int l = 0; l < 6; ++l) w->gy[l] = take(M * 128);
+    w->wstream_bwd = take(bwd_chain_stream_floats());
     return o;
 }
 
@@ -650,6 +738,8 @@ static int run_tn(hipStream_t st, int m, const float* G, int ldg, int Nout, cons
 }
 
 #define RUN(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+const char* build_flags_mlp_bwd() { return "mlp_bwd: " UCNERF_FLAG(UCNERF_TN_EXP) UCNERF_FLAG(UCNERF_TN_BF16X3) UCNERF_FLAG(UCNERF_TN_DEPTH2); }
 
 }  // namespace ucnerf
 
@@ -729,6 +819,38 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
         RUN(ucnerf_embed(&e, st));
     }
 
+    const int KV = MLP_W + MLP_PE_DIR;
+    UCNERF_REQUIRE(bp->bwd_mode == 0 || bp->bwd_mode == 1, "mlp_bwd: bwd_mode %d", bp->bwd_mode);
+    if (bp->bwd_mode == 0) {
+        // A. every data gradient in ONE launch (mlp_bwd_chain.hip): g stays in registers from the output stage to the two bias nets;
+        //    written: the G operands of the weight-gradient GEMMs below, g_feats, g_base / g_adapt
+        RUN(launch_pack_bwd(v, P, w.wstream_bwd, st));
+        RUN(launch_mlp_bwd_chain(v, m, w.raw, bp->g_raw, f.feats, ldf, &w.sv, w.wstream_bwd, w.g1, w.g2, w.g3, w.gx, w.gbd, w.gy, bp->g_feats, ldgf,
+                                 w.g_base, w.g_adapt, st));
+        // B. parameter gradients: the four head layers, then one GEMM per (g, input) pair
+        HeadWArgs hw;
+        hw.m = m; hw.g_base = w.g_base; hw.g_adapt = w.g_adapt; hw.h5 = w.sv.h[5]; hw.vc = w.sv.vc;
+        hw.gw_crgb = G + L.p_crw; hw.gw_a1 = G + L.p_a1w; hw.gw_rgb = G + L.p_rw; hw.gw_a = G + L.p_aw;
+        hw.gb_crgb = G + L.p_crb; hw.gb_a1 = G + L.p_a1b; hw.gb_rgb = G + L.p_rb; hw.gb_a = G + L.p_ab;
+        {
+            int blocks = cdiv(m, HEAD_SLOTS);
+            if (blocks > device_cus()) blocks = device_cus();
+            hipLaunchKernelGGL(head_wgrad_kernel, dim3(blocks), dim3(32 * HEAD_SLOTS), 0, st, hw);
+        }
+        RUN(check_launch("mlp_bwd head_wgrad"));
+        RUN(run_tn(st, m, w.g1, 128, 128, w.sv.ft, 128, 1, 128, G + L.p_vw, KV, G + L.p_vb, G + L.p_vcw, G + L.p_vcb));
+        RUN(run_tn(st, m, w.g1, 128, 128, ped, ld_ped, xdiv_dir, 27, G + L.p_vw + 128, KV, nullptr, G + L.p_vcw + 128, nullptr));
+        RUN(run_tn(st, m, w.g2, 128, 128, w.gx, 128, 1, 128, G + L.p_fw, 128, G + L.p_fb));
+        RUN(run_tn(st, m, w.g3, 128, 128, f.feats + n_mvs, ldf, 1, n_img, G + L.p_bcw, n_img, G + L.p_bcb));
+        RUN(run_tn(st, m, w.gy[5], 128, 128, pep, ld_pep, 1, 63, G + L.p_lw[5], 191, G + L.p_lb[5]));
+        RUN(run_tn(st, m, w.gy[5], 128, 128, w.sv.h[4], 128, 1, 128, G + L.p_lw[5] + 63, 191, nullptr));
+        for (int l = 4; l >= 1; --l) RUN(run_tn(st, m, w.gy[l], 128, 128, w.sv.h[l - 1], 128, 1, 128, G + L.p_lw[l], 128, G + L.p_lb[l]));
+        RUN(run_tn(st, m, w.gy[0], 128, 128, pep, ld_pep, 1, 63, G + L.p_lw[0], 63, G + L.p_lb[0]));
+        RUN(run_tn(st, m, w.gbd, 128, 128, f.feats, ldf, 1, n_mvs, G + L.p_bdw, n_mvs, G + L.p_bdb));
+        return UCNERF_OK;
+    }
+
+    // bwd_mode 1: layer by layer, exact-fp32 data-gradient GEMMs
     // 1. output stage + heads: g_base, g_adapt, d/d(confidence), g_vc -> g1, and the four head layers' parameter gradients
     HeadArgs ha;
     ha.m = m; ha.F = F; ha.raw = w.raw; ha.g_raw = bp->g_raw; ha.feats = f.feats; ha.ldf = ldf; ha.h5 = w.sv.h[5]; ha.vc = w.sv.vc;
@@ -745,7 +867,6 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     RUN(check_launch("mlp_bwd head"));
 
     // 2. views_linears / view_confi_linears: weights [64,155] on [f | dir encoding]; g_f -> g2
-    const int KV = MLP_W + MLP_PE_DIR;
     //    (g1 = [g_views | g_view_confi]: one 128-row product per operand, rows 64.. go to the second layer)
     RUN(run_tn(st, m, w.g1, 128, 128, w.sv.ft, 128, 1, 128, G + L.p_vw, KV, G + L.p_vb, G + L.p_vcw, G + L.p_vcb));
     RUN(run_tn(st, m, w.g1, 128, 128, ped, ld_ped, xdiv_dir, 27, G + L.p_vw + 128, KV, nullptr, G + L.p_vcw + 128, nullptr));

@@ -1,0 +1,486 @@
+// K6 backward, data-gradient half: ONE persistent kernel walks the whole network backwards for a 32-sample tile with the
+// gradient kept in accumulator registers from the output stage down to the two bias nets (autograd of network/models.py:138-184).
+//
+// It replaces head_bwd + 7 gemm_nn launches + trunk_top_bwd of the layer-by-layer backward (mlp_bwd.hip): those streamed g, h, b_d
+// and g_bd through HBM once per layer (read-modify-write), 2 GB per 131 k samples.  Here a tile's gradient lives where the
+// forward's activations live (mlp_bf16.hip): transposed, lane = sample, accumulator register r of row tile kt on lane half h =
+// feature 32 kt + (r & 3) + 8 (r >> 2) + 4 h, so
+//     G_in^T[k][sample] = W^T[k][n] * G_out^T[n][sample]
+// takes W^T as the A operand (packed stream of bf16 (hi, lo) fragments, L2-resident) and the previous layer's accumulators,
+// re-split into (hi, lo), as the B operand: three v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate (the forward's bf16x3
+// scheme, 2^-16 relative).  Per layer the kernel reads the kept activation it needs for the relu mask and the b_d product (h_{l-1},
+// once) and writes g_y (once) for the weight-gradient GEMMs: nothing else touches HBM.
+//
+// The kernel is bound by those reads and writes (~10 KB per sample against ~750 MFMAs per tile), not by the matrix pipe, so it is
+// built for memory-level parallelism and simplicity rather than for MFMA issue rate: one wave per SIMD with 512 registers (the
+// resident state is b_d, the g_bd sum, the accumulators, the B fragments and one prefetched activation set), every wave independent
+// (no barrier, no LDS ring: the 512-KB weight stream is read straight from L2 / L1 two half-steps ahead), tiles dealt round-robin.
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace ucnerf {
+
+typedef float c_f32x16 __attribute__((ext_vector_type(16)));
+typedef float c_f32x4 __attribute__((ext_vector_type(4)));
+typedef float c_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 c_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned c_u32x4 __attribute__((ext_vector_type(4)));
+#define CSB __builtin_amdgcn_sched_barrier(0)
+#define CMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+constexpr int BWD_HALF_STEPS = 128;            // VC 16 | FT 16 | BC 8 | L5 16 | L4 16 | L3 16 | L2 16 | L1 16 | BD 8
+constexpr int BWD_HALF_BYTES = 4096;           // [t 0..1][hi, lo][64 lanes][8 bf16]
+constexpr int BWD_HEAD_FLOATS = 8 * 128 + 8;   // head table [o][feature] (base rgb x3, base sigma, adapt rgb x3, adapt sigma) + 8 biases
+
+// one transposed layer of the stream: rows = input features of the layer (padded to 32 * 2 * pairs), contraction over its outputs
+struct BwdSec { int hs0, pairs, ld, col0, rows; long long base, base_hi; };
+struct BwdPackArgs {
+    BwdSec sec[9];
+    const float* flat;
+    unsigned short* out;           // [128][2048] bf16
+    float* head;                   // [BWD_HEAD_FLOATS]
+    long long p_crw, p_a1w, p_rw, p_aw, p_crb, p_a1b, p_rb, p_ab;
+};
+
+// feature held by element j of lane-half hh in k16-step q = (kt, s): accumulator register 8 s + j of row tile kt (as mlp_bf16.hip)
+__host__ __device__ inline int c_hid_feature16(int kt, int s, int j, int hh) { return 32 * kt + (j & 3) + 8 * (2 * s + (j >> 2)) + 4 * hh; }
+
+// Thread = one 16-byte fragment of the stream.  A[row][n] = W[n][col0 + row]: lane l supplies row 32 (2 pair + t) + (l & 31),
+// its eight elements the outputs n the B operand holds in that k16-step.
+__global__ void __launch_bounds__(256) pack_bwd_kernel(BwdPackArgs a) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f < BWD_HALF_STEPS * 256) {
+        const int hs = f >> 8, t = (f >> 7) & 1, part = (f >> 6) & 1, lane = f & 63;
+        int si = 0;
+#pragma unroll
+        for (int i = 1; i < 9; ++i) si = hs >= a.sec[i].hs0 ? i : si;
+        const BwdSec sc = a.sec[si];
+        const int lhs = hs - sc.hs0, pair = lhs >> 3, q = lhs & 7;
+        const int row = 32 * (2 * pair + t) + (lane & 31);
+        unsigned short v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = c_hid_feature16(q >> 1, q & 1, e, lane >> 5);
+            float w = 0.f;
+            if (row < sc.rows) w = (sc.base_hi >= 0 && n >= 64) ? a.flat[sc.base_hi + (long long)(n - 64) * sc.ld + sc.col0 + row] : a.flat[sc.base + (long long)n * sc.ld + sc.col0 + row];
+            const __bf16 hi = (__bf16)w;
+            const __bf16 val = part ? (__bf16)(w - (float)hi) : hi;
+            v[e] = __builtin_bit_cast(unsigned short, val);
+        }
+        c_u32x4 o = {v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16), v[6] | ((unsigned)v[7] << 16)};
+        reinterpret_cast<c_u32x4*>(a.out)[f] = o;
+    }
+    if (f < BWD_HEAD_FLOATS) {
+        float w = 0.f;
+        if (f < 1024) {
+            const int o = f >> 7, k = f & 127;
+            if (o < 3) w = a.flat[a.p_crw + o * 128 + k];
+            else if (o == 3) w = a.flat[a.p_a1w + k];
+            else if (o < 7) w = k < 64 ? a.flat[a.p_rw + (o - 4) * 64 + k] : 0.f;       // rgb_linear reads the views half of vc
+            else w = k >= 64 ? a.flat[a.p_aw + k - 64] : 0.f;                           // alpha_linear the view_confi half
+        } else {
+            const int o = f - 1024;
+            w = o < 3 ? a.flat[a.p_crb + o] : o == 3 ? a.flat[a.p_a1b] : o < 7 ? a.flat[a.p_rb + o - 4] : a.flat[a.p_ab];
+        }
+        a.head[f] = w;
+    }
+}
+
+struct ChainArgs {
+    int m, n_tiles, F, ldf, ldgf, n_mvs, n_img;
+    const float* raw;              // [m,4] forward output
+    const float* g_raw;            // [m,4]
+    const float* feats;            // conf = feats[s * ldf + F - 1]
+    MlpSaved sv;
+    const char* wstream;           // pack_bwd_kernel's stream
+    const float* head;             // ... and head table
+    float* G_vc; float* G_f; float* G_bc; float* gx; float* G_bd; float* G_y[6];      // [m,128] each: operands of the weight-gradient GEMMs
+    float* g_feats;                // [m, ldgf]
+    float* g_base; float* g_adapt; // [m,4]
+};
+
+__device__ __forceinline__ int c_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// a result that is only needed at the end of the tile would be SUNK there, its operands kept alive (spilled) meanwhile: pin it where it is written
+__device__ __forceinline__ void c_pin(float& v) { asm volatile("" : "+v"(v)); }
+
+struct CFrag { c_bf16x8 hi, lo; };
+struct CAF { c_bf16x8 h0, l0, h1, l1; };
+
+// (hi, lo) split of eight values: hi = truncated bf16, lo = bf16_rne(x - hi) (mlp_bf16.hip's split8)
+__device__ __forceinline__ CFrag c_split8(const float (&x)[8]) {
+    c_u32x4 hi;
+    CFrag f;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const unsigned b0 = __builtin_bit_cast(unsigned, x[j]), b1 = __builtin_bit_cast(unsigned, x[j + 1]);
+        hi[j >> 1] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+        const c_f32x2 l = (c_f32x2){x[j], x[j + 1]} - (c_f32x2){__builtin_bit_cast(float, b0 & 0xffff0000u), __builtin_bit_cast(float, b1 & 0xffff0000u)};
+        f.lo[j] = (__bf16)l.x;
+        f.lo[j + 1] = (__bf16)l.y;
+    }
+    f.hi = __builtin_bit_cast(c_bf16x8, hi);
+    return f;
+}
+__device__ __forceinline__ void c_split_tile(const c_f32x16& x, CFrag& f0, CFrag& f1) {
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = x[e];
+    f0 = c_split8(t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = x[8 + e];
+    f1 = c_split8(t);
+}
+
+__device__ __forceinline__ CAF c_ldaf(const char* lane_base, int hs) {
+    const c_bf16x8* a = reinterpret_cast<const c_bf16x8*>(lane_base + (size_t)hs * BWD_HALF_BYTES);
+    CAF f;
+    f.h0 = a[0]; f.l0 = a[64]; f.h1 = a[128]; f.l1 = a[192];
+    return f;
+}
+
+// row tile nt of this lane's row piece (row = set + s * 128 + 4 h): registers 4 q + c <-> floats 32 nt + 8 q + c
+__device__ __forceinline__ c_f32x16 c_ld_tile(const float* row, int nt) {
+    c_f32x16 x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const c_f32x4 v = *reinterpret_cast<const c_f32x4*>(row + 32 * nt + 8 * q);
+        x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+    }
+    return x;
+}
+__device__ __forceinline__ void c_st_tile(float* row, int nt, const c_f32x16& x, bool valid) {
+    if (valid) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<c_f32x4*>(row + 32 * nt + 8 * q) = (c_f32x4){x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+    }
+}
+
+// PAIRS row-tile pairs x 8 k16-steps of one transposed layer, starting at half-step HS0 of the stream; the fragments of the next two
+// half-steps are in flight (ring index = half-step mod 3: compile-time after unrolling)
+template <int HS0, int PAIRS>
+__device__ __forceinline__ void c_section(const char* wl, CAF (&ring)[3], const CFrag (&B)[8], c_f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int hs = HS0 + 8 * p + q;
+            CSB;              // (keeps the scheduler from hoisting every fragment load of the section to its top)
+            ring[(hs + 2) % 3] = c_ldaf(wl, (hs + 2) % BWD_HALF_STEPS);
+            const CAF& a = ring[hs % 3];
+            acc[2 * p] = CMFMA(a.h0, B[q].hi, acc[2 * p]);
+            acc[2 * p] = CMFMA(a.h0, B[q].lo, acc[2 * p]);
+            acc[2 * p] = CMFMA(a.l0, B[q].hi, acc[2 * p]);
+            acc[2 * p + 1] = CMFMA(a.h1, B[q].hi, acc[2 * p + 1]);
+            acc[2 * p + 1] = CMFMA(a.h1, B[q].lo, acc[2 * p + 1]);
+            acc[2 * p + 1] = CMFMA(a.l1, B[q].hi, acc[2 * p + 1]);
+        }
+}
+
+__device__ __forceinline__ void c_zero(c_f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+}
+
+constexpr int CHAIN_WAVES = 4;
+constexpr int CHAIN_HEAD_PAD = (BWD_HEAD_FLOATS + 3) & ~3;
+constexpr int CHAIN_LDS_BYTES = (CHAIN_HEAD_PAD + CHAIN_WAVES * 2 * 16 * 64 * 4) * 4;     // 4 KB + 128 KB
+
+__global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(ChainArgs a) {
+    // LDS: [head table][per wave: b_d and the running g_bd sum of its tile, 16 KB each, as [row tile][q][lane][4 floats] -- parked here
+    // rather than in 128 registers: with them resident the register allocator spilled ~200 values around every layer's MFMA section]
+    extern __shared__ __attribute__((aligned(16))) float chain_lds[];
+    float* hw = chain_lds;
+    for (int i = threadIdx.x; i < BWD_HEAD_FLOATS; i += 64 * CHAIN_WAVES) hw[i] = a.head[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c_f32x4* park = reinterpret_cast<c_f32x4*>(chain_lds + CHAIN_HEAD_PAD) + (size_t)wave * (2 * 16 * 64) + lane;      // [which][nt * 4 + q][lane]
+    auto ld_park = [&](int which, int nt) {
+        c_f32x16 x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const c_f32x4 v = park[(which * 16 + nt * 4 + q) * 64];
+            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        }
+        return x;
+    };
+    auto st_park = [&](int which, int nt, const c_f32x16& x) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) park[(which * 16 + nt * 4 + q) * 64] = (c_f32x4){x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+    };
+    const int j = lane & 31, h = lane >> 5;
+    // (the stream does not depend on the tile: unless its address is laundered per section, every one of its 2048 fragment registers is
+    //  hoisted out of the tile loop and spilled; the OFFSET is laundered -- a pointer passed through an integer asm operand comes back
+    //  as a flat pointer)
+    const char* wl = a.wstream + lane * 16;
+    auto launder = [&]() { unsigned o_ = (unsigned)lane * 16u; asm volatile("" : "+v"(o_)); wl = a.wstream + o_; };
+    CAF ring[3];
+    ring[0] = c_ldaf(wl, 0);
+    ring[1] = c_ldaf(wl, 1);
+
+    for (int tile = blockIdx.x * CHAIN_WAVES + wave; tile < a.n_tiles; tile += gridDim.x * CHAIN_WAVES) {
+        const int s_raw = tile * 32 + j;
+        const bool valid = s_raw < a.m;
+        const int s = valid ? s_raw : a.m - 1;
+        const size_t ro = (size_t)s * 128 + 4 * h;             // this lane's piece of a [m,128] row
+
+        // ---- output stage (models.py:177-178 backwards)
+        const c_f32x4 raw = reinterpret_cast<const c_f32x4*>(a.raw)[s];
+        c_f32x4 gr = reinterpret_cast<const c_f32x4*>(a.g_raw)[s];
+        if (!valid) gr = (c_f32x4){0.f, 0.f, 0.f, 0.f};
+        const float conf = a.feats[(size_t)s * a.ldf + a.F - 1];
+        const float u = 1.f - conf, omu = 1.f - u;
+        const float gp[4] = {gr.x * raw.x * (1.f - raw.x), gr.y * raw.y * (1.f - raw.y), gr.z * raw.z * (1.f - raw.z), raw.w > 0.f ? gr.w : 0.f};
+        const float gb4[4] = {gp[0] * omu, gp[1] * omu, gp[2] * omu, gp[3] * u};
+        const float ga4[4] = {gp[0] * u, gp[1] * u, gp[2] * u, gp[3] * omu};
+        if (h == 0 && valid) {
+            reinterpret_cast<c_f32x4*>(a.g_base)[s] = (c_f32x4){gb4[0], gb4[1], gb4[2], gb4[3]};
+            reinterpret_cast<c_f32x4*>(a.g_adapt)[s] = (c_f32x4){ga4[0], ga4[1], ga4[2], ga4[3]};
+        }
+
+        c_f32x16 acc[4], hn[4];
+        CFrag X[8];
+        float ad[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};      // this lane's share of the adapt / base head outputs
+
+        // ---- adapt heads backwards + relu of [views | view_confi]: g_vc
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) hn[nt] = c_ld_tile(a.sv.vc + ro, nt);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f0 = 32 * nt + 8 * q + 4 * c_opaque(h);       // (laundered: the table never changes, so its reads would be hoisted out of the tile loop and spilled)
+                c_f32x4 w[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) w[o] = *reinterpret_cast<const c_f32x4*>(&hw[(4 + o) * 128 + f0]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = hn[nt][4 * q + c];
+                    const float g = ga4[0] * w[0][c] + ga4[1] * w[1][c] + ga4[2] * w[2][c] + ga4[3] * w[3][c];
+                    acc[nt][4 * q + c] = v > 0.f ? g : 0.f;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) ad[o] += v * w[o][c];
+                }
+                c_pin(ad[0]); c_pin(ad[1]); c_pin(ad[2]); c_pin(ad[3]);
+                CSB;                                         // (a fence per group: the scheduler otherwise reads every head weight of the tile up front and spills them)
+            }
+            c_st_tile(a.G_vc + ro, nt, acc[nt], valid);
+            c_split_tile(acc[nt], X[2 * nt], X[2 * nt + 1]);
+            CSB;
+        }
+
+        // ---- [views | view_confi]^T: g_f (f = feature_linear's output, no activation)
+        c_zero(acc);
+        launder(); c_section<0, 2>(wl, ring, X, acc);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            c_st_tile(a.G_f + ro, nt, acc[nt], valid);
+            c_split_tile(acc[nt], X[2 * nt], X[2 * nt + 1]);
+            CSB;
+        }
+
+        // ---- feature_linear^T: g_gx
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) hn[nt] = c_ld_tile(a.sv.h[5] + ro, nt);       // (h5 lands under the section's MFMAs)
+        c_zero(acc);
+        launder(); c_section<16, 2>(wl, ring, X, acc);
+
+        // ---- confidence-bias net^T first (its operand g_bc = g_gx * h5 dies before the trunk's state is born): gradient of the image
+        //      features, columns n_mvs .. n_mvs + n_img of g_feats
+        auto small_out = [&](const c_f32x16 (&r2)[4], int col0, int rows) {
+            if (valid) {
+                float* dst = a.g_feats + (size_t)s * a.ldgf + col0;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int f0 = 32 * t + 8 * q + 4 * h;
+                        if (f0 < rows) {                      // (rows is a multiple of 4: a group is in or out as a whole)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) dst[f0 + c] = r2[t][4 * q + c];
+                        }
+                    }
+            }
+        };
+        {
+            CFrag Z[8];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                c_f32x16 gbc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gbc[r] = acc[nt][r] * hn[nt][r];
+                c_st_tile(a.G_bc + ro, nt, gbc, valid);
+                c_split_tile(gbc, Z[2 * nt], Z[2 * nt + 1]);
+                CSB;
+            }
+            c_f32x16 a2[4];
+            c_zero(a2);
+            launder(); c_section<32, 1>(wl, ring, Z, a2);
+            small_out(a2, a.n_mvs, a.n_img);
+        }
+        CSB;
+
+        // ---- gx = h5 * bc (feature_linear's input), g_h5 = g_gx * bc + base heads^T g_base, relu / b_d backward of layer 5
+        {
+            c_f32x16 bct = c_ld_tile(a.sv.bc + ro, 0), bdt = c_ld_tile(a.sv.bd + ro, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                c_f32x16 bcn, bdn;
+                if (nt < 3) { bcn = c_ld_tile(a.sv.bc + ro, nt + 1); bdn = c_ld_tile(a.sv.bd + ro, nt + 1); }      // next tile's operands under this one's arithmetic
+                c_f32x16 gxv, gy, gb;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f0 = 32 * nt + 8 * q + 4 * c_opaque(h);       // (laundered: the table never changes, so its reads would be hoisted out of the tile loop and spilled)
+                    c_f32x4 w[4];
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) w[o] = *reinterpret_cast<const c_f32x4*>(&hw[o * 128 + f0]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int r = 4 * q + c;
+                        const float hv = hn[nt][r], gg = acc[nt][r];
+                        gxv[r] = hv * bct[r];
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) bs[o] += hv * w[o][c];
+                        const float gh = gg * bct[r] + gb4[0] * w[0][c] + gb4[1] * w[1][c] + gb4[2] * w[2][c] + gb4[3] * w[3][c];
+                        const float gpre = hv > 0.f ? gh : 0.f;
+                        gb[r] = gpre * hv;
+                        gy[r] = gpre * bdt[r];
+                    }
+                    c_pin(bs[0]); c_pin(bs[1]); c_pin(bs[2]); c_pin(bs[3]);
+                    CSB;
+                }
+                st_park(0, nt, bdt);
+                st_park(1, nt, gb);
+                c_st_tile(a.gx + ro, nt, gxv, valid);
+                c_st_tile(a.G_y[5] + ro, nt, gy, valid);
+                c_split_tile(gy, X[2 * nt], X[2 * nt + 1]);
+                if (nt < 3) { bct = bcn; bdt = bdn; }
+                CSB;
+            }
+        }
+
+        // ---- trunk: layer 5 (hidden part) down to layer 1; the element-wise backward of layer l - 1 is the epilogue of layer l
+        auto trunk_epi = [&](float* G_out) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const c_f32x16 bdt = ld_park(0, nt);
+                c_f32x16 gb = ld_park(1, nt), gy;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float hv = hn[nt][r];
+                    const float gpre = hv > 0.f ? acc[nt][r] : 0.f;
+                    gb[r] += gpre * hv;
+                    gy[r] = gpre * bdt[r];
+                }
+                st_park(1, nt, gb);
+                c_st_tile(G_out + ro, nt, gy, valid);
+                c_split_tile(gy, X[2 * nt], X[2 * nt + 1]);
+                CSB;
+            }
+        };
+#define UCNERF_CHAIN_LAYER(HS0, L)                                                        \
+        {                                                                                 \
+            _Pragma("unroll")                                                             \
+            for (int nt = 0; nt < 4; ++nt) hn[nt] = c_ld_tile(a.sv.h[(L) - 1] + ro, nt);  \
+            c_zero(acc);                                                                  \
+            launder(); c_section<HS0, 2>(wl, ring, X, acc);                               \
+            trunk_epi(a.G_y[(L) - 1]);                                                    \
+        }
+        UCNERF_CHAIN_LAYER(40, 5)
+        UCNERF_CHAIN_LAYER(56, 4)
+        UCNERF_CHAIN_LAYER(72, 3)
+        UCNERF_CHAIN_LAYER(88, 2)
+        UCNERF_CHAIN_LAYER(104, 1)
+#undef UCNERF_CHAIN_LAYER
+
+        // ---- depth-bias net: g_bd = sum_l g_pre_l * y_l with y_l = h_l / b_d on the active units; then its transposed layer
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const c_f32x16 bdt = ld_park(0, nt), gb = ld_park(1, nt);
+            c_f32x16 g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[r] = gb[r] != 0.f ? gb[r] / bdt[r] : 0.f;
+            c_st_tile(a.G_bd + ro, nt, g, valid);
+            c_split_tile(g, X[2 * nt], X[2 * nt + 1]);
+            CSB;
+        }
+        {
+            c_f32x16 a2[4];
+            c_zero(a2);
+            launder(); c_section<120, 1>(wl, ring, X, a2);
+            small_out(a2, 0, a.n_mvs);
+        }
+
+        // ---- d/d(confidence): u = 1 - confidence blends the two head pairs
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            ad[o] += __shfl_xor(ad[o], 32);
+            bs[o] += __shfl_xor(bs[o], 32);
+            ad[o] += hw[c_opaque(1024 + 4 + o)];
+            bs[o] += hw[c_opaque(1024 + o)];
+        }
+        const float gu = gp[0] * (ad[0] - bs[0]) + gp[1] * (ad[1] - bs[1]) + gp[2] * (ad[2] - bs[2]) + gp[3] * (bs[3] - ad[3]);
+        if (h == 0 && valid) a.g_feats[(size_t)s * a.ldgf + a.F - 1] = -gu;
+
+        // the stream wrapped: half-steps 0 and 1 of the next tile sit in ring[2] and ring[0] (128 = 2 mod 3)
+        const CAF t0 = ring[2], t1 = ring[0];
+        ring[0] = t0; ring[1] = t1;
+    }
+}
+
+// ---- host side
+size_t bwd_chain_stream_floats() { return (size_t)BWD_HALF_STEPS * BWD_HALF_BYTES / 4 + ((BWD_HEAD_FLOATS + 3) & ~3); }
+
+int launch_pack_bwd(int n_src, const float* flat, float* stream_out, hipStream_t st) {
+    MlpLayout L;
+    UCNERF_REQUIRE(mlp_layout(n_src, &L), "mlp_bwd: n_src %d outside 1..8", n_src);
+    const int v = L.v, KV = MLP_W + MLP_PE_DIR;
+    BwdPackArgs a;
+    memset(&a, 0, sizeof(a));
+    int hs = 0, i = 0;
+    auto sec = [&](int pairs, long long base, int ld, int col0, int rows, long long base_hi) {
+        a.sec[i].hs0 = hs; a.sec[i].pairs = pairs; a.sec[i].ld = ld; a.sec[i].col0 = col0; a.sec[i].rows = rows; a.sec[i].base = base; a.sec[i].base_hi = base_hi;
+        hs += 8 * pairs; ++i;
+    };
+    sec(2, L.p_vw, KV, 0, 128, L.p_vcw);                    // [views | view_confi]^T, feature part of their input
+    sec(2, L.p_fw, 128, 0, 128, -1);                        // feature_linear^T
+    sec(1, L.p_bcw, 8 * v, 0, 8 * v, -1);                   // confidence-bias net^T
+    sec(2, L.p_lw[5], 128 + MLP_PE_PTS, MLP_PE_PTS, 128, -1);   // layer 5, hidden part of [pe | h4]
+    for (int l = 4; l >= 1; --l) sec(2, L.p_lw[l], 128, 0, 128, -1);
+    sec(1, L.p_bdw, 24 + 4 * v, 0, 24 + 4 * v, -1);         // depth-bias net^T
+    if (hs != BWD_HALF_STEPS || i != 9) return fail(UCNERF_EINVAL, "mlp_bwd: stream schedule mismatch");
+    a.flat = flat;
+    a.out = reinterpret_cast<unsigned short*>(stream_out);
+    a.head = stream_out + (size_t)BWD_HALF_STEPS * BWD_HALF_BYTES / 4;
+    a.p_crw = L.p_crw; a.p_a1w = L.p_a1w; a.p_rw = L.p_rw; a.p_aw = L.p_aw; a.p_crb = L.p_crb; a.p_a1b = L.p_a1b; a.p_rb = L.p_rb; a.p_ab = L.p_ab;
+    hipLaunchKernelGGL(pack_bwd_kernel, dim3(BWD_HALF_STEPS), dim3(256), 0, st, a);
+    return check_launch("mlp_bwd pack");
+}
+
+// g_* / G_* operands: see ChainArgs.  `stream` = launch_pack_bwd's output.
+int launch_mlp_bwd_chain(int n_src, int m, const float* raw, const float* g_raw, const float* feats, int ldf, const MlpSaved* sv, const float* stream,
+                         float* G_vc, float* G_f, float* G_bc, float* gx, float* G_bd, float* const* G_y, float* g_feats, int ldgf, float* g_base,
+                         float* g_adapt, hipStream_t st) {
+    MlpLayout L;
+    UCNERF_REQUIRE(mlp_layout(n_src, &L), "mlp_bwd: n_src %d outside 1..8", n_src);
+    UCNERF_REQUIRE(m > 0 && m <= (1 << 24), "mlp_bwd: %d samples in one pass (limit 2^24)", m);
+    ChainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.m = m; a.n_tiles = cdiv(m, 32); a.F = L.F; a.ldf = ldf; a.ldgf = ldgf; a.n_mvs = 24 + 4 * L.v; a.n_img = 8 * L.v;
+    a.raw = raw; a.g_raw = g_raw; a.feats = feats; a.sv = *sv;
+    a.wstream = reinterpret_cast<const char*>(stream);
+    a.head = stream + (size_t)BWD_HALF_STEPS * BWD_HALF_BYTES / 4;
+    a.G_vc = G_vc; a.G_f = G_f; a.G_bc = G_bc; a.gx = gx; a.G_bd = G_bd;
+    for (int l = 0; l < 6; ++l) a.G_y[l] = G_y[l];
+    a.g_feats = g_feats; a.g_base = g_base; a.g_adapt = g_adapt;
+    const int cus = device_cus();
+    if (cus <= 0) return fail(UCNERF_EHIP, "mlp_bwd: no device");
+    int blocks = cdiv(a.n_tiles, CHAIN_WAVES);
+    if (blocks > cus) blocks = cus;                        // one 4-wave block per CU (512 registers per wave), persistent
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_bwd_chain_kernel), CHAIN_LDS_BYTES, "mlp_bwd chain")) return rc;
+    hipLaunchKernelGGL(mlp_bwd_chain_kernel, dim3(blocks), dim3(64 * CHAIN_WAVES), CHAIN_LDS_BYTES, st, a);
+    return check_launch("mlp_bwd chain");
+}
+
+}  // namespace ucnerf

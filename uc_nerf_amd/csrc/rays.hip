@@ -306,6 +306,16 @@ extern "C" {
 const char* ucnerf_last_error(void) { return last_error_buf(); }
 int ucnerf_abi_version(void) { return UCNERF_ABI_VERSION; }
 int ucnerf_device_cus(void) { return device_cus(); }
+const char* ucnerf_build_flags(void) {
+    static char buf[2048];
+    static bool done = false;          // (idempotent content: a race writes the same bytes)
+    if (!done) {
+        snprintf(buf, sizeof(buf), "%s| %s| %s| %s| %s", build_flags_mlp_bf16x3(), build_flags_mlp_bf16_plain(), build_flags_mlp_f32(), build_flags_mlp_bwd(),
+                 build_flags_gather_cl());
+        done = true;
+    }
+    return buf;
+}
 
 void* ucnerf_event_create(void) {
     hipEvent_t e = nullptr;

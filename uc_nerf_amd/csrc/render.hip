@@ -229,7 +229,7 @@ int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* bp, void* stream) {
     if (p->dir_feat) mb.fwd.dirs = p->dir_feat;
     mb.fwd.raw = g_raw;                      // placeholder (not written by the backward)
     mb.g_raw = g_raw; mb.flat_params = bp->flat_params; mb.g_feats = g_feats; mb.g_flat = bp->g_flat; mb.workspace = mlp_ws;
-    mb.saved_valid = bp->saved_valid;
+    mb.saved_valid = bp->saved_valid; mb.bwd_mode = bp->bwd_mode;
     if ((rc = ucnerf_mlp_bwd(&mb, st))) return rc;
 
     if (bp->g_vol[0] || bp->g_vol[1] || bp->g_vol[2] || bp->g_conf || bp->g_img_feat) {

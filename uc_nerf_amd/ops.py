@@ -4,6 +4,7 @@ PyTorch is plumbing here (device memory, streams, autograd bookkeeping); every c
 libucnerf_hip.so.  All functions require float32 tensors on a ROCm device and raise otherwise.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -402,6 +403,17 @@ def feat_gather(vols, conf, img_feat, imgs, w2cs, intrinsics, pts, ndc1, ndc2, n
 
 
 # ------------------------------------------------------------------------------------------------ a6
+BACKWARD_MODES = {"chain": 0, "layerwise": 1}
+_backward_mode = BACKWARD_MODES[os.environ.get("UCNERF_BWD_MODE", "chain")]
+
+
+def set_backward_mode(mode):
+    """MLP backward: "chain" (default) = the register-resident gradient chain (one kernel walks the network backwards per 32-sample tile,
+    split-bf16 data gradients, include/ucnerf_hip.h: bwd_mode 0), "layerwise" = the exact-fp32 layer-by-layer GEMMs (bwd_mode 1)."""
+    global _backward_mode
+    _backward_mode = BACKWARD_MODES[mode]
+
+
 class PackedWeights:
     """Pack index (host-built by the library, cached on device) + packing of a flat parameter vector."""
     _cache = {}
@@ -498,6 +510,7 @@ def mlp_bwd(pw, wstream, flat, pts, dirs, feats, S, g_raw):
     g_flat = torch.zeros(pw.n_params, device=pts.device)
     p.pts, p.dirs, p.feats, p.wstream, p.raw = _ptr(pts), _ptr(dirs), _ptr(feats), _ptr(wstream), _ptr(g_raw)
     bp.g_raw, bp.flat_params, bp.g_feats, bp.g_flat, bp.workspace = _ptr(g_raw), _ptr(flat), _ptr(g_feats), _ptr(g_flat), _ptr(ws)
+    bp.bwd_mode = _backward_mode
     _launch("ucnerf_mlp_bwd", bp, pts.device)
     return g_feats, g_flat
 
@@ -574,6 +587,7 @@ class _MLPEncoded(torch.autograd.Function):
         bp.fwd.wstream, bp.fwd.raw = _ptr(ws), _ptr(g_raw)
         bp.g_raw, bp.flat_params, bp.g_flat, bp.workspace = _ptr(g_raw), _ptr(flat), _ptr(g_flat), _ptr(work)
         bp.g_feats, bp.g_feat_stride = g_x.data_ptr() + 4 * 63, X
+        bp.bwd_mode = _backward_mode
         _launch("ucnerf_mlp_bwd", bp, x.device)
         return g_flat, g_x, None, None
 
@@ -946,6 +960,7 @@ class RenderPass:
         saved = getattr(self, "_saved_for", None) == (n, S, kept["raw"].data_ptr())
         ws = self._bwd_ws if saved else torch.empty(L.lib().ucnerf_render_bwd_workspace_floats(n, S, self.src.V), device=dev)
         bp.saved_valid = int(saved)
+        bp.bwd_mode = _backward_mode
         if not saved and self.pw.cfg.precision != 0:
             if f32_weights is None:
                 raise RuntimeError("uc_nerf_amd.RenderPass.backward: the activations of this bf16x3 training forward were overwritten "
