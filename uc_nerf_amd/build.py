@@ -11,10 +11,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libucnerf_hip.so")
-SOURCES = ["rays.hip", "gather.hip", "gather_cl.hip", "mlp.hip", "mlp_bf16.hip", "mlp_bwd.hip", "mlp_bwd_chain.hip", "composite.hip", "sample_pdf.hip", "render.hip", "mvs.hip"]
+SOURCES = ["rays.hip", "gather.hip", "gather_cl.hip", "mlp.hip", "mlp_bf16.hip", "mlp_bwd.hip", "mlp_bwd_chain.hip", "mlp_wgrad.hip", "composite.hip", "sample_pdf.hip", "render.hip", "mvs.hip"]
 # (source, object name, extra flags): translation units built more than once with different switches
 VARIANTS = [("mlp_bf16.hip", "mlp_bf16_plain.o", ["-DUCNERF_BF16_BUILD_TERMS=1"])]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mlp_layout.h"), os.path.join(CSRC, "sincos_cw.h"), os.path.join(CSRC, "gather_cl_device.h"),
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mlp_layout.h"), os.path.join(CSRC, "sincos_cw.h"), os.path.join(CSRC, "gather_cl_device.h"), os.path.join(CSRC, "mlp_bwd_parts.h"),
            os.path.join(HERE, "..", "include", "ucnerf_hip.h")]
 # -ffp-contract=off: the sample_pdf / sampling kernels reproduce torch-CPU roundings (separate mul and add)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

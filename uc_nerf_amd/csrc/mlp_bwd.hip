@@ -11,6 +11,7 @@
 // flat parameter-gradient vector (same layout as the flat parameter vector), so no unpacking is needed.
 #include "common.h"
 #include "mlp_layout.h"
+#include "mlp_bwd_parts.h"
 
 namespace ucnerf {
 
@@ -20,12 +21,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st);
 int launch_mlp_fwd_bf16x3_save(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st);      // mlp_bf16.hip
-// mlp_bwd_chain.hip: the data-gradient half of the backward as one register-resident kernel (bwd_mode 0)
-size_t bwd_chain_stream_floats();
-int launch_pack_bwd(int n_src, const float* flat, float* stream_out, hipStream_t st);
-int launch_mlp_bwd_chain(int n_src, int m, const float* raw, const float* g_raw, const float* feats, int ldf, const MlpSaved* sv, const float* stream,
-                         float* G_vc, float* G_f, float* G_bc, float* gx, float* G_bd, float* const* G_y, float* g_feats, int ldgf, float* g_base,
-                         float* g_adapt, hipStream_t st);
 
 // 4 consecutive parameters (parameter tensors are only 4-byte aligned inside the flat vector)
 __device__ __forceinline__ f32x4 ld4(const float* p) { return f32x4{p[0], p[1], p[2], p[3]}; }
@@ -827,26 +822,23 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
         RUN(launch_pack_bwd(v, P, w.wstream_bwd, st));
         RUN(launch_mlp_bwd_chain(v, m, w.raw, bp->g_raw, f.feats, ldf, &w.sv, w.wstream_bwd, w.g1, w.g2, w.g3, w.gx, w.gbd, w.gy, bp->g_feats, ldgf,
                                  w.g_base, w.g_adapt, st));
-        // B. parameter gradients: the four head layers, then one GEMM per (g, input) pair
-        HeadWArgs hw;
-        hw.m = m; hw.g_base = w.g_base; hw.g_adapt = w.g_adapt; hw.h5 = w.sv.h[5]; hw.vc = w.sv.vc;
-        hw.gw_crgb = G + L.p_crw; hw.gw_a1 = G + L.p_a1w; hw.gw_rgb = G + L.p_rw; hw.gw_a = G + L.p_aw;
-        hw.gb_crgb = G + L.p_crb; hw.gb_a1 = G + L.p_a1b; hw.gb_rgb = G + L.p_rb; hw.gb_a = G + L.p_ab;
-        {
-            int blocks = cdiv(m, HEAD_SLOTS);
-            if (blocks > device_cus()) blocks = device_cus();
-            hipLaunchKernelGGL(head_wgrad_kernel, dim3(blocks), dim3(32 * HEAD_SLOTS), 0, st, hw);
-        }
-        RUN(check_launch("mlp_bwd head_wgrad"));
-        RUN(run_tn(st, m, w.g1, 128, 128, w.sv.ft, 128, 1, 128, G + L.p_vw, KV, G + L.p_vb, G + L.p_vcw, G + L.p_vcb));
-        RUN(run_tn(st, m, w.g1, 128, 128, ped, ld_ped, xdiv_dir, 27, G + L.p_vw + 128, KV, nullptr, G + L.p_vcw + 128, nullptr));
-        RUN(run_tn(st, m, w.g2, 128, 128, w.gx, 128, 1, 128, G + L.p_fw, 128, G + L.p_fb));
-        RUN(run_tn(st, m, w.g3, 128, 128, f.feats + n_mvs, ldf, 1, n_img, G + L.p_bcw, n_img, G + L.p_bcb));
-        RUN(run_tn(st, m, w.gy[5], 128, 128, pep, ld_pep, 1, 63, G + L.p_lw[5], 191, G + L.p_lb[5]));
-        RUN(run_tn(st, m, w.gy[5], 128, 128, w.sv.h[4], 128, 1, 128, G + L.p_lw[5] + 63, 191, nullptr));
-        for (int l = 4; l >= 1; --l) RUN(run_tn(st, m, w.gy[l], 128, 128, w.sv.h[l - 1], 128, 1, 128, G + L.p_lw[l], 128, G + L.p_lb[l]));
-        RUN(run_tn(st, m, w.gy[0], 128, 128, pep, ld_pep, 1, 63, G + L.p_lw[0], 63, G + L.p_lb[0]));
-        RUN(run_tn(st, m, w.gbd, 128, 128, f.feats, ldf, 1, n_mvs, G + L.p_bdw, n_mvs, G + L.p_bdb));
+        // B. every parameter gradient in ONE launch (mlp_wgrad.hip): one (g, layer input) pair per product
+        WgArgs wg;
+        wgrad_begin(&wg, m);
+        RUN(wgrad_add(&wg, w.g1, 128, 128, w.sv.ft, 128, 1, 128, G + L.p_vw, KV, G + L.p_vb, G + L.p_vcw, G + L.p_vcb, 64));       // [views | view_confi] x f
+        RUN(wgrad_add(&wg, w.g1, 128, 128, ped, ld_ped, xdiv_dir, 27, G + L.p_vw + 128, KV, nullptr, G + L.p_vcw + 128, nullptr, 64));   // ... x dir encoding
+        RUN(wgrad_add(&wg, w.g2, 128, 128, w.gx, 128, 1, 128, G + L.p_fw, 128, G + L.p_fb, nullptr, nullptr, 0));                    // feature_linear
+        RUN(wgrad_add(&wg, w.g3, 128, 128, f.feats + n_mvs, ldf, 1, n_img, G + L.p_bcw, n_img, G + L.p_bcb, nullptr, nullptr, 0));   // confidence-bias net
+        RUN(wgrad_add(&wg, w.gy[5], 128, 128, pep, ld_pep, 1, 63, G + L.p_lw[5], 191, G + L.p_lb[5], nullptr, nullptr, 0));          // layer 5 on [pe | h4]
+        RUN(wgrad_add(&wg, w.gy[5], 128, 128, w.sv.h[4], 128, 1, 128, G + L.p_lw[5] + 63, 191, nullptr, nullptr, nullptr, 0));
+        for (int l = 4; l >= 1; --l) RUN(wgrad_add(&wg, w.gy[l], 128, 128, w.sv.h[l - 1], 128, 1, 128, G + L.p_lw[l], 128, G + L.p_lb[l], nullptr, nullptr, 0));
+        RUN(wgrad_add(&wg, w.gy[0], 128, 128, pep, ld_pep, 1, 63, G + L.p_lw[0], 63, G + L.p_lb[0], nullptr, nullptr, 0));
+        RUN(wgrad_add(&wg, w.gbd, 128, 128, f.feats, ldf, 1, n_mvs, G + L.p_bdw, n_mvs, G + L.p_bdb, nullptr, nullptr, 0));          // depth-bias net
+        // the four head layers: base rgb (3 rows) + base sigma (row 3) on h5; adapt rgb on the views half of vc, adapt sigma on the view_confi half
+        RUN(wgrad_add(&wg, w.g_base, 4, 4, w.sv.h[5], 128, 1, 128, G + L.p_crw, 128, G + L.p_crb, G + L.p_a1w, G + L.p_a1b, 3));
+        RUN(wgrad_add(&wg, w.g_adapt, 4, 3, w.sv.vc, 128, 1, 64, G + L.p_rw, 64, G + L.p_rb, nullptr, nullptr, 0));
+        RUN(wgrad_add(&wg, w.g_adapt + 3, 4, 1, w.sv.vc + 64, 128, 1, 64, G + L.p_aw, 64, G + L.p_ab, nullptr, nullptr, 0));
+        RUN(wgrad_launch(&wg, st));
         return UCNERF_OK;
     }
 

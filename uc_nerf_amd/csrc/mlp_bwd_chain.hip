@@ -17,6 +17,7 @@
 // (no barrier, no LDS ring: the 512-KB weight stream is read straight from L2 / L1 two half-steps ahead), tiles dealt round-robin.
 #include "common.h"
 #include "mlp_layout.h"
+#include "mlp_bwd_parts.h"
 
 namespace ucnerf {
 
