@@ -3,7 +3,7 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 PREC=$1; shift
 for v in "$@"; do
-  if [ "$v" = "-" ]; then unset UCNERF_LIB; else export UCNERF_LIB=$R/uc_nerf_amd/libucnerf_hip_$v.so; fi
+  if [ "$v" = "-" ]; then unset UCNERF_LIB; else export UCNERF_LIB=$R/build/variants/libucnerf_hip_$v.so; fi
   timeout -k 10 120 python $R/bench.py --precision $PREC --cpu-rays 0 --no-reuse 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); r=d['roofline']

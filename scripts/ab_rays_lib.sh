@@ -4,7 +4,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 LIBS=$1; shift
 for n in "$@"; do
   for v in $LIBS; do
-    if [ "$v" = "-" ]; then unset UCNERF_LIB; else export UCNERF_LIB=$R/uc_nerf_amd/libucnerf_hip_$v.so; fi
+    if [ "$v" = "-" ]; then unset UCNERF_LIB; else export UCNERF_LIB=$R/build/variants/libucnerf_hip_$v.so; fi
     timeout -k 10 120 python $R/bench.py --rays $n --cpu-rays 0 --no-reuse --steps 200 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline())

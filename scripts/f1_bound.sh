@@ -8,7 +8,7 @@ for rays in 4096 512; do
   steps=200; [ $rays = 512 ] && steps=800
   for rep in 1 2; do
     for v in - f1bound; do
-      if [ "$v" = "-" ]; then unset UCNERF_LIB; else export UCNERF_LIB=$R/uc_nerf_amd/libucnerf_hip_$v.so; fi
+      if [ "$v" = "-" ]; then unset UCNERF_LIB; else export UCNERF_LIB=$R/build/variants/libucnerf_hip_$v.so; fi
       timeout -k 10 120 python $R/bench.py --rays $rays --steps $steps --cpu-rays 0 --no-reuse 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); r=d['roofline']

@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
-  if [ "$v" = "-" ]; then unset UCNERF_LIB; else export UCNERF_LIB=$R/uc_nerf_amd/libucnerf_hip_$v.so; fi
+  if [ "$v" = "-" ]; then unset UCNERF_LIB; else export UCNERF_LIB=$R/build/variants/libucnerf_hip_$v.so; fi
   rm -rf $R/gpurun_out/bv_$v
   [ -n "$RAYS" ] && echo "-- rays per step: $RAYS"
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/bv_$v -- python3 $R/bench.py --rays ${RAYS:-4096} --steps 100 --warmup 20 --no-reuse --cpu-rays 0 > $R/gpurun_out/bv_$v.log 2>&1 || exit 1

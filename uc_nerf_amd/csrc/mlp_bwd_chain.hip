@@ -156,18 +156,19 @@ __device__ __forceinline__ void c_st_tile(float* row, int nt, const c_f32x16& x,
     }
 }
 
-// PAIRS row-tile pairs x 8 k16-steps of one transposed layer, starting at half-step HS0 of the stream; the fragments of the next two
-// half-steps are in flight (ring index = half-step mod 3: compile-time after unrolling)
+// PAIRS row-tile pairs x 8 k16-steps of one transposed layer, starting at half-step HS0 of the stream; the fragments of the next three
+// half-steps are in flight (ring index = half-step mod 4: compile-time after unrolling; 128 half-steps per tile = 0 mod 4)
+constexpr int CHAIN_RING = 4;
 template <int HS0, int PAIRS>
-__device__ __forceinline__ void c_section(const char* wl, CAF (&ring)[3], const CFrag (&B)[8], c_f32x16 (&acc)[4]) {
+__device__ __forceinline__ void c_section(const char* wl, CAF (&ring)[CHAIN_RING], const CFrag (&B)[8], c_f32x16 (&acc)[4]) {
 #pragma unroll
     for (int p = 0; p < PAIRS; ++p)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int hs = HS0 + 8 * p + q;
             CSB;              // (keeps the scheduler from hoisting every fragment load of the section to its top)
-            ring[(hs + 2) % 3] = c_ldaf(wl, (hs + 2) % BWD_HALF_STEPS);
-            const CAF& a = ring[hs % 3];
+            ring[(hs + CHAIN_RING - 1) % CHAIN_RING] = c_ldaf(wl, (hs + CHAIN_RING - 1) % BWD_HALF_STEPS);
+            const CAF& a = ring[hs % CHAIN_RING];
             acc[2 * p] = CMFMA(a.h0, B[q].hi, acc[2 * p]);
             acc[2 * p] = CMFMA(a.h0, B[q].lo, acc[2 * p]);
             acc[2 * p] = CMFMA(a.l0, B[q].hi, acc[2 * p]);
@@ -216,9 +217,10 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
     //  as a flat pointer)
     const char* wl = a.wstream + lane * 16;
     auto launder = [&]() { unsigned o_ = (unsigned)lane * 16u; asm volatile("" : "+v"(o_)); wl = a.wstream + o_; };
-    CAF ring[3];
+    CAF ring[CHAIN_RING];
     ring[0] = c_ldaf(wl, 0);
     ring[1] = c_ldaf(wl, 1);
+    ring[2] = c_ldaf(wl, 2);
 
     for (int tile = blockIdx.x * CHAIN_WAVES + wave; tile < a.n_tiles; tile += gridDim.x * CHAIN_WAVES) {
         const int s_raw = tile * 32 + j;
@@ -240,7 +242,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
             reinterpret_cast<c_f32x4*>(a.g_adapt)[s] = (c_f32x4){ga4[0], ga4[1], ga4[2], ga4[3]};
         }
 
-        c_f32x16 acc[4], hn[4];
+        c_f32x16 acc[4], hn[4], hm[4];
         CFrag X[8];
         float ad[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};      // this lane's share of the adapt / base head outputs
 
@@ -315,6 +317,8 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
                 c_split_tile(gbc, Z[2 * nt], Z[2 * nt + 1]);
                 CSB;
             }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) hm[nt] = c_ld_tile(a.sv.h[4] + ro, nt);      // for the first trunk epilogue, two sections away
             c_f32x16 a2[4];
             c_zero(a2);
             launder(); c_section<32, 1>(wl, ring, Z, a2);
@@ -362,14 +366,14 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
         }
 
         // ---- trunk: layer 5 (hidden part) down to layer 1; the element-wise backward of layer l - 1 is the epilogue of layer l
-        auto trunk_epi = [&](float* G_out) {
+        auto trunk_epi = [&](float* G_out, const c_f32x16 (&hcur)[4]) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const c_f32x16 bdt = ld_park(0, nt);
                 c_f32x16 gb = ld_park(1, nt), gy;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float hv = hn[nt][r];
+                    const float hv = hcur[nt][r];
                     const float gpre = hv > 0.f ? acc[nt][r] : 0.f;
                     gb[r] += gpre * hv;
                     gy[r] = gpre * bdt[r];
@@ -380,19 +384,25 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
                 CSB;
             }
         };
-#define UCNERF_CHAIN_LAYER(HS0, L)                                                        \
-        {                                                                                 \
-            _Pragma("unroll")                                                             \
-            for (int nt = 0; nt < 4; ++nt) hn[nt] = c_ld_tile(a.sv.h[(L) - 1] + ro, nt);  \
-            c_zero(acc);                                                                  \
-            launder(); c_section<HS0, 2>(wl, ring, X, acc);                               \
-            trunk_epi(a.G_y[(L) - 1]);                                                    \
+        // (the activation set a layer's epilogue needs is requested one layer early, into the other of two register sets, and AFTER the
+        //  previous section: vector-memory operations return in issue order, so a request in front of a section holds back every weight
+        //  fragment issued behind it for a whole HBM latency; behind it, the epilogue and the ring's three half-steps run meanwhile)
+#define UCNERF_CHAIN_LAYER(HS0, L, CUR, NXT)                                                            \
+        {                                                                                                 \
+            c_zero(acc);                                                                                  \
+            launder(); c_section<HS0, 2>(wl, ring, X, acc);                                               \
+            if ((L) >= 2) {                                                                               \
+                _Pragma("unroll")                                                                         \
+                for (int nt = 0; nt < 4; ++nt) NXT[nt] = c_ld_tile(a.sv.h[(L) - 2] + ro, nt);             \
+            }                                                                                             \
+            CSB;                                                                                          \
+            trunk_epi(a.G_y[(L) - 1], CUR);                                                               \
         }
-        UCNERF_CHAIN_LAYER(40, 5)
-        UCNERF_CHAIN_LAYER(56, 4)
-        UCNERF_CHAIN_LAYER(72, 3)
-        UCNERF_CHAIN_LAYER(88, 2)
-        UCNERF_CHAIN_LAYER(104, 1)
+        UCNERF_CHAIN_LAYER(40, 5, hm, hn)       // (h4 was requested into hm before the confidence-bias net's section)
+        UCNERF_CHAIN_LAYER(56, 4, hn, hm)
+        UCNERF_CHAIN_LAYER(72, 3, hm, hn)
+        UCNERF_CHAIN_LAYER(88, 2, hn, hm)
+        UCNERF_CHAIN_LAYER(104, 1, hm, hn)
 #undef UCNERF_CHAIN_LAYER
 
         // ---- depth-bias net: g_bd = sum_l g_pre_l * y_l with y_l = h_l / b_d on the active units; then its transposed layer
@@ -424,9 +434,6 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
         const float gu = gp[0] * (ad[0] - bs[0]) + gp[1] * (ad[1] - bs[1]) + gp[2] * (ad[2] - bs[2]) + gp[3] * (bs[3] - ad[3]);
         if (h == 0 && valid) a.g_feats[(size_t)s * a.ldgf + a.F - 1] = -gu;
 
-        // the stream wrapped: half-steps 0 and 1 of the next tile sit in ring[2] and ring[0] (128 = 2 mod 3)
-        const CAF t0 = ring[2], t1 = ring[0];
-        ring[0] = t0; ring[1] = t1;
     }
 }
 

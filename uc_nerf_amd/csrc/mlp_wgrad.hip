@@ -13,7 +13,6 @@
 //   * the launch is persistent over the CONCATENATION of all pairs: the total cost (bytes per 64-sample stage, summed over
 //     pairs) is cut into equal ranges, one per block, two blocks per CU; a block flushes its 128 x 128 partial sum with float
 //     atomics on 128-byte row segments when its range leaves a pair -- ~530 flushes per step instead of ~3 300, no tail.
-#include <cstdlib>
 #include "common.h"
 #include "mlp_layout.h"
 #include "mlp_bwd_parts.h"
@@ -226,7 +225,8 @@ int wgrad_add(WgArgs* a, const float* G, int ldg, int nout, const float* X, int 
         q.div_m = (unsigned)((((unsigned long long)1 << (31 + l)) + (unsigned)xdiv - 1) / (unsigned)xdiv);
         q.div_sh = l - 1;
     }
-    q.cost = getenv("UCNERF_WG_UNIFORM") ? 256 : ((nout + 31) & ~31) + ((w + 31) & ~31) + 64;      // ~ bytes moved per stage (+ a fixed part: barriers, fragment reads)
+    q.cost = ((nout + 31) & ~31) + ((w + 31) & ~31) + 256;      // ~ bytes moved per stage + a fixed part (a stage is mostly latency: measured, weighting by bytes alone
+                                                                 //   left the blocks of the narrow pairs running 1.5x longer than the rest)
     a->prefix[a->n_pairs + 1] = a->prefix[a->n_pairs] + (long long)a->stages * q.cost;
     ++a->n_pairs;
     return UCNERF_OK;
