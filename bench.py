@@ -3,12 +3,14 @@
 192), 4096 synthetic rays per GPU (BASELINE.json configs[1]).
 
   python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus N ...                 (WORLD_SIZE unset: starts the N ranks itself -- see self_launch_command -- and relays rank 0's line)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W [--scaling strong] [--mode train]
+         bench.py --gpus N --steps K --warmup W [--scaling weak] [--mode train]
 
 One process per GPU.  Rays are independent, so the batch is sharded across ranks with no data-path collective:
-  --scaling weak   (default) 4096 rays per GPU, global batch 4096 N
-  --scaling strong a 4096-ray global batch split N ways (512 rays per GPU at N = 8: the north-star's strong-scaling regime)
+  --scaling strong (default) a 4096-ray global batch split N ways (512 rays per GPU at N = 8: the north-star's strong-scaling target);
+                   at N > 1 the weak-scaling step is measured too and reported as the secondary field `weak`
+  --scaling weak   4096 rays per GPU, global batch 4096 N
 The only collectives of the render mode are the barrier and the MAX of the timed interval.  Rank 0 prints ONE JSON line.
   --mode train     the line's metric becomes training rays/sec: rendering() drop-in forward + backward on this rank's
                    shard of a live-path batch (2000 rays x 90 cascade samples per GPU), ONE flat-bucket all-reduce of the
@@ -36,7 +38,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: v_mfma_f32_32x32x16
 BF16X3_EXECUTED_FLOP_PER_SAMPLE = 3 * 2 * 72 * 16 * 128
 
 
-def cpu_baseline(scene_cpu, sd, n_rays, n_coarse, n_fine, budget_s=20.0):
+def cpu_baseline(scene_cpu, sd, n_rays, n_coarse, n_fine, budget_s=45.0):
     """The CPU oracle (torch-CPU restatement of the reference path, all host cores) on a bounded sample of the
     same workload.  Test infrastructure used ONLY as the reported baseline."""
     from oracle import ucnerf_oracle as O
@@ -45,8 +47,9 @@ def cpu_baseline(scene_cpu, sd, n_rays, n_coarse, n_fine, budget_s=20.0):
     # oversubscribes (measured: 256 threads -> 1.5 rays/s)
     cores = min(os.cpu_count() or 1, int(os.environ.get("UCNERF_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
-    xs, ys = random_pixels(n_rays, scene_cpu["H"], scene_cpu["W"], seed=1)
-    noise = torch.rand(n_rays, n_coarse, generator=torch.Generator().manual_seed(2))
+    xs, ys = random_pixels(4096, scene_cpu["H"], scene_cpu["W"], seed=0)          # the GPU's own seed-0 batch ("same inputs")
+    xs, ys = xs[:n_rays], ys[:n_rays]
+    noise = torch.rand(n_rays, n_coarse, generator=torch.Generator().manual_seed(100))
     times = []
     with torch.no_grad():
         O.render_coarse_fine(sd, scene_cpu, xs[:64], ys[:64], n_coarse, n_fine, noise=noise[:64], perturb=1.0)   # warm-up
@@ -58,8 +61,34 @@ def cpu_baseline(scene_cpu, sd, n_rays, n_coarse, n_fine, budget_s=20.0):
     times.sort()
     med = times[len(times) // 2]
     return {"value": n_rays / med, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": "%d rays x (%d+%d) samples of the same synthetic scene, torch-CPU fp32 oracle, median of %d runs"
-                      % (n_rays, n_coarse, n_fine, len(times))}
+            "sample": "the first %d rays of the GPU's seed-0 batch x (%d+%d) samples, same synthetic scene, torch-CPU fp32 oracle, "
+                      "median of %d runs" % (n_rays, n_coarse, n_fine, len(times))}
+
+
+def self_launch_command(gpus, argv, env, port=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE / RANK unset): the command that starts the N ranks --
+    one process per GPU through torch.distributed.run, rendezvous on 127.0.0.1 -- or None when this process IS a rank (or N = 1).
+    The parent never touches the GPU (nothing here initialises HIP) and never replaces itself: the ranks are children."""
+    if gpus <= 1 or "WORLD_SIZE" in env or "RANK" in env:
+        return None
+    if port is None:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % gpus, "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(gpus, argv):
+    cmd = self_launch_command(gpus, argv, os.environ)
+    if cmd is None:
+        return
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)      # stdout is inherited: rank 0's JSON line passes through
 
 
 class Ctx:
@@ -70,7 +99,7 @@ class Ctx:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
         if self.world != args.gpus:
-            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, self.world))
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
         # one rank per GPU; UCNERF_BENCH_BACKEND=gloo is a rehearsal mode for a box with fewer GPUs than ranks (ranks then
@@ -258,9 +287,12 @@ def main():
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step (weak) / global rays per step (strong)")
     ap.add_argument("--coarse", type=int, default=64)
     ap.add_argument("--fine", type=int, default=128)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong (default): --rays is the GLOBAL batch, split over the GPUs (the north-star's 4096-ray strong-scaling target); "
+                         "weak: --rays per GPU.  Identical at N = 1.")
     ap.add_argument("--mode", choices=["render", "train"], default="render")
-    ap.add_argument("--cpu-rays", type=int, default=2048, help="size of the CPU-baseline sample (0 = skip); 2048 rays = five runs of 2-3 s on 16 host threads")
+    ap.add_argument("--cpu-rays", type=int, default=4096, help="size of the CPU-baseline sample (0 = skip): the first N rays of the GPU's own seed-0 "
+                    "batch; 4096 = the whole stated batch, five runs of ~5 s on 16 host threads")
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--fused-min-rounds", type=int, default=0,
                     help="bf16x3_fused: passes with fewer tiles per wave than this take the two-kernel route (0: always the fused kernel)")
@@ -272,6 +304,7 @@ def main():
                          "1e-4 parity bar); plain bf16 (1 MFMA per product, NOT within the parity bar: PSNR reported); bf16x3_fused (default): "
                          "split-bf16 with the feature gather inside the MLP kernel -- one launch per pass, no feature buffer")
     args = ap.parse_args()
+    self_launch(args.gpus, sys.argv[1:])          # N > 1 without a launcher: start the ranks (this process then only relays and exits)
     ctx = Ctx(args)
     rank, world, dev = ctx.rank, ctx.world, ctx.dev
 
@@ -476,7 +509,16 @@ def main():
                 x5, y5, nz5 = xs[:n].contiguous(), ys[:n].contiguous(), noise[:n].contiguous()
                 dt5 = ctx.timed(lambda: renderer.render(x5, y5, perturb=1.0, noise=nz5, repack=False), 300, 60)
                 dt5r = ctx.timed(lambda: renderer.render(x5, y5, perturb=1.0, noise=nz5, repack=True), 300, 60)
+                # the same two steps as replays of ONE captured HIP graph each (row f1: the launch-bound regime the graph is for); the
+                # caller writes into the graph's static inputs once, a replay is then a single hipGraphLaunch -- no per-replay copies
+                g5, g5r = renderer.capture(n, perturb=1.0, repack=False), renderer.capture(n, perturb=1.0, repack=True)
+                for g in (g5, g5r):
+                    g.inputs["xs"].copy_(x5); g.inputs["ys"].copy_(y5); g.inputs["noise"].copy_(nz5)
+                dt5g, dt5gr = ctx.timed(lambda: g5(), 300, 60), ctx.timed(lambda: g5r(), 300, 60)
+                og, ref = g5(), renderer.render(x5, y5, perturb=1.0, noise=nz5, repack=False)
+                assert torch.equal(og["rgb"], ref["rgb"]) and torch.equal(og["depth"], ref["depth"])
                 return {"ms_per_step": dt5 * 1e3, "ms_per_step_with_repack": dt5r * 1e3, "rays": n,
+                        "hip_graph_ms_per_step": dt5g * 1e3, "hip_graph_ms_per_step_with_repack": dt5gr * 1e3,
                         "projected_speedup_at_8_gpus": (dt / args.steps) / dt5 if rays == 4096 else None,
                         "note": "512 rays x (64+128) on one GPU, sources constant across batches (repack hoisted); the projection "
                                 "divides this run's 4096-ray step by it and ignores the (collective-free) gather of 80 KB of outputs"}
@@ -501,8 +543,9 @@ def main():
                 """The headline step (source repack included) captured once into a HIP graph and replayed: the same launches without the
                 host's per-launch work (`CoarseFineRenderer.capture`, replay asserted bit-identical to the eager step)."""
                 g = renderer.capture(rays, perturb=1.0)
-                dtg = ctx.timed(lambda: g(xs, ys, noise), args.steps, args.warmup)
-                og = g(xs, ys, noise)
+                og = g(xs, ys, noise)                       # (fills the graph's static inputs once; the timed replays copy nothing)
+                dtg = ctx.timed(lambda: g(), args.steps, args.warmup)
+                og = g()
                 ref = renderer.render(xs, ys, perturb=1.0, noise=noise)
                 assert torch.equal(og["rgb"], ref["rgb"]) and torch.equal(og["depth"], ref["depth"])
                 return {"value": global_rays / dtg, "unit": "rays/s", "ms_per_step": dtg * 1e3,
@@ -510,6 +553,17 @@ def main():
             if not args.graph:
                 extra["hip_graph_replay"] = guarded(hip_graph_replay)
         else:
+            def other_scaling():
+                """The step under the OTHER scaling rule, so that one N > 1 line carries both: weak = --rays per GPU, strong = --rays in all."""
+                o_rays = args.rays if args.scaling == "strong" else max(1, args.rays // world)          # per rank
+                xo_all, yo_all = random_pixels(o_rays * world, scene_cpu["H"], scene_cpu["W"], seed=0)
+                xo, yo = xo_all[rank * o_rays:(rank + 1) * o_rays].to(dev), yo_all[rank * o_rays:(rank + 1) * o_rays].to(dev)
+                no = torch.rand(o_rays, args.coarse, generator=torch.Generator().manual_seed(100 + rank)).to(dev)
+                dto = ctx.timed(lambda: renderer.render(xo, yo, perturb=1.0, noise=no), args.steps, args.warmup)
+                return {"value": o_rays * world / dto, "unit": "rays/s", "ms_per_step": dto * 1e3, "rays_per_gpu": o_rays, "global_rays": o_rays * world,
+                        "scaling": "weak" if args.scaling == "strong" else "strong",
+                        "note": "NOT the headline: the same step under the other scaling rule (barrier + MAX over ranks as the headline)"}
+            extra["weak" if args.scaling == "strong" else "strong"] = guarded(other_scaling)
             extra["train_dp"] = guarded(lambda: bench_train_dp(ctx, scene, sd, 2000 if args.scaling == "weak" else max(1, 2000 // world)))
 
     psnr_vs_f32 = None
@@ -571,7 +625,7 @@ def main():
         if psnr_vs_f32 is not None:
             line["parity_vs_f32"] = psnr_vs_f32
         line.update(extra)
-        if world == 1 and args.cpu_rays > 0:
+        if args.cpu_rays > 0:           # (rank 0 only; at N > 1 the other ranks wait at the closing barrier)
             line["cpu_baseline"] = cpu_baseline(scene_cpu, sd, args.cpu_rays, args.coarse, args.fine)
         print(json.dumps(line), flush=True)
     if ctx.dist is not None:

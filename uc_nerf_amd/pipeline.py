@@ -113,13 +113,18 @@ class CoarseFineRenderer:
         with torch.cuda.graph(graph):
             out = self.render(xs_s, ys_s, **kw)
 
-        def replay(xs, ys, noise=None):
-            xs_s.copy_(xs, non_blocking=True)
-            ys_s.copy_(ys, non_blocking=True)
+        def replay(xs=None, ys=None, noise=None):
+            """One hipGraphLaunch.  Arguments given are first copied into the graph's static inputs (one small launch each); a caller
+            that wants none of those writes into `replay.inputs` itself and calls replay()."""
+            if xs is not None:
+                xs_s.copy_(xs, non_blocking=True)
+            if ys is not None:
+                ys_s.copy_(ys, non_blocking=True)
             if noise_s is not None and noise is not None:
                 noise_s.copy_(noise, non_blocking=True)
             graph.replay()
             return out
 
         replay.graph = graph
+        replay.inputs = {"xs": xs_s, "ys": ys_s, "noise": noise_s}
         return replay
