@@ -237,8 +237,8 @@ typedef struct {
                                 against the f32 render); offered because the reference configuration names bf16.
                              3: bf16x3 with the feature gather INSIDE the MLP kernel: the stream is packed in the
                                 order that kernel's lane halves produce the bias nets' operands and serves ucnerf_render_fused_fwd
-                                only (channel-last sources, coordinates derived from (ray, depth), no kept features, no
-                                per-sample uncertainty); ucnerf_mlp_fwd refuses it.  Same arithmetic as 1. */
+                                only (channel-last sources, coordinates derived from (ray, depth) or handed over -- pts_in ... ndc_in --,
+                                no kept features, no per-sample uncertainty); ucnerf_mlp_fwd refuses it.  Same arithmetic as 1. */
 } ucnerf_mlp_config;
 
 /* Sizes: floats in the flat parameter vector, floats (4-byte units) of the packed stream, int32 entries of the pack
@@ -251,6 +251,12 @@ int64_t ucnerf_mlp_index_count(const ucnerf_mlp_config* cfg);
 int ucnerf_mlp_pack_index(const ucnerf_mlp_config* cfg, int32_t* idx_host);
 /* Device-side: builds the packed stream from the flat parameters; idx is the device copy of the table above. */
 int ucnerf_mlp_pack(const ucnerf_mlp_config* cfg, const float* flat_params, const int32_t* idx, float* stream_out, void* stream);
+/* The same from parameters that live in SEPARATE device tensors (a torch module's, in state_dict order: their concatenation is the flat
+ * vector), without first concatenating them: tensor_ptrs_host / tensor_numel_host are HOST arrays of n_tensors (<= 48) device pointers
+ * and element counts.  Lets a drop-in re-pack from the live parameters in every call -- in-place writes through `.data` (the reference's
+ * own weights_init, network/models.py:15-17) leave no trace a cache could key on. */
+int ucnerf_mlp_pack_tensors(const ucnerf_mlp_config* cfg, int32_t n_tensors, const void* const* tensor_ptrs_host, const int64_t* tensor_numel_host,
+                            const int32_t* idx, float* stream_out, void* stream);
 /* Transpose of the pack for gradients: g_flat[idx[i]] += g_stream[i] (g_flat zeroed by the caller). */
 int ucnerf_mlp_unpack_grad(const float* g_stream, const int32_t* idx, float* g_flat, int64_t n, void* stream);
 

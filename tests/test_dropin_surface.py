@@ -346,9 +346,9 @@ def test_rendering_takes_the_fused_route_and_its_caches_follow_parameter_and_sou
         sess = dropin.session_of(net)
         assert ("f32", 0) in sess.passes and sess.passes[("f32", 0)].use_cl     # fused pass + channel-last gather were used
         close(rgb, g["rgb_first"], 1e-4, 0); close(depth, g["depth_first"], 1e-4, 0)
-        ws0, src0 = sess.weights[("f32", 0)][3], sess.src
+        ws0, src0 = sess.weights[("f32", 0)]["ws"], sess.src
         rgb_b, _ = _g10_call(mods, g, net, qfn)                                    # new tensor objects, same content: same render,
-        assert torch.equal(rgb_b, rgb) and sess.weights[("f32", 0)][3] is ws0     # weight stream reused (sources re-bound: new objects)
+        assert torch.equal(rgb_b, rgb) and sess.weights[("f32", 0)]["ws"] is ws0  # stream buffer reused, re-packed in place ("verify" policy)
         # extras: the opt-in outputs
         u17 = load_golden("g17_uncertainty")
         _, _, ex = _g10_call(mods, g, net, qfn, extras=("acc", "weights", "var", "u", "wu"))
@@ -363,7 +363,41 @@ def test_rendering_takes_the_fused_route_and_its_caches_follow_parameter_and_sou
                               {"stage1": g["ndc1"], "stage2": g["ndc2"], "stage3": g["ndc3"], "ndc": g["ndc"]}, g["z"], g["rays_d"],
                               [g["vol1"], g["vol2"], g["vol3"]], g["imgs"], g["img_feat"], g["conf"], V)
         close(rgb_c, want, 1e-4, 0)
-        assert sess.weights[("f32", 0)][3] is not ws0 and (rgb_c - rgb).abs().max() > 1e-3
+        assert (rgb_c - rgb).abs().max() > 1e-3
+        # ... and so does a write through `.data`, which bumps NO version counter (the reference's weights_init does exactly that,
+        # network/models.py:15-17): the default "verify" policy re-packs from the live tensors in every call
+        v_before = net.nerf.rgb_linear.bias._version
+        net.nerf.rgb_linear.bias.data.sub_(0.3)
+        assert net.nerf.rgb_linear.bias._version == v_before
+        rgb_d, _ = _g10_call(mods, g, net, qfn)
+        close(rgb_d, rgb, 1e-6, 0)
+        # the opt-in "versions" cache keys on version counters: it follows ordinary in-place updates, is blind to `.data` writes (by
+        # construction, documented) until invalidate() is called
+        dropin.set_weight_cache("versions")
+        try:
+            r_v0, _ = _g10_call(mods, g, net, qfn)
+            ws_v = sess.weights[("f32", 0)]["ws"]
+            r_v1, _ = _g10_call(mods, g, net, qfn)
+            assert torch.equal(r_v0, r_v1) and sess.weights[("f32", 0)]["ws"] is ws_v          # cached: same stream object
+            net.nerf.rgb_linear.bias.add_(0.3)
+            r_v2, _ = _g10_call(mods, g, net, qfn)
+            close(r_v2, rgb_c, 1e-6, 0)
+            assert sess.weights[("f32", 0)]["ws"] is not ws_v
+            net.nerf.rgb_linear.bias.data.sub_(0.3)
+            r_v3, _ = _g10_call(mods, g, net, qfn)
+            assert torch.equal(r_v3, r_v2)                                                      # stale, as documented ...
+            sess.invalidate()
+            r_v4, _ = _g10_call(mods, g, net, qfn)
+            close(r_v4, rgb, 1e-6, 0)                                                           # ... until told
+            net.nerf.rgb_linear.bias.add_(0.3)
+        finally:
+            dropin.set_weight_cache("verify")
+        with pytest.raises(ValueError):
+            dropin.set_weight_cache("never")
+        with pytest.raises(ValueError):
+            dropin.set_inference_precision("fp8")
+        with pytest.raises(ValueError):
+            _g10_call(mods, g, net, qfn, args_extra={"inference_precision": "bf16x3-fused"})
         # ... and an in-place write to a source invalidates the channel-last copies; the same objects again hit the cache
         vols = [dev(g["vol%d" % k]) for k in (1, 2, 3)]
         img_feat, conf = dev(g["img_feat"]), dev(g["conf"])
@@ -389,6 +423,14 @@ def test_rendering_takes_the_fused_route_and_its_caches_follow_parameter_and_sou
         assert not torch.equal(r3, r2d[0])
         r4, _ = _g10_call(mods, g, net, qfn, vols=vols, img_feat=img_feat, conf=conf, args_extra={"inference_precision": "bf16x3"})
         assert torch.equal(r4, r3)
+        # the headline kernel from the reference's call surface: gather inside the MLP kernel, on the coordinates rendering() was handed
+        r6, d6 = _g10_call(mods, g, net, qfn, vols=vols, img_feat=img_feat, conf=conf, args_extra={"inference_precision": "bf16x3_fused"})
+        assert ("bf16x3_fused", 0) in sess.passes
+        close(r6, r2d[0], 1e-4, 0); close(d6, r2d[1], 1e-4, 0)
+        close(r6, r3, 2e-5, 0); close(d6, d3, 4e-5, 0)                              # same arithmetic as bf16x3, other summation order in the bias nets
+        _, _, ex6 = _g10_call(mods, g, net, qfn, vols=vols, img_feat=img_feat, conf=conf, extras=("acc", "u", "wu"),
+                              args_extra={"inference_precision": "bf16x3_fused"})   # per-sample extras: served by the two-kernel bf16x3 pass
+        assert ex6["u"].dim() == 2 and ("bf16x3", 0) in sess.passes
         # a feature buffer past the 2 GiB addressing range is split over rays: same image
         monkeypatch.setattr(dropin, "_MAX_FEATURE_BYTES", 7 * 32 * 97 * 4)         # 7 rays per chunk
         r5 = _g10_call(mods, g, net, qfn, vols=vols, img_feat=img_feat, conf=conf)
@@ -410,7 +452,7 @@ def test_rendering_takes_the_fused_route_and_its_caches_follow_parameter_and_sou
 
 
 @pytest.mark.parametrize("fixture", ["g10_rendering", "g16_rendering_v4"])
-def test_training_forward_on_the_split_bf16_matrix_cores_matches_the_exact_one(mods, fixture, sd_v7):
+def test_training_forward_on_the_split_bf16_matrix_cores_matches_the_exact_one(mods, fixture, sd_v7, monkeypatch):
     """rendering() under autograd with the opt-in bf16x3 training forward (activations kept) against the exact-f32 one (default):
     outputs within 1e-4, gradients equal in direction and norm (see the note on relu ties below); and a backward whose kept
     activations were overwritten by a later forward falls back to the exact recompute."""
@@ -443,8 +485,12 @@ def test_training_forward_on_the_split_bf16_matrix_cores_matches_the_exact_one(m
         rgb32, d32, g32, _ = run("f32")
         rgb16, d16, g16, sess = run("bf16x3")
         assert ("bf16x3", 0) in sess.passes and ("f32", 0) not in sess.passes      # the bf16x3 pass alone served forward + backward
+        from uc_nerf_amd import ops as P_
+        packs, orig_pack = [], P_.PackedWeights.pack
+        monkeypatch.setattr(P_.PackedWeights, "pack", lambda self, flat: (packs.append(self.precision), orig_pack(self, flat))[1])
         rgbx, dx, gx, sessx = run("bf16x3", second_forward=True)
-        assert ("f32", 0) in sessx.weights                                          # ... here the exact recompute was needed
+        monkeypatch.undo()
+        assert "f32" in packs        # ... here the exact recompute was needed: an f32 stream packed from the forward-time parameters (ctx.flat)
     finally:
         uc_nerf_amd.set_training_precision("f32")
     close(rgb16, rgb32, 1e-4, 0); close(d16, d32, 1e-4, 0); close(rgbx, rgb32, 1e-4, 0)

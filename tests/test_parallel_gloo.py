@@ -164,6 +164,44 @@ def test_flat_bucket_keeps_replicas_identical_when_a_shard_is_empty():
         assert g0[-1] is None and g1[-1] is None         # a parameter no rank differentiated keeps grad = None (as in the reference)
 
 
+def _pattern_change_rank(rank, world):
+    """The set of parameters that receive gradients changes after step 1 (a loss term switched on by a schedule): step 0 uses the
+    first layer pair only, from step 1 on a second head joins.  Rank 1 has an EMPTY shard throughout -- it cannot see the change
+    locally -- and must still end every step with the gradients rank 0 has."""
+    torch.manual_seed(4)
+    body, head_a, head_b = torch.nn.Linear(4, 8), torch.nn.Linear(8, 2), torch.nn.Linear(8, 3)
+    params = list(body.parameters()) + list(head_a.parameters()) + list(head_b.parameters())
+    bucket = P.FlatGradBucket(params)
+    out = []
+    for step in range(4):
+        for p in params:
+            p.grad = None
+        if rank == 0:
+            h = torch.tanh(body(torch.randn(5, 4, generator=torch.Generator().manual_seed(step))))
+            loss = head_a(h).pow(2).mean()
+            if step >= 1 and step != 3:
+                loss = loss + head_b(h).pow(2).mean()                 # on for steps 1 and 2, off again at step 3
+            loss.backward()
+            bucket.allreduce(1.0)
+        else:
+            bucket.allreduce(0.0)
+        out.append([None if p.grad is None else p.grad.clone() for p in params])
+    return out
+
+
+def test_flat_bucket_follows_a_gradient_pattern_that_changes_between_steps():
+    res = run_world(_pattern_change_rank, 2)
+    for step in range(4):
+        g0, g1 = res[0][step], res[1][step]
+        for a, b in zip(g0, g1):
+            assert (a is None) == (b is None), "step %d: replicas disagree on which parameters have gradients" % step
+            if a is not None:
+                assert torch.equal(a, b)
+        head_b_on = step in (1, 2)
+        assert (g0[4] is not None) == head_b_on and (g1[5] is not None) == head_b_on
+        assert all(g is not None for g in g0[:4])
+
+
 # ---- row f3: the training step's loss under ray sharding ------------------------------------------------------
 def _f3_problem():
     g = torch.Generator().manual_seed(33)

@@ -12,9 +12,17 @@ __version__ = "0.2.0"
 
 
 def set_inference_precision(precision):
-    """MLP arithmetic of the `rendering()` drop-in under torch.no_grad(): "f32" (default), "bf16x3" or "bf16" (dropin.py)."""
+    """MLP arithmetic of the `rendering()` drop-in under torch.no_grad(): "f32" (default), "bf16x3", "bf16x3_fused" (the headline kernel: feature gather
+    inside the MLP kernel) or "bf16" (dropin.py)."""
     from . import dropin
     dropin.set_inference_precision(precision)
+
+
+def set_weight_cache(policy):
+    """How a no_grad `rendering()` call obtains its packed weight stream: "verify" (default: re-packed from the live parameters in every
+    call, nothing can go stale) or "versions" (cached per parameter version counter: one launch less per call) -- dropin.set_weight_cache."""
+    from . import dropin
+    dropin.set_weight_cache(policy)
 
 
 def set_training_precision(precision):

@@ -179,6 +179,7 @@ SYMBOLS = {
     "ucnerf_mlp_index_count": (C.c_int64, [_P]),
     "ucnerf_mlp_pack_index": (C.c_int, [_P, _P]),
     "ucnerf_mlp_pack": (C.c_int, [_P, _P, _P, _P, _P]),
+    "ucnerf_mlp_pack_tensors": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "ucnerf_mlp_unpack_grad": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "ucnerf_mlp_fwd": (C.c_int, [_P, _P]),
     "ucnerf_mlp_bwd_workspace_floats": (C.c_int64, [_P, C.c_int32]),

@@ -52,6 +52,25 @@ const char* build_flags_mlp_f32();
 int ensure_dynamic_lds(const void* kernel, int bytes, const char* what);
 
 
+// Parameters living in SEPARATE tensors (a torch module's) addressed as if they were the flat parameter vector: tensor j holds flat
+// indices [start[j], start[j + 1]).  Passed by value to the pack kernels of ucnerf_mlp_pack_tensors, searched from an LDS copy.
+constexpr int MAX_PACK_TENSORS = 48;
+struct ParamTable { const float* ptr[MAX_PACK_TENSORS]; int start[MAX_PACK_TENSORS + 1]; int n; };
+#ifdef __HIPCC__
+struct ParamTableLds { const float* ptr[MAX_PACK_TENSORS]; int start[MAX_PACK_TENSORS + 1]; };
+__device__ __forceinline__ void param_table_to_lds(const ParamTable& t, ParamTableLds* l) {      // all threads of the block; ends with a barrier
+    for (int i = threadIdx.x; i < MAX_PACK_TENSORS; i += blockDim.x) { l->ptr[i] = i < t.n ? t.ptr[i] : nullptr; l->start[i] = i <= t.n ? t.start[i] : 0x7fffffff; }
+    if (threadIdx.x == 0) l->start[MAX_PACK_TENSORS] = t.n == MAX_PACK_TENSORS ? t.start[MAX_PACK_TENSORS] : 0x7fffffff;
+    __syncthreads();
+}
+__device__ __forceinline__ float param_table_load(const ParamTableLds* l, int f) {
+    int lo = 0, hi = MAX_PACK_TENSORS - 1;                    // largest j with start[j] <= f
+#pragma unroll
+    for (int it = 0; it < 6; ++it) { const int mid = (lo + hi + 1) >> 1; if (l->start[mid] <= f) lo = mid; else hi = mid - 1; }
+    return l->ptr[lo][f - l->start[lo]];
+}
+#endif
+
 // Segmented pre-combination of float atomics inside a wave (HIP device code only).  Lanes STRIDE apart hold consecutive
 // positions of a run dimension (samples of a ray, depth hypotheses of a pixel; pos = lane / STRIDE); runs of equal `key`
 // along it are summed with a suffix scan in log2(64 / STRIDE) shuffle steps and only the first lane of a run issues the

@@ -132,6 +132,13 @@ __global__ void pack_kernel(const float* __restrict__ flat, const int32_t* __res
     if (i < n) { int32_t k = idx[i]; out[i] = k >= 0 ? flat[k] : 0.f; }
 }
 
+__global__ void pack_tab_kernel(ParamTable t, const int32_t* __restrict__ idx, float* __restrict__ out, int64_t n) {
+    __shared__ ParamTableLds l;
+    param_table_to_lds(t, &l);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { int32_t k = idx[i]; out[i] = k >= 0 ? param_table_load(&l, k) : 0.f; }
+}
+
 __global__ void unpack_grad_kernel(const float* __restrict__ g, const int32_t* __restrict__ idx, float* __restrict__ gflat, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { int32_t k = idx[i]; if (k >= 0) atomicAdd(gflat + k, g[i]); }
@@ -598,6 +605,7 @@ int build_pack_index_bf16(const ucnerf_mlp_config* cfg, int32_t* idx);
 int64_t bf16_index_count(const ucnerf_mlp_config* cfg);
 int64_t bf16_stream_floats(const ucnerf_mlp_config* cfg);
 int launch_pack_bf16(const ucnerf_mlp_config* cfg, const float* flat, const int32_t* idx, float* out, hipStream_t st);
+int launch_pack_bf16_tab(const ucnerf_mlp_config* cfg, const ParamTable& t, const int32_t* idx, float* out, hipStream_t st);
 int launch_mlp_fwd_bf16x3(const ucnerf_mlp_params* p, hipStream_t st);      // mlp_bf16.hip built with TERMS = 3
 int launch_mlp_fwd_bf16_plain(const ucnerf_mlp_params* p, hipStream_t st);   // ... and with TERMS = 1
 
@@ -660,6 +668,30 @@ int ucnerf_mlp_pack(const ucnerf_mlp_config* cfg, const float* flat, const int32
     UCNERF_REQUIRE(n > 0, "mlp_pack: bad config");
     hipLaunchKernelGGL(pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, flat, idx, out, n);
     return check_launch("mlp_pack");
+}
+
+int ucnerf_mlp_pack_tensors(const ucnerf_mlp_config* cfg, int32_t n_tensors, const void* const* tensor_ptrs_host, const int64_t* tensor_numel_host,
+                            const int32_t* idx, float* out, void* stream) {
+    UCNERF_REQUIRE(cfg && tensor_ptrs_host && tensor_numel_host && idx && out, "mlp_pack_tensors: null pointer");
+    UCNERF_REQUIRE(n_tensors >= 1 && n_tensors <= MAX_PACK_TENSORS, "mlp_pack_tensors: %d tensors (1..%d)", n_tensors, MAX_PACK_TENSORS);
+    const int64_t n_params = ucnerf_mlp_param_count(cfg);
+    UCNERF_REQUIRE(n_params > 0, "mlp_pack_tensors: bad config");
+    ParamTable t;
+    memset(&t, 0, sizeof(t));
+    t.n = n_tensors;
+    int64_t off = 0;
+    for (int j = 0; j < n_tensors; ++j) {
+        UCNERF_REQUIRE(tensor_ptrs_host[j] && tensor_numel_host[j] > 0, "mlp_pack_tensors: tensor %d is empty", j);
+        t.ptr[j] = (const float*)tensor_ptrs_host[j]; t.start[j] = (int)off;
+        off += tensor_numel_host[j];
+    }
+    t.start[n_tensors] = (int)off;
+    UCNERF_REQUIRE(off == n_params, "mlp_pack_tensors: the tensors hold %lld floats, the network has %lld parameters", (long long)off, (long long)n_params);
+    if (cfg->precision != 0) return launch_pack_bf16_tab(cfg, t, idx, out, (hipStream_t)stream);
+    const int64_t n = ucnerf_mlp_stream_count(cfg);
+    UCNERF_REQUIRE(n > 0, "mlp_pack_tensors: bad config");
+    hipLaunchKernelGGL(pack_tab_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, t, idx, out, n);
+    return check_launch("mlp_pack_tensors");
 }
 
 int ucnerf_mlp_unpack_grad(const float* g, const int32_t* idx, float* gflat, int64_t n, void* stream) {

@@ -231,6 +231,22 @@ __global__ void pack_bf16_kernel(const float* __restrict__ flat, const int32_t* 
     out[i] = r;
 }
 
+__global__ void pack_bf16_tab_kernel(ParamTable t, const int32_t* __restrict__ idx, unsigned short* __restrict__ out, int64_t n) {
+    __shared__ ParamTableLds l;
+    param_table_to_lds(t, &l);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t k = idx[i];
+    unsigned short r = 0;
+    if (k >= 0) {
+        const float w = param_table_load(&l, k & 0x3fffffff);
+        const __bf16 hi = (__bf16)w;
+        const __bf16 val = (k >> 30) ? (__bf16)(w - (float)hi) : hi;
+        r = __builtin_bit_cast(unsigned short, val);
+    }
+    out[i] = r;
+}
+
 #endif   // UCNERF_BF16_BUILD_TERMS == 3 (host-side packing)
 
 // ------------------------------------------------------------------------------------------------ device helpers
@@ -554,11 +570,16 @@ struct FusedGather {
     const float* w2cs;
     const float* Ks;
     unsigned div_m, div_sh;
+    // COORDS instantiation: coordinates GIVEN by the caller (what rendering() of the reference receives from build_rays / build_rays_test,
+    // network/renderer.py:215-255) instead of derived from (ray, depth): world points, the three stage copies, the encoded copy -- [M,3] each
+    const float* pts_in;
+    const float* ndc_in[3];
+    const float* ndc_enc;
 };
 [[maybe_unused]] constexpr int FUSED_MAX_V = 8;    // (seven and eight views: with a two-slot weight ring, fused_ring_slots)
 constexpr int VIEW_TAB = 24;      // floats per source view in the LDS table: w2c (12), K (9), pad
 
-template <bool TILED, int NSRC, int TERMS, bool SAVE, bool FUSED = false>       // TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only); SAVE: training forward
+template <bool TILED, int NSRC, int TERMS, bool SAVE, bool FUSED = false, bool COORDS = false>       // TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only); SAVE: training forward; COORDS (FUSED only): sample coordinates given
 #ifndef UCNERF_BF16_WPS
 #define UCNERF_BF16_WPS 2      // waves per SIMD: 2 -> 256 VGPRs per wave, 1 -> 512
 #endif
@@ -693,8 +714,21 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     ImgFp fi[NP];
     float4 va[16], vb3[8], vi_[NP][12];
     float cv[4];
+    float gcs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};           // COORDS: (u, v, z) of this lane's first volume and of stage 3
     auto g_pre = [&](int tile) {
         const unsigned s = (unsigned)sample_of(tile);
+        if (COORDS) {                                        // world point -> grd, encoded copy -> npx (dead since this tile's encoding), stage copies -> gcs
+            const int hl = opaque(h);
+            const float* pw_ = fg.pts_in + 3 * (size_t)s;
+            grd[0] = pw_[0]; grd[1] = pw_[1]; grd[2] = pw_[2];
+            const float* pe_ = fg.ndc_enc + 3 * (size_t)s;
+            npx[0] = pe_[0]; npx[1] = pe_[1]; npx[2] = pe_[2];
+            const float* pa_ = (hl ? fg.ndc_in[1] : fg.ndc_in[0]) + 3 * (size_t)s;
+            gcs[0] = pa_[0]; gcs[1] = pa_[1]; gcs[2] = pa_[2];
+            const float* p3_ = fg.ndc_in[2] + 3 * (size_t)s;
+            gcs[3] = p3_[0]; gcs[4] = p3_[1]; gcs[5] = p3_[2];
+            return;
+        }
         const unsigned r = fg.S == 1 ? s : (__umulhi(s, fg.div_m) >> fg.div_sh);
         gz = fg.z[s];
         const float* rd = fg.rays_d + 3 * (size_t)r;
@@ -718,9 +752,10 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     auto g_part = [&](int part) {
         constexpr bool so_ = !UCNERF_FUSED_FOOT_UNDER_GEMM;
         const int gW = sopaque(fg.W, so_), gH = sopaque(fg.H, so_);
-        const float x = ro[0] + gz * grd[0], y = ro[1] + gz * grd[1], w = ro[2] + gz * grd[2];
+        const float x = COORDS ? grd[0] : ro[0] + gz * grd[0], y = COORDS ? grd[1] : ro[1] + gz * grd[1], w = COORDS ? grd[2] : ro[2] + gz * grd[2];
         const int hl = opaque(h);
         if (part == 0) {
+            if (COORDS) return;                              // (the encoded copy came in as it is)
             float qx, qy, qz;
             project_cl(fg.w2c_ref, fg.K_ref, x, y, w, &qx, &qy, &qz);
             npx[0] = (qx / qz + 0.0f) / (float)(gW - 1); npx[1] = (qy / qz + 0.0f) / (float)(gH - 1);
@@ -728,10 +763,11 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             gqz = qz;
             return;
         }
-        const float u = npx[0], v = npx[1], qz = gqz;
+        const float qz = gqz;
         // volumes: `unit` is this lane's (hl in the first sweep, 2 in the second), `c0` the first byte of its channels in a voxel
         auto vol_fp = [&](int unit, unsigned c0, float nk, float fk) {
-            const float zn = (qz - nk) / (fk - nk);
+            const float u = COORDS ? gcs[unit == 2 ? 3 : 0] : npx[0], v = COORDS ? gcs[unit == 2 ? 4 : 1] : npx[1];
+            const float zn = COORDS ? gcs[unit == 2 ? 5 : 2] : (qz - nk) / (fk - nk);
             // (wave-uniform sizes pass through an empty asm: their float forms are otherwise hoisted out of the tile loop into vector registers and spilled)
             const int D = unit == 2 ? sopaque(fg.vol_d[2], so_) : fg.vol_d[unit], hh = unit == 2 ? sopaque(fg.vol_h[2], so_) : fg.vol_h[unit], ww = unit == 2 ? sopaque(fg.vol_w[2], so_) : fg.vol_w[unit];
             const LerpCl ax = axis_cl(u * 2.f - 1.0f, ww, false), ay = axis_cl(v * 2.f - 1.0f, hh, false), az = axis_cl(zn * 2.f - 1.0f, D, false);
@@ -747,7 +783,8 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         if (part == 1) { fa = vol_fp(hl, 0u, gnf[0], gnf[1]); return; }
         if (part == 2) {
             fb3 = vol_fp(2, 16u * hl, gnf[2], gnf[3]);
-            const LerpCl ax = axis_cl(u * 2.f - 1.0f, gW, false), ay = axis_cl(v * 2.f - 1.0f, gH, false);      // confidence
+            const float u = COORDS ? gcs[3] : npx[0], v = COORDS ? gcs[4] : npx[1];                           // confidence: the stage-3 grid
+            const LerpCl ax = axis_cl(u * 2.f - 1.0f, gW, false), ay = axis_cl(v * 2.f - 1.0f, gH, false);
             co[0] = (unsigned)(ay.i0 * gW + ax.i0); co[1] = (unsigned)(ay.i0 * gW + ax.i1);
             co[2] = (unsigned)(ay.i1 * gW + ax.i0); co[3] = (unsigned)(ay.i1 * gW + ax.i1);
             cw[0] = ay.w0 * ax.w0; cw[1] = ay.w0 * ax.w1; cw[2] = ay.w1 * ax.w0; cw[3] = ay.w1 * ax.w1;
@@ -1249,10 +1286,15 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
         fg = *fuse;
         const size_t smem_f = bf16_smem_bytes_fused(B.v);
 #define X(N)                                                                                                                   \
-        if (B.v == N) {                                                                                                        \
+        if (B.v == N && !fg.pts_in) {                                                                                          \
             const void* fn = (const void*)mlp_fwd_bf16_kernel<true, N, 3, false, true>;                                        \
             if (int rc = ensure_dynamic_lds(fn, (int)smem_f, "mlp_fwd (bf16x3, gather fused)")) return rc;                    \
             hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, 3, false, true>), grid, block, smem_f, st, *p, g, n_tiles, sv, fg); \
+        }                                                                                                                      \
+        if (B.v == N && fg.pts_in) {                                                                                           \
+            const void* fn = (const void*)mlp_fwd_bf16_kernel<true, N, 3, false, true, true>;                                  \
+            if (int rc = ensure_dynamic_lds(fn, (int)smem_f, "mlp_fwd (bf16x3, gather fused, given coordinates)")) return rc; \
+            hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, 3, false, true, true>), grid, block, smem_f, st, *p, g, n_tiles, sv, fg); \
         }
         UCNERF_BF16_FOR_ALL(X)
 #undef X
@@ -1331,6 +1373,7 @@ int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* re
     memcpy(f.w2c_ref, rp->w2c_ref, sizeof(f.w2c_ref));
     memcpy(f.K_ref, rp->K_ref, sizeof(f.K_ref));
     f.w2cs = rp->w2cs; f.Ks = rp->intrinsics;
+    f.pts_in = rp->pts_in; f.ndc_in[0] = rp->ndc1_in; f.ndc_in[1] = rp->ndc2_in; f.ndc_in[2] = rp->ndc3_in; f.ndc_enc = rp->ndc_in;
     {   // magic for idx / S (gather_cl.hip)
         unsigned l = 1;
         while ((1u << l) < (unsigned)rp->S) ++l;
@@ -1369,6 +1412,23 @@ int launch_pack_bf16(const ucnerf_mlp_config* cfg, const float* flat, const int3
     hipLaunchKernelGGL(pack_f32_kernel, dim3(cdiv(CONST_FLOATS, 256)), dim3(256), 0, st, flat, idx + n16,
                        reinterpret_cast<float*>(reinterpret_cast<char*>(out) + B.const_off_bytes), CONST_FLOATS);
     return check_launch("mlp_pack (bf16x3)");
+}
+
+__global__ void pack_f32_tab_kernel(ParamTable t, const int32_t* __restrict__ idx, float* __restrict__ out, int n) {
+    __shared__ ParamTableLds l;
+    param_table_to_lds(t, &l);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int32_t k = idx[i]; out[i] = k >= 0 ? param_table_load(&l, k) : 0.f; }
+}
+
+int launch_pack_bf16_tab(const ucnerf_mlp_config* cfg, const ParamTable& t, const int32_t* idx, float* out, hipStream_t st) {
+    Bf16Layout B;
+    UCNERF_REQUIRE(bf16_layout(cfg->n_src, &B), "mlp_pack: n_src %d outside 1..8", cfg->n_src);
+    const int64_t n16 = (int64_t)B.slots * (SLOT_BYTES / 2);
+    hipLaunchKernelGGL(pack_bf16_tab_kernel, dim3(cdiv(n16, 256)), dim3(256), 0, st, t, idx, reinterpret_cast<unsigned short*>(out), n16);
+    hipLaunchKernelGGL(pack_f32_tab_kernel, dim3(cdiv(CONST_FLOATS, 256)), dim3(256), 0, st, t, idx + n16,
+                       reinterpret_cast<float*>(reinterpret_cast<char*>(out) + B.const_off_bytes), CONST_FLOATS);
+    return check_launch("mlp_pack_tensors (bf16x3)");
 }
 
 #endif   // UCNERF_BF16_BUILD_TERMS == 3

@@ -132,9 +132,9 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
     ucnerf_feat_gather_params g;
     float* raw_fused = nullptr;
     if (p->cfg.precision == 3) {                        // row f1: gather + PE + MLP in one launch, no feature buffer at all
-        UCNERF_REQUIRE(p->sources_cl && !keep_feats && !coords_given(p) && !p->u_sampled && !p->train_workspace,
-                       "render_fused_fwd: precision 3 (gather fused into the MLP kernel) needs the channel-last sources and derives its "
-                       "coordinates from (ray, depth); it keeps no features and returns no per-sample uncertainty");
+        UCNERF_REQUIRE(p->sources_cl && !keep_feats && !p->u_sampled && !p->train_workspace,
+                       "render_fused_fwd: precision 3 (gather fused into the MLP kernel) needs the channel-last sources; it keeps no features "
+                       "and returns no per-sample uncertainty");
         if (!p->dir_feat && (rc = launch_dirs(p, st, w))) return rc;
         raw_fused = p->raw ? p->raw : w->raw;
         if (p->ev_mlp_start && (rc = ucnerf_event_record(p->ev_mlp_start, st))) return rc;

@@ -25,16 +25,35 @@ from . import ops
 
 _INFERENCE_PRECISION = "f32"
 _TRAINING_PRECISION = "f32"         # arithmetic of the training FORWARD (activations are kept in fp32 either way)
+_INFERENCE_PRECISIONS = ("f32", "bf16x3", "bf16", "bf16x3_fused")
+_WEIGHT_CACHE = "verify"            # how an inference call gets its packed weight stream, see set_weight_cache
 _MAX_FEATURE_BYTES = (1 << 31) - (1 << 20)       # the MLP kernels address a pass's feature buffer with 32-bit byte offsets
 
 
 def set_inference_precision(precision):
     """MLP arithmetic of `rendering()` under torch.no_grad(): "f32" (exact fp32 MFMA, default), "bf16x3" (split-bf16 matrix
-    cores, within the 1e-4 parity bar) or "bf16" (plain bf16 operands, NOT within the bar).  Training always runs f32."""
+    cores, within the 1e-4 parity bar), "bf16x3_fused" (the same arithmetic with the feature gather INSIDE the MLP kernel -- the
+    kernel the headline benchmark is quoted on, reading the coordinates rendering() was handed; per-sample uncertainty extras fall
+    back to "bf16x3") or "bf16" (plain bf16 operands, NOT within the bar).  Training always runs f32 (set_training_precision)."""
     global _INFERENCE_PRECISION
-    if precision not in ops.PackedWeights.PRECISIONS:
-        raise ValueError("uc_nerf_amd: unknown precision %r" % (precision,))
+    if precision not in _INFERENCE_PRECISIONS:
+        raise ValueError("uc_nerf_amd: inference precision must be one of %s, got %r" % (", ".join(_INFERENCE_PRECISIONS), precision))
     _INFERENCE_PRECISION = precision
+
+
+def set_weight_cache(policy):
+    """How a no_grad `rendering()` call obtains the packed weight stream of its network:
+      "verify"   (default) re-packed from the LIVE parameter tensors in every call -- one small launch (ucnerf_mlp_pack_tensors, ~3 us
+                 of GPU time).  Nothing can go stale: in-place writes through `.data` (the reference's own weights_init, network/models.py:15-17;
+                 EMA / clamping code; older optimizers) do not bump a tensor's version counter, so no cache key can see them.
+      "versions" the stream is cached and rebuilt only when a parameter's version counter or storage changed (optimizer steps,
+                 load_state_dict, ordinary in-place ops).  One launch less per call; for evaluation loops that do not write parameters
+                 through `.data` -- or that call `uc_nerf_amd.dropin.session_of(net).invalidate()` after doing so.
+    Calls under autograd always pack afresh (once per training step; the backward needs the flat vector of that moment anyway)."""
+    global _WEIGHT_CACHE
+    if policy not in ("verify", "versions"):
+        raise ValueError("uc_nerf_amd: weight cache policy must be 'verify' or 'versions', got %r" % (policy,))
+    _WEIGHT_CACHE = policy
 
 
 def set_training_precision(precision):
@@ -49,7 +68,10 @@ def set_training_precision(precision):
 
 
 def inference_precision(args=None):
-    return getattr(args, "inference_precision", None) or _INFERENCE_PRECISION
+    prec = getattr(args, "inference_precision", None) or _INFERENCE_PRECISION
+    if prec not in _INFERENCE_PRECISIONS:
+        raise ValueError("uc_nerf_amd: args.inference_precision must be one of %s, got %r" % (", ".join(_INFERENCE_PRECISIONS), prec))
+    return prec
 
 
 # Parameters the reference's autograd never reaches: they keep grad = None here too.
@@ -78,16 +100,42 @@ class FusedSession:
         self.src, self.src_sig, self.src_refs = None, None, None
 
     # ---- caches
-    def packed(self, precision, layout):
-        sig = tuple((p._version, p.data_ptr()) for p in self.params)
-        ent = self.weights.get((precision, layout))
-        if ent is None or ent[0] != sig:
-            dev = self.params[0].device
+    def invalidate(self):
+        """Forget every packed weight stream and source copy (for callers that write parameters or sources behind torch's back while the
+        "versions" weight cache is selected)."""
+        self.weights.clear()
+        self.src, self.src_sig, self.src_refs = None, None, None
+
+    def packed(self, precision, layout, fresh=False):
+        """(flat parameter vector, packer, packed stream) of the network's CURRENT parameters.
+        fresh=True (calls under autograd): concatenated and packed now -- the flat vector is the one the backward will use.
+        Otherwise the stream follows the weight-cache policy (set_weight_cache) and `flat` is only a placeholder of the right size."""
+        dev = self.params[0].device
+        key = (precision, layout)
+        pw = ops.PackedWeights.get(self.n_src, layout, dev, precision)
+        ent = self.weights.get(key)
+        if fresh:
             flat = torch.cat([p.detach().reshape(-1) for p in self.params]).float()
-            pw = ops.PackedWeights.get(self.n_src, layout, dev, precision)
-            ent = (sig, flat, pw, pw.pack(flat))
-            self.weights[(precision, layout)] = ent
-        return ent[1], ent[2], ent[3]
+            ent = self.weights[key] = {"sig": None, "flat": flat, "ws": pw.pack(flat), "table": None}
+            return flat, pw, ent["ws"]
+        if _WEIGHT_CACHE == "versions":
+            sig = tuple((p._version, p.data_ptr()) for p in self.params)
+            if ent is None or ent["sig"] != sig:
+                flat = torch.cat([p.detach().reshape(-1) for p in self.params]).float()
+                ent = self.weights[key] = {"sig": sig, "flat": flat, "ws": pw.pack(flat), "table": None}
+            return ent["flat"], pw, ent["ws"]
+        # "verify": one launch re-packs the stream IN PLACE from the live tensors (no concatenation); the pointer table is rebuilt only
+        # when a parameter's storage moved
+        ptrs = tuple(p.data_ptr() for p in self.params)
+        if ent is None or ent["table"] is None or ent["table"].key != ptrs:
+            if any(p.dtype != torch.float32 or not p.is_contiguous() for p in self.params):
+                raise RuntimeError("uc_nerf_amd: network parameters must be contiguous float32 tensors")
+            flat = ent["flat"] if ent is not None else torch.empty(sum(self.sizes), device=dev)
+            ws = ent["ws"] if ent is not None else torch.empty(pw.n_stream, device=dev)
+            ent = self.weights[key] = {"sig": None, "flat": flat, "ws": ws, "table": ops.TensorTable(self.params)}
+        pw.pack_table(ent["table"], ent["ws"])
+        ent["sig"] = None
+        return ent["flat"], pw, ent["ws"]
 
     def sources(self, vols, conf, imgs, img_feat, w2cs, intrinsics):
         """GatherSources for these tensors.  Two signatures: the HEAVY sources (volumes, images, image features -- what the
@@ -106,8 +154,8 @@ class FusedSession:
         self.src_sig, self.src_refs = (hsig, lsig), ([r for _, r in heavy], [r for _, r in light])
         return self.src
 
-    def render_pass(self, precision, layout, src, white_bkgd):
-        flat, pw, ws = self.packed(precision, layout)
+    def render_pass(self, precision, layout, src, white_bkgd, fresh=False):
+        flat, pw, ws = self.packed(precision, layout, fresh)
         rp = self.passes.get((precision, layout))
         if rp is None:
             rp = self.passes[(precision, layout)] = ops.RenderPass(src, pw, ws, white_bkgd=white_bkgd)
@@ -136,7 +184,7 @@ class _FusedRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sess, layout, white_bkgd, coords, z, rays_dir, angle, imgs, w2cs, intrinsics, vol1, vol2, vol3, conf, img_feat, *params):
         src = sess.sources([vol1, vol2, vol3], conf, imgs, img_feat, w2cs, intrinsics)
-        rp, flat = sess.render_pass(_TRAINING_PRECISION, layout, src, white_bkgd)
+        rp, flat = sess.render_pass(_TRAINING_PRECISION, layout, src, white_bkgd, fresh=True)       # packed from the parameters as they are NOW
         out = rp(rays_dir, z, want=(), keep=("raw", "feats"), dir_feat=angle, coords=coords)
         ctx.sess, ctx.rp, ctx.src, ctx.pw, ctx.ws, ctx.flat, ctx.white_bkgd = sess, rp, src, rp.pw, rp.wstream, flat, white_bkgd
         ctx.layout = layout
@@ -160,15 +208,18 @@ class _FusedRender(torch.autograd.Function):
         need = (need[0], need[1], need[2], need[3], need[4])
         f32w = None
         if rp.pw.cfg.precision != 0 and getattr(rp, "_saved_for", None) != (z.shape[0], z.shape[1], ctx.kept["raw"].data_ptr()):
-            _, pw32, ws32 = sess.packed("f32", ctx.layout)       # another forward overwrote the kept activations: recompute them exactly
-            f32w = (pw32, ws32)
+            # another forward overwrote the kept activations: recompute them exactly -- from the parameters of THIS call's forward
+            # (ctx.flat, which the weight gradients below are taken against), not from whatever the parameters hold by now
+            pw32 = ops.PackedWeights.get(sess.n_src, ctx.layout, z.device, "f32")
+            f32w = (pw32, pw32.pack(ctx.flat))
         g_flat, gv1, gv2, gv3, gc, gi = rp.backward(rays_dir, z, ctx.kept, g_rgb.contiguous(), g_depth, ctx.flat, need=need,
                                                     coords=ctx.coords, dir_feat=angle, f32_weights=f32w)
         grads = [g.reshape(s) if g is not None else None for g, s in zip((gv1, gv2, gv3, gc, gi), ctx.shapes)]
         g_params = []
         for piece, p, has, req in zip(torch.split(g_flat, sess.sizes), sess.params, sess.grad_mask, ctx.needs_input_grad[15:]):
             g_params.append(piece.view_as(p) if (has and req) else None)
-        ctx.kept = None
+        # (ctx.kept stays: a second backward over the same graph -- retain_graph=True -- finds the kept activations overwritten and
+        #  recomputes them through the route above)
         return (None,) * 10 + tuple(grads) + tuple(g_params)
 
 
@@ -198,7 +249,10 @@ def fused_rendering(net, layout, args, w2c_dir, rays_pts, rays_ndc, z, rays_dir,
         return _FusedRender.apply(sess, layout, bool(white_bkgd), coords, z, rays_dir, angle, imgs, w2cs, intrinsics,
                                   vols[0], vols[1], vols[2], conf, img_feat, *sess.params)
     src = sess.sources(vols, conf, imgs, img_feat, w2cs, intrinsics)
-    rp, _ = sess.render_pass(inference_precision(args), layout, src, white_bkgd)
+    prec = inference_precision(args)
+    if prec == "bf16x3_fused" and ("u" in extras or "wu" in extras):
+        prec = "bf16x3"                              # the gather-fused kernel keeps nothing per sample: same arithmetic on the two-kernel pass
+    rp, _ = sess.render_pass(prec, layout, src, white_bkgd)
     out = rp(rays_dir, z, want=tuple(extras), dir_feat=angle, coords=coords)
     if extras:
         return out["rgb"], out["depth"], {k: out[k] for k in extras if k in out}

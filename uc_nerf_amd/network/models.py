@@ -118,10 +118,11 @@ class BaseAdapt_Renderer(nn.Module):
         """(flat parameter vector for autograd, packer, packed stream).  The stream -- and, when no gradient is wanted, the
         flat vector too -- comes from the per-network cache, rebuilt only when a parameter changed (dropin.FusedSession)."""
         from .. import dropin
-        flat, pw, ws = dropin.session_of(self).packed("f32", pe_layout)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            flat = self.flat_parameters()
-        return flat, pw, ws
+            flat = self.flat_parameters()                     # autograd-aware; the stream is packed from this very vector
+            pw = self.packer(pe_layout)
+            return flat, pw, pw.pack(flat.detach().float())
+        return dropin.session_of(self).packed("f32", pe_layout)
 
     def forward(self, x, pe_layout=0):
         """x [..., 63 + F + 27] = [encoded pts | features | encoded dirs] -> [..., 4] (rgb, sigma)."""

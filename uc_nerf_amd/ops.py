@@ -453,12 +453,39 @@ class PackedWeights:
             L.check(L.lib().ucnerf_mlp_pack(C.addressof(self.cfg), _ptr(flat), _ptr(self.idx), _ptr(out), _stream()), "ucnerf_mlp_pack")
         return out
 
+    def pack_table(self, table, out):
+        """Packs the stream straight from separate parameter tensors (TensorTable) into `out`, in place: one launch, no concatenation."""
+        if table.total != self.n_params:
+            raise RuntimeError("uc_nerf_amd: the parameter tensors hold %d floats, expected %d" % (table.total, self.n_params))
+        if out.numel() != self.n_stream or out.dtype != torch.float32 or not out.is_contiguous():
+            raise RuntimeError("uc_nerf_amd: stream buffer must be %d contiguous float32" % self.n_stream)
+        with _on(out.device):
+            L.check(L.lib().ucnerf_mlp_pack_tensors(C.addressof(self.cfg), table.n, table.ptrs, table.numel, _ptr(self.idx), _ptr(out), _stream()),
+                    "ucnerf_mlp_pack_tensors")
+        return out
+
     def unpack_grad(self, g_stream):
         g_flat = torch.zeros(self.n_params, device=g_stream.device)
         with _on(g_stream.device):
             L.check(L.lib().ucnerf_mlp_unpack_grad(_ptr(g_stream), _ptr(self.idx), _ptr(g_flat), self.n_stream, _stream()),
                     "ucnerf_mlp_unpack_grad")
         return g_flat
+
+
+class TensorTable:
+    """Host-side table of device pointers / element counts of a network's parameter tensors (state_dict order) for
+    PackedWeights.pack_table; `key` = the data pointers it was built from."""
+
+    def __init__(self, tensors):
+        tensors = list(tensors)
+        for t in tensors:
+            if t.device.type != "cuda" or t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError("uc_nerf_amd.TensorTable: parameters must be contiguous float32 tensors on a ROCm device")
+        self.n = len(tensors)
+        self.key = tuple(t.data_ptr() for t in tensors)
+        self.ptrs = (C.c_void_p * self.n)(*self.key)
+        self.numel = (C.c_int64 * self.n)(*[t.numel() for t in tensors])
+        self.total = sum(t.numel() for t in tensors)
 
 
 def mlp_fwd(pw, wstream, pts, dirs, feats, S, feats_tiled=False, max_blocks=0):

@@ -79,7 +79,13 @@ class FlatGradBucket:
     reduced flags are read back ONCE (the only host synchronisation this class ever makes) and cached: parameters some
     rank differentiated get their p.grad materialised from the reduced segment on every rank, parameters no rank touched
     keep grad = None as in the reference.  Nothing else reads device memory: scalars are written into the bucket with a
-    device-side copy."""
+    device-side copy.
+
+    The cached flags are refreshed (one more read-back) whenever they could have changed: when THIS rank's own pattern of
+    None / not-None gradients differs from the previous step's (a loss term switched on by a schedule, layers unfrozen -- every
+    rank runs the same model and loss, so every rank with rays sees the change and refreshes in the same step), and in every
+    step on a rank that differentiated nothing at all (an empty shard: it cannot see such a change locally, and its step time
+    does not matter)."""
 
     def __init__(self, params, n_scalars=0):
         self.params = [p for p in params if p.requires_grad]
@@ -88,7 +94,8 @@ class FlatGradBucket:
         self.n_grads = sum(self.sizes)
         self.numel = self.n_grads + n_scalars + len(self.params)
         self.flat = None
-        self.has_grad = None         # cached after the first reduction: list of bool, one per parameter
+        self.has_grad = None         # cached reduced flags: list of bool, one per parameter
+        self.local_flags = None      # this rank's own None / not-None pattern at the step has_grad was read
 
     def allreduce(self, weight, scalars=(), group=None):
         """In place on p.grad.  Returns the reduced scalars (e.g. global loss terms) as a device tensor."""
@@ -109,14 +116,15 @@ class FlatGradBucket:
             vals = torch.stack([torch.as_tensor(s, dtype=torch.float32, device=dev).reshape(()) for s in scalars])
             torch.mul(vals, weight, out=self.flat[off:off + self.n_scalars])
         off += self.n_scalars
-        if self.has_grad is None:
-            self.flat[off:].copy_(torch.tensor([0.0 if p.grad is None else 1.0 for p in self.params]), non_blocking=True)
-        else:
-            self.flat[off:].zero_()
+        local = tuple(p.grad is not None for p in self.params)                     # (host-side: no device access)
+        refresh = self.has_grad is None or local != self.local_flags or not any(local)
+        # the flags always travel (every rank must contribute the same bucket layout); they are only READ when a refresh is due
+        self.flat[off:].copy_(torch.tensor([1.0 if f else 0.0 for f in local]), non_blocking=True)
         if dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        if self.has_grad is None:
-            self.has_grad = [bool(v > 0) for v in self.flat[off:].tolist()]       # the one read-back, first step only
+        if refresh:
+            self.has_grad = [bool(v > 0) for v in self.flat[off:].tolist()]       # the read-back: first step, pattern change, empty shard
+            self.local_flags = local
         off = 0
         for p, n, has in zip(self.params, self.sizes, self.has_grad):
             if p.grad is not None:
