@@ -286,7 +286,7 @@ int ucnerf_mlp_fwd(const ucnerf_mlp_params* p, void* stream);
  * sets the reference never uses (pts_bias_confidence_1, feature_linear_1, confi_linear) get no contribution.
  * Positions and view directions receive no gradient (the reference path is non-differentiable there). */
 typedef struct {
-    ucnerf_mlp_params fwd;     /* forward arguments; feats must be row-major [m,F]; raw is not written */
+    ucnerf_mlp_params fwd;     /* forward arguments (feats row-major [m,F], or tiled with bwd_mode 0); raw is not written */
     const float* g_raw;        /* [m,4] upstream gradient */
     const float* flat_params;  /* [param_count] the parameters the wstream was packed from */
     float* g_feats;            /* [m,F] out, rows g_feat_stride floats apart (every one of the F columns written) */
@@ -301,7 +301,7 @@ typedef struct {
 } ucnerf_mlp_bwd_params;
 int64_t ucnerf_mlp_bwd_workspace_floats(const ucnerf_mlp_config* cfg, int32_t m);
 int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* p, void* stream);
-/* Training forward: ucnerf_mlp_fwd (f32 precision) that also keeps the per-layer activations in `bwd_workspace`
+/* Training forward: ucnerf_mlp_fwd (f32 or bf16x3 precision, features row-major or tiled) that also keeps the per-layer activations in `bwd_workspace`
  * (ucnerf_mlp_bwd_workspace_floats floats), for a following ucnerf_mlp_bwd with saved_valid = 1. */
 int ucnerf_mlp_fwd_train(const ucnerf_mlp_params* p, float* bwd_workspace, void* stream);
 
@@ -495,6 +495,9 @@ typedef struct {
     const float* ndc2_in;
     const float* ndc3_in;
     const float* ndc_in;       /* [n*S,3] scene-normalised copy fed to the positional encoding */
+    int32_t feats_tiled;       /* layout of `feats` when it is kept: 0 row-major [n*S,F]; 1 the MLP's tile layout [ceil(n*S/32)][F][32]
+                                  (ceil(n*S/32)*32*F floats) -- what the training forward reads three times faster (coalesced 128-byte
+                                  rows instead of 4-byte pieces of 388-byte rows) and ucnerf_render_fused_bwd (bwd_mode 0) accepts */
 } ucnerf_render_params;
 int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream);

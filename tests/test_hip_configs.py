@@ -138,7 +138,9 @@ def test_hamlyn_view_count_fused_pass_forward_and_backward_vs_reference(fast):
     rays_d, z, co = dev(g["rays_d"]), dev(g["z"]), coords_of(g)
     N, S = g["z"].shape
     out = rp(rays_d, z, want=("acc", "weights", "var", "u", "wu"), keep=("raw", "feats"), coords=co)
-    close(out["feats"].view(N, S, -1), g["feats"], 2e-5, 1e-5)
+    from uc_nerf_amd import ops as P_
+    feats = P_.untile_feats(out["feats"], N * S, g["feats"].shape[-1]) if out.get("feats_tiled") else out["feats"]      # (training forward: tile layout)
+    close(feats.view(N, S, -1), g["feats"], 2e-5, 1e-5)
     scale = max(1.0, g["raw"][..., 3].abs().max().item())
     close(out["raw"][..., :3], g["raw"][..., :3], 2e-5); close(out["raw"][..., 3], g["raw"][..., 3], 2e-5 * scale, 1e-5)
     close(out["rgb"], g["rgb_first"], 1e-4); close(out["depth"], g["depth_first"], 1e-4)

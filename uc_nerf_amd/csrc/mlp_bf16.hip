@@ -1301,13 +1301,17 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
         return check_launch("mlp_fwd (bf16x3, gather fused)");
     }
     if (save) {
-        UCNERF_REQUIRE(!tiled, "mlp_fwd_train: features must be row-major [m,F]");
         sv = *save;
 #define X(N)                                                                                                                   \
-        if (B.v == N) {                                                                                                        \
+        if (B.v == N && !tiled) {                                                                                              \
             const void* fn = (const void*)mlp_fwd_bf16_kernel<false, N, 3, true>;                                              \
             if (int rc = ensure_dynamic_lds(fn, (int)smem, "mlp_fwd_train (bf16x3)")) return rc;                              \
             hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, N, 3, true>), grid, block, smem, st, *p, g, n_tiles, sv, fg);           \
+        }                                                                                                                      \
+        if (B.v == N && tiled) {                                                                                               \
+            const void* fn = (const void*)mlp_fwd_bf16_kernel<true, N, 3, true>;                                               \
+            if (int rc = ensure_dynamic_lds(fn, (int)smem, "mlp_fwd_train (bf16x3, tiled features)")) return rc;              \
+            hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, 3, true>), grid, block, smem, st, *p, g, n_tiles, sv, fg);            \
         }
         UCNERF_BF16_FOR_ALL(X)
 #undef X

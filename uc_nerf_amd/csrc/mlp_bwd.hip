@@ -753,7 +753,6 @@ int ucnerf_mlp_fwd_train(const ucnerf_mlp_params* p, float* bwd_workspace, void*
     UCNERF_REQUIRE(p && bwd_workspace, "mlp_fwd_train: null pointer");
     if (p->m <= 0) return UCNERF_OK;
     UCNERF_REQUIRE(p->cfg.precision == 0 || p->cfg.precision == 1, "mlp_fwd_train: the training forward runs in f32 or bf16x3 precision");
-    UCNERF_REQUIRE(!p->feats_tiled, "mlp_fwd_train: features must be row-major [m,F]");
     UCNERF_REQUIRE(((uintptr_t)bwd_workspace & 15) == 0, "mlp_fwd_train: workspace must be 16-byte aligned");
     BwdWork w;
     carve_bwd(bwd_workspace, p->m, p->dirs_per_sample ? p->m : p->m / (p->S > 0 ? p->S : 1), &w);
@@ -772,7 +771,7 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     if (f.m <= 0) return UCNERF_OK;
     UCNERF_REQUIRE(f.pts && f.dirs && f.feats && f.wstream && bp->g_raw && bp->flat_params && bp->g_flat && bp->g_feats &&
                        bp->workspace, "mlp_bwd: null pointer");
-    UCNERF_REQUIRE(!f.feats_tiled, "mlp_bwd: features must be row-major [m,F]");
+    UCNERF_REQUIRE(!f.feats_tiled || (bp->bwd_mode == 0 && !f.encoded), "mlp_bwd: features in the tile layout are read by the gradient chain (bwd_mode 0) only");
     UCNERF_REQUIRE(f.cfg.pe_layout == 0 || f.cfg.pe_layout == 1, "mlp_bwd: pe_layout %d", f.cfg.pe_layout);
     UCNERF_REQUIRE(((uintptr_t)bp->workspace & 15) == 0 && ((uintptr_t)bp->g_raw & 15) == 0, "mlp_bwd: workspace/g_raw must be 16-byte aligned");
     MlpLayout L;
@@ -820,7 +819,7 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
         // A. every data gradient in ONE launch (mlp_bwd_chain.hip): g stays in registers from the output stage to the two bias nets;
         //    written: the G operands of the weight-gradient GEMMs below, g_feats, g_base / g_adapt
         RUN(launch_pack_bwd(v, P, w.wstream_bwd, st));
-        RUN(launch_mlp_bwd_chain(v, m, w.raw, bp->g_raw, f.feats, ldf, &w.sv, w.wstream_bwd, w.g1, w.g2, w.g3, w.gx, w.gbd, w.gy, bp->g_feats, ldgf,
+        RUN(launch_mlp_bwd_chain(v, m, w.raw, bp->g_raw, f.feats, ldf, f.feats_tiled, &w.sv, w.wstream_bwd, w.g1, w.g2, w.g3, w.gx, w.gbd, w.gy, bp->g_feats, ldgf,
                                  w.g_base, w.g_adapt, st));
         // B. every parameter gradient in ONE launch (mlp_wgrad.hip): one (g, layer input) pair per product
         WgArgs wg;
@@ -828,12 +827,13 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
         RUN(wgrad_add(&wg, w.g1, 128, 128, w.sv.ft, 128, 1, 128, G + L.p_vw, KV, G + L.p_vb, G + L.p_vcw, G + L.p_vcb, 64));       // [views | view_confi] x f
         RUN(wgrad_add(&wg, w.g1, 128, 128, ped, ld_ped, xdiv_dir, 27, G + L.p_vw + 128, KV, nullptr, G + L.p_vcw + 128, nullptr, 64));   // ... x dir encoding
         RUN(wgrad_add(&wg, w.g2, 128, 128, w.gx, 128, 1, 128, G + L.p_fw, 128, G + L.p_fb, nullptr, nullptr, 0));                    // feature_linear
-        RUN(wgrad_add(&wg, w.g3, 128, 128, f.feats + n_mvs, ldf, 1, n_img, G + L.p_bcw, n_img, G + L.p_bcb, nullptr, nullptr, 0));   // confidence-bias net
+        const int xt = f.feats_tiled ? F : 0;                 // (tile layout: column c of the features = row c of every tile)
+        RUN(wgrad_add(&wg, w.g3, 128, 128, f.feats + (xt ? 32 * n_mvs : n_mvs), ldf, 1, n_img, G + L.p_bcw, n_img, G + L.p_bcb, nullptr, nullptr, 0, xt));   // confidence-bias net
         RUN(wgrad_add(&wg, w.gy[5], 128, 128, pep, ld_pep, 1, 63, G + L.p_lw[5], 191, G + L.p_lb[5], nullptr, nullptr, 0));          // layer 5 on [pe | h4]
         RUN(wgrad_add(&wg, w.gy[5], 128, 128, w.sv.h[4], 128, 1, 128, G + L.p_lw[5] + 63, 191, nullptr, nullptr, nullptr, 0));
         for (int l = 4; l >= 1; --l) RUN(wgrad_add(&wg, w.gy[l], 128, 128, w.sv.h[l - 1], 128, 1, 128, G + L.p_lw[l], 128, G + L.p_lb[l], nullptr, nullptr, 0));
         RUN(wgrad_add(&wg, w.gy[0], 128, 128, pep, ld_pep, 1, 63, G + L.p_lw[0], 63, G + L.p_lb[0], nullptr, nullptr, 0));
-        RUN(wgrad_add(&wg, w.gbd, 128, 128, f.feats, ldf, 1, n_mvs, G + L.p_bdw, n_mvs, G + L.p_bdb, nullptr, nullptr, 0));          // depth-bias net
+        RUN(wgrad_add(&wg, w.gbd, 128, 128, f.feats, ldf, 1, n_mvs, G + L.p_bdw, n_mvs, G + L.p_bdb, nullptr, nullptr, 0, xt));      // depth-bias net
         // the four head layers: base rgb (3 rows) + base sigma (row 3) on h5; adapt rgb on the views half of vc, adapt sigma on the view_confi half
         RUN(wgrad_add(&wg, w.g_base, 4, 4, w.sv.h[5], 128, 1, 128, G + L.p_crw, 128, G + L.p_crb, G + L.p_a1w, G + L.p_a1b, 3));
         RUN(wgrad_add(&wg, w.g_adapt, 4, 3, w.sv.vc, 128, 1, 64, G + L.p_rw, 64, G + L.p_rb, nullptr, nullptr, 0));

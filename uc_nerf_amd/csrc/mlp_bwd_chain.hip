@@ -88,10 +88,10 @@ __global__ void __launch_bounds__(256) pack_bwd_kernel(BwdPackArgs a) {
 }
 
 struct ChainArgs {
-    int m, n_tiles, F, ldf, ldgf, n_mvs, n_img;
+    int m, n_tiles, F, ldf, ldgf, n_mvs, n_img, feats_tiled;
     const float* raw;              // [m,4] forward output
     const float* g_raw;            // [m,4]
-    const float* feats;            // conf = feats[s * ldf + F - 1]
+    const float* feats;            // conf = feats[s * ldf + F - 1], or feature F - 1 of the tile layout [m / 32][F][32] (feats_tiled)
     MlpSaved sv;
     const char* wstream;           // pack_bwd_kernel's stream
     const float* head;             // ... and head table
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
         const c_f32x4 raw = reinterpret_cast<const c_f32x4*>(a.raw)[s];
         c_f32x4 gr = reinterpret_cast<const c_f32x4*>(a.g_raw)[s];
         if (!valid) gr = (c_f32x4){0.f, 0.f, 0.f, 0.f};
-        const float conf = a.feats[(size_t)s * a.ldf + a.F - 1];
+        const float conf = a.feats_tiled ? a.feats[((size_t)(s >> 5) * a.F + a.F - 1) * 32 + (s & 31)] : a.feats[(size_t)s * a.ldf + a.F - 1];
         const float u = 1.f - conf, omu = 1.f - u;
         const float gp[4] = {gr.x * raw.x * (1.f - raw.x), gr.y * raw.y * (1.f - raw.y), gr.z * raw.z * (1.f - raw.z), raw.w > 0.f ? gr.w : 0.f};
         const float gb4[4] = {gp[0] * omu, gp[1] * omu, gp[2] * omu, gp[3] * u};
@@ -467,7 +467,7 @@ int launch_pack_bwd(int n_src, const float* flat, float* stream_out, hipStream_t
 }
 
 // g_* / G_* operands: see ChainArgs.  `stream` = launch_pack_bwd's output.
-int launch_mlp_bwd_chain(int n_src, int m, const float* raw, const float* g_raw, const float* feats, int ldf, const MlpSaved* sv, const float* stream,
+int launch_mlp_bwd_chain(int n_src, int m, const float* raw, const float* g_raw, const float* feats, int ldf, int feats_tiled, const MlpSaved* sv, const float* stream,
                          float* G_vc, float* G_f, float* G_bc, float* gx, float* G_bd, float* const* G_y, float* g_feats, int ldgf, float* g_base,
                          float* g_adapt, hipStream_t st) {
     MlpLayout L;
@@ -476,7 +476,7 @@ int launch_mlp_bwd_chain(int n_src, int m, const float* raw, const float* g_raw,
     ChainArgs a;
     memset(&a, 0, sizeof(a));
     a.m = m; a.n_tiles = cdiv(m, 32); a.F = L.F; a.ldf = ldf; a.ldgf = ldgf; a.n_mvs = 24 + 4 * L.v; a.n_img = 8 * L.v;
-    a.raw = raw; a.g_raw = g_raw; a.feats = feats; a.sv = *sv;
+    a.raw = raw; a.g_raw = g_raw; a.feats = feats; a.feats_tiled = feats_tiled; a.sv = *sv;
     a.wstream = reinterpret_cast<const char*>(stream);
     a.head = stream + (size_t)BWD_HALF_STEPS * BWD_HALF_BYTES / 4;
     a.G_vc = G_vc; a.G_f = G_f; a.G_bc = G_bc; a.gx = gx; a.G_bd = G_bd;

@@ -11,7 +11,7 @@ namespace ucnerf {
 // ---- mlp_bwd_chain.hip
 size_t bwd_chain_stream_floats();
 int launch_pack_bwd(int n_src, const float* flat, float* stream_out, hipStream_t st);
-int launch_mlp_bwd_chain(int n_src, int m, const float* raw, const float* g_raw, const float* feats, int ldf, const MlpSaved* sv, const float* stream,
+int launch_mlp_bwd_chain(int n_src, int m, const float* raw, const float* g_raw, const float* feats, int ldf, int feats_tiled, const MlpSaved* sv, const float* stream,
                          float* G_vc, float* G_f, float* G_bc, float* gx, float* G_bd, float* const* G_y, float* g_feats, int ldgf, float* g_base,
                          float* g_adapt, hipStream_t st);
 
@@ -22,6 +22,7 @@ struct WgPair {
     float* gW; float* gb;                 // gW[n][k] at gW + n * ldw + k; gb may be NULL
     float* gW_hi; float* gb_hi;           // optional: rows n >= split belong to a second layer (row n - split of these)
     int ldg, nout, ldx, w, xdiv, ldw, split, cost;
+    int xtile_f;                          // > 0: X lives in the MLP tile layout [m / 32][xtile_f][32] (X points at its first column's row): ldx unused
     unsigned div_m, div_sh;               // s / xdiv = __umulhi(s, div_m) >> div_sh
 };
 struct WgArgs {
@@ -31,7 +32,7 @@ struct WgArgs {
 };
 void wgrad_begin(WgArgs* a, int m);
 int wgrad_add(WgArgs* a, const float* G, int ldg, int nout, const float* X, int ldx, int xdiv, int w, float* gW, int ldw, float* gb, float* gW_hi,
-              float* gb_hi, int split);
+              float* gb_hi, int split, int xtile_f = 0);
 int wgrad_launch(const WgArgs* a, hipStream_t st);
 
 }  // namespace ucnerf

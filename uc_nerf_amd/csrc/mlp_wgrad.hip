@@ -96,7 +96,9 @@ __global__ void __launch_bounds__(WG_THREADS, 4) mlp_wgrad_kernel(WgArgs a) {
                 const unsigned sc = (unsigned)(s < a.m ? s : a.m - 1);
                 const unsigned xrow = (sc & one) | ((__umulhi(sc, q.div_m) >> q.div_sh) & ~one);
                 r.g[8 * f + e] = q.G[(size_t)(sc * (unsigned)q.ldg + gc)];
-                r.x[8 * f + e] = q.X[(size_t)(xrow * (unsigned)q.ldx + xc)];
+                // (X in the MLP tile layout [m / 32][F][32]: column c of sample s at ((s / 32) F + c) 32 + s % 32)
+                const unsigned xo = q.xtile_f > 0 ? ((sc >> 5) * (unsigned)q.xtile_f + xc) * 32u + (sc & 31u) : xrow * (unsigned)q.ldx + xc;
+                r.x[8 * f + e] = q.X[(size_t)xo];
             }
         }
     };
@@ -212,13 +214,15 @@ __global__ void __launch_bounds__(WG_THREADS, 4) mlp_wgrad_kernel(WgArgs a) {
 void wgrad_begin(WgArgs* a, int m) { memset(a, 0, sizeof(*a)); a->m = m; a->stages = cdiv(m, WG_STAGE); }
 
 int wgrad_add(WgArgs* a, const float* G, int ldg, int nout, const float* X, int ldx, int xdiv, int w, float* gW, int ldw, float* gb, float* gW_hi,
-              float* gb_hi, int split) {
+              float* gb_hi, int split, int xtile_f) {
     if (a->n_pairs >= WG_MAX_PAIRS) return fail(UCNERF_EINVAL, "mlp_bwd: more than %d weight-gradient pairs", WG_MAX_PAIRS);
     if ((long long)a->m * (ldg > ldx ? ldg : ldx) >= (1ll << 32)) return fail(UCNERF_EINVAL, "mlp_bwd: %d samples x row stride %d overflow the kernel's 32-bit element offsets", a->m, ldg > ldx ? ldg : ldx);
     if (nout < 1 || nout > 128 || w < 1 || w > 128 || xdiv < 1) return fail(UCNERF_EINVAL, "mlp_bwd: weight-gradient pair %d x %d (xdiv %d) outside the kernel's tile", nout, w, xdiv);
     WgPair& q = a->p[a->n_pairs];
     q.G = G; q.ldg = ldg; q.nout = nout; q.X = X; q.ldx = ldx; q.xdiv = xdiv; q.w = w; q.gW = gW; q.ldw = ldw; q.gb = gb; q.gW_hi = gW_hi; q.gb_hi = gb_hi;
     q.split = gW_hi || gb_hi ? split : 1 << 30;
+    q.xtile_f = xtile_f;
+    if (xtile_f > 0 && xdiv != 1) return fail(UCNERF_EINVAL, "mlp_bwd: a tiled weight-gradient operand has one row per sample");
     {   // magic numbers for s / xdiv (s < 2^31): __umulhi(s, div_m) >> div_sh
         unsigned l = 1;
         while ((1u << l) < (unsigned)xdiv) ++l;

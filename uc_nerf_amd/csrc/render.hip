@@ -141,13 +141,13 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
         if ((rc = launch_mlp_fwd_bf16x3_gather(p, p->sources_cl, p->dir_feat ? p->dir_feat : w->angle, raw_fused, st))) return rc;
         if (p->ev_mlp_stop && (rc = ucnerf_event_record(p->ev_mlp_stop, st))) return rc;
     } else if (p->sources_cl) {                                // fast path: channel-last sources, coordinates derived in-kernel
-        g.out_tiled = keep_feats ? 0 : 1;
+        g.out_tiled = keep_feats ? (p->feats_tiled ? 1 : 0) : 1;
         g.feats = keep_feats ? p->feats : w->feats;
         if ((rc = launch_gather_cl(p, p->sources_cl, g.feats, g.out_tiled, w->ndc, st))) return rc;
     } else {
         if (!coords_given(p) && (rc = launch_points(p, st, w))) return rc;
         gather_geometry(p, w, &g);
-        g.out_tiled = keep_feats ? 0 : 1;
+        g.out_tiled = keep_feats ? (p->feats_tiled ? 1 : 0) : 1;
         g.feats = keep_feats ? p->feats : w->feats;
         g.u_out = p->u_sampled;
         if ((rc = ucnerf_feat_gather_fwd(&g, st))) return rc;
@@ -225,7 +225,7 @@ int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* bp, void* stream) {
 
     ucnerf_mlp_bwd_params mb;
     memset(&mb, 0, sizeof(mb));
-    mlp_args(&q, &w, p->feats, 0, nullptr, &mb.fwd);
+    mlp_args(&q, &w, p->feats, p->feats_tiled ? 1 : 0, nullptr, &mb.fwd);
     if (p->dir_feat) mb.fwd.dirs = p->dir_feat;
     mb.fwd.raw = g_raw;                      // placeholder (not written by the backward)
     mb.g_raw = g_raw; mb.flat_params = bp->flat_params; mb.g_feats = g_feats; mb.g_flat = bp->g_flat; mb.workspace = mlp_ws;

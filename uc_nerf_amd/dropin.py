@@ -188,7 +188,7 @@ class _FusedRender(torch.autograd.Function):
         out = rp(rays_dir, z, want=(), keep=("raw", "feats"), dir_feat=angle, coords=coords)
         ctx.sess, ctx.rp, ctx.src, ctx.pw, ctx.ws, ctx.flat, ctx.white_bkgd = sess, rp, src, rp.pw, rp.wstream, flat, white_bkgd
         ctx.layout = layout
-        ctx.coords, ctx.kept = coords, {"raw": out["raw"], "feats": out["feats"]}
+        ctx.coords, ctx.kept = coords, {"raw": out["raw"], "feats": out["feats"], "feats_tiled": out.get("feats_tiled", False)}
         ctx.geom = (z, rays_dir, angle)
         ctx.shapes = tuple(t.shape for t in (vol1, vol2, vol3, conf, img_feat))
         return out["rgb"], out["depth"]

@@ -623,6 +623,11 @@ def mlp_encoded(flat, x, pw, wstream=None):
     return _MLPEncoded.apply(flat, x, pw, wstream)
 
 
+def untile_feats(feats, m, F):
+    """Row-major [m, F] view-copy of features kept in the MLP's tile layout [ceil(m/32)][F][32] (what a training forward keeps)."""
+    return feats.view(-1, F, 32).permute(0, 2, 1).reshape(-1, F)[:m]
+
+
 # ------------------------------------------------------------------------------------------------ a9
 def composite_fwd(raw, z, variant=0, white_bkgd=False, rays_d=None, noise=None, want_var=True, u=None):
     """u: optional [n,S] per-sample uncertainty -> out["wu"] [n] = sum_i w_i u_i (composited uncertainty)."""
@@ -937,8 +942,14 @@ class RenderPass:
             out["var"] = torch.empty(n, device=dev)
         if "raw" in keep:
             out["raw"] = torch.empty(n, S, 4, device=dev)
+        # training forward (raw + features kept, exact f32 or split-bf16): the features stay in the MLP's tile layout -- the forward reads
+        # them as coalesced 128-byte rows (row-major: 4-byte pieces of 388-byte rows, 2x the launch time) and the backward takes them as they are
+        training = "raw" in keep and "feats" in keep and self.pw.cfg.precision in (0, 1)
         if "feats" in keep:
-            out["feats"] = torch.empty(n * S, self.src.F, device=dev)
+            tiled = training and _backward_mode == 0          # (the layer-by-layer backward reads row-major features)
+            out["feats"] = torch.empty((n * S + 31) // 32 * 32 * self.src.F, device=dev) if tiled else torch.empty(n * S, self.src.F, device=dev)
+            out["feats_tiled"] = tiled
+        p.feats_tiled = int(bool(out.get("feats_tiled", False)))
         if "u" in want or "wu" in want:
             out["u"] = torch.empty(n, S, device=dev)
         if "wu" in want:
@@ -952,7 +963,7 @@ class RenderPass:
         p.train_workspace = None
         p.dir_feat = _ptr(dir_feat)
         self._saved_for = None
-        if "raw" in keep and "feats" in keep and self.pw.cfg.precision in (0, 1):
+        if training:
             # training forward (exact f32 or split-bf16): keep the MLP activations in the backward's workspace so that
             # backward() need not repeat the network forward
             need_b = L.lib().ucnerf_render_bwd_workspace_floats(n, S, self.src.V)
@@ -979,6 +990,9 @@ class RenderPass:
         near_far = _f32(near_far) if near_far is not None else None
         p.rays_d, p.z, p.near_far = _ptr(rays_d), _ptr(z), _ptr(near_far)
         p.raw, p.feats = _ptr(kept["raw"]), _ptr(kept["feats"])
+        p.feats_tiled = int(bool(kept.get("feats_tiled", False)))
+        if p.feats_tiled and _backward_mode != 0:
+            raise RuntimeError("uc_nerf_amd.RenderPass.backward: features kept in the tile layout need the gradient chain (set_backward_mode('chain'))")
         p.u_sampled = p.wu_map = None
         _alive = self._coords(p, coords, n * S)      # noqa: F841
         dir_feat = _f32(dir_feat, "dir_feat") if dir_feat is not None else None
