@@ -192,15 +192,24 @@ def bench_dropin(ctx, scene, sd, steps=40, warmup=10):
     out = {}
     # evaluation: one 1024-pixel chunk x 90 samples under no_grad (train.py:254-272)
     ev = live_path_batch(scene, outputs, 1024, 90, seed=3, chunk_idx=7)
+    precs = ("f32", "bf16x3", "bf16x3_fused")      # bf16x3_fused: the headline kernel (gather inside the MLP kernel) on the coordinates rendering() is handed
     with torch.no_grad():
-        for prec in ("f32", "bf16x3"):
+        for prec in precs:
             uc_nerf_amd.set_inference_precision(prec)
             dt = ctx.timed(lambda: dropin_call(a, kw, scene, outputs, ev), steps * 4, warmup * 4)
-            out["dropin_eval_" + prec] = {"ms_per_call": dt * 1e3, "value": 1024 / dt, "unit": "rays/s", "rays": 1024, "samples_per_ray": 90}
+            out["dropin_eval_" + prec] = {"ms_per_call": dt * 1e3, "value": 1024 / dt, "unit": "rays/s", "rays": 1024, "samples_per_ray": 90,
+                                          "weight_cache": "verify (re-packed from the live parameters in every call)"}
+            # the opt-in version-keyed weight cache (one small launch less per call; blind to `.data` writes, see dropin.set_weight_cache)
+            uc_nerf_amd.set_weight_cache("versions")
+            try:
+                dtv = ctx.timed(lambda: dropin_call(a, kw, scene, outputs, ev), steps * 4, warmup * 4)
+            finally:
+                uc_nerf_amd.set_weight_cache("verify")
+            out["dropin_eval_" + prec]["ms_per_call_versions_cache"] = dtv * 1e3
         uc_nerf_amd.set_inference_precision("f32")
         # the same chunk through the library's own RenderPass (coordinates derived in-kernel from ray + depth + cascade ranges)
         src = ops.GatherSources(scene["vols"], scene["confidence"], scene["imgs"], scene["img_feat"], scene["w2cs"][1:], scene["intrinsics"][1:])
-        for prec in ("f32", "bf16x3"):
+        for prec in precs:
             pw = ops.PackedWeights.get(6, 0, dev, prec)
             rp = ops.RenderPass(src, pw, pw.pack(flat_params_of(sd).to(dev)), scene["c2w"][:3, 3].to(dev), scene["w2cs"][0], scene["intrinsics"][0],
                                 scene["w2cs"][0], scene["near"], scene["far"])
@@ -208,9 +217,10 @@ def bench_dropin(ctx, scene, sd, steps=40, warmup=10):
             ang, _ = ops.dir_feature(ev["rays_dir"], scene["w2cs"][0])
             dt = ctx.timed(lambda: rp(ev["rays_dir"], ev["depth_candidates"], near_far=ev["ranges"], want=(), dir_feat=ang), steps * 4, warmup * 4)
             out["render_pass_1024x90_" + prec] = {"ms_per_call": dt * 1e3, "value": 1024 / dt, "unit": "rays/s"}
-        for prec in ("f32", "bf16x3"):
-            out["dropin_eval_" + prec]["speed_vs_render_pass"] = (out["render_pass_1024x90_" + prec]["ms_per_call"]
-                                                                  / out["dropin_eval_" + prec]["ms_per_call"])
+        for prec in precs:
+            rp_ms = out["render_pass_1024x90_" + prec]["ms_per_call"]
+            out["dropin_eval_" + prec]["speed_vs_render_pass"] = rp_ms / out["dropin_eval_" + prec]["ms_per_call"]
+            out["dropin_eval_" + prec]["speed_vs_render_pass_versions_cache"] = rp_ms / out["dropin_eval_" + prec]["ms_per_call_versions_cache"]
     # training: 2000 rays x 90 samples, forward + loss + backward into the network AND the gather sources + Adam (train.py:147-188, 85-92)
     tr = live_path_batch(scene, outputs, 2000, 90, seed=4)
     vols = [v.detach().clone().requires_grad_(True) for v in scene["vols"]]

@@ -1,6 +1,5 @@
 #!/bin/bash
-# Bench lines and rocprofv3 kernel stats of the three routes on one box -> gpurun_out/final_* (GPU box); copy into profiles/ by hand
-# (profiles/r02_bench_bf16x3_fused.json, r02_bench_f32.json, r02_bench_kernel_stats_{bf16x3_fused,bf16x3,f32}.csv)
+# Bench lines, rocprofv3 kernel stats and PMC passes of one box -> gpurun_out/final_* (GPU box); scripts/collect_profiles.sh copies them into profiles/rNN/
 set -e
 R=$GRAFT_REPO_ROOT
 cd $R
@@ -12,4 +11,16 @@ for v in bf16x3_fused bf16x3 f32; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_ks_$v -- python3 $R/bench.py --cpu-rays 0 --no-reuse --precision $v > $R/gpurun_out/final_ks_$v.log 2>&1
   cp $R/gpurun_out/final_ks_$v/*/*kernel_stats.csv $R/gpurun_out/final_kernel_stats_$v.csv
 done
+# training: the library's fused pass (1024 x 128) and the rendering() drop-in step (2000 x 90), per-kernel times
+rm -rf $R/gpurun_out/final_ks_train $R/gpurun_out/final_ks_dropin_train
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_ks_train -- python3 $R/scripts/time_train_step.py > $R/gpurun_out/final_ks_train.log 2>&1
+cp $R/gpurun_out/final_ks_train/*/*kernel_stats.csv $R/gpurun_out/final_kernel_stats_train_step.csv
+MODE=train rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_ks_dropin_train -- python3 $R/scripts/time_dropin.py > $R/gpurun_out/final_ks_dropin_train.log 2>&1
+cp $R/gpurun_out/final_ks_dropin_train/*/*kernel_stats.csv $R/gpurun_out/final_kernel_stats_dropin_train.csv
+cd $R
+# PMC passes (separate runs per counter group): the fused forward kernel of the bench, and the training-step kernels
+PREC=bf16x3_fused KERNEL=mlp_fwd_bf16 bash scripts/pmc_mlp.sh final_pmc_fused > gpurun_out/final_pmc_fused.log 2>&1
+python scripts/pmc_summary.py gpurun_out/final_pmc_fused gpurun_out/final_mlp_bf16_fused_hbm_traffic.json > gpurun_out/final_pmc_fused_summary.log 2>&1 || true
+KERNEL="mlp_bwd_chain|mlp_wgrad|mlp_fwd_kernel|feat_gather" SCRIPT=scripts/time_train_step.py bash scripts/pmc_mlp.sh final_pmc_train > gpurun_out/final_pmc_train.log 2>&1
+python scripts/pmc_by_kernel.py gpurun_out/final_pmc_train gpurun_out/final_train_step_hbm_traffic.json > gpurun_out/final_pmc_train_summary.log 2>&1 || true
 tail -c 300 $R/gpurun_out/final_bf16x3_fused.json

@@ -231,22 +231,6 @@ __global__ void pack_bf16_kernel(const float* __restrict__ flat, const int32_t* 
     out[i] = r;
 }
 
-__global__ void pack_bf16_tab_kernel(ParamTable t, const int32_t* __restrict__ idx, unsigned short* __restrict__ out, int64_t n) {
-    __shared__ ParamTableLds l;
-    param_table_to_lds(t, &l);
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t k = idx[i];
-    unsigned short r = 0;
-    if (k >= 0) {
-        const float w = param_table_load(&l, k & 0x3fffffff);
-        const __bf16 hi = (__bf16)w;
-        const __bf16 val = (k >> 30) ? (__bf16)(w - (float)hi) : hi;
-        r = __builtin_bit_cast(unsigned short, val);
-    }
-    out[i] = r;
-}
-
 #endif   // UCNERF_BF16_BUILD_TERMS == 3 (host-side packing)
 
 // ------------------------------------------------------------------------------------------------ device helpers
@@ -1418,20 +1402,35 @@ int launch_pack_bf16(const ucnerf_mlp_config* cfg, const float* flat, const int3
     return check_launch("mlp_pack (bf16x3)");
 }
 
-__global__ void pack_f32_tab_kernel(ParamTable t, const int32_t* __restrict__ idx, float* __restrict__ out, int n) {
+// ONE launch for the whole stream (the drop-in re-packs in every no_grad call): blocks [0, nb16) convert the bf16 half-steps, the rest copy the fp32 constants
+__global__ void pack_all_tab_kernel(ParamTable t, const int32_t* __restrict__ idx, unsigned short* __restrict__ out16, int64_t n16, float* __restrict__ outc, int nc, int nb16) {
     __shared__ ParamTableLds l;
     param_table_to_lds(t, &l);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const int32_t k = idx[i]; out[i] = k >= 0 ? param_table_load(&l, k) : 0.f; }
+    if ((int)blockIdx.x < nb16) {
+        const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= n16) return;
+        const int32_t k = idx[i];
+        unsigned short r = 0;
+        if (k >= 0) {
+            const float w = param_table_load(&l, k & 0x3fffffff);
+            const __bf16 hi = (__bf16)w;
+            const __bf16 val = (k >> 30) ? (__bf16)(w - (float)hi) : hi;
+            r = __builtin_bit_cast(unsigned short, val);
+        }
+        out16[i] = r;
+    } else {
+        const int i = ((int)blockIdx.x - nb16) * blockDim.x + threadIdx.x;
+        if (i < nc) { const int32_t k = idx[n16 + i]; outc[i] = k >= 0 ? param_table_load(&l, k) : 0.f; }
+    }
 }
 
 int launch_pack_bf16_tab(const ucnerf_mlp_config* cfg, const ParamTable& t, const int32_t* idx, float* out, hipStream_t st) {
     Bf16Layout B;
     UCNERF_REQUIRE(bf16_layout(cfg->n_src, &B), "mlp_pack: n_src %d outside 1..8", cfg->n_src);
     const int64_t n16 = (int64_t)B.slots * (SLOT_BYTES / 2);
-    hipLaunchKernelGGL(pack_bf16_tab_kernel, dim3(cdiv(n16, 256)), dim3(256), 0, st, t, idx, reinterpret_cast<unsigned short*>(out), n16);
-    hipLaunchKernelGGL(pack_f32_tab_kernel, dim3(cdiv(CONST_FLOATS, 256)), dim3(256), 0, st, t, idx + n16,
-                       reinterpret_cast<float*>(reinterpret_cast<char*>(out) + B.const_off_bytes), CONST_FLOATS);
+    const int nb16 = cdiv(n16, 256), nbc = cdiv(CONST_FLOATS, 256);
+    hipLaunchKernelGGL(pack_all_tab_kernel, dim3(nb16 + nbc), dim3(256), 0, st, t, idx, reinterpret_cast<unsigned short*>(out), n16,
+                       reinterpret_cast<float*>(reinterpret_cast<char*>(out) + B.const_off_bytes), CONST_FLOATS, nb16);
     return check_launch("mlp_pack_tensors (bf16x3)");
 }
 
