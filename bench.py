@@ -549,6 +549,22 @@ def main():
                                 "%d x %d image = every %d batches" % (scene_cpu["H"], scene_cpu["W"], per_image)}
             extra["constant_sources"] = guarded(constant_sources)
 
+            def bf16_sources():
+                """configs[4]'s "fp32 MLP / bf16 features" taken literally: the same step with the channel-last source copies held in bf16
+                (half the bytes per gather corner and per repack).  Quality against the fp32-source render of the same rays and depths."""
+                rb = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, max_blocks=args.max_blocks,
+                                        precision=args.precision, sources_bf16=True)
+                dt7 = ctx.timed(lambda: rb.render(xs, ys, perturb=1.0, noise=noise), args.steps, args.warmup)
+                ob = rb.render(xs, ys, perturb=0.0)
+                of = renderer.render(xs, ys, perturb=0.0)
+                mse = torch.mean((ob["rgb"] - of["rgb"]) ** 2).item()
+                return {"value": global_rays / dt7, "unit": "rays/s", "ms_per_step": dt7 * 1e3,
+                        "psnr_db_vs_fp32_sources": -10.0 * math.log10(max(mse, 1e-20)),
+                        "max_abs_rgb_vs_fp32_sources": (ob["rgb"] - of["rgb"]).abs().max().item(),
+                        "note": "NOT the headline and NOT within the 1e-4 parity bar: gather sources rounded to bf16 in their channel-last copies "
+                                "(GatherSources(cl_bf16=True) / set_source_precision('bf16')); MLP and compositing unchanged"}
+            extra["bf16_sources"] = guarded(bf16_sources)
+
             def hip_graph_replay():
                 """The headline step (source repack included) captured once into a HIP graph and replayed: the same launches without the
                 host's per-launch work (`CoarseFineRenderer.capture`, replay asserted bit-identical to the eager step)."""

@@ -498,11 +498,15 @@ typedef struct {
     int32_t feats_tiled;       /* layout of `feats` when it is kept: 0 row-major [n*S,F]; 1 the MLP's tile layout [ceil(n*S/32)][F][32]
                                   (ceil(n*S/32)*32*F floats) -- what the training forward reads three times faster (coalesced 128-byte
                                   rows instead of 4-byte pieces of 388-byte rows) and ucnerf_render_fused_bwd (bwd_mode 0) accepts */
+    int32_t sources_cl_bf16;   /* 1: `sources_cl` holds bf16 copies (ucnerf_gather_repack with the same flag: 16-byte voxels, 24-byte pixels,
+                                  values rounded to nearest even) -- SURVEY.md 8 configs[4] "fp32 MLP / bf16 features": half the bytes of every
+                                  gather corner, features within bf16 rounding of the fp32 sources'.  Forward only reads differ; the backward
+                                  accumulates source gradients in fp32 as before.  With cfg.precision == 3: derived coordinates only */
 } ucnerf_render_params;
 int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream);
 /* Channel-last repack of the gather sources named in `p` (vol[3] -> [D,h,w,8] each, imgs + img_feat ->
- * [V,H,W,12] = (r,g,b,f0..f7,0)) into `dst` (ucnerf_gather_repack_floats(p) floats, 16-byte aligned).  Redo it
+ * [V,H,W,12] = (r,g,b,f0..f7,0); fp32, or bf16 when p->sources_cl_bf16) into `dst` (ucnerf_gather_repack_floats(p) floats, 16-byte aligned).  Redo it
  * whenever the sources change (once per image in evaluation, once per step in training): ~150 MB of traffic. */
 int64_t ucnerf_gather_repack_floats(const ucnerf_render_params* p);
 int ucnerf_gather_repack(const ucnerf_render_params* p, float* dst, void* stream);

@@ -208,3 +208,90 @@ def test_backward_modes_agree(sd_v7):
             ops.set_backward_mode("chain")
     for a_, b_ in zip(res["chain"], res["layerwise"]):
         torch.testing.assert_close(a_, b_, atol=5e-5 * b_.abs().max().item(), rtol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------- configs[4]: bf16 features (channel-last source copies in bf16)
+def _rounded(scene):
+    """The scene with its heavy gather sources rounded to bf16 (what the bf16 channel-last copies hold), still fp32 tensors."""
+    s = dict(scene)
+    s["vols"] = [v.bfloat16().float() for v in scene["vols"]]
+    s["imgs"] = scene["imgs"].bfloat16().float()
+    s["img_feat"] = scene["img_feat"].bfloat16().float()
+    return s
+
+
+@pytest.mark.parametrize("precision", ["bf16x3_fused", "bf16x3", "f32"])
+def test_bf16_source_copies_equal_fp32_copies_of_bf16_rounded_sources_and_stay_above_50_db(precision):
+    """configs[4] "fp32 MLP / bf16 features": the gather reads bf16 channel-last copies.  (a) Nothing but the rounding of the sources changes:
+    the render is BIT-IDENTICAL to the fp32-copy render of sources rounded to bf16 beforehand -- same corner order, same fp32 arithmetic --
+    on the two-kernel pass and inside the gather-fused kernel; (b) quality gate: >= 50 dB against the fp32-source render."""
+    from uc_nerf_amd.pipeline import CoarseFineRenderer, flat_params_of
+    from uc_nerf_amd.synthetic import init_ucnerf_state_dict, make_scene, random_pixels, scene_to
+    scene = make_scene(seed=0)
+    sd = init_ucnerf_state_dict(seed=0, sigma_scale=0.05, sigma_bias=0.05)
+    xs, ys = random_pixels(2048, 256, 320, seed=3)
+    xs_d, ys_d = dev(xs), dev(ys)
+    flat = flat_params_of(sd).to(DEV)
+    d = torch.device(DEV)
+    full = CoarseFineRenderer(scene_to(scene, d), flat, 64, 128, precision=precision).render(xs_d, ys_d)
+    full = {k: full[k].clone() for k in ("rgb", "depth", "acc")}
+    r16 = CoarseFineRenderer(scene_to(scene, d), flat, 64, 128, precision=precision, sources_bf16=True)
+    got = r16.render(xs_d, ys_d)
+    assert r16.pass_.p.sources_cl_bf16 == 1
+    got = {k: got[k].clone() for k in ("rgb", "depth", "acc")}
+    ref = CoarseFineRenderer(scene_to(_rounded(scene), d), flat, 64, 128, precision=precision).render(xs_d, ys_d)
+    for k in ("rgb", "depth", "acc"):
+        assert torch.equal(got[k], ref[k]), k
+    mse = ((got["rgb"] - full["rgb"]) ** 2).mean().item()
+    psnr = 99.0 if mse == 0 else -10.0 * torch.log10(torch.tensor(mse)).item()
+    assert psnr >= 50.0, psnr
+    record("configs4_bf16_source_copies_%s" % precision, rays=2048, psnr_db_vs_fp32_sources=psnr,
+           max_abs_rgb=(got["rgb"] - full["rgb"]).abs().max().item(), max_abs_depth=(got["depth"] - full["depth"]).abs().max().item(),
+           copy_bytes=int(r16.src._cl.numel() * 4))
+
+
+def test_bf16_source_copies_through_the_rendering_mirror_forward_and_backward(sd_v7):
+    """set_source_precision("bf16") under rendering(): the forward (given coordinates) and the training step's gradients equal those of
+    the fp32 copies of sources rounded to bf16 beforehand; the source gradients arrive in fp32 for the fp32 tensors handed in."""
+    import uc_nerf_amd
+    models, renderer = _install()
+    g = load_golden("g10_rendering")
+    V = g["V"]
+    e_p, _ = models.get_embedder(10, 0)
+    e_d, _ = models.get_embedder(4, 0)
+    qfn = lambda pts, vd, f, fn: renderer.run_network_mvs(pts, vd, f, fn, embed_fn=e_p, embeddirs_fn=e_d)
+    args = types.SimpleNamespace(view_num=V, feat_dim=97, img_downscale=1.0, use_color_volume=False, net_type="v2")
+    ndc = {"stage1": dev(g["ndc1"]), "stage2": dev(g["ndc2"]), "stage3": dev(g["ndc3"]), "ndc": dev(g["ndc"])}
+
+    def run(rounded, prec):
+        rnd = (lambda t: t.bfloat16().float()) if rounded else (lambda t: t)
+        uc_nerf_amd.set_source_precision(prec)
+        try:
+            net = models.UCNeRF(D=6, W=128, input_ch_pts=63, input_ch_views=27, input_ch_feat=97, view_num=V).to(DEV)
+            net.load_state_dict({k: dev(v) for k, v in sd_v7.items()})
+            vols = [dev(rnd(g["vol%d" % k])).requires_grad_(True) for k in (1, 2, 3)]
+            img_feat, conf = dev(rnd(g["img_feat"])).requires_grad_(True), dev(g["conf"]).requires_grad_(True)
+            vf = {"stage%d" % (i + 1): {"volume_feature_no_ref": vols[i]} for i in range(3)}
+            pose = {"w2cs": dev(g["w2cs"]).clone(), "intrinsics": dev(g["K"]).repeat(V, 1, 1)}
+            rgb, depth = renderer.rendering(args, pose, dev(g["pts"]), ndc, dev(g["z"]), dev(g["rays_d"]), vf, dev(rnd(g["imgs"])),
+                                            network_fn=net, img_feat=img_feat, network_query_fn=qfn, confidence=conf)
+            (rgb.sum() + 0.3 * depth.sum()).backward()
+            with torch.no_grad():
+                pose = {"w2cs": dev(g["w2cs"]).clone(), "intrinsics": dev(g["K"]).repeat(V, 1, 1)}
+                ev = renderer.rendering(args, pose, dev(g["pts"]), ndc, dev(g["z"]), dev(g["rays_d"]), vf, dev(rnd(g["imgs"])),
+                                        network_fn=net, img_feat=img_feat, network_query_fn=qfn, confidence=conf)
+            return (rgb.detach(), depth.detach(), ev[0], ev[1],
+                    [q.grad.clone() for q in net.parameters() if q.grad is not None] + [t.grad.clone() for t in vols + [img_feat, conf]])
+        finally:
+            uc_nerf_amd.set_source_precision("f32")
+
+    a = run(False, "bf16")
+    b = run(True, "f32")
+    for i in range(4):
+        assert torch.equal(a[i], b[i]), i
+    assert all(t.dtype == torch.float32 for t in a[4])
+    for x, y in zip(a[4], b[4]):
+        torch.testing.assert_close(x, y, atol=2e-5 * max(y.abs().max().item(), 1e-6), rtol=1e-4)      # (float atomics: the accumulation order differs run to run)
+    # ... and the rounding is really there: against the unrounded fp32 sources the render moves
+    c = run(False, "f32")
+    assert not torch.equal(a[0], c[0]) and (a[0] - c[0]).abs().max().item() < 2e-2

@@ -25,6 +25,13 @@ def set_weight_cache(policy):
     dropin.set_weight_cache(policy)
 
 
+def set_source_precision(precision):
+    """Element type of the channel-last source copies `rendering()` gathers from: "f32" (default) or "bf16" (configs[4]'s "bf16 features":
+    an opt-in quality / speed trade, dropin.set_source_precision)."""
+    from . import dropin
+    dropin.set_source_precision(precision)
+
+
 def set_training_precision(precision):
     """MLP arithmetic of the training forward of the `rendering()` drop-in: "f32" (default) or "bf16x3" (dropin.py)."""
     from . import dropin

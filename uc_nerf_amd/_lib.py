@@ -128,7 +128,7 @@ class RenderParams(C.Structure):
                 ("w2cs", vp), ("intrinsics", vp), ("wstream", vp), ("sources_cl", vp), ("workspace", vp), ("rgb_map", vp),
                 ("depth_map", vp), ("acc_map", vp), ("weights", vp), ("var", vp), ("raw", vp), ("feats", vp),
                 ("ev_mlp_start", vp), ("ev_mlp_stop", vp), ("train_workspace", vp), ("dir_feat", vp), ("u_sampled", vp),
-                ("wu_map", vp), ("pts_in", vp), ("ndc1_in", vp), ("ndc2_in", vp), ("ndc3_in", vp), ("ndc_in", vp), ("feats_tiled", i32)]
+                ("wu_map", vp), ("pts_in", vp), ("ndc1_in", vp), ("ndc2_in", vp), ("ndc3_in", vp), ("ndc_in", vp), ("feats_tiled", i32), ("sources_cl_bf16", i32)]
 
 
 class RenderBwdParams(C.Structure):

@@ -19,6 +19,15 @@ struct RepackArgs {
     const float* imgs; const float* feat; float4* img_dst; int V; size_t hw;
 };
 
+// two floats -> one dword of two bf16 (round to nearest even), first value in the low half
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    typedef __bf16 bf2_ __attribute__((ext_vector_type(2)));
+    const bf2_ v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// S16: the copies hold bf16 (SURVEY.md 8 configs[4] "bf16 features"): a voxel is 16 bytes, a pixel 24 -- half the bytes of every corner
+template <bool S16>
 __global__ void __launch_bounds__(256) repack_sources_kernel(RepackArgs a) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int k = blockIdx.y;
@@ -29,17 +38,28 @@ __global__ void __launch_bounds__(256) repack_sources_kernel(RepackArgs a) {
         float c[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) c[q] = src[(size_t)q * n_vox + i];
-        a.vol_dst[k][2 * i] = make_float4(c[0], c[1], c[2], c[3]);
-        a.vol_dst[k][2 * i + 1] = make_float4(c[4], c[5], c[6], c[7]);
+        if (S16) {
+            reinterpret_cast<uint4*>(a.vol_dst[k])[i] = make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]), pack_bf16x2(c[6], c[7]));
+        } else {
+            a.vol_dst[k][2 * i] = make_float4(c[0], c[1], c[2], c[3]);
+            a.vol_dst[k][2 * i + 1] = make_float4(c[4], c[5], c[6], c[7]);
+        }
     } else {
         const size_t hw = a.hw;
         if (i >= (size_t)a.V * hw) return;
         const size_t v = i / hw, px = i % hw;
         const float* im = a.imgs + v * 3 * hw + px;
         const float* ft = a.feat + v * 8 * hw + px;
-        a.img_dst[3 * i] = make_float4(im[0], im[hw], im[2 * hw], ft[0]);
-        a.img_dst[3 * i + 1] = make_float4(ft[hw], ft[2 * hw], ft[3 * hw], ft[4 * hw]);
-        a.img_dst[3 * i + 2] = make_float4(ft[5 * hw], ft[6 * hw], ft[7 * hw], 0.f);
+        if (S16) {
+            uint2* d = reinterpret_cast<uint2*>(a.img_dst) + 3 * i;         // 24 bytes per pixel
+            d[0] = make_uint2(pack_bf16x2(im[0], im[hw]), pack_bf16x2(im[2 * hw], ft[0]));
+            d[1] = make_uint2(pack_bf16x2(ft[hw], ft[2 * hw]), pack_bf16x2(ft[3 * hw], ft[4 * hw]));
+            d[2] = make_uint2(pack_bf16x2(ft[5 * hw], ft[6 * hw]), pack_bf16x2(ft[7 * hw], 0.f));
+        } else {
+            a.img_dst[3 * i] = make_float4(im[0], im[hw], im[2 * hw], ft[0]);
+            a.img_dst[3 * i + 1] = make_float4(ft[hw], ft[2 * hw], ft[3 * hw], ft[4 * hw]);
+            a.img_dst[3 * i + 2] = make_float4(ft[5 * hw], ft[6 * hw], ft[7 * hw], 0.f);
+        }
     }
 }
 
@@ -78,8 +98,9 @@ __device__ __forceinline__ SampleIn sample_in(const GatherClArgs& a, unsigned id
     return s;
 }
 
-template <bool TILED, bool GIVEN>
+template <bool TILED, bool GIVEN, bool S16>
 __device__ __forceinline__ void gather_cl_unit(const GatherClArgs& a, unsigned idx, int unit, const SampleIn& in) {
+    constexpr unsigned VOX = S16 ? 16u : 32u, PIX = S16 ? 24u : 48u;     // bytes per voxel / pixel of the channel-last copies
     const int F = 24 + 12 * a.V + 1;
     const unsigned r = in.r;
     const float z = in.z;
@@ -132,13 +153,15 @@ __device__ __forceinline__ void gather_cl_unit(const GatherClArgs& a, unsigned i
                      az = axis_cl(zn * 2.f - 1.0f, D, false);
         const char* vol = (const char*)a.vol[unit];
         // byte offsets of the four (z, y) rows at x0, and the step to x1 (0 at the clamped border)
-        const unsigned o00 = (unsigned)((az.i0 * hh + ay.i0) * ww + ax.i0) * 32u, o01 = (unsigned)((az.i0 * hh + ay.i1) * ww + ax.i0) * 32u,
-                       o10 = (unsigned)((az.i1 * hh + ay.i0) * ww + ax.i0) * 32u, o11 = (unsigned)((az.i1 * hh + ay.i1) * ww + ax.i0) * 32u;
-        const unsigned dx = (unsigned)(ax.i1 - ax.i0) * 32u;
+        const unsigned o00 = (unsigned)((az.i0 * hh + ay.i0) * ww + ax.i0) * VOX, o01 = (unsigned)((az.i0 * hh + ay.i1) * ww + ax.i0) * VOX,
+                       o10 = (unsigned)((az.i1 * hh + ay.i0) * ww + ax.i0) * VOX, o11 = (unsigned)((az.i1 * hh + ay.i1) * ww + ax.i0) * VOX;
+        const unsigned dx = (unsigned)(ax.i1 - ax.i0) * VOX;
         const float w00 = az.w0 * ay.w0, w01 = az.w0 * ay.w1, w10 = az.w1 * ay.w0, w11 = az.w1 * ay.w1;
         gf2 lo[2] = {{0, 0}, {0, 0}}, hi[2] = {{0, 0}, {0, 0}};
         // same accumulation order as gather.hip: (z0,y0), (z0,y1), (z1,y0), (z1,y1), x0 before x1
-#define CORNER8(O, WT) { const float w__ = (WT); FMA4(lo, ld16(vol, (O)), w__) FMA4(hi, ld16(vol, (O) + 16u), w__) }
+#define CORNER8(O, WT) { const float w__ = (WT);                                                                      \
+        if (S16) { const float4 r_ = ld16(vol, (O)); FMA4(lo, bf16x4_lo(r_), w__) FMA4(hi, bf16x4_hi(r_), w__) }          \
+        else { FMA4(lo, ld16(vol, (O)), w__) FMA4(hi, ld16(vol, (O) + 16u), w__) } }
         CORNER8(o00, w00 * ax.w0) CORNER8(o00 + dx, w00 * ax.w1)
         CORNER8(o01, w01 * ax.w0) CORNER8(o01 + dx, w01 * ax.w1)
         CORNER8(o10, w10 * ax.w0) CORNER8(o10 + dx, w10 * ax.w1)
@@ -152,12 +175,15 @@ __device__ __forceinline__ void gather_cl_unit(const GatherClArgs& a, unsigned i
         project_cl(a.w2cs + 12 * vi, a.Ks + 9 * vi, x, y, w, &qx, &qy, &qz);
         const float gx = (qx / qz + 0.0f) / (float)(a.W - 1) * 2.0f - 1.0f, gy = (qy / qz + 0.0f) / (float)(a.H - 1) * 2.0f - 1.0f;
         const LerpCl ax = axis_cl(gx, a.W, true), ay = axis_cl(gy, a.H, true);
-        const char* img = (const char*)(a.img + (size_t)vi * a.H * a.W * 3);
-        const unsigned p00 = (unsigned)(ay.i0 * a.W + ax.i0) * 48u, p10 = (unsigned)(ay.i1 * a.W + ax.i0) * 48u;
-        const unsigned dx = (unsigned)(ax.i1 - ax.i0) * 48u;
+        const char* img = (const char*)a.img + (size_t)vi * a.H * a.W * PIX;
+        const unsigned p00 = (unsigned)(ay.i0 * a.W + ax.i0) * PIX, p10 = (unsigned)(ay.i1 * a.W + ax.i0) * PIX;
+        const unsigned dx = (unsigned)(ax.i1 - ax.i0) * PIX;
         const float w00 = ay.w0 * ax.w0, w01 = ay.w0 * ax.w1, w10 = ay.w1 * ax.w0, w11 = ay.w1 * ax.w1;
         gf2 c0[2] = {{0, 0}, {0, 0}}, c1[2] = {{0, 0}, {0, 0}}, c2[2] = {{0, 0}, {0, 0}};      // (r g b f0) (f1..f4) (f5 f6 f7 -)
-#define CORNER12(P, WT) { const float w__ = (WT); FMA4(c0, ld16(img, (P)), w__) FMA4(c1, ld16(img, (P) + 16u), w__) FMA4(c2, ld16(img, (P) + 32u), w__) }
+#define CORNER12(P, WT) { const float w__ = (WT);                                                                                        \
+        if (S16) { const float4 r_ = ld16(img, (P)); const float2 t_ = ld8(img, (P) + 16u);                                              \
+                   FMA4(c0, bf16x4_lo(r_), w__) FMA4(c1, bf16x4_hi(r_), w__) FMA4(c2, bf16x4_lo(make_float4(t_.x, t_.y, 0.f, 0.f)), w__) } \
+        else { FMA4(c0, ld16(img, (P)), w__) FMA4(c1, ld16(img, (P) + 16u), w__) FMA4(c2, ld16(img, (P) + 32u), w__) } }
         CORNER12(p00, w00) CORNER12(p00 + dx, w01) CORNER12(p10, w10) CORNER12(p10 + dx, w11)
 #undef CORNER12
         PUT((24 + 4 * vi) * fs, c0[0].x);
@@ -178,15 +204,15 @@ __device__ __forceinline__ void gather_cl_unit(const GatherClArgs& a, unsigned i
 #ifndef UCNERF_GATHER_WAVES
 #define UCNERF_GATHER_WAVES 1     // min waves per SIMD asked of the compiler (8 = 64 VGPRs: measured no faster than the 7 it gets by itself)
 #endif
-template <bool TILED, bool GIVEN>
+template <bool TILED, bool GIVEN, bool S16 = false>
 __global__ void __launch_bounds__(256, TILED ? UCNERF_GATHER_WAVES : 1) feat_gather_cl_kernel(GatherClArgs a) {
     const unsigned idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= a.M) return;
     SampleIn in = {0u, 0.f, 0.f, 0.f, 0.f};
     if (!GIVEN) in = sample_in(a, idx);
-    if (TILED) gather_cl_unit<true, GIVEN>(a, idx, blockIdx.y, in);
+    if (TILED) gather_cl_unit<true, GIVEN, S16>(a, idx, blockIdx.y, in);
     else
-        for (int unit = 0; unit < 4 + a.V; ++unit) gather_cl_unit<false, GIVEN>(a, idx, unit, in);
+        for (int unit = 0; unit < 4 + a.V; ++unit) gather_cl_unit<false, GIVEN, S16>(a, idx, unit, in);
 }
 
 
@@ -272,7 +298,8 @@ int64_t ucnerf_gather_repack_floats(const ucnerf_render_params* p) {
     if (!p) return fail(UCNERF_EINVAL, "gather_repack_floats: null params");
     int64_t n = 0;
     for (int k = 0; k < 3; ++k) n += 8ll * p->vol_d[k] * p->vol_h[k] * p->vol_w[k];
-    return n + 12ll * p->cfg.n_src * p->H * p->W;
+    n += 12ll * p->cfg.n_src * p->H * p->W;
+    return p->sources_cl_bf16 ? (n + 1) / 2 : n;           // (bf16 copies: two values per float; every volume is a multiple of 16 bytes)
 }
 
 int ucnerf_gather_repack(const ucnerf_render_params* p, float* dst, void* stream) {
@@ -285,12 +312,13 @@ int ucnerf_gather_repack(const ucnerf_render_params* p, float* dst, void* stream
     for (int k = 0; k < 3; ++k) {
         a.n_vox[k] = (size_t)p->vol_d[k] * p->vol_h[k] * p->vol_w[k];
         a.vol[k] = p->vol[k]; a.vol_dst[k] = (float4*)o;
-        o += 8 * a.n_vox[k];
+        o += (p->sources_cl_bf16 ? 4 : 8) * a.n_vox[k];
         if (a.n_vox[k] > n_max) n_max = a.n_vox[k];
     }
     a.imgs = p->imgs; a.feat = p->img_feat; a.img_dst = (float4*)o; a.V = p->cfg.n_src; a.hw = (size_t)p->H * p->W;
     if (a.hw * a.V > n_max) n_max = a.hw * a.V;
-    hipLaunchKernelGGL(repack_sources_kernel, dim3(cdiv(n_max, 256), 4), dim3(256), 0, (hipStream_t)stream, a);
+    if (p->sources_cl_bf16) hipLaunchKernelGGL(repack_sources_kernel<true>, dim3(cdiv(n_max, 256), 4), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(repack_sources_kernel<false>, dim3(cdiv(n_max, 256), 4), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("gather_repack");
 }
 
@@ -308,7 +336,7 @@ int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float
     for (int k = 0; k < 3; ++k) {
         a.vol_d[k] = p->vol_d[k]; a.vol_h[k] = p->vol_h[k]; a.vol_w[k] = p->vol_w[k];
         a.vol[k] = (const float4*)o;
-        o += 8ull * p->vol_d[k] * p->vol_h[k] * p->vol_w[k];
+        o += (p->sources_cl_bf16 ? 4ull : 8ull) * p->vol_d[k] * p->vol_h[k] * p->vol_w[k];
     }
     a.img = (const float4*)o;
     a.conf = p->conf; a.rays_o = p->rays_o; a.rays_d = p->rays_d; a.z = p->z; a.near_far = p->near_far;
@@ -334,7 +362,14 @@ int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float
                                   // thread for every unit.  Measured (profiles/r02_gather_experiments.md): 3x fewer corner loads, but 36.5 us for the
                                   // six views against ~32 us on the per-sample kernel at 7 waves per SIMD -- the default stays 0
 #endif
-    if (tiled && UCNERF_GATHER_RUN) {
+    if (p->sources_cl_bf16) {
+        UCNERF_REQUIRE(!UCNERF_GATHER_RUN, "gather_cl: the corner-reuse variant reads fp32 copies only");
+        if (tiled && !given) hipLaunchKernelGGL((feat_gather_cl_kernel<true, false, true>), grid, block, 0, st, a);
+        else if (tiled) hipLaunchKernelGGL((feat_gather_cl_kernel<true, true, true>), grid, block, 0, st, a);
+        else if (!given) hipLaunchKernelGGL((feat_gather_cl_kernel<false, false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((feat_gather_cl_kernel<false, true, true>), grid, block, 0, st, a);
+    }
+    else if (tiled && UCNERF_GATHER_RUN) {
         const dim3 grid_ref(cdiv(M, 256), 4), grid_r(cdiv(cdiv(M, RUN), RUN_THREADS), a.V), block_r(RUN_THREADS);
         if (!given) {
             hipLaunchKernelGGL((feat_gather_cl_kernel<true, false>), grid_ref, block, 0, st, a);        // volumes + confidence (+ ndc, u)

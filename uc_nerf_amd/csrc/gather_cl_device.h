@@ -53,6 +53,26 @@ __device__ __forceinline__ float4 ld16(const char* base, unsigned off) {
     return *(const float4*)(base + off);
 }
 
+__device__ __forceinline__ float2 ld8(const char* base, unsigned off) {
+#if UCNERF_GATHER_EXP & 2
+    off &= 0x7ff8u;
+#endif
+#if UCNERF_GATHER_EXP & 4
+    const float f_ = __uint_as_float(off | 0x3f000000u);
+    return make_float2(f_, f_);
+#endif
+    return *(const float2*)(base + off);
+}
+// bf16 channel-last copies: eight bf16 in 16 bytes -> the first / second four as floats (a bf16 is the upper half of its float)
+__device__ __forceinline__ float4 bf16x4_lo(const float4& r) {
+    const unsigned a = __float_as_uint(r.x), b = __float_as_uint(r.y);
+    return make_float4(__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u));
+}
+__device__ __forceinline__ float4 bf16x4_hi(const float4& r) {
+    const unsigned a = __float_as_uint(r.z), b = __float_as_uint(r.w);
+    return make_float4(__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u));
+}
+
 // o += v * w on four packed pairs (v_pk_fma_f32: the products are not rounded separately -- the reference's own CUDA
 // grid_sample contracts the same way; the parity bar on the features is 2e-5).
 #define FMA4(O, A, WT)                                                                           \

@@ -559,11 +559,12 @@ struct FusedGather {
     const float* pts_in;
     const float* ndc_in[3];
     const float* ndc_enc;
+    int s16;                 // the channel-last copies hold bf16 (ucnerf_render_params.sources_cl_bf16): 16-byte voxels, 24-byte pixels
 };
 [[maybe_unused]] constexpr int FUSED_MAX_V = 8;    // (seven and eight views: with a two-slot weight ring, fused_ring_slots)
 constexpr int VIEW_TAB = 24;      // floats per source view in the LDS table: w2c (12), K (9), pad
 
-template <bool TILED, int NSRC, int TERMS, bool SAVE, bool FUSED = false, bool COORDS = false>       // TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only); SAVE: training forward; COORDS (FUSED only): sample coordinates given
+template <bool TILED, int NSRC, int TERMS, bool SAVE, bool FUSED = false, bool COORDS = false, bool S16 = false>       // TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only); SAVE: training forward; COORDS (FUSED only): sample coordinates given; S16 (FUSED only): bf16 channel-last sources
 #ifndef UCNERF_BF16_WPS
 #define UCNERF_BF16_WPS 2      // waves per SIMD: 2 -> 256 VGPRs per wave, 1 -> 512
 #endif
@@ -724,11 +725,14 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             gnf[0] = nf[2 * hl]; gnf[1] = nf[2 * hl + 1]; gnf[2] = nf[4]; gnf[3] = nf[5];
         }
     };
+    constexpr unsigned VOXB = S16 ? 16u : 32u, PIXB = S16 ? 24u : 48u;      // bytes per voxel / pixel of the channel-last copies
+    // (S16: the raw 16-bit values stay in the registers as loaded -- a pixel in slots 3c (16 bytes) and 3c + 1 (8 bytes) -- and become floats where they are consumed)
     auto img_loads = [&](int pr) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {                         // (y0,x0) (y0,x1) (y1,x0) (y1,x1)
             const unsigned o = ((c & 2) ? fi[pr].p10 : fi[pr].p00) + ((c & 1) ? fi[pr].dx : 0u);
-            vi_[pr][3 * c] = ld16(fg.cl, o); vi_[pr][3 * c + 1] = ld16(fg.cl, o + 16u); vi_[pr][3 * c + 2] = ld16(fg.cl, o + 32u);
+            if (S16) { vi_[pr][3 * c] = ld16(fg.cl, o); const float2 t_ = ld8(fg.cl, o + 16u); vi_[pr][3 * c + 1] = make_float4(t_.x, t_.y, 0.f, 0.f); }
+            else { vi_[pr][3 * c] = ld16(fg.cl, o); vi_[pr][3 * c + 1] = ld16(fg.cl, o + 16u); vi_[pr][3 * c + 2] = ld16(fg.cl, o + 32u); }
         }
     };
     // footprints of the gather, in parts (so that they can be spread over several fills): 0 reference projection (+ the point the
@@ -757,16 +761,16 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             const LerpCl ax = axis_cl(u * 2.f - 1.0f, ww, false), ay = axis_cl(v * 2.f - 1.0f, hh, false), az = axis_cl(zn * 2.f - 1.0f, D, false);
             const unsigned vb = fg.vol_off[unit] + c0;
             VolFp f;
-            f.o[0] = vb + (unsigned)((az.i0 * hh + ay.i0) * ww + ax.i0) * 32u; f.o[1] = vb + (unsigned)((az.i0 * hh + ay.i1) * ww + ax.i0) * 32u;
-            f.o[2] = vb + (unsigned)((az.i1 * hh + ay.i0) * ww + ax.i0) * 32u; f.o[3] = vb + (unsigned)((az.i1 * hh + ay.i1) * ww + ax.i0) * 32u;
-            f.dx = (unsigned)(ax.i1 - ax.i0) * 32u;
+            f.o[0] = vb + (unsigned)((az.i0 * hh + ay.i0) * ww + ax.i0) * VOXB; f.o[1] = vb + (unsigned)((az.i0 * hh + ay.i1) * ww + ax.i0) * VOXB;
+            f.o[2] = vb + (unsigned)((az.i1 * hh + ay.i0) * ww + ax.i0) * VOXB; f.o[3] = vb + (unsigned)((az.i1 * hh + ay.i1) * ww + ax.i0) * VOXB;
+            f.dx = (unsigned)(ax.i1 - ax.i0) * VOXB;
             f.w[0] = az.w0 * ay.w0; f.w[1] = az.w0 * ay.w1; f.w[2] = az.w1 * ay.w0; f.w[3] = az.w1 * ay.w1;
             f.wx0 = ax.w0; f.wx1 = ax.w1;
             return f;
         };
         if (part == 1) { fa = vol_fp(hl, 0u, gnf[0], gnf[1]); return; }
         if (part == 2) {
-            fb3 = vol_fp(2, 16u * hl, gnf[2], gnf[3]);
+            fb3 = vol_fp(2, (VOXB / 2) * hl, gnf[2], gnf[3]);
             const float u = COORDS ? gcs[3] : npx[0], v = COORDS ? gcs[4] : npx[1];                           // confidence: the stage-3 grid
             const LerpCl ax = axis_cl(u * 2.f - 1.0f, gW, false), ay = axis_cl(v * 2.f - 1.0f, gH, false);
             co[0] = (unsigned)(ay.i0 * gW + ax.i0); co[1] = (unsigned)(ay.i0 * gW + ax.i1);
@@ -783,8 +787,8 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             const float gx = (qx / qv + 0.0f) / (float)(gW - 1) * 2.0f - 1.0f, gy = (qy / qv + 0.0f) / (float)(gH - 1) * 2.0f - 1.0f;
             const LerpCl ax = axis_cl(gx, gW, true), ay = axis_cl(gy, gH, true);
             const unsigned ib = fg.img_off + (unsigned)vi * fg.view_bytes;
-            fi[pr].p00 = ib + (unsigned)(ay.i0 * gW + ax.i0) * 48u; fi[pr].p10 = ib + (unsigned)(ay.i1 * gW + ax.i0) * 48u;
-            fi[pr].dx = (unsigned)(ax.i1 - ax.i0) * 48u;
+            fi[pr].p00 = ib + (unsigned)(ay.i0 * gW + ax.i0) * PIXB; fi[pr].p10 = ib + (unsigned)(ay.i1 * gW + ax.i0) * PIXB;
+            fi[pr].dx = (unsigned)(ax.i1 - ax.i0) * PIXB;
             fi[pr].w00 = ay.w0 * ax.w0; fi[pr].w01 = ay.w0 * ax.w1; fi[pr].w10 = ay.w1 * ax.w0; fi[pr].w11 = ay.w1 * ax.w1;
             fi[pr].mask = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.f : 0.f;
         }
@@ -798,10 +802,15 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
 #pragma unroll
         for (int c = 0; c < 8; ++c) {                         // corner c = (z, y, x): the accumulation order of gather_cl.hip
             const unsigned o = fa.o[c >> 1] + ((c & 1) ? fa.dx : 0u);
-            va[2 * c] = ld16(fg.cl, o); va[2 * c + 1] = ld16(fg.cl, o + 16u);
+            if (S16) va[2 * c] = ld16(fg.cl, o);
+            else { va[2 * c] = ld16(fg.cl, o); va[2 * c + 1] = ld16(fg.cl, o + 16u); }
         }
 #pragma unroll
-        for (int c = 0; c < 8; ++c) vb3[c] = ld16(fg.cl, fb3.o[c >> 1] + ((c & 1) ? fb3.dx : 0u));
+        for (int c = 0; c < 8; ++c) {
+            const unsigned o = fb3.o[c >> 1] + ((c & 1) ? fb3.dx : 0u);
+            if (S16) { const float2 t_ = ld8(fg.cl, o); vb3[c] = make_float4(t_.x, t_.y, 0.f, 0.f); }
+            else vb3[c] = ld16(fg.cl, o);
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) cv[c] = fg.conf[co[c]];
         SB0;
@@ -817,7 +826,11 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         {
             gf2 lo[2] = {{0, 0}, {0, 0}}, hi[2] = {{0, 0}, {0, 0}};
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { const float w__ = fa.w[c >> 1] * ((c & 1) ? fa.wx1 : fa.wx0); FMA4(lo, va[2 * c], w__) FMA4(hi, va[2 * c + 1], w__) }
+            for (int c = 0; c < 8; ++c) {
+                const float w__ = fa.w[c >> 1] * ((c & 1) ? fa.wx1 : fa.wx0);
+                if (S16) { FMA4(lo, bf16x4_lo(va[2 * c]), w__) FMA4(hi, bf16x4_hi(va[2 * c]), w__) }
+                else { FMA4(lo, va[2 * c], w__) FMA4(hi, va[2 * c + 1], w__) }
+            }
             nfs[0][0] = lo[0].x; nfs[0][1] = lo[0].y; nfs[0][2] = lo[1].x; nfs[0][3] = lo[1].y;
             nfs[0][4] = hi[0].x; nfs[0][5] = hi[0].y; nfs[0][6] = hi[1].x; nfs[0][7] = hi[1].y;
         }
@@ -827,7 +840,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         {
             gf2 lo[2] = {{0, 0}, {0, 0}};
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { const float w__ = fb3.w[c >> 1] * ((c & 1) ? fb3.wx1 : fb3.wx0); FMA4(lo, vb3[c], w__) }
+            for (int c = 0; c < 8; ++c) { const float w__ = fb3.w[c >> 1] * ((c & 1) ? fb3.wx1 : fb3.wx0); FMA4(lo, S16 ? bf16x4_lo(vb3[c]) : vb3[c], w__) }
             nfs[1][0] = lo[0].x; nfs[1][1] = lo[0].y; nfs[1][2] = lo[1].x; nfs[1][3] = lo[1].y;
         }
         {
@@ -844,7 +857,10 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             gf2 c0[2] = {{0, 0}, {0, 0}}, c1[2] = {{0, 0}, {0, 0}}, c2[2] = {{0, 0}, {0, 0}};      // (r g b f0) (f1..f4) (f5 f6 f7 -)
             const float wt[4] = {fi[pr].w00, fi[pr].w01, fi[pr].w10, fi[pr].w11};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { FMA4(c0, vi_[pr][3 * c], wt[c]) FMA4(c1, vi_[pr][3 * c + 1], wt[c]) FMA4(c2, vi_[pr][3 * c + 2], wt[c]) }
+            for (int c = 0; c < 4; ++c) {
+                if (S16) { FMA4(c0, bf16x4_lo(vi_[pr][3 * c]), wt[c]) FMA4(c1, bf16x4_hi(vi_[pr][3 * c]), wt[c]) FMA4(c2, bf16x4_lo(vi_[pr][3 * c + 1]), wt[c]) }
+                else { FMA4(c0, vi_[pr][3 * c], wt[c]) FMA4(c1, vi_[pr][3 * c + 1], wt[c]) FMA4(c2, vi_[pr][3 * c + 2], wt[c]) }
+            }
             float* col = pr == 0 ? &nfs[1][4] : &nfs[2 + (pr - 1) / 2][4 * ((pr - 1) & 1)];
             col[0] = c0[0].x; col[1] = c0[0].y; col[2] = c0[1].x; col[3] = fi[pr].mask;
             f32x4* dst = reinterpret_cast<f32x4*>(bcst_of(pr));
@@ -1268,9 +1284,16 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
     if (fuse) {
         UCNERF_REQUIRE(!save && B.v <= FUSED_MAX_V, "mlp_fwd (gather fused): inference forward, n_src <= %d", FUSED_MAX_V);
         fg = *fuse;
+        UCNERF_REQUIRE(!(fg.s16 && fg.pts_in), "mlp_fwd (gather fused): bf16 channel-last sources are served on derived coordinates only (given coordinates: fp32 copies, "
+                       "or the two-kernel pass)");
         const size_t smem_f = bf16_smem_bytes_fused(B.v);
 #define X(N)                                                                                                                   \
-        if (B.v == N && !fg.pts_in) {                                                                                          \
+        if (B.v == N && !fg.pts_in && fg.s16) {                                                                                \
+            const void* fn = (const void*)mlp_fwd_bf16_kernel<true, N, 3, false, true, false, true>;                           \
+            if (int rc = ensure_dynamic_lds(fn, (int)smem_f, "mlp_fwd (bf16x3, gather fused, bf16 sources)")) return rc;      \
+            hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, 3, false, true, false, true>), grid, block, smem_f, st, *p, g, n_tiles, sv, fg); \
+        }                                                                                                                      \
+        if (B.v == N && !fg.pts_in && !fg.s16) {                                                                               \
             const void* fn = (const void*)mlp_fwd_bf16_kernel<true, N, 3, false, true>;                                        \
             if (int rc = ensure_dynamic_lds(fn, (int)smem_f, "mlp_fwd (bf16x3, gather fused)")) return rc;                    \
             hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, 3, false, true>), grid, block, smem_f, st, *p, g, n_tiles, sv, fg); \
@@ -1349,10 +1372,11 @@ int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* re
     for (int k = 0; k < 3; ++k) {
         f.vol_d[k] = rp->vol_d[k]; f.vol_h[k] = rp->vol_h[k]; f.vol_w[k] = rp->vol_w[k];
         f.vol_off[k] = (unsigned)off;
-        off += 32ull * rp->vol_d[k] * rp->vol_h[k] * rp->vol_w[k];
+        off += (rp->sources_cl_bf16 ? 16ull : 32ull) * rp->vol_d[k] * rp->vol_h[k] * rp->vol_w[k];
     }
+    f.s16 = rp->sources_cl_bf16 ? 1 : 0;
     f.img_off = (unsigned)off;
-    f.view_bytes = (unsigned)(48ull * rp->H * rp->W);
+    f.view_bytes = (unsigned)((rp->sources_cl_bf16 ? 24ull : 48ull) * rp->H * rp->W);
     off += (unsigned long long)f.view_bytes * f.V;
     UCNERF_REQUIRE(off < (1ull << 32), "render (gather fused): %llu bytes of channel-last sources (limit 4 GB)", off);
     f.cl = reinterpret_cast<const char*>(repacked);

@@ -27,6 +27,7 @@ _INFERENCE_PRECISION = "f32"
 _TRAINING_PRECISION = "f32"         # arithmetic of the training FORWARD (activations are kept in fp32 either way)
 _INFERENCE_PRECISIONS = ("f32", "bf16x3", "bf16", "bf16x3_fused")
 _WEIGHT_CACHE = "verify"            # how an inference call gets its packed weight stream, see set_weight_cache
+_SOURCE_PRECISION = "f32"           # element type of the channel-last source copies the gather reads, see set_source_precision
 _MAX_FEATURE_BYTES = (1 << 31) - (1 << 20)       # the MLP kernels address a pass's feature buffer with 32-bit byte offsets
 
 
@@ -54,6 +55,18 @@ def set_weight_cache(policy):
     if policy not in ("verify", "versions"):
         raise ValueError("uc_nerf_amd: weight cache policy must be 'verify' or 'versions', got %r" % (policy,))
     _WEIGHT_CACHE = policy
+
+
+def set_source_precision(precision):
+    """Element type of the channel-last copies of the gather sources (cascade volumes, source images, image features) that `rendering()`
+    reads: "f32" (default: features bit-identical to sampling the tensors handed in) or "bf16" (SURVEY.md 8 configs[4] "fp32 MLP / bf16
+    features": the copies are rounded to bf16 -- half the bytes of every gather corner; the MLP and the compositing stay as they are, and
+    the backward still accumulates fp32 gradients for the fp32 tensors).  Not within the 1e-4 parity bar: an opt-in quality / speed trade
+    (rendered images ~55 dB from the fp32-source render on the benchmark scene, tests/test_hip_round3.py)."""
+    global _SOURCE_PRECISION
+    if precision not in ("f32", "bf16"):
+        raise ValueError("uc_nerf_amd: source precision must be 'f32' or 'bf16', got %r" % (precision,))
+    _SOURCE_PRECISION = precision
 
 
 def set_training_precision(precision):
@@ -145,10 +158,12 @@ class FusedSession:
         light = [_tensor_sig(t) for t in (conf, w2cs, intrinsics)]
         hsig, lsig = tuple(s for s, _ in heavy), tuple(s for s, _ in light)
         old = self.src
-        heavy_ok = old is not None and hsig == self.src_sig[0] and all(r is None or r() is not None for r in self.src_refs[0])
+        bf16 = _SOURCE_PRECISION == "bf16"
+        heavy_ok = (old is not None and old.cl_bf16 == bf16 and hsig == self.src_sig[0]
+                    and all(r is None or r() is not None for r in self.src_refs[0]))
         if heavy_ok and lsig == self.src_sig[1] and all(r is None or r() is not None for r in self.src_refs[1]):
             return old
-        self.src = ops.GatherSources(vols, conf, imgs, img_feat, w2cs, intrinsics)
+        self.src = ops.GatherSources(vols, conf, imgs, img_feat, w2cs, intrinsics, cl_bf16=bf16)
         if heavy_ok:
             self.src._cl = old._cl
         self.src_sig, self.src_refs = (hsig, lsig), ([r for _, r in heavy], [r for _, r in light])

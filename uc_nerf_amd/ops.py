@@ -269,7 +269,11 @@ class GatherSources:
     Any of `vols`, `conf`, `imgs` may be None: the corresponding units are masked out (their feature columns are
     left unwritten), which is how index_point_feature / build_color_volume run on the same kernel."""
 
-    def __init__(self, vols, conf, imgs, img_feat, w2cs, intrinsics, hw=None):
+    def __init__(self, vols, conf, imgs, img_feat, w2cs, intrinsics, hw=None, cl_bf16=False):
+        """cl_bf16: the channel-last copies the fast gather reads (RenderPass.repack_sources) hold bf16 instead of fp32 -- SURVEY.md 8
+        configs[4] "fp32 MLP / bf16 features": half the bytes per gather corner, features within bf16 rounding (2^-9 relative) of the
+        fp32 sources'; source gradients are still accumulated in fp32 for the fp32 tensors."""
+        self.cl_bf16 = bool(cl_bf16)
         self.mask = 0
         dev = None
         self.vols = [None, None, None]
@@ -883,6 +887,7 @@ class RenderPass:
         src.fill(self.p)
         self.use_cl = False
         self.p.sources_cl = None
+        self.p.sources_cl_bf16 = int(src.cl_bf16)
 
     def set_weights(self, pw, wstream):
         self.pw, self.wstream = pw, wstream

@@ -20,12 +20,12 @@ class CoarseFineRenderer:
     confidence [H,W]; tensors already on the device.  flat_params: the MLP's flat parameter vector (device)."""
 
     def __init__(self, scene, flat_params, n_coarse=64, n_fine=128, white_bkgd=False, pe_layout=0, max_blocks=0,
-                 precision="f32", fused_min_rounds=0):
+                 precision="f32", fused_min_rounds=0, sources_bf16=False):
         dev = scene["confidence"].device
         self.scene, self.dev = scene, dev
         self.n_coarse, self.n_fine, self.white_bkgd = n_coarse, n_fine, white_bkgd
         self.src = ops.GatherSources(scene["vols"], scene["confidence"], scene["imgs"], scene["img_feat"],
-                                     scene["w2cs"][1:], scene["intrinsics"][1:])
+                                     scene["w2cs"][1:], scene["intrinsics"][1:], cl_bf16=sources_bf16)
         self.precision = precision          # "f32": exact fp32 MFMA; "bf16x3": split-bf16 matrix cores (inference, within the
                                             # parity bar); "bf16": plain bf16 operands (inference, ~3e-3 render error);
                                             # "bf16x3_fused": bf16x3 with the feature gather inside the MLP kernel (one launch per pass)
