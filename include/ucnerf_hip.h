@@ -41,6 +41,10 @@ int ucnerf_device_cus(void);
  * UCNERF_BF16_EXP, UCNERF_TN_EXP, UCNERF_GATHER_EXP, UCNERF_BF16_NO_PK, UCNERF_BF16_BW, UCNERF_BF16_NBUF, ...).  A production build
  * reports every experiment switch as 0; the host side refuses to load a library that does not (tests/test_abi_host.py). */
 const char* ucnerf_build_flags(void);
+/* Digest of the sources, headers and flags this binary was linked from (uc_nerf_amd/build.py: source_hash()): a host can tell a library
+ * that does not belong to the tree it sits in (tests/test_abi_host.py), and __graft_entry__.build() rebuilds one that was not linked on
+ * the machine it runs on. */
+const char* ucnerf_source_hash(void);
 /* HIP timing events for measuring kernels inside a call chain (bench harness): create / record on a stream /
  * elapsed milliseconds between two recorded events (waits for `stop`) / destroy. */
 void* ucnerf_event_create(void);

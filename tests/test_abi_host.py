@@ -52,6 +52,16 @@ def test_library_was_built_with_production_switches(L):
         assert value == PRODUCTION_FLAGS.get(name, "0"), "%s=%s in the shipped library (%s)" % (name, value, flags)
 
 
+def test_library_belongs_to_the_sources_in_this_tree(L):
+    """The digest linked into the binary (uc_nerf_amd/build.py) equals the digest of the sources beside it: a stale or foreign .so is caught
+    here instead of producing results of some other code (on the GPU box the tree travels with its prebuilt library)."""
+    from uc_nerf_amd import build as B
+    if os.environ.get("UCNERF_LIB"):
+        pytest.skip("an A/B variant library is selected")
+    assert L.lib().ucnerf_source_hash().decode() == B.source_hash()
+    assert isinstance(B.built_here(), bool)
+
+
 def test_argument_validation_reports_instead_of_launching(L):
     lib = L.lib()
     assert lib.ucnerf_ray_gen(None, None) == -1 and b"null params" in lib.ucnerf_last_error()

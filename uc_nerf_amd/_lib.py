@@ -159,6 +159,7 @@ SYMBOLS = {
     "ucnerf_sizeof": (C.c_int, [C.c_char_p]),
     "ucnerf_device_cus": (C.c_int, []),
     "ucnerf_build_flags": (C.c_char_p, []),
+    "ucnerf_source_hash": (C.c_char_p, []),
     "ucnerf_event_create": (C.c_void_p, []),
     "ucnerf_event_record": (C.c_int, [_P, _P]),
     "ucnerf_event_elapsed_ms": (C.c_int, [_P, _P, _P]),
