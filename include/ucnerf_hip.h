@@ -306,8 +306,10 @@ typedef struct {
 int64_t ucnerf_mlp_bwd_workspace_floats(const ucnerf_mlp_config* cfg, int32_t m);
 int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* p, void* stream);
 /* Training forward: ucnerf_mlp_fwd (f32 or bf16x3 precision, features row-major or tiled) that also keeps the per-layer activations in `bwd_workspace`
- * (ucnerf_mlp_bwd_workspace_floats floats), for a following ucnerf_mlp_bwd with saved_valid = 1. */
-int ucnerf_mlp_fwd_train(const ucnerf_mlp_params* p, float* bwd_workspace, void* stream);
+ * (ucnerf_mlp_bwd_workspace_floats floats), for a following ucnerf_mlp_bwd with saved_valid = 1 and THE SAME bwd_mode: for bwd_mode 0 the ten
+ * [m,128] sets are kept as 24-bit floats (sign, exponent, 15 mantissa bits: the 16 significant bits the chain's and the weight-gradient launch's
+ * split-bf16 operands carry -- three quarters of the bytes every kernel of the step moves), for bwd_mode 1 as fp32. */
+int ucnerf_mlp_fwd_train(const ucnerf_mlp_params* p, float* bwd_workspace, int32_t bwd_mode, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a9  alpha compositing -- network/renderer.py:25-36,109-140 (variant 0 "live": alpha = 1-exp(-sigma),
@@ -506,6 +508,8 @@ typedef struct {
                                   values rounded to nearest even) -- SURVEY.md 8 configs[4] "fp32 MLP / bf16 features": half the bytes of every
                                   gather corner, features within bf16 rounding of the fp32 sources'.  Forward only reads differ; the backward
                                   accumulates source gradients in fp32 as before.  With cfg.precision == 3: derived coordinates only */
+    int32_t train_bwd_mode;    /* with train_workspace: the bwd_mode of the coming ucnerf_render_fused_bwd call (it fixes the format the
+                                  activations are kept in, see ucnerf_mlp_fwd_train) */
 } ucnerf_render_params;
 int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream);

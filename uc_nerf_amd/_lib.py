@@ -128,7 +128,7 @@ class RenderParams(C.Structure):
                 ("w2cs", vp), ("intrinsics", vp), ("wstream", vp), ("sources_cl", vp), ("workspace", vp), ("rgb_map", vp),
                 ("depth_map", vp), ("acc_map", vp), ("weights", vp), ("var", vp), ("raw", vp), ("feats", vp),
                 ("ev_mlp_start", vp), ("ev_mlp_stop", vp), ("train_workspace", vp), ("dir_feat", vp), ("u_sampled", vp),
-                ("wu_map", vp), ("pts_in", vp), ("ndc1_in", vp), ("ndc2_in", vp), ("ndc3_in", vp), ("ndc_in", vp), ("feats_tiled", i32), ("sources_cl_bf16", i32)]
+                ("wu_map", vp), ("pts_in", vp), ("ndc1_in", vp), ("ndc2_in", vp), ("ndc3_in", vp), ("ndc_in", vp), ("feats_tiled", i32), ("sources_cl_bf16", i32), ("train_bwd_mode", i32)]
 
 
 class RenderBwdParams(C.Structure):
@@ -185,7 +185,7 @@ SYMBOLS = {
     "ucnerf_mlp_fwd": (C.c_int, [_P, _P]),
     "ucnerf_mlp_bwd_workspace_floats": (C.c_int64, [_P, C.c_int32]),
     "ucnerf_mlp_bwd": (C.c_int, [_P, _P]),
-    "ucnerf_mlp_fwd_train": (C.c_int, [_P, _P, _P]),
+    "ucnerf_mlp_fwd_train": (C.c_int, [_P, _P, C.c_int32, _P]),
     "ucnerf_composite_fwd": (C.c_int, [_P, _P]),
     "ucnerf_composite_bwd": (C.c_int, [_P, _P]),
     "ucnerf_sample_pdf": (C.c_int, [_P, _P]),

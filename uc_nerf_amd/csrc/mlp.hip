@@ -6,6 +6,7 @@
 // A 256-thread block = 4 independent waves; the grid is persistent (waves stride over tiles).
 #include "common.h"
 #include "mlp_layout.h"
+#include "p24.h"
 #include "sincos_cw.h"
 
 #include <cstdlib>
@@ -336,23 +337,33 @@ __device__ __forceinline__ void load_encoded(const float* __restrict__ row, int 
         (DST)[nt][r] = fmaxf(m_.x, 0.f); (DST)[nt][r + 1] = fmaxf(m_.y, 0.f);          \
     }
 
-// accumulator-layout activation set -> row-major [m,128] (lane = sample, 4 consecutive features per float4)
+// accumulator-layout activation set -> row-major [m,128] (lane = sample, 4 consecutive features per piece): fp32 (16-byte pieces), or
+// P24: the 24-bit format of p24.h (12-byte pieces, 384-byte rows) the gradient chain and the weight-gradient launch read
+template <bool P24>
 __device__ __forceinline__ void save_rows(float* buf, int s, int h, bool valid, const f32x16 (&x)[4]) {
     if (!valid) return;
     f32x4* row = reinterpret_cast<f32x4*>(buf + (size_t)s * 128);
+    char* row24 = reinterpret_cast<char*>(buf) + (size_t)s * P24_ROW_BYTES;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 v = {x[nt][4 * q], x[nt][4 * q + 1], x[nt][4 * q + 2], x[nt][4 * q + 3]};
-            __builtin_nontemporal_store(v, &row[8 * nt + 2 * q + h]);      // (streaming hint: 670 MB per 131 k samples, read back a pass later; 411 -> 391 us)
+            if (P24) {
+                const P24Piece pc = p24_pack4(x[nt][4 * q], x[nt][4 * q + 1], x[nt][4 * q + 2], x[nt][4 * q + 3]);
+                // (plain stores: 12-byte pieces do not fill whole 32-byte sectors one by one -- as streaming stores each partial sector became a
+                //  read-modify-write at the memory side, 757 us per 131 k samples; through the L2 the pieces of a line meet before it is evicted)
+                p24_store(row24 + 12 * (8 * nt + 2 * q + h), pc);
+            } else {
+                f32x4 v = {x[nt][4 * q], x[nt][4 * q + 1], x[nt][4 * q + 2], x[nt][4 * q + 3]};
+                __builtin_nontemporal_store(v, &row[8 * nt + 2 * q + h]);      // (streaming hint: 670 MB per 131 k samples, read back a pass later; 411 -> 391 us)
+            }
         }
 }
 
 // NSRC > 0 fixes the number of source views at compile time: the two bias-net sections then have constant trip
 // counts and the whole tile body is straight-line code.  (With runtime counts hipcc wraps the k-steps in uniform
 // branches and drains the prefetch ring -- vmcnt(3),(2),(1),(0) -- at every join: ~12 full L2 latencies per tile.)
-template <bool TILED, bool SAVE, bool ENC, int NSRC>
+template <bool TILED, int SAVE, bool ENC, int NSRC>       // SAVE: 0 inference, 1 training forward keeping fp32 activation sets, 2 keeping 24-bit sets
 __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(ucnerf_mlp_params p, MlpGeom g, int n_tiles, MlpSaved sv) {
     constexpr int KD_STATIC = ((24 + 4 * NSRC) / 2 + RING - 1) / RING * RING, KC_STATIC = (4 * NSRC + RING - 1) / RING * RING;
     const int kd = NSRC ? KD_STATIC : g.kd, kc = NSRC ? KC_STATIC : g.kc;
@@ -449,7 +460,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         init_bias(cst, SEC_BD, h, bd);
         PRIO_GEMM(); gemm_feats(S, fsec, kd, bd); PRIO_VALU();
         DIAG_STAMP(2)
-        if (SAVE) save_rows(sv.bd, s, h, valid, bd);
+        if (SAVE) save_rows<SAVE == 2>(sv.bd, s, h, valid, bd);
         const float u = 1.f - conf, omu = 1.f - u;          // models.py:149,177-178 (consumed at the very end)
 
         // ---- layer 0
@@ -457,7 +468,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         PRIO_GEMM(); gemm_regs<KS_PE_PTS>(S, pe, acc); PRIO_VALU();
         DIAG_STAMP(3)
         EPILOGUE_RELU_MOD(hin, acc, bd)
-        if (SAVE) save_rows(sv.h[0], s, h, valid, hin);
+        if (SAVE) save_rows<SAVE == 2>(sv.h[0], s, h, valid, hin);
         DIAG_STAMP(4)
 
         // ---- layers 1..4                                                        (models.py:153-155)
@@ -466,7 +477,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
             init_bias(cst, SEC_L0 + l, h, acc);
             PRIO_GEMM(); gemm_hidden(S, hin, acc); PRIO_VALU();
             EPILOGUE_RELU_MOD(hin, acc, bd)
-            if (SAVE) save_rows(sv.h[l], s, h, valid, hin);
+            if (SAVE) save_rows<SAVE == 2>(sv.h[l], s, h, valid, hin);
         }
 
         // ---- layer 5 on [pe | h]                                                (models.py:156-157)
@@ -478,7 +489,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         EPILOGUE_RELU_MOD(hin, acc, bd)
         // operands of the confidence-bias net: issued now (b_d's registers are free), they land during the base heads
         load_section_feats<TILED>(FS, (g.f_img + h) * fstride * 4, 2 * fstride * 4, kc, fsec);
-        if (SAVE) save_rows(sv.h[5], s, h, valid, hin);
+        if (SAVE) save_rows<SAVE == 2>(sv.h[5], s, h, valid, hin);
 
         // ---- base heads: confi_rgb_linear, alpha_linear_1                       (models.py:161-162)
         const f32x4 base = head4(hb, h, hin);
@@ -488,7 +499,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         init_bias(cst, SEC_BC, h, bd);
         PRIO_GEMM(); gemm_feats(S, fsec, kc, bd); PRIO_VALU();
         DIAG_STAMP(8)
-        if (SAVE) save_rows(sv.bc, s, h, valid, bd);
+        if (SAVE) save_rows<SAVE == 2>(sv.bc, s, h, valid, bd);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -504,7 +515,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         init_bias(cst, SEC_FT, h, acc);
         PRIO_GEMM(); gemm_hidden(S, hin, acc); PRIO_VALU();
         DIAG_STAMP(10)
-        if (SAVE) save_rows(sv.ft, s, h, valid, acc);
+        if (SAVE) save_rows<SAVE == 2>(sv.ft, s, h, valid, acc);
 
         // ---- views_linears | view_confi_linears on [feature | dir encoding], relu   (models.py:166-173)
         init_bias(cst, SEC_VC, h, hin);
@@ -520,7 +531,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) hin[nt][r] = fmaxf(hin[nt][r], 0.f);
-        if (SAVE) save_rows(sv.vc, s, h, valid, hin);
+        if (SAVE) save_rows<SAVE == 2>(sv.vc, s, h, valid, hin);
 
         // ---- adapt heads (rgb_linear on rows 0..63, alpha_linear on rows 64..127), uncertainty blend
         const f32x4 adapt = head4(ha, h, hin);
@@ -592,9 +603,13 @@ int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t
     dim3 grid(blocks), block(64 * MLP_WAVES);
 #define LAUNCH(T, SV, E, N) hipLaunchKernelGGL((mlp_fwd_kernel<T, SV, E, N>), grid, block, 0, st, *p, g, n_tiles, sv)
 #define LAUNCH_V(T, SV) { if (L.v == 6) LAUNCH(T, SV, false, 6); else if (L.v == 3) LAUNCH(T, SV, false, 3); else LAUNCH(T, SV, false, 0); }
-    if (p->encoded) { if (save) LAUNCH(false, true, true, 0); else LAUNCH(false, false, true, 0); }
-    else if (save) { if (p->feats_tiled) LAUNCH_V(true, true) else LAUNCH_V(false, true) }
-    else { if (p->feats_tiled) LAUNCH_V(true, false) else LAUNCH_V(false, false) }
+    if (p->encoded) { if (save && sv.p24) LAUNCH(false, 2, true, 0); else if (save) LAUNCH(false, 1, true, 0); else LAUNCH(false, 0, true, 0); }
+    else if (save && sv.p24) { if (p->feats_tiled) LAUNCH_V(true, 2) else LAUNCH_V(false, 2) }
+    else if (save) {
+        UCNERF_REQUIRE(!p->feats_tiled, "mlp_fwd_train: fp32 activation sets serve the layer-by-layer backward, which reads row-major features");
+        LAUNCH_V(false, 1)
+    }
+    else { if (p->feats_tiled) LAUNCH_V(true, 0) else LAUNCH_V(false, 0) }
 #undef LAUNCH_V
 #undef LAUNCH
     return check_launch("mlp_fwd");

@@ -33,6 +33,7 @@
 #include "mlp_layout.h"
 #include "sincos_cw.h"
 #include "gather_cl_device.h"
+#include "p24.h"
 
 // the LDS-DMA asm below names m0 as a clobber on purpose (it loads the LDS base into it)
 #pragma clang diagnostic ignored "-Winline-asm"
@@ -303,25 +304,34 @@ template <class T> __device__ __forceinline__ void pin(T& v) { asm volatile("" :
 
 // Training forward (SAVE): the activation sets the backward reads (MlpSaved, mlp_layout.h), row-major [m,128].  A lane owns 64 of its
 // sample's 128 values per set: register group (nt, q = reg / 4) of lane-half h sits at floats 32 nt + 8 q + 4 h of the row.
+// P24: the sets in the 24-bit format of p24.h instead (`row` then = set + 384 s + 12 h BYTES: the same four-column groups as 12-byte pieces)
+template <bool P24>
 __device__ __forceinline__ void save8(float* row, int nt, int s, const float (&t)[8]) {       // fragment s of row-tile nt
     // (plain stores: the eight 16-byte pieces of a 128-byte line leave this wave hundreds of cycles apart -- between MFMA groups --
     //  and have to meet in L2; as streaming stores each piece went to memory on its own)
-    *reinterpret_cast<f32x4*>(row + 32 * nt + 16 * s) = (f32x4){t[0], t[1], t[2], t[3]};
-    *reinterpret_cast<f32x4*>(row + 32 * nt + 16 * s + 8) = (f32x4){t[4], t[5], t[6], t[7]};
+    if (P24) {
+        char* r24 = reinterpret_cast<char*>(row) + 96 * nt + 48 * s;
+        p24_store(r24, p24_pack4(t[0], t[1], t[2], t[3]));
+        p24_store(r24 + 24, p24_pack4(t[4], t[5], t[6], t[7]));
+    } else {
+        *reinterpret_cast<f32x4*>(row + 32 * nt + 16 * s) = (f32x4){t[0], t[1], t[2], t[3]};
+        *reinterpret_cast<f32x4*>(row + 32 * nt + 16 * s + 8) = (f32x4){t[4], t[5], t[6], t[7]};
+    }
 }
-template <bool RELU>
+template <bool RELU, bool P24>
 __device__ __forceinline__ void save_tile(float* row, int nt, const f32x16& x) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         f32x4 v = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
         if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<f32x4*>(row + 32 * nt + 8 * q) = v;
+        if (P24) p24_store(reinterpret_cast<char*>(row) + 96 * nt + 24 * q, p24_pack4(v.x, v.y, v.z, v.w));
+        else *reinterpret_cast<f32x4*>(row + 32 * nt + 8 * q) = v;
     }
 }
 
 // fragment s (0/1) of an accumulator tile: MODE 0 plain, 1 times m, 2 relu(times m)   (two values per v_pk_mul_f32);
 // SV: the eight fp32 values also go to `srow` (this lane's row of an activation set, NULL past the last sample) as row-tile nt
-template <int MODE, bool SV = false>
+template <int MODE, int SV = 0>       // SV: the kernel's SAVE (0 none, 1 fp32 sets, 2 24-bit sets)
 __device__ __forceinline__ Frag frag_of(const f32x16& a, const f32x16& m, int s, float* srow = nullptr, int nt = 0) {
 #if UCNERF_BF16_EXP & 128      // timing experiment: no epilogue arithmetic at all (wrong results)
     Frag e;
@@ -342,7 +352,7 @@ __device__ __forceinline__ Frag frag_of(const f32x16& a, const f32x16& m, int s,
         t[j] = MODE == 2 ? fmaxf(v.x, 0.f) : v.x;
         t[j + 1] = MODE == 2 ? fmaxf(v.y, 0.f) : v.y;
     }
-    if (SV && srow) save8(srow, nt, s, t);
+    if (SV && srow) save8<SV == 2>(srow, nt, s, t);
     Frag f = split8(t);
     pin(f.hi); pin(f.lo);
     return f;
@@ -564,7 +574,7 @@ struct FusedGather {
 [[maybe_unused]] constexpr int FUSED_MAX_V = 8;    // (seven and eight views: with a two-slot weight ring, fused_ring_slots)
 constexpr int VIEW_TAB = 24;      // floats per source view in the LDS table: w2c (12), K (9), pad
 
-template <bool TILED, int NSRC, int TERMS, bool SAVE, bool FUSED = false, bool COORDS = false, bool S16 = false>       // TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only); SAVE: training forward; COORDS (FUSED only): sample coordinates given; S16 (FUSED only): bf16 channel-last sources
+template <bool TILED, int NSRC, int TERMS, int SAVE, bool FUSED = false, bool COORDS = false, bool S16 = false>       // TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only); SAVE: training forward keeping the activation sets (1: fp32, 2: the 24-bit format of p24.h); COORDS (FUSED only): sample coordinates given; S16 (FUSED only): bf16 channel-last sources
 #ifndef UCNERF_BF16_WPS
 #define UCNERF_BF16_WPS 2      // waves per SIMD: 2 -> 256 VGPRs per wave, 1 -> 512
 #endif
@@ -917,7 +927,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         // SAVE: this lane's row of an activation set (re-derived at every use: nothing tile-long is kept in a register)
         auto srow = [&](float* base) -> float* {
             const int l_ = opaque(lane), s_ = tile * 32 + (l_ & 31);
-            return s_ < p.m ? base + (size_t)s_ * 128 + 4 * (l_ >> 5) : nullptr;
+            return s_ < p.m ? base + (size_t)s_ * (SAVE == 2 ? 96 : 128) + (SAVE == 2 ? 3 : 4) * (l_ >> 5) : nullptr;      // (24-bit sets: 384-byte rows, 12-byte pieces)
         };
         const size_t hstride = SAVE ? (size_t)(sv.h[1] - sv.h[0]) : 0;      // the six trunk sets are carved back to back
         // (few scalars are carried through the trunk -- every VGPR there is spoken for: sample index, feature base
@@ -990,7 +1000,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         DIAG_STAMP(2)
         if (SAVE) {
             float* r_ = srow(sv.bd);
-            if (r_) { save_tile<false>(r_, 0, bd[0]); save_tile<false>(r_, 1, bd[1]); save_tile<false>(r_, 2, bd[2]); save_tile<false>(r_, 3, bd[3]); }
+            if (r_) { save_tile<false, SAVE == 2>(r_, 0, bd[0]); save_tile<false, SAVE == 2>(r_, 1, bd[1]); save_tile<false, SAVE == 2>(r_, 2, bd[2]); save_tile<false, SAVE == 2>(r_, 3, bd[3]); }
         }
 
         // ---- layer 0 (pair-split) on the point encoding
@@ -1116,7 +1126,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         DIAG_STAMP(7)
         if (SAVE) {
             float* r_ = srow(sv.h[5]);
-            if (r_) { save_tile<false>(r_, 0, acc[0]); save_tile<false>(r_, 1, acc[1]); save_tile<false>(r_, 2, acc[2]); save_tile<false>(r_, 3, acc[3]); }
+            if (r_) { save_tile<false, SAVE == 2>(r_, 0, acc[0]); save_tile<false, SAVE == 2>(r_, 1, acc[1]); save_tile<false, SAVE == 2>(r_, 2, acc[2]); save_tile<false, SAVE == 2>(r_, 3, acc[3]); }
         }
 
         // ---- confidence-bias net (step-major) -> bd; base heads of row tiles 0,1 underneath
@@ -1142,7 +1152,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         DIAG_STAMP(8)
         if (SAVE) {
             float* r_ = srow(sv.bc);
-            if (r_) { save_tile<false>(r_, 0, bd[0]); save_tile<false>(r_, 1, bd[1]); save_tile<false>(r_, 2, bd[2]); save_tile<false>(r_, 3, bd[3]); }
+            if (r_) { save_tile<false, SAVE == 2>(r_, 0, bd[0]); save_tile<false, SAVE == 2>(r_, 1, bd[1]); save_tile<false, SAVE == 2>(r_, 2, bd[2]); save_tile<false, SAVE == 2>(r_, 3, bd[3]); }
         }
         // g = h5 * b_c: fragments of row tiles 0,1 now, of 2,3 under feature_linear's phase A
 #pragma unroll
@@ -1204,14 +1214,14 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                if (q < 4) head_part(hadapt, ha, h, acc[q >> 1], q >> 1, (q & 1) * 8, 8, relu);
                if (FUSED && UCNERF_FUSED_FOOT_UNDER_GEMM && q >= 4 && q - 4 < NP) g_part(3 + q - 4);      // ... its view pairs
                if (FUSED && !UCNERF_FUSED_FOOT_UNDER_GEMM && q == 9) g_pre(tile + tiles_per_round);              // (after the tile's last advance(): its counted wait would sit on these loads too; clamped past the end: harmless)
-               if (SAVE && (q == 4 || q == 5)) { float* r_ = srow(sv.vc); if (r_) save_tile<true>(r_, q - 4, acc[q - 4]); });
+               if (SAVE && (q == 4 || q == 5)) { float* r_ = srow(sv.vc); if (r_) save_tile<true, SAVE == 2>(r_, q - 4, acc[q - 4]); });
         }
         DIAG_STAMP(11)
         __builtin_amdgcn_s_setprio(UCNERF_BF16_PRIO_VALU);
         if (!FUSED) fetch(tile + tiles_per_round);         // next tile's inputs (clamped past the end: harmless)
         if (SAVE) {
             float* r_ = srow(sv.vc);
-            if (r_) { save_tile<true>(r_, 2, acc[2]); save_tile<true>(r_, 3, acc[3]); }
+            if (r_) { save_tile<true, SAVE == 2>(r_, 2, acc[2]); save_tile<true, SAVE == 2>(r_, 3, acc[3]); }
         }
         // ---- adapt heads of row tiles 2,3, uncertainty blend
         head_part(hadapt, ha, h, acc[2], 2, 0, 16, relu);
@@ -1309,16 +1319,22 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
     }
     if (save) {
         sv = *save;
+        UCNERF_REQUIRE(sv.p24 || !tiled, "mlp_fwd_train (bf16x3): fp32 activation sets serve the layer-by-layer backward, which reads row-major features");
 #define X(N)                                                                                                                   \
-        if (B.v == N && !tiled) {                                                                                              \
-            const void* fn = (const void*)mlp_fwd_bf16_kernel<false, N, 3, true>;                                              \
+        if (B.v == N && !tiled && !sv.p24) {                                                                                   \
+            const void* fn = (const void*)mlp_fwd_bf16_kernel<false, N, 3, 1>;                                                 \
             if (int rc = ensure_dynamic_lds(fn, (int)smem, "mlp_fwd_train (bf16x3)")) return rc;                              \
-            hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, N, 3, true>), grid, block, smem, st, *p, g, n_tiles, sv, fg);           \
+            hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, N, 3, 1>), grid, block, smem, st, *p, g, n_tiles, sv, fg);              \
+        }                                                                                                                      \
+        if (B.v == N && !tiled && sv.p24) {                                                                                    \
+            const void* fn = (const void*)mlp_fwd_bf16_kernel<false, N, 3, 2>;                                                 \
+            if (int rc = ensure_dynamic_lds(fn, (int)smem, "mlp_fwd_train (bf16x3, 24-bit sets)")) return rc;                 \
+            hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, N, 3, 2>), grid, block, smem, st, *p, g, n_tiles, sv, fg);              \
         }                                                                                                                      \
         if (B.v == N && tiled) {                                                                                               \
-            const void* fn = (const void*)mlp_fwd_bf16_kernel<true, N, 3, true>;                                               \
-            if (int rc = ensure_dynamic_lds(fn, (int)smem, "mlp_fwd_train (bf16x3, tiled features)")) return rc;              \
-            hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, 3, true>), grid, block, smem, st, *p, g, n_tiles, sv, fg);            \
+            const void* fn = (const void*)mlp_fwd_bf16_kernel<true, N, 3, 2>;                                                  \
+            if (int rc = ensure_dynamic_lds(fn, (int)smem, "mlp_fwd_train (bf16x3, tiled features, 24-bit sets)")) return rc; \
+            hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, 3, 2>), grid, block, smem, st, *p, g, n_tiles, sv, fg);               \
         }
         UCNERF_BF16_FOR_ALL(X)
 #undef X

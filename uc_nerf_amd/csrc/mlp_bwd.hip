@@ -659,7 +659,7 @@ __global__ void __launch_bounds__(256) trunk_top_bwd_kernel(TopArgs a) {
 // ------------------------------------------------------------------------------------------------
 struct BwdWork {
     MlpSaved sv;
-    float *pep, *ped, *g1, *g2, *g3, *gbd, *gx, *g_base, *g_adapt, *raw;
+    float *pep, *ped, *g1, *g2, *g3, *gbd, *gx, *g_base, *g_adapt, *g_sigma, *raw;
     float* gy[6];           // bwd_mode 0: g_y of the six trunk layers (operands of their weight-gradient GEMMs)
     float* wstream_bwd;     // bwd_mode 0: transposed weights as split-bf16 fragments + head table (mlp_bwd_chain.hip)
 };
@@ -668,12 +668,13 @@ static size_t carve_bwd(float* base, int m, int n_dirs, BwdWork* w) {
     size_t o = 0;
     auto take = [&](size_t k) { float* r = base ? base + o : nullptr; o += (k + 3) & ~(size_t)3; return r; };
     const size_t M = (size_t)m;
+    w->sv.p24 = 0;
     w->sv.bd = take(M * 128);
     for (int l = 0; l < 6; ++l) w->sv.h[l] = take(M * 128);
     w->sv.bc = take(M * 128); w->sv.ft = take(M * 128); w->sv.vc = take(M * 128);
     w->pep = take(M * 63); w->ped = take((size_t)n_dirs * 27);
     w->g1 = take(M * 128); w->g2 = take(M * 128); w->g3 = take(M * 128); w->gbd = take(M * 128); w->gx = take(M * 128);
-    w->g_base = take(M * 4); w->g_adapt = take(M * 4); w->raw = take(M * 4);
+    w->g_base = take(M * 4); w->g_adapt = take(M * 4); w->g_sigma = take(M * 4); w->raw = take(M * 4);
     for (int l = 0; l < 6; ++l) w->gy[l] = take(M * 128);
     w->wstream_bwd = take(bwd_chain_stream_floats());
     return o;
@@ -749,15 +750,17 @@ int64_t ucnerf_mlp_bwd_workspace_floats(const ucnerf_mlp_config* cfg, int32_t m)
     return (int64_t)carve_bwd(nullptr, m, m, &w);      // upper bound (direction rows <= m)
 }
 
-int ucnerf_mlp_fwd_train(const ucnerf_mlp_params* p, float* bwd_workspace, void* stream) {
+int ucnerf_mlp_fwd_train(const ucnerf_mlp_params* p, float* bwd_workspace, int32_t bwd_mode, void* stream) {
     UCNERF_REQUIRE(p && bwd_workspace, "mlp_fwd_train: null pointer");
+    UCNERF_REQUIRE(bwd_mode == 0 || bwd_mode == 1, "mlp_fwd_train: bwd_mode %d", bwd_mode);
     if (p->m <= 0) return UCNERF_OK;
     UCNERF_REQUIRE(p->cfg.precision == 0 || p->cfg.precision == 1, "mlp_fwd_train: the training forward runs in f32 or bf16x3 precision");
     UCNERF_REQUIRE(((uintptr_t)bwd_workspace & 15) == 0, "mlp_fwd_train: workspace must be 16-byte aligned");
     BwdWork w;
     carve_bwd(bwd_workspace, p->m, p->dirs_per_sample ? p->m : p->m / (p->S > 0 ? p->S : 1), &w);
     hipStream_t st = (hipStream_t)stream;
-    if (p->cfg.precision == 1) { RUN(launch_mlp_fwd_bf16x3_save(p, &w.sv, st)); }      // split-bf16 matrix cores, activations kept in fp32
+    w.sv.p24 = bwd_mode == 0;                       // the gradient chain reads the sets as 24-bit floats, the layer-by-layer backward as fp32
+    if (p->cfg.precision == 1) { RUN(launch_mlp_fwd_bf16x3_save(p, &w.sv, st)); }      // split-bf16 matrix cores
     else RUN(launch_mlp_fwd(p, &w.sv, st));
     // the backward reads the forward's output from its own slot
     if (hipMemcpyAsync(w.raw, p->raw, (size_t)p->m * 4 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -796,6 +799,7 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     if (!bp->saved_valid) {
         ucnerf_mlp_params fw = f;
         fw.raw = w.raw;
+        w.sv.p24 = bp->bwd_mode == 0;
         RUN(launch_mlp_fwd(&fw, &w.sv, st));
     }
     const float *pep = w.pep, *ped = w.ped;      // encodings as matrices: [m,63] and [n_dirs,27]
@@ -820,24 +824,27 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
         //    written: the G operands of the weight-gradient GEMMs below, g_feats, g_base / g_adapt
         RUN(launch_pack_bwd(v, P, w.wstream_bwd, st));
         RUN(launch_mlp_bwd_chain(v, m, w.raw, bp->g_raw, f.feats, ldf, f.feats_tiled, &w.sv, w.wstream_bwd, w.g1, w.g2, w.g3, w.gx, w.gbd, w.gy, bp->g_feats, ldgf,
-                                 w.g_base, w.g_adapt, st));
-        // B. every parameter gradient in ONE launch (mlp_wgrad.hip): one (g, layer input) pair per product
+                                 w.g_base, w.g_adapt, w.g_sigma, st));
+        // B. every parameter gradient in ONE launch (mlp_wgrad.hip): one (g, layer input) pair per product.  Every G and every kept
+        //    activation set is in the 24-bit format (rows of 384 bytes; the head G's: 12); encodings and gathered features are fp32
+        constexpr int R = P24_ROW_BYTES;
+        const char* vc24 = reinterpret_cast<const char*>(w.sv.vc);
         WgArgs wg;
         wgrad_begin(&wg, m);
-        RUN(wgrad_add(&wg, w.g1, 128, 128, w.sv.ft, 128, 1, 128, G + L.p_vw, KV, G + L.p_vb, G + L.p_vcw, G + L.p_vcb, 64));       // [views | view_confi] x f
-        RUN(wgrad_add(&wg, w.g1, 128, 128, ped, ld_ped, xdiv_dir, 27, G + L.p_vw + 128, KV, nullptr, G + L.p_vcw + 128, nullptr, 64));   // ... x dir encoding
-        RUN(wgrad_add(&wg, w.g2, 128, 128, w.gx, 128, 1, 128, G + L.p_fw, 128, G + L.p_fb, nullptr, nullptr, 0));                    // feature_linear
+        RUN(wgrad_add(&wg, w.g1, R, 128, w.sv.ft, 1, R, 1, 128, G + L.p_vw, KV, G + L.p_vb, G + L.p_vcw, G + L.p_vcb, 64));       // [views | view_confi] x f
+        RUN(wgrad_add(&wg, w.g1, R, 128, ped, 0, ld_ped, xdiv_dir, 27, G + L.p_vw + 128, KV, nullptr, G + L.p_vcw + 128, nullptr, 64));   // ... x dir encoding
+        RUN(wgrad_add(&wg, w.g2, R, 128, w.gx, 1, R, 1, 128, G + L.p_fw, 128, G + L.p_fb, nullptr, nullptr, 0));                    // feature_linear
         const int xt = f.feats_tiled ? F : 0;                 // (tile layout: column c of the features = row c of every tile)
-        RUN(wgrad_add(&wg, w.g3, 128, 128, f.feats + (xt ? 32 * n_mvs : n_mvs), ldf, 1, n_img, G + L.p_bcw, n_img, G + L.p_bcb, nullptr, nullptr, 0, xt));   // confidence-bias net
-        RUN(wgrad_add(&wg, w.gy[5], 128, 128, pep, ld_pep, 1, 63, G + L.p_lw[5], 191, G + L.p_lb[5], nullptr, nullptr, 0));          // layer 5 on [pe | h4]
-        RUN(wgrad_add(&wg, w.gy[5], 128, 128, w.sv.h[4], 128, 1, 128, G + L.p_lw[5] + 63, 191, nullptr, nullptr, nullptr, 0));
-        for (int l = 4; l >= 1; --l) RUN(wgrad_add(&wg, w.gy[l], 128, 128, w.sv.h[l - 1], 128, 1, 128, G + L.p_lw[l], 128, G + L.p_lb[l], nullptr, nullptr, 0));
-        RUN(wgrad_add(&wg, w.gy[0], 128, 128, pep, ld_pep, 1, 63, G + L.p_lw[0], 63, G + L.p_lb[0], nullptr, nullptr, 0));
-        RUN(wgrad_add(&wg, w.gbd, 128, 128, f.feats, ldf, 1, n_mvs, G + L.p_bdw, n_mvs, G + L.p_bdb, nullptr, nullptr, 0, xt));      // depth-bias net
+        RUN(wgrad_add(&wg, w.g3, R, 128, f.feats + (xt ? 32 * n_mvs : n_mvs), 0, ldf, 1, n_img, G + L.p_bcw, n_img, G + L.p_bcb, nullptr, nullptr, 0, xt));   // confidence-bias net
+        RUN(wgrad_add(&wg, w.gy[5], R, 128, pep, 0, ld_pep, 1, 63, G + L.p_lw[5], 191, G + L.p_lb[5], nullptr, nullptr, 0));          // layer 5 on [pe | h4]
+        RUN(wgrad_add(&wg, w.gy[5], R, 128, w.sv.h[4], 1, R, 1, 128, G + L.p_lw[5] + 63, 191, nullptr, nullptr, nullptr, 0));
+        for (int l = 4; l >= 1; --l) RUN(wgrad_add(&wg, w.gy[l], R, 128, w.sv.h[l - 1], 1, R, 1, 128, G + L.p_lw[l], 128, G + L.p_lb[l], nullptr, nullptr, 0));
+        RUN(wgrad_add(&wg, w.gy[0], R, 128, pep, 0, ld_pep, 1, 63, G + L.p_lw[0], 63, G + L.p_lb[0], nullptr, nullptr, 0));
+        RUN(wgrad_add(&wg, w.gbd, R, 128, f.feats, 0, ldf, 1, n_mvs, G + L.p_bdw, n_mvs, G + L.p_bdb, nullptr, nullptr, 0, xt));      // depth-bias net
         // the four head layers: base rgb (3 rows) + base sigma (row 3) on h5; adapt rgb on the views half of vc, adapt sigma on the view_confi half
-        RUN(wgrad_add(&wg, w.g_base, 4, 4, w.sv.h[5], 128, 1, 128, G + L.p_crw, 128, G + L.p_crb, G + L.p_a1w, G + L.p_a1b, 3));
-        RUN(wgrad_add(&wg, w.g_adapt, 4, 3, w.sv.vc, 128, 1, 64, G + L.p_rw, 64, G + L.p_rb, nullptr, nullptr, 0));
-        RUN(wgrad_add(&wg, w.g_adapt + 3, 4, 1, w.sv.vc + 64, 128, 1, 64, G + L.p_aw, 64, G + L.p_ab, nullptr, nullptr, 0));
+        RUN(wgrad_add(&wg, w.g_base, 12, 4, w.sv.h[5], 1, R, 1, 128, G + L.p_crw, 128, G + L.p_crb, G + L.p_a1w, G + L.p_a1b, 3));
+        RUN(wgrad_add(&wg, w.g_adapt, 12, 3, vc24, 1, R, 1, 64, G + L.p_rw, 64, G + L.p_rb, nullptr, nullptr, 0));
+        RUN(wgrad_add(&wg, w.g_sigma, 12, 1, vc24 + 3 * 64, 1, R, 1, 64, G + L.p_aw, 64, G + L.p_ab, nullptr, nullptr, 0));
         RUN(wgrad_launch(&wg, st));
         return UCNERF_OK;
     }

@@ -95,9 +95,9 @@ struct ChainArgs {
     MlpSaved sv;
     const char* wstream;           // pack_bwd_kernel's stream
     const float* head;             // ... and head table
-    float* G_vc; float* G_f; float* G_bc; float* gx; float* G_bd; float* G_y[6];      // [m,128] each: operands of the weight-gradient GEMMs
+    float* G_vc; float* G_f; float* G_bc; float* gx; float* G_bd; float* G_y[6];      // [m,128] each, 24-bit (p24.h): operands of the weight-gradient GEMMs
     float* g_feats;                // [m, ldgf]
-    float* g_base; float* g_adapt; // [m,4]
+    float* g_base; float* g_adapt; float* g_sigma; // [m,4] each, 24-bit: (base rgb, base sigma), (adapt rgb, 0), (adapt sigma, 0, 0, 0)
 };
 
 __device__ __forceinline__ int c_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
@@ -139,20 +139,25 @@ __device__ __forceinline__ CAF c_ldaf(const char* lane_base, int hs) {
     return f;
 }
 
-// row tile nt of this lane's row piece (row = set + s * 128 + 4 h): registers 4 q + c <-> floats 32 nt + 8 q + c
-__device__ __forceinline__ c_f32x16 c_ld_tile(const float* row, int nt) {
+// Every [m,128] set this kernel reads or writes is in the 24-bit format of p24.h (384-byte rows).
+// row tile nt of this lane's row piece (row = set + 384 s + 12 h bytes): registers 4 q + c <-> columns 32 nt + 8 q + 4 h + c = 12 bytes at 96 nt + 24 q
+__device__ __forceinline__ c_f32x16 c_ld_tile(const float* set, size_t rb, int nt) {
+    const char* row = reinterpret_cast<const char*>(set) + rb;
     c_f32x16 x;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const c_f32x4 v = *reinterpret_cast<const c_f32x4*>(row + 32 * nt + 8 * q);
-        x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        const P24Piece v = p24_load(row + 96 * nt + 24 * q);
+        float t0, t1, t2, t3;
+        p24_unpack4(v, t0, t1, t2, t3);
+        x[4 * q] = t0; x[4 * q + 1] = t1; x[4 * q + 2] = t2; x[4 * q + 3] = t3;
     }
     return x;
 }
-__device__ __forceinline__ void c_st_tile(float* row, int nt, const c_f32x16& x, bool valid) {
+__device__ __forceinline__ void c_st_tile(float* set, size_t rb, int nt, const c_f32x16& x, bool valid) {
     if (valid) {
+        char* row = reinterpret_cast<char*>(set) + rb;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<c_f32x4*>(row + 32 * nt + 8 * q) = (c_f32x4){x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+        for (int q = 0; q < 4; ++q) p24_store(row + 96 * nt + 24 * q, p24_pack4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]));
     }
 }
 
@@ -226,7 +231,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
         const int s_raw = tile * 32 + j;
         const bool valid = s_raw < a.m;
         const int s = valid ? s_raw : a.m - 1;
-        const size_t ro = (size_t)s * 128 + 4 * h;             // this lane's piece of a [m,128] row
+        const size_t ro = (size_t)s * P24_ROW_BYTES + 12 * h;  // this lane's piece of a [m,128] row, in bytes
 
         // ---- output stage (models.py:177-178 backwards)
         const c_f32x4 raw = reinterpret_cast<const c_f32x4*>(a.raw)[s];
@@ -237,9 +242,10 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
         const float gp[4] = {gr.x * raw.x * (1.f - raw.x), gr.y * raw.y * (1.f - raw.y), gr.z * raw.z * (1.f - raw.z), raw.w > 0.f ? gr.w : 0.f};
         const float gb4[4] = {gp[0] * omu, gp[1] * omu, gp[2] * omu, gp[3] * u};
         const float ga4[4] = {gp[0] * u, gp[1] * u, gp[2] * u, gp[3] * omu};
-        if (h == 0 && valid) {
-            reinterpret_cast<c_f32x4*>(a.g_base)[s] = (c_f32x4){gb4[0], gb4[1], gb4[2], gb4[3]};
-            reinterpret_cast<c_f32x4*>(a.g_adapt)[s] = (c_f32x4){ga4[0], ga4[1], ga4[2], ga4[3]};
+        if (h == 0 && valid) {      // the G operands of the four head layers' weight gradients: three [m,4] sets (12-byte rows)
+            p24_store(reinterpret_cast<char*>(a.g_base) + (size_t)s * 12, p24_pack4(gb4[0], gb4[1], gb4[2], gb4[3]));      // base rgb | base sigma
+            p24_store(reinterpret_cast<char*>(a.g_adapt) + (size_t)s * 12, p24_pack4(ga4[0], ga4[1], ga4[2], 0.f));       // adapt rgb
+            p24_store(reinterpret_cast<char*>(a.g_sigma) + (size_t)s * 12, p24_pack4(ga4[3], 0.f, 0.f, 0.f));             // adapt sigma
         }
 
         c_f32x16 acc[4], hn[4], hm[4];
@@ -248,7 +254,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
 
         // ---- adapt heads backwards + relu of [views | view_confi]: g_vc
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) hn[nt] = c_ld_tile(a.sv.vc + ro, nt);
+        for (int nt = 0; nt < 4; ++nt) hn[nt] = c_ld_tile(a.sv.vc, ro, nt);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
@@ -268,7 +274,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
                 c_pin(ad[0]); c_pin(ad[1]); c_pin(ad[2]); c_pin(ad[3]);
                 CSB;                                         // (a fence per group: the scheduler otherwise reads every head weight of the tile up front and spills them)
             }
-            c_st_tile(a.G_vc + ro, nt, acc[nt], valid);
+            c_st_tile(a.G_vc, ro, nt, acc[nt], valid);
             c_split_tile(acc[nt], X[2 * nt], X[2 * nt + 1]);
             CSB;
         }
@@ -278,14 +284,14 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
         launder(); c_section<0, 2>(wl, ring, X, acc);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            c_st_tile(a.G_f + ro, nt, acc[nt], valid);
+            c_st_tile(a.G_f, ro, nt, acc[nt], valid);
             c_split_tile(acc[nt], X[2 * nt], X[2 * nt + 1]);
             CSB;
         }
 
         // ---- feature_linear^T: g_gx
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) hn[nt] = c_ld_tile(a.sv.h[5] + ro, nt);       // (h5 lands under the section's MFMAs)
+        for (int nt = 0; nt < 4; ++nt) hn[nt] = c_ld_tile(a.sv.h[5], ro, nt);       // (h5 lands under the section's MFMAs)
         c_zero(acc);
         launder(); c_section<16, 2>(wl, ring, X, acc);
 
@@ -313,12 +319,12 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
                 c_f32x16 gbc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gbc[r] = acc[nt][r] * hn[nt][r];
-                c_st_tile(a.G_bc + ro, nt, gbc, valid);
+                c_st_tile(a.G_bc, ro, nt, gbc, valid);
                 c_split_tile(gbc, Z[2 * nt], Z[2 * nt + 1]);
                 CSB;
             }
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) hm[nt] = c_ld_tile(a.sv.h[4] + ro, nt);      // for the first trunk epilogue, two sections away
+            for (int nt = 0; nt < 4; ++nt) hm[nt] = c_ld_tile(a.sv.h[4], ro, nt);      // for the first trunk epilogue, two sections away
             c_f32x16 a2[4];
             c_zero(a2);
             launder(); c_section<32, 1>(wl, ring, Z, a2);
@@ -328,11 +334,11 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
 
         // ---- gx = h5 * bc (feature_linear's input), g_h5 = g_gx * bc + base heads^T g_base, relu / b_d backward of layer 5
         {
-            c_f32x16 bct = c_ld_tile(a.sv.bc + ro, 0), bdt = c_ld_tile(a.sv.bd + ro, 0);
+            c_f32x16 bct = c_ld_tile(a.sv.bc, ro, 0), bdt = c_ld_tile(a.sv.bd, ro, 0);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 c_f32x16 bcn, bdn;
-                if (nt < 3) { bcn = c_ld_tile(a.sv.bc + ro, nt + 1); bdn = c_ld_tile(a.sv.bd + ro, nt + 1); }      // next tile's operands under this one's arithmetic
+                if (nt < 3) { bcn = c_ld_tile(a.sv.bc, ro, nt + 1); bdn = c_ld_tile(a.sv.bd, ro, nt + 1); }      // next tile's operands under this one's arithmetic
                 c_f32x16 gxv, gy, gb;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -357,8 +363,8 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
                 }
                 st_park(0, nt, bdt);
                 st_park(1, nt, gb);
-                c_st_tile(a.gx + ro, nt, gxv, valid);
-                c_st_tile(a.G_y[5] + ro, nt, gy, valid);
+                c_st_tile(a.gx, ro, nt, gxv, valid);
+                c_st_tile(a.G_y[5], ro, nt, gy, valid);
                 c_split_tile(gy, X[2 * nt], X[2 * nt + 1]);
                 if (nt < 3) { bct = bcn; bdt = bdn; }
                 CSB;
@@ -379,7 +385,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
                     gy[r] = gpre * bdt[r];
                 }
                 st_park(1, nt, gb);
-                c_st_tile(G_out + ro, nt, gy, valid);
+                c_st_tile(G_out, ro, nt, gy, valid);
                 c_split_tile(gy, X[2 * nt], X[2 * nt + 1]);
                 CSB;
             }
@@ -393,7 +399,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
             launder(); c_section<HS0, 2>(wl, ring, X, acc);                                               \
             if ((L) >= 2) {                                                                               \
                 _Pragma("unroll")                                                                         \
-                for (int nt = 0; nt < 4; ++nt) NXT[nt] = c_ld_tile(a.sv.h[(L) - 2] + ro, nt);             \
+                for (int nt = 0; nt < 4; ++nt) NXT[nt] = c_ld_tile(a.sv.h[(L) - 2], ro, nt);             \
             }                                                                                             \
             CSB;                                                                                          \
             trunk_epi(a.G_y[(L) - 1], CUR);                                                               \
@@ -412,7 +418,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
             c_f32x16 g;
 #pragma unroll
             for (int r = 0; r < 16; ++r) g[r] = gb[r] != 0.f ? gb[r] / bdt[r] : 0.f;
-            c_st_tile(a.G_bd + ro, nt, g, valid);
+            c_st_tile(a.G_bd, ro, nt, g, valid);
             c_split_tile(g, X[2 * nt], X[2 * nt + 1]);
             CSB;
         }
@@ -469,7 +475,7 @@ int launch_pack_bwd(int n_src, const float* flat, float* stream_out, hipStream_t
 // g_* / G_* operands: see ChainArgs.  `stream` = launch_pack_bwd's output.
 int launch_mlp_bwd_chain(int n_src, int m, const float* raw, const float* g_raw, const float* feats, int ldf, int feats_tiled, const MlpSaved* sv, const float* stream,
                          float* G_vc, float* G_f, float* G_bc, float* gx, float* G_bd, float* const* G_y, float* g_feats, int ldgf, float* g_base,
-                         float* g_adapt, hipStream_t st) {
+                         float* g_adapt, float* g_sigma, hipStream_t st) {
     MlpLayout L;
     UCNERF_REQUIRE(mlp_layout(n_src, &L), "mlp_bwd: n_src %d outside 1..8", n_src);
     UCNERF_REQUIRE(m > 0 && m <= (1 << 24), "mlp_bwd: %d samples in one pass (limit 2^24)", m);
@@ -481,7 +487,7 @@ int launch_mlp_bwd_chain(int n_src, int m, const float* raw, const float* g_raw,
     a.head = stream + (size_t)BWD_HALF_STEPS * BWD_HALF_BYTES / 4;
     a.G_vc = G_vc; a.G_f = G_f; a.G_bc = G_bc; a.gx = gx; a.G_bd = G_bd;
     for (int l = 0; l < 6; ++l) a.G_y[l] = G_y[l];
-    a.g_feats = g_feats; a.g_base = g_base; a.g_adapt = g_adapt;
+    a.g_feats = g_feats; a.g_base = g_base; a.g_adapt = g_adapt; a.g_sigma = g_sigma;
     const int cus = device_cus();
     if (cus <= 0) return fail(UCNERF_EHIP, "mlp_bwd: no device");
     int blocks = cdiv(a.n_tiles, CHAIN_WAVES);

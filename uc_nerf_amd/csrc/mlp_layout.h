@@ -87,8 +87,10 @@ inline bool mlp_layout(int v, MlpLayout* L) {
     return true;
 }
 
-// Activations the training forward keeps for the backward, all row-major [m,128] float32.
+// Activations the training forward keeps for the backward: [m,128] each, row-major -- float32 (p24 = 0: what the layer-by-layer backward,
+// bwd_mode 1, reads) or the 24-bit format of p24.h (p24 = 1: the gradient chain and the weight-gradient launch, bwd_mode 0).
 struct MlpSaved {
+    int p24;
     float* bd;      // depth-bias net output b_d
     float* h[6];    // trunk activations h_l = relu((W_l x + b_l) * b_d)
     float* bc;      // confidence-bias net output b_c

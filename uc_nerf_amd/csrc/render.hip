@@ -164,7 +164,7 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
             Workspace wb;
             float *g_raw, *g_feats, *mlp_ws;
             carve_bwd_render(p->train_workspace, p->n, p->S, V, &wb, &g_raw, &g_feats, &mlp_ws);
-            if ((rc = ucnerf_mlp_fwd_train(&m, mlp_ws, st))) return rc;
+            if ((rc = ucnerf_mlp_fwd_train(&m, mlp_ws, p->train_bwd_mode, st))) return rc;
         } else if ((rc = ucnerf_mlp_fwd(&m, st))) return rc;
         if (p->ev_mlp_stop && (rc = ucnerf_event_record(p->ev_mlp_stop, st))) return rc;
     }
@@ -206,6 +206,8 @@ int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* bp, void* stream) {
     UCNERF_REQUIRE(p->rays_o && p->rays_d && p->z && p->wstream && p->raw && p->feats && bp->g_rgb && bp->flat_params && bp->g_flat &&
                        bp->workspace, "render_fused_bwd: null pointer (fwd.raw and fwd.feats must hold the forward's outputs)");
     UCNERF_REQUIRE(((uintptr_t)bp->workspace & 15) == 0, "render_fused_bwd: workspace must be 16-byte aligned");
+    UCNERF_REQUIRE(!bp->saved_valid || p->train_bwd_mode == bp->bwd_mode, "render_fused_bwd: the forward kept its activations for bwd_mode %d, this call asks for %d "
+                   "(the two modes read different formats)", p->train_bwd_mode, bp->bwd_mode);
     hipStream_t st = (hipStream_t)stream;
     const int V = p->cfg.n_src;
     Workspace w;

@@ -599,6 +599,13 @@ class _MLPEncoded(torch.autograd.Function):
     def forward(ctx, flat, x, pw, ws=None):
         ws = pw.pack(flat) if ws is None else ws
         x = _f32(x, "x")
+        if x.requires_grad or flat.requires_grad:
+            # the weight-gradient kernel reads its operands in 16-byte pieces: the last piece of the last row (direction columns 24 .. 27 of 27)
+            # ends four bytes past the matrix -- keep the copy the backward reads inside a buffer that has them
+            buf = torch.empty(x.numel() + 4, device=x.device)
+            xp = buf[:x.numel()].view(x.shape)
+            xp.copy_(x)
+            x = xp
         ctx.pw = pw
         ctx.save_for_backward(flat, x, ws)
         return mlp_fwd_encoded(pw, ws, x)
@@ -975,7 +982,8 @@ class RenderPass:
             if getattr(self, "_bwd_ws", None) is None or self._bwd_ws.numel() < need_b:
                 self._bwd_ws = torch.empty(need_b, device=dev)
             p.train_workspace = _ptr(self._bwd_ws)
-            self._saved_for = (n, S, out["raw"].data_ptr())
+            p.train_bwd_mode = _backward_mode          # (fixes the format the activations are kept in: 24-bit for the chain, fp32 layer by layer)
+            self._saved_for = (n, S, out["raw"].data_ptr(), _backward_mode)
         _launch("ucnerf_render_fused_fwd", p, dev)
         return out
 
@@ -1003,7 +1011,7 @@ class RenderPass:
         dir_feat = _f32(dir_feat, "dir_feat") if dir_feat is not None else None
         p.dir_feat = _ptr(dir_feat)
         p.ev_mlp_start = p.ev_mlp_stop = None
-        saved = getattr(self, "_saved_for", None) == (n, S, kept["raw"].data_ptr())
+        saved = getattr(self, "_saved_for", None) == (n, S, kept["raw"].data_ptr(), _backward_mode)
         ws = self._bwd_ws if saved else torch.empty(L.lib().ucnerf_render_bwd_workspace_floats(n, S, self.src.V), device=dev)
         bp.saved_valid = int(saved)
         bp.bwd_mode = _backward_mode
