@@ -343,16 +343,15 @@ template <bool P24>
 __device__ __forceinline__ void save_rows(float* buf, int s, int h, bool valid, const f32x16 (&x)[4]) {
     if (!valid) return;
     f32x4* row = reinterpret_cast<f32x4*>(buf + (size_t)s * 128);
-    char* row24 = reinterpret_cast<char*>(buf) + (size_t)s * P24_ROW_BYTES;
+    char* row24 = reinterpret_cast<char*>(buf) + p24_offset((size_t)s, 0, 32);      // this sample's piece of group 0; group g is g * 384 bytes on
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (P24) {
                 const P24Piece pc = p24_pack4(x[nt][4 * q], x[nt][4 * q + 1], x[nt][4 * q + 2], x[nt][4 * q + 3]);
-                // (plain stores: 12-byte pieces do not fill whole 32-byte sectors one by one -- as streaming stores each partial sector became a
-                //  read-modify-write at the memory side, 757 us per 131 k samples; through the L2 the pieces of a line meet before it is evicted)
-                p24_store(row24 + 12 * (8 * nt + 2 * q + h), pc);
+                // (plain stores; the 64 lanes of one store write 768 contiguous bytes of the tiled set)
+                p24_store(row24 + P24_GROUP_BYTES * (8 * nt + 2 * q + h), pc);
             } else {
                 f32x4 v = {x[nt][4 * q], x[nt][4 * q + 1], x[nt][4 * q + 2], x[nt][4 * q + 3]};
                 __builtin_nontemporal_store(v, &row[8 * nt + 2 * q + h]);      // (streaming hint: 670 MB per 131 k samples, read back a pass later; 411 -> 391 us)

@@ -304,15 +304,15 @@ template <class T> __device__ __forceinline__ void pin(T& v) { asm volatile("" :
 
 // Training forward (SAVE): the activation sets the backward reads (MlpSaved, mlp_layout.h), row-major [m,128].  A lane owns 64 of its
 // sample's 128 values per set: register group (nt, q = reg / 4) of lane-half h sits at floats 32 nt + 8 q + 4 h of the row.
-// P24: the sets in the 24-bit format of p24.h instead (`row` then = set + 384 s + 12 h BYTES: the same four-column groups as 12-byte pieces)
+// P24: the sets in the 24-bit tiled format of p24.h instead (`row` then = this lane's piece of column group h)
 template <bool P24>
 __device__ __forceinline__ void save8(float* row, int nt, int s, const float (&t)[8]) {       // fragment s of row-tile nt
     // (plain stores: the eight 16-byte pieces of a 128-byte line leave this wave hundreds of cycles apart -- between MFMA groups --
     //  and have to meet in L2; as streaming stores each piece went to memory on its own)
     if (P24) {
-        char* r24 = reinterpret_cast<char*>(row) + 96 * nt + 48 * s;
+        char* r24 = reinterpret_cast<char*>(row) + P24_GROUP_BYTES * (8 * nt + 4 * s);      // groups 8 nt + 2 q + h, q = 2 s and 2 s + 1 (`row` carries h)
         p24_store(r24, p24_pack4(t[0], t[1], t[2], t[3]));
-        p24_store(r24 + 24, p24_pack4(t[4], t[5], t[6], t[7]));
+        p24_store(r24 + 2 * P24_GROUP_BYTES, p24_pack4(t[4], t[5], t[6], t[7]));
     } else {
         *reinterpret_cast<f32x4*>(row + 32 * nt + 16 * s) = (f32x4){t[0], t[1], t[2], t[3]};
         *reinterpret_cast<f32x4*>(row + 32 * nt + 16 * s + 8) = (f32x4){t[4], t[5], t[6], t[7]};
@@ -324,7 +324,7 @@ __device__ __forceinline__ void save_tile(float* row, int nt, const f32x16& x) {
     for (int q = 0; q < 4; ++q) {
         f32x4 v = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
         if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (P24) p24_store(reinterpret_cast<char*>(row) + 96 * nt + 24 * q, p24_pack4(v.x, v.y, v.z, v.w));
+        if (P24) p24_store(reinterpret_cast<char*>(row) + P24_GROUP_BYTES * (8 * nt + 2 * q), p24_pack4(v.x, v.y, v.z, v.w));
         else *reinterpret_cast<f32x4*>(row + 32 * nt + 8 * q) = v;
     }
 }
@@ -927,7 +927,9 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         // SAVE: this lane's row of an activation set (re-derived at every use: nothing tile-long is kept in a register)
         auto srow = [&](float* base) -> float* {
             const int l_ = opaque(lane), s_ = tile * 32 + (l_ & 31);
-            return s_ < p.m ? base + (size_t)s_ * (SAVE == 2 ? 96 : 128) + (SAVE == 2 ? 3 : 4) * (l_ >> 5) : nullptr;      // (24-bit sets: 384-byte rows, 12-byte pieces)
+            if (SAVE == 2)       // 24-bit sets (p24.h, tiled): this lane's piece of group h; the piece of group 8 nt + 2 q + h is (8 nt + 2 q) * 384 bytes on
+                return s_ < p.m ? base + (p24_offset((size_t)s_, l_ >> 5, 32) >> 2) : nullptr;
+            return s_ < p.m ? base + (size_t)s_ * 128 + 4 * (l_ >> 5) : nullptr;
         };
         const size_t hstride = SAVE ? (size_t)(sv.h[1] - sv.h[0]) : 0;      // the six trunk sets are carved back to back
         // (few scalars are carried through the trunk -- every VGPR there is spoken for: sample index, feature base

@@ -673,9 +673,11 @@ static size_t carve_bwd(float* base, int m, int n_dirs, BwdWork* w) {
     for (int l = 0; l < 6; ++l) w->sv.h[l] = take(M * 128);
     w->sv.bc = take(M * 128); w->sv.ft = take(M * 128); w->sv.vc = take(M * 128);
     w->pep = take(M * 63); w->ped = take((size_t)n_dirs * 27);
-    w->g1 = take(M * 128); w->g2 = take(M * 128); w->g3 = take(M * 128); w->gbd = take(M * 128); w->gx = take(M * 128);
-    w->g_base = take(M * 4); w->g_adapt = take(M * 4); w->g_sigma = take(M * 4); w->raw = take(M * 4);
-    for (int l = 0; l < 6; ++l) w->gy[l] = take(M * 128);
+    // (the sets the gradient chain writes have one spare row behind row m - 1 -- lanes without a sample store there, mlp_bwd_chain.hip --: as 24-bit
+    //  rows they fill three quarters of M * 128 floats, which leaves it for M >= 3; the explicit tail covers smaller M)
+    w->g1 = take(M * 128 + 96); w->g2 = take(M * 128 + 96); w->g3 = take(M * 128 + 96); w->gbd = take(M * 128 + 96); w->gx = take(M * 128 + 96);
+    w->g_base = take(M * 4 + 4); w->g_adapt = take(M * 4 + 4); w->g_sigma = take(M * 4 + 4); w->raw = take(M * 4);
+    for (int l = 0; l < 6; ++l) w->gy[l] = take(M * 128 + 96);
     w->wstream_bwd = take(bwd_chain_stream_floats());
     return o;
 }

@@ -11,10 +11,11 @@
 // scheme, 2^-16 relative).  Per layer the kernel reads the kept activation it needs for the relu mask and the b_d product (h_{l-1},
 // once) and writes g_y (once) for the weight-gradient GEMMs: nothing else touches HBM.
 //
-// The kernel is bound by those reads and writes (~10 KB per sample against ~750 MFMAs per tile), not by the matrix pipe, so it is
-// built for memory-level parallelism and simplicity rather than for MFMA issue rate: one wave per SIMD with 512 registers (the
-// resident state is b_d, the g_bd sum, the accumulators, the B fragments and one prefetched activation set), every wave independent
-// (no barrier, no LDS ring: the 512-KB weight stream is read straight from L2 / L1 two half-steps ahead), tiles dealt round-robin.
+// One wave per SIMD with 512 registers (the resident state is the accumulators, the B fragments and two activation sets; b_d and the
+// running g_bd sum are parked in LDS).  The 512-KB stream of W^T fragments reaches the four waves of a block through ONE ring in LDS,
+// filled by global_load_lds (each wave copies a quarter of every half-step, eight half-steps ahead) -- round 3's first version had every
+// wave read the stream for itself from L2, three half-steps ahead: 2 GB of L2 traffic per launch and an L2 round trip (~1 000 cycles
+// under that load) in front of most half-steps: 183 k cycles per tile against 25 k of MFMA work (SQ_WAIT_INST_ANY 0.61).
 #include "common.h"
 #include "mlp_layout.h"
 #include "mlp_bwd_parts.h"
@@ -27,6 +28,10 @@ typedef float c_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 c_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned c_u32x4 __attribute__((ext_vector_type(4)));
 #define CSB __builtin_amdgcn_sched_barrier(0)
+#ifndef UCNERF_CHAIN_EXP
+#define UCNERF_CHAIN_EXP 0      // timing experiments (wrong results), bit mask: 1 no activation-set loads, 2 no set stores, 4 no wait for the weight copies,
+                                //   8 no barrier, 16 no weight copies, 64 / 128 all set loads / stores inside the sets' first 1024 samples (cache resident)
+#endif
 #define CMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 constexpr int BWD_HALF_STEPS = 128;            // VC 16 | FT 16 | BC 8 | L5 16 | L4 16 | L3 16 | L2 16 | L1 16 | BD 8
@@ -132,54 +137,110 @@ __device__ __forceinline__ void c_split_tile(const c_f32x16& x, CFrag& f0, CFrag
     f1 = c_split8(t);
 }
 
-__device__ __forceinline__ CAF c_ldaf(const char* lane_base, int hs) {
-    const c_bf16x8* a = reinterpret_cast<const c_bf16x8*>(lane_base + (size_t)hs * BWD_HALF_BYTES);
+// ---- the weight ring: CHAIN_NB slots of one half-step (4 KB) each in LDS, shared by the block's four waves.  128 half-steps per tile
+// = 0 mod CHAIN_NB, so slot and source of every copy are compile-time constants of the unrolled tile body and the ring runs on across tiles.
+constexpr int CHAIN_NB = 8;
+struct CPipe {
+    const char* gsrc;        // this lane's byte of half-step 0: stream + wave * 1024 + lane * 16 (laundered per section, see launder())
+    unsigned dst;            // LDS byte address of this wave's quarter of slot 0
+    const char* rd;          // this lane's 16 bytes of slot 0 (LDS)
+};
+// (issued from inline asm: the compiler treats a global_load_lds as an access to both memories and degrades every counted wait around it)
+__device__ __forceinline__ void c_dma(const CPipe& P, int hs_src, int slot) {
+    const char* src = P.gsrc + (size_t)hs_src * BWD_HALF_BYTES;
+    const unsigned dst = P.dst + slot * BWD_HALF_BYTES;
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+}
+__device__ __forceinline__ CAF c_ldaf(const CPipe& P, int slot) {
+    const c_bf16x8* a = reinterpret_cast<const c_bf16x8*>(P.rd + slot * BWD_HALF_BYTES);
     CAF f;
     f.h0 = a[0]; f.l0 = a[64]; f.h1 = a[128]; f.l1 = a[192];
     return f;
 }
+// Start of half-step hs (its fragments are in `cur`): the next half-step's slot has landed for the whole block and everybody is done reading
+// this half-step's slot, which is refilled with the half-step CHAIN_NB ahead; returns the next half-step's fragments.
+// vmcnt: vector-memory operations retire in issue order.  Behind the awaited copy this wave has issued CHAIN_NB - 2 younger copies and -- in the
+// first CHAIN_NB - 1 half-steps of a section -- the loads and stores of the epilogue in front of the section: YOUNGER = a lower bound of their
+// number, known at compile time because every one of them is issued unconditionally by every wave (c_st_tile).  Waiting for all but the youngest
+// CHAIN_NB - 2 operations regardless (the first build) made every epilogue's stores and the next layer's activation loads retire before the
+// section behind them could start: 180 of the launch's 350 us (profiles/r03_experiments.md).
+// (hs: a constant once the caller's loops are unrolled)
+template <int YOUNGER>
+__device__ __forceinline__ CAF c_advance(const CPipe& P, int hs) {
+#if !(UCNERF_CHAIN_EXP & 4)
+    static_assert(YOUNGER >= CHAIN_NB - 2 && YOUNGER <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(YOUNGER) : "memory");
+#endif
+#if !(UCNERF_CHAIN_EXP & 8)
+    __builtin_amdgcn_s_barrier();
+#endif
+#if !(UCNERF_CHAIN_EXP & 16)
+    c_dma(P, (hs + CHAIN_NB) % BWD_HALF_STEPS, hs % CHAIN_NB);
+#endif
+    return c_ldaf(P, (hs + 1) % CHAIN_NB);
+}
 
-// Every [m,128] set this kernel reads or writes is in the 24-bit format of p24.h (384-byte rows).
-// row tile nt of this lane's row piece (row = set + 384 s + 12 h bytes): registers 4 q + c <-> columns 32 nt + 8 q + 4 h + c = 12 bytes at 96 nt + 24 q
-__device__ __forceinline__ c_f32x16 c_ld_tile(const float* set, size_t rb, int nt) {
+// Every [m,128] set this kernel reads or writes is in the 24-bit tiled format of p24.h.
+// row tile nt of this lane (rb = byte offset of its piece of column group h): registers 4 q + c <-> columns 32 nt + 8 q + 4 h + c = the piece of group 8 nt + 2 q + h
+// (loaded as the pieces they are and unpacked where they are used: unpacked at the load, the byte permutes sit right behind it and with them
+//  the wait for the data -- a full memory latency in front of the section the load was meant to fly under; 12 registers per row tile, not 16)
+struct CRaw { unsigned d[12]; };
+__device__ __forceinline__ CRaw c_ld_tile(const float* set, size_t rb, int nt) {
     const char* row = reinterpret_cast<const char*>(set) + rb;
+    CRaw x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#if UCNERF_CHAIN_EXP & 1
+        unsigned z_ = 0x3f000000u + (unsigned)rb;
+        asm volatile("" : "+v"(z_));
+        const P24Piece v = {{z_, z_, z_}};
+#else
+        const P24Piece v = p24_load(row + P24_GROUP_BYTES * (8 * nt + 2 * q));
+#endif
+        x.d[3 * q] = v.d[0]; x.d[3 * q + 1] = v.d[1]; x.d[3 * q + 2] = v.d[2];
+    }
+    return x;
+}
+__device__ __forceinline__ c_f32x16 c_unpack(const CRaw& r) {
     c_f32x16 x;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const P24Piece v = p24_load(row + 96 * nt + 24 * q);
+        const P24Piece v = {{r.d[3 * q], r.d[3 * q + 1], r.d[3 * q + 2]}};
         float t0, t1, t2, t3;
         p24_unpack4(v, t0, t1, t2, t3);
         x[4 * q] = t0; x[4 * q + 1] = t1; x[4 * q + 2] = t2; x[4 * q + 3] = t3;
     }
     return x;
 }
-__device__ __forceinline__ void c_st_tile(float* set, size_t rb, int nt, const c_f32x16& x, bool valid) {
-    if (valid) {
-        char* row = reinterpret_cast<char*>(set) + rb;
+// (no predicate: the stores of a lane without a sample go to the spare row behind the set's last one -- `rb` then points there -- so that every
+//  wave issues the same number of vector-memory operations, which c_advance's counted waits rely on)
+__device__ __forceinline__ void c_st_tile(float* set, size_t rb, int nt, const c_f32x16& x) {
+#if UCNERF_CHAIN_EXP & 2
+    if (x[0] != 12345.678f) return;
+#endif
+    char* row = reinterpret_cast<char*>(set) + rb;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) p24_store(row + 96 * nt + 24 * q, p24_pack4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]));
-    }
+    for (int q = 0; q < 4; ++q) p24_store(row + P24_GROUP_BYTES * (8 * nt + 2 * q), p24_pack4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]));
 }
 
-// PAIRS row-tile pairs x 8 k16-steps of one transposed layer, starting at half-step HS0 of the stream; the fragments of the next three
-// half-steps are in flight (ring index = half-step mod 4: compile-time after unrolling; 128 half-steps per tile = 0 mod 4)
-constexpr int CHAIN_RING = 4;
-template <int HS0, int PAIRS>
-__device__ __forceinline__ void c_section(const char* wl, CAF (&ring)[CHAIN_RING], const CFrag (&B)[8], c_f32x16 (&acc)[4]) {
+// PAIRS row-tile pairs x 8 k16-steps of one transposed layer, starting at half-step HS0 of the stream; EPI = vector-memory operations every wave
+// has issued between the previous section and this one (see c_advance)
+constexpr int c_younger(int epi) { return CHAIN_NB - 2 + epi > 63 ? 63 : CHAIN_NB - 2 + epi; }
+template <int HS0, int PAIRS, int EPI>
+__device__ __forceinline__ void c_section(const CPipe& P, CAF& cur, const CFrag (&B)[8], c_f32x16 (&acc)[4]) {
 #pragma unroll
     for (int p = 0; p < PAIRS; ++p)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int hs = HS0 + 8 * p + q;
-            CSB;              // (keeps the scheduler from hoisting every fragment load of the section to its top)
-            ring[(hs + CHAIN_RING - 1) % CHAIN_RING] = c_ldaf(wl, (hs + CHAIN_RING - 1) % BWD_HALF_STEPS);
-            const CAF& a = ring[hs % CHAIN_RING];
-            acc[2 * p] = CMFMA(a.h0, B[q].hi, acc[2 * p]);
-            acc[2 * p] = CMFMA(a.h0, B[q].lo, acc[2 * p]);
-            acc[2 * p] = CMFMA(a.l0, B[q].hi, acc[2 * p]);
-            acc[2 * p + 1] = CMFMA(a.h1, B[q].hi, acc[2 * p + 1]);
-            acc[2 * p + 1] = CMFMA(a.h1, B[q].lo, acc[2 * p + 1]);
-            acc[2 * p + 1] = CMFMA(a.l1, B[q].hi, acc[2 * p + 1]);
+            CSB;              // (one half-step at a time)
+            const CAF nxt = 8 * p + q < CHAIN_NB - 1 ? c_advance<c_younger(EPI)>(P, HS0 + 8 * p + q) : c_advance<CHAIN_NB - 2>(P, HS0 + 8 * p + q);
+            acc[2 * p] = CMFMA(cur.h0, B[q].hi, acc[2 * p]);
+            acc[2 * p] = CMFMA(cur.h0, B[q].lo, acc[2 * p]);
+            acc[2 * p] = CMFMA(cur.l0, B[q].hi, acc[2 * p]);
+            acc[2 * p + 1] = CMFMA(cur.h1, B[q].hi, acc[2 * p + 1]);
+            acc[2 * p + 1] = CMFMA(cur.h1, B[q].lo, acc[2 * p + 1]);
+            acc[2 * p + 1] = CMFMA(cur.l1, B[q].hi, acc[2 * p + 1]);
+            cur = nxt;
         }
 }
 
@@ -192,46 +253,85 @@ __device__ __forceinline__ void c_zero(c_f32x16 (&acc)[4]) {
 
 constexpr int CHAIN_WAVES = 4;
 constexpr int CHAIN_HEAD_PAD = (BWD_HEAD_FLOATS + 3) & ~3;
-constexpr int CHAIN_LDS_BYTES = (CHAIN_HEAD_PAD + CHAIN_WAVES * 2 * 16 * 64 * 4) * 4;     // 4 KB + 128 KB
+// LDS: [head table 4 KB][weight ring CHAIN_NB x 4 KB][per wave: b_d of its tile as 24-bit pieces (12 KB) | the running g_bd sum in fp32 (16 KB)]
+constexpr int CHAIN_RING_OFF = CHAIN_HEAD_PAD * 4;
+constexpr int CHAIN_PARK_OFF = CHAIN_RING_OFF + CHAIN_NB * BWD_HALF_BYTES;
+constexpr int CHAIN_PARK_BD = 16 * 64 * 12, CHAIN_PARK_GBD = 16 * 64 * 16;
+constexpr int CHAIN_LDS_BYTES = CHAIN_PARK_OFF + CHAIN_WAVES * (CHAIN_PARK_BD + CHAIN_PARK_GBD);      // 4 + 32 + 112 KB
 
 __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(ChainArgs a) {
-    // LDS: [head table][per wave: b_d and the running g_bd sum of its tile, 16 KB each, as [row tile][q][lane][4 floats] -- parked here
-    // rather than in 128 registers: with them resident the register allocator spilled ~200 values around every layer's MFMA section]
+    // (b_d and the g_bd sum are parked in LDS rather than in 128 registers: with them resident the register allocator spilled ~200 values
+    //  around every layer's MFMA section; b_d as the 24-bit pieces it was loaded as, which is what leaves room for the weight ring)
     extern __shared__ __attribute__((aligned(16))) float chain_lds[];
     float* hw = chain_lds;
     for (int i = threadIdx.x; i < BWD_HEAD_FLOATS; i += 64 * CHAIN_WAVES) hw[i] = a.head[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    c_f32x4* park = reinterpret_cast<c_f32x4*>(chain_lds + CHAIN_HEAD_PAD) + (size_t)wave * (2 * 16 * 64) + lane;      // [which][nt * 4 + q][lane]
-    auto ld_park = [&](int which, int nt) {
+    char* const lds = reinterpret_cast<char*>(chain_lds);
+    char* const park_bd = lds + CHAIN_PARK_OFF + wave * (CHAIN_PARK_BD + CHAIN_PARK_GBD) + lane * 12;          // piece (nt, q) of this lane at + (4 nt + q) * 64 * 12
+    c_f32x4* const park_gbd = reinterpret_cast<c_f32x4*>(lds + CHAIN_PARK_OFF + wave * (CHAIN_PARK_BD + CHAIN_PARK_GBD) + CHAIN_PARK_BD) + lane;
+    auto ld_bd = [&](int nt) {
         c_f32x16 x;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const c_f32x4 v = park[(which * 16 + nt * 4 + q) * 64];
+            const p24_u32x3 v = *reinterpret_cast<const p24_u32x3_a4*>(park_bd + (4 * nt + q) * 64 * 12);
+            const P24Piece pc = {{v.x, v.y, v.z}};
+            float t0, t1, t2, t3;
+            p24_unpack4(pc, t0, t1, t2, t3);
+            x[4 * q] = t0; x[4 * q + 1] = t1; x[4 * q + 2] = t2; x[4 * q + 3] = t3;
+        }
+        return x;
+    };
+    auto st_bd = [&](int nt, const CRaw& x) {          // (the pieces as they were loaded)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<p24_u32x3_a4*>(park_bd + (4 * nt + q) * 64 * 12) = (p24_u32x3){x.d[3 * q], x.d[3 * q + 1], x.d[3 * q + 2]};
+    };
+    auto ld_gbd = [&](int nt) {
+        c_f32x16 x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const c_f32x4 v = park_gbd[(nt * 4 + q) * 64];
             x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
         }
         return x;
     };
-    auto st_park = [&](int which, int nt, const c_f32x16& x) {
+    auto st_gbd = [&](int nt, const c_f32x16& x) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) park[(which * 16 + nt * 4 + q) * 64] = (c_f32x4){x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+        for (int q = 0; q < 4; ++q) park_gbd[(nt * 4 + q) * 64] = (c_f32x4){x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
     };
     const int j = lane & 31, h = lane >> 5;
     // (the stream does not depend on the tile: unless its address is laundered per section, every one of its 2048 fragment registers is
     //  hoisted out of the tile loop and spilled; the OFFSET is laundered -- a pointer passed through an integer asm operand comes back
     //  as a flat pointer)
-    const char* wl = a.wstream + lane * 16;
-    auto launder = [&]() { unsigned o_ = (unsigned)lane * 16u; asm volatile("" : "+v"(o_)); wl = a.wstream + o_; };
-    CAF ring[CHAIN_RING];
-    ring[0] = c_ldaf(wl, 0);
-    ring[1] = c_ldaf(wl, 1);
-    ring[2] = c_ldaf(wl, 2);
+    CPipe P;
+    P.gsrc = a.wstream + wave * 1024 + lane * 16;
+    P.dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + CHAIN_RING_OFF) + wave * 1024;
+    P.rd = lds + CHAIN_RING_OFF + lane * 16;
+    auto launder = [&]() { unsigned o_ = (unsigned)(wave * 1024 + lane * 16); asm volatile("" : "+v"(o_)); P.gsrc = a.wstream + o_; };
+#pragma unroll
+    for (int i = 0; i < CHAIN_NB; ++i) c_dma(P, i, i);        // half-steps 0 .. CHAIN_NB - 1 of the first tile
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CHAIN_NB - 1) : "memory");      // slot 0 has landed ...
+    __builtin_amdgcn_s_barrier();                                             // ... for every wave
+    CAF cur = c_ldaf(P, 0);
 
-    for (int tile = blockIdx.x * CHAIN_WAVES + wave; tile < a.n_tiles; tile += gridDim.x * CHAIN_WAVES) {
+    // Every wave of the block walks the same number of tiles (the ring is turned by all four together): a wave whose tile lies past the end
+    // computes on the last sample's rows and stores nothing.
+    const int rounds = (a.n_tiles + gridDim.x * CHAIN_WAVES - 1) / (gridDim.x * CHAIN_WAVES);
+    for (int rnd = 0; rnd < rounds; ++rnd) {
+        const int tile = (rnd * gridDim.x + blockIdx.x) * CHAIN_WAVES + wave;
         const int s_raw = tile * 32 + j;
         const bool valid = s_raw < a.m;
         const int s = valid ? s_raw : a.m - 1;
-        const size_t ro = (size_t)s * P24_ROW_BYTES + 12 * h;  // this lane's piece of a [m,128] row, in bytes
+#if UCNERF_CHAIN_EXP & 64        // timing experiment: every load falls into the first 1024 samples of its set (cache resident)
+        const size_t ro = p24_offset((size_t)(s & 1023), h, 32);
+#else
+        const size_t ro = p24_offset((size_t)s, h, 32);        // this lane's piece of column group h of a [m,128] set, in bytes
+#endif
+#if UCNERF_CHAIN_EXP & 128       // ... every store
+        const size_t ro_st = p24_offset((size_t)((valid ? s_raw : a.m) & 1023), h, 32);
+#else
+        const size_t ro_st = p24_offset((size_t)(valid ? s_raw : a.m), h, 32);      // ... for stores: sample m is the spare row of every set written here
+#endif
 
         // ---- output stage (models.py:177-178 backwards)
         const c_f32x4 raw = reinterpret_cast<const c_f32x4*>(a.raw)[s];
@@ -242,13 +342,15 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
         const float gp[4] = {gr.x * raw.x * (1.f - raw.x), gr.y * raw.y * (1.f - raw.y), gr.z * raw.z * (1.f - raw.z), raw.w > 0.f ? gr.w : 0.f};
         const float gb4[4] = {gp[0] * omu, gp[1] * omu, gp[2] * omu, gp[3] * u};
         const float ga4[4] = {gp[0] * u, gp[1] * u, gp[2] * u, gp[3] * omu};
-        if (h == 0 && valid) {      // the G operands of the four head layers' weight gradients: three [m,4] sets (12-byte rows)
-            p24_store(reinterpret_cast<char*>(a.g_base) + (size_t)s * 12, p24_pack4(gb4[0], gb4[1], gb4[2], gb4[3]));      // base rgb | base sigma
-            p24_store(reinterpret_cast<char*>(a.g_adapt) + (size_t)s * 12, p24_pack4(ga4[0], ga4[1], ga4[2], 0.f));       // adapt rgb
-            p24_store(reinterpret_cast<char*>(a.g_sigma) + (size_t)s * 12, p24_pack4(ga4[3], 0.f, 0.f, 0.f));             // adapt sigma
+        if (h == 0) {               // the G operands of the four head layers' weight gradients: three [m,4] sets (12-byte rows; row m = spare)
+            const size_t r12 = (size_t)(valid ? s_raw : a.m) * 12;
+            p24_store(reinterpret_cast<char*>(a.g_base) + r12, p24_pack4(gb4[0], gb4[1], gb4[2], gb4[3]));      // base rgb | base sigma
+            p24_store(reinterpret_cast<char*>(a.g_adapt) + r12, p24_pack4(ga4[0], ga4[1], ga4[2], 0.f));       // adapt rgb
+            p24_store(reinterpret_cast<char*>(a.g_sigma) + r12, p24_pack4(ga4[3], 0.f, 0.f, 0.f));             // adapt sigma
         }
 
-        c_f32x16 acc[4], hn[4], hm[4];
+        c_f32x16 acc[4];
+        CRaw hn[4], hm[4], hx[4], bcr[4], bdr[4];
         CFrag X[8];
         float ad[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};      // this lane's share of the adapt / base head outputs
 
@@ -257,6 +359,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
         for (int nt = 0; nt < 4; ++nt) hn[nt] = c_ld_tile(a.sv.vc, ro, nt);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
+            const c_f32x16 hv_ = c_unpack(hn[nt]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int f0 = 32 * nt + 8 * q + 4 * c_opaque(h);       // (laundered: the table never changes, so its reads would be hoisted out of the tile loop and spilled)
@@ -265,7 +368,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
                 for (int o = 0; o < 4; ++o) w[o] = *reinterpret_cast<const c_f32x4*>(&hw[(4 + o) * 128 + f0]);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float v = hn[nt][4 * q + c];
+                    const float v = hv_[4 * q + c];
                     const float g = ga4[0] * w[0][c] + ga4[1] * w[1][c] + ga4[2] * w[2][c] + ga4[3] * w[3][c];
                     acc[nt][4 * q + c] = v > 0.f ? g : 0.f;
 #pragma unroll
@@ -274,17 +377,17 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
                 c_pin(ad[0]); c_pin(ad[1]); c_pin(ad[2]); c_pin(ad[3]);
                 CSB;                                         // (a fence per group: the scheduler otherwise reads every head weight of the tile up front and spills them)
             }
-            c_st_tile(a.G_vc, ro, nt, acc[nt], valid);
+            c_st_tile(a.G_vc, ro_st, nt, acc[nt]);
             c_split_tile(acc[nt], X[2 * nt], X[2 * nt + 1]);
             CSB;
         }
 
         // ---- [views | view_confi]^T: g_f (f = feature_linear's output, no activation)
         c_zero(acc);
-        launder(); c_section<0, 2>(wl, ring, X, acc);
+        launder(); c_section<0, 2, 16 + 19>(P, cur, X, acc)          /* vc loads | three head-G stores + G_vc */;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            c_st_tile(a.G_f, ro, nt, acc[nt], valid);
+            c_st_tile(a.G_f, ro_st, nt, acc[nt]);
             c_split_tile(acc[nt], X[2 * nt], X[2 * nt + 1]);
             CSB;
         }
@@ -293,7 +396,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) hn[nt] = c_ld_tile(a.sv.h[5], ro, nt);       // (h5 lands under the section's MFMAs)
         c_zero(acc);
-        launder(); c_section<16, 2>(wl, ring, X, acc);
+        launder(); c_section<16, 2, 32>(P, cur, X, acc)              /* G_f stores, h5 loads */;
 
         // ---- confidence-bias net^T first (its operand g_bc = g_gx * h5 dies before the trunk's state is born): gradient of the image
         //      features, columns n_mvs .. n_mvs + n_img of g_feats
@@ -317,28 +420,29 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 c_f32x16 gbc;
+                const c_f32x16 h5_ = c_unpack(hn[nt]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) gbc[r] = acc[nt][r] * hn[nt][r];
-                c_st_tile(a.G_bc, ro, nt, gbc, valid);
+                for (int r = 0; r < 16; ++r) gbc[r] = acc[nt][r] * h5_[r];
+                c_st_tile(a.G_bc, ro_st, nt, gbc);
                 c_split_tile(gbc, Z[2 * nt], Z[2 * nt + 1]);
                 CSB;
             }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) hm[nt] = c_ld_tile(a.sv.h[4], ro, nt);      // for the first trunk epilogue, two sections away
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) { bcr[nt] = c_ld_tile(a.sv.bc, ro, nt); bdr[nt] = c_ld_tile(a.sv.bd, ro, nt); }      // for the epilogue behind this section
             c_f32x16 a2[4];
             c_zero(a2);
-            launder(); c_section<32, 1>(wl, ring, Z, a2);
+            launder(); c_section<32, 1, 64>(P, cur, Z, a2)               /* G_bc stores, h4, b_c and b_d loads */;
             small_out(a2, a.n_mvs, a.n_img);
         }
         CSB;
 
         // ---- gx = h5 * bc (feature_linear's input), g_h5 = g_gx * bc + base heads^T g_base, relu / b_d backward of layer 5
         {
-            c_f32x16 bct = c_ld_tile(a.sv.bc, ro, 0), bdt = c_ld_tile(a.sv.bd, ro, 0);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                c_f32x16 bcn, bdn;
-                if (nt < 3) { bcn = c_ld_tile(a.sv.bc, ro, nt + 1); bdn = c_ld_tile(a.sv.bd, ro, nt + 1); }      // next tile's operands under this one's arithmetic
+                const c_f32x16 bct = c_unpack(bcr[nt]), bdt = c_unpack(bdr[nt]), h5_ = c_unpack(hn[nt]);
                 c_f32x16 gxv, gy, gb;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -349,7 +453,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const int r = 4 * q + c;
-                        const float hv = hn[nt][r], gg = acc[nt][r];
+                        const float hv = h5_[r], gg = acc[nt][r];
                         gxv[r] = hv * bct[r];
 #pragma unroll
                         for (int o = 0; o < 4; ++o) bs[o] += hv * w[o][c];
@@ -361,71 +465,74 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
                     c_pin(bs[0]); c_pin(bs[1]); c_pin(bs[2]); c_pin(bs[3]);
                     CSB;
                 }
-                st_park(0, nt, bdt);
-                st_park(1, nt, gb);
-                c_st_tile(a.gx, ro, nt, gxv, valid);
-                c_st_tile(a.G_y[5], ro, nt, gy, valid);
+                st_bd(nt, bdr[nt]);
+                st_gbd(nt, gb);
+                c_st_tile(a.gx, ro_st, nt, gxv);
+                c_st_tile(a.G_y[5], ro_st, nt, gy);
                 c_split_tile(gy, X[2 * nt], X[2 * nt + 1]);
-                if (nt < 3) { bct = bcn; bdt = bdn; }
                 CSB;
             }
         }
 
         // ---- trunk: layer 5 (hidden part) down to layer 1; the element-wise backward of layer l - 1 is the epilogue of layer l
-        auto trunk_epi = [&](float* G_out, const c_f32x16 (&hcur)[4]) {
+        auto trunk_epi = [&](float* G_out, const CRaw (&hraw)[4]) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const c_f32x16 bdt = ld_park(0, nt);
-                c_f32x16 gb = ld_park(1, nt), gy;
+                const c_f32x16 hcur_ = c_unpack(hraw[nt]);
+                const c_f32x16 bdt = ld_bd(nt);
+                c_f32x16 gb = ld_gbd(nt), gy;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float hv = hcur[nt][r];
+                    const float hv = hcur_[r];
                     const float gpre = hv > 0.f ? acc[nt][r] : 0.f;
                     gb[r] += gpre * hv;
                     gy[r] = gpre * bdt[r];
                 }
-                st_park(1, nt, gb);
-                c_st_tile(G_out, ro, nt, gy, valid);
+                st_gbd(nt, gb);
+                c_st_tile(G_out, ro_st, nt, gy);
                 c_split_tile(gy, X[2 * nt], X[2 * nt + 1]);
                 CSB;
             }
         };
-        // (the activation set a layer's epilogue needs is requested one layer early, into the other of two register sets, and AFTER the
-        //  previous section: vector-memory operations return in issue order, so a request in front of a section holds back every weight
-        //  fragment issued behind it for a whole HBM latency; behind it, the epilogue and the ring's three half-steps run meanwhile)
-#define UCNERF_CHAIN_LAYER(HS0, L, CUR, NXT)                                                            \
+        // The activation set a layer's epilogue needs is requested TWO layers early, into one of three register sets (hx takes the registers b_c and
+        // b_d have just left), and BEHIND a section: vector-memory operations return in issue order, so a request in front of a section would hold
+        // back the weight copies issued behind it.  One layer early (the first build) a set had one section (~4 us) to arrive: the launch spent
+        // ~90 of its 330 us waiting for DRAM (scripts/prof_chain_variants.sh, UCNERF_CHAIN_EXP 64).
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) hx[nt] = c_ld_tile(a.sv.h[3], ro, nt);
+#define UCNERF_CHAIN_LAYER(HS0, L, CUR, NXT, EPI)                                                          \
         {                                                                                                 \
             c_zero(acc);                                                                                  \
-            launder(); c_section<HS0, 2>(wl, ring, X, acc);                                               \
-            if ((L) >= 2) {                                                                               \
+            launder(); c_section<HS0, 2, EPI>(P, cur, X, acc);                                               \
+            if ((L) >= 3) {                                                                               \
                 _Pragma("unroll")                                                                         \
-                for (int nt = 0; nt < 4; ++nt) NXT[nt] = c_ld_tile(a.sv.h[(L) - 2], ro, nt);             \
+                for (int nt = 0; nt < 4; ++nt) NXT[nt] = c_ld_tile(a.sv.h[(L) - 3], ro, nt);             \
             }                                                                                             \
             CSB;                                                                                          \
             trunk_epi(a.G_y[(L) - 1], CUR);                                                               \
         }
-        UCNERF_CHAIN_LAYER(40, 5, hm, hn)       // (h4 was requested into hm before the confidence-bias net's section)
-        UCNERF_CHAIN_LAYER(56, 4, hn, hm)
-        UCNERF_CHAIN_LAYER(72, 3, hm, hn)
-        UCNERF_CHAIN_LAYER(88, 2, hn, hm)
-        UCNERF_CHAIN_LAYER(104, 1, hm, hn)
+        UCNERF_CHAIN_LAYER(40, 5, hm, hn, 48)   // uses h4 (requested before the confidence-bias net's section), requests h2; in front: gx, G_y[5] stores, h3 loads
+        UCNERF_CHAIN_LAYER(56, 4, hx, hm, 32)   // uses h3, requests h1; in front of each: a set's loads (while there are any), G_y stores
+        UCNERF_CHAIN_LAYER(72, 3, hn, hx, 32)   // uses h2, requests h0
+        UCNERF_CHAIN_LAYER(88, 2, hm, hn, 32)   // uses h1
+        UCNERF_CHAIN_LAYER(104, 1, hx, hn, 16)  // uses h0
 #undef UCNERF_CHAIN_LAYER
 
         // ---- depth-bias net: g_bd = sum_l g_pre_l * y_l with y_l = h_l / b_d on the active units; then its transposed layer
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const c_f32x16 bdt = ld_park(0, nt), gb = ld_park(1, nt);
+            const c_f32x16 bdt = ld_bd(nt), gb = ld_gbd(nt);
             c_f32x16 g;
 #pragma unroll
             for (int r = 0; r < 16; ++r) g[r] = gb[r] != 0.f ? gb[r] / bdt[r] : 0.f;
-            c_st_tile(a.G_bd, ro, nt, g, valid);
+            c_st_tile(a.G_bd, ro_st, nt, g);
             c_split_tile(g, X[2 * nt], X[2 * nt + 1]);
             CSB;
         }
         {
             c_f32x16 a2[4];
             c_zero(a2);
-            launder(); c_section<120, 1>(wl, ring, X, a2);
+            launder(); c_section<120, 1, 32>(P, cur, X, a2)              /* G_y[0] and G_bd stores */;
             small_out(a2, 0, a.n_mvs);
         }
 
@@ -441,6 +548,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
         if (h == 0 && valid) a.g_feats[(size_t)s * a.ldgf + a.F - 1] = -gu;
 
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the copies still in flight land before the block gives its LDS back
 }
 
 // ---- host side
@@ -496,5 +604,7 @@ int launch_mlp_bwd_chain(int n_src, int m, const float* raw, const float* g_raw,
     hipLaunchKernelGGL(mlp_bwd_chain_kernel, dim3(blocks), dim3(64 * CHAIN_WAVES), CHAIN_LDS_BYTES, st, a);
     return check_launch("mlp_bwd chain");
 }
+
+const char* build_flags_mlp_bwd_chain() { return "mlp_bwd_chain: " UCNERF_FLAG(UCNERF_CHAIN_EXP); }
 
 }  // namespace ucnerf

@@ -4,7 +4,10 @@
 // lo = bf16(x - hi)): 16 mantissa bits.  A value stored as the top 24 bits of its fp32 form (sign, exponent, 15 explicit mantissa
 // bits; the dropped byte rounded half up) carries exactly those, so the fp32 sets' fourth byte was traffic nobody read:
 //   a set [m, C] is m rows of 3 C bytes; column c of sample s = bytes 3 c .. 3 c + 2 of row s (little endian);
-//   four consecutive columns = 12 bytes = one dwordx3 access of the lane that owns them in the MFMA accumulator layout.
+//   four consecutive columns (a column GROUP) = 12 bytes = one dwordx3 access of the lane that owns them in the MFMA accumulator layout.
+// (A TILED variant -- [tile of 32 samples][group][sample][12 bytes], 768 contiguous bytes per accumulator-layout access -- was built and measured:
+//  the training forward's stores gained 54 us per 131 k samples, the gradient chain nothing (its memory time is DRAM latency, not line requests),
+//  and the weight-gradient launch, whose lanes run over column groups, lost 90-290 us: profiles/r03_experiments.md.  Rows it is.)
 // Relative error of a stored value <= 2^-17 (the split-bf16 products themselves are good to 2^-16).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -15,7 +18,10 @@ typedef unsigned p24_u32x3 __attribute__((ext_vector_type(3)));
 typedef p24_u32x3 p24_u32x3_a4 __attribute__((aligned(4)));                // ... at a 4-byte aligned address
 struct P24Piece { unsigned d[3]; };     // 12 bytes
 
-constexpr int P24_ROW_BYTES = 384;      // a [m,128] set
+constexpr int P24_ROW_BYTES = 384;       // a [m,128] set
+constexpr int P24_GROUP_BYTES = 12;      // from one column group of a sample to the next
+// byte offset of the 12-byte piece of (sample s, column group g) in a set with G groups per row
+__host__ __device__ inline size_t p24_offset(size_t s, int g, int G) { return (s * G + g) * 12; }
 
 // four fp32 -> 12 bytes
 __device__ __forceinline__ P24Piece p24_pack4(float v0, float v1, float v2, float v3) {
