@@ -45,5 +45,6 @@ for k, o in out.items():
 json.dump({"source": "scripts/pmc_mlp.sh (rocprofv3 --pmc, separate passes) on scripts/time_train_step.py (1024 rays x 128 samples)", "kernels": out},
           open(sys.argv[2], "w"), indent=1, sort_keys=True)
 PY
+[ -s $G/final_n2_gloo.json ] && cp $G/final_n2_gloo.json $R/profiles/${P}_bench_n2_gloo_rehearsal.json
 [ -f $G/parity_errors.json ] && cp $G/parity_errors.json $R/profiles/${P}_parity_errors.json
 echo collected into profiles/${P}_*

@@ -23,4 +23,6 @@ PREC=bf16x3_fused KERNEL=mlp_fwd_bf16 bash scripts/pmc_mlp.sh final_pmc_fused > 
 python scripts/pmc_summary.py gpurun_out/final_pmc_fused gpurun_out/final_mlp_bf16_fused_hbm_traffic.json > gpurun_out/final_pmc_fused_summary.log 2>&1 || true
 KERNEL="mlp_bwd_chain|mlp_wgrad|mlp_fwd_kernel|feat_gather" SCRIPT=scripts/time_train_step.py bash scripts/pmc_mlp.sh final_pmc_train > gpurun_out/final_pmc_train.log 2>&1
 python scripts/pmc_by_kernel.py gpurun_out/final_pmc_train gpurun_out/final_train_step_hbm_traffic.json > gpurun_out/final_pmc_train_summary.log 2>&1 || true
+# the self-launched two-rank line (both ranks on this GPU, gloo for the collective): only the JSON line is kept
+UCNERF_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 30 --warmup 5 2> gpurun_out/final_n2_gloo.err | grep '^{' > gpurun_out/final_n2_gloo.json || true
 tail -c 300 $R/gpurun_out/final_bf16x3_fused.json
