@@ -503,7 +503,7 @@ def main():
             dt4 = ctx.timed(train_step, 30, 5)
             assert all(torch.isfinite(t).all() for t in train_step() if t is not None)
             return {"ms_per_step": dt4 * 1e3, "value": n_t / dt4, "unit": "rays/s", "rays": n_t, "samples_per_ray": s_t,
-                    "dtype": "f32" if fwd_precision == "f32" else "forward bf16x3 (activations kept in f32), backward f32 / bf16x3 GEMMs",
+                    "dtype": "f32 forward (activations kept as 24-bit floats), bf16x3 backward" if fwd_precision == "f32" else "forward bf16x3 (activations kept as 24-bit floats), backward bf16x3 gradient chain + weight-gradient launch",
                     "note": "NOT the headline: source repack + forward + full backward of one fused render pass on one GPU "
                             "(no optimizer, no collective)"}
         if world == 1:

@@ -337,25 +337,52 @@ __device__ __forceinline__ void load_encoded(const float* __restrict__ row, int 
         (DST)[nt][r] = fmaxf(m_.x, 0.f); (DST)[nt][r + 1] = fmaxf(m_.y, 0.f);          \
     }
 
-// accumulator-layout activation set -> row-major [m,128] (lane = sample, 4 consecutive features per piece): fp32 (16-byte pieces), or
-// P24: the 24-bit format of p24.h (12-byte pieces, 384-byte rows) the gradient chain and the weight-gradient launch read
+// accumulator-layout activation set -> row-major [m,128] (lane = sample, 4 consecutive features per piece).
+// fp32 (P24 = false): 16-byte pieces straight from the registers.
+// P24: the 24-bit format of p24.h (12-byte pieces, 384-byte rows) the gradient chain and the weight-gradient launch read.  Stored straight from
+// the accumulator layout a store instruction writes 24 bytes into each of 32 rows; instead the wave TRANSPOSES half a set at a time (64
+// columns = 192 bytes of each of its 32 rows) through a 6.5-KB LDS buffer of its own and writes it out as six 1-KB instructions that walk the
+// rows' bytes in order (runs of 192 contiguous bytes) -- the stores of a tiled set layout gained the forward 54 us per 131 k samples, but that
+// layout is hostile to the weight-gradient launch (profiles/r03_experiments.md); this gets the store side of it with rows kept.
+constexpr int XPOSE_ROW = 192 + 16;                   // LDS row stride of the transpose buffer (the pad spreads the rows over the banks)
+constexpr int XPOSE_BYTES = 32 * XPOSE_ROW;
 template <bool P24>
-__device__ __forceinline__ void save_rows(float* buf, int s, int h, bool valid, const f32x16 (&x)[4]) {
+__device__ __forceinline__ void save_rows(float* buf, int s, int h, bool valid, const f32x16 (&x)[4], char* xbuf = nullptr, int lane = 0, int tile = 0, int m = 0) {
+    if (P24) {
+        asm volatile("" : "+v"(lane));                // (the chunk addresses below do not depend on the tile: unlaundered they are hoisted out of the tile loop -- 24 registers for the whole kernel)
+        const int j = lane & 31;
+        char* const gtile = reinterpret_cast<char*>(buf) + (size_t)tile * 32 * P24_ROW_BYTES;
+        const int rows = m - tile * 32;               // valid rows of this tile (>= 32: all)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nt = 2 * half + t;
+                    const P24Piece pc = p24_pack4(x[nt][4 * q], x[nt][4 * q + 1], x[nt][4 * q + 2], x[nt][4 * q + 3]);
+                    *reinterpret_cast<p24_u32x3_a4*>(xbuf + j * XPOSE_ROW + 12 * (8 * t + 2 * q + h)) = (p24_u32x3){pc.d[0], pc.d[1], pc.d[2]};
+                }
+            // (LDS operations of a wave execute in order: the reads below see the writes above, and the next half's writes come after these reads)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                __builtin_amdgcn_sched_barrier(0);                    // (one chunk at a time: four registers, not twenty-four)
+                const int c = k * 64 + lane;                          // 16-byte chunk of the half set: row c / 12, chunk c % 12 of its 192 bytes
+                const int row = (c * 2731) >> 15, within = c - 12 * row;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xbuf + row * XPOSE_ROW + 16 * within);
+                if (row < rows) *reinterpret_cast<f32x4*>(gtile + row * P24_ROW_BYTES + 192 * half + 16 * within) = v;
+            }
+        }
+        return;
+    }
     if (!valid) return;
     f32x4* row = reinterpret_cast<f32x4*>(buf + (size_t)s * 128);
-    char* row24 = reinterpret_cast<char*>(buf) + p24_offset((size_t)s, 0, 32);      // this sample's piece of group 0; group g is g * 384 bytes on
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (P24) {
-                const P24Piece pc = p24_pack4(x[nt][4 * q], x[nt][4 * q + 1], x[nt][4 * q + 2], x[nt][4 * q + 3]);
-                // (plain stores; the 64 lanes of one store write 768 contiguous bytes of the tiled set)
-                p24_store(row24 + P24_GROUP_BYTES * (8 * nt + 2 * q + h), pc);
-            } else {
-                f32x4 v = {x[nt][4 * q], x[nt][4 * q + 1], x[nt][4 * q + 2], x[nt][4 * q + 3]};
-                __builtin_nontemporal_store(v, &row[8 * nt + 2 * q + h]);      // (streaming hint: 670 MB per 131 k samples, read back a pass later; 411 -> 391 us)
-            }
+            f32x4 v = {x[nt][4 * q], x[nt][4 * q + 1], x[nt][4 * q + 2], x[nt][4 * q + 3]};
+            __builtin_nontemporal_store(v, &row[8 * nt + 2 * q + h]);      // (streaming hint: 670 MB per 131 k samples, read back a pass later; 411 -> 391 us)
         }
 }
 
@@ -368,6 +395,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
     const int kd = NSRC ? KD_STATIC : g.kd, kc = NSRC ? KC_STATIC : g.kc;
     __shared__ __attribute__((aligned(16))) float cst[CONST_FLOATS];
     __shared__ __attribute__((aligned(16))) float pe_stash[MLP_WAVES][KS_PE_PTS * 64];
+    __shared__ __attribute__((aligned(16))) char xpose[SAVE == 2 ? MLP_WAVES : 1][SAVE == 2 ? XPOSE_BYTES : 16];      // per-wave transpose buffer of save_rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const float* __restrict__ ws = p.wstream;
@@ -459,7 +487,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         init_bias(cst, SEC_BD, h, bd);
         PRIO_GEMM(); gemm_feats(S, fsec, kd, bd); PRIO_VALU();
         DIAG_STAMP(2)
-        if (SAVE) save_rows<SAVE == 2>(sv.bd, s, h, valid, bd);
+        if (SAVE) save_rows<SAVE == 2>(sv.bd, s, h, valid, bd, xpose[SAVE == 2 ? wave : 0], lane, tile, p.m);
         const float u = 1.f - conf, omu = 1.f - u;          // models.py:149,177-178 (consumed at the very end)
 
         // ---- layer 0
@@ -467,7 +495,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         PRIO_GEMM(); gemm_regs<KS_PE_PTS>(S, pe, acc); PRIO_VALU();
         DIAG_STAMP(3)
         EPILOGUE_RELU_MOD(hin, acc, bd)
-        if (SAVE) save_rows<SAVE == 2>(sv.h[0], s, h, valid, hin);
+        if (SAVE) save_rows<SAVE == 2>(sv.h[0], s, h, valid, hin, xpose[SAVE == 2 ? wave : 0], lane, tile, p.m);
         DIAG_STAMP(4)
 
         // ---- layers 1..4                                                        (models.py:153-155)
@@ -476,7 +504,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
             init_bias(cst, SEC_L0 + l, h, acc);
             PRIO_GEMM(); gemm_hidden(S, hin, acc); PRIO_VALU();
             EPILOGUE_RELU_MOD(hin, acc, bd)
-            if (SAVE) save_rows<SAVE == 2>(sv.h[l], s, h, valid, hin);
+            if (SAVE) save_rows<SAVE == 2>(sv.h[l], s, h, valid, hin, xpose[SAVE == 2 ? wave : 0], lane, tile, p.m);
         }
 
         // ---- layer 5 on [pe | h]                                                (models.py:156-157)
@@ -488,7 +516,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         EPILOGUE_RELU_MOD(hin, acc, bd)
         // operands of the confidence-bias net: issued now (b_d's registers are free), they land during the base heads
         load_section_feats<TILED>(FS, (g.f_img + h) * fstride * 4, 2 * fstride * 4, kc, fsec);
-        if (SAVE) save_rows<SAVE == 2>(sv.h[5], s, h, valid, hin);
+        if (SAVE) save_rows<SAVE == 2>(sv.h[5], s, h, valid, hin, xpose[SAVE == 2 ? wave : 0], lane, tile, p.m);
 
         // ---- base heads: confi_rgb_linear, alpha_linear_1                       (models.py:161-162)
         const f32x4 base = head4(hb, h, hin);
@@ -498,7 +526,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         init_bias(cst, SEC_BC, h, bd);
         PRIO_GEMM(); gemm_feats(S, fsec, kc, bd); PRIO_VALU();
         DIAG_STAMP(8)
-        if (SAVE) save_rows<SAVE == 2>(sv.bc, s, h, valid, bd);
+        if (SAVE) save_rows<SAVE == 2>(sv.bc, s, h, valid, bd, xpose[SAVE == 2 ? wave : 0], lane, tile, p.m);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -514,7 +542,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         init_bias(cst, SEC_FT, h, acc);
         PRIO_GEMM(); gemm_hidden(S, hin, acc); PRIO_VALU();
         DIAG_STAMP(10)
-        if (SAVE) save_rows<SAVE == 2>(sv.ft, s, h, valid, acc);
+        if (SAVE) save_rows<SAVE == 2>(sv.ft, s, h, valid, acc, xpose[SAVE == 2 ? wave : 0], lane, tile, p.m);
 
         // ---- views_linears | view_confi_linears on [feature | dir encoding], relu   (models.py:166-173)
         init_bias(cst, SEC_VC, h, hin);
@@ -530,7 +558,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) hin[nt][r] = fmaxf(hin[nt][r], 0.f);
-        if (SAVE) save_rows<SAVE == 2>(sv.vc, s, h, valid, hin);
+        if (SAVE) save_rows<SAVE == 2>(sv.vc, s, h, valid, hin, xpose[SAVE == 2 ? wave : 0], lane, tile, p.m);
 
         // ---- adapt heads (rgb_linear on rows 0..63, alpha_linear on rows 64..127), uncertainty blend
         const f32x4 adapt = head4(ha, h, hin);

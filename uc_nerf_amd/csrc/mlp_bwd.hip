@@ -537,84 +537,6 @@ __global__ void __launch_bounds__(32 * HEAD_SLOTS) head_bwd_kernel(HeadArgs a) {
     }
 }
 
-// Parameter gradients of the four head layers alone (bwd_mode 0: the gradient chain has already written g_base / g_adapt):
-// head_bwd_kernel's register accumulation -- every lane keeps the 4 x 4 products of its four features with the head gradients
-// over its samples, block sums through LDS, one atomic per weight and block.
-struct HeadWArgs {
-    int m;
-    const float* g_base; const float* g_adapt;       // [m,4]
-    const float* h5; const float* vc;                 // [m,128]
-    float *gw_crgb, *gw_a1, *gw_rgb, *gw_a, *gb_crgb, *gb_a1, *gb_rgb, *gb_a;
-};
-__global__ void __launch_bounds__(32 * HEAD_SLOTS) head_wgrad_kernel(HeadWArgs a) {
-    __shared__ float red[HEAD_SLOTS][32][33];
-    __shared__ float redb[HEAD_SLOTS][8];
-    const int slot = threadIdx.x >> 5, c = threadIdx.x & 31;
-    float accb[4][4], acca[4][4], bsum[8];
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) accb[o][k] = acca[o][k] = 0.f;
-#pragma unroll
-    for (int o = 0; o < 8; ++o) bsum[o] = 0.f;
-    struct In { f32x4 hv, vv, gb, ga; };
-    auto fetch = [&](int s) {
-        In x;
-        const int sc = s < a.m ? s : a.m - 1;
-        x.hv = reinterpret_cast<const f32x4*>(a.h5 + (size_t)sc * 128)[c];
-        x.vv = reinterpret_cast<const f32x4*>(a.vc + (size_t)sc * 128)[c];
-        x.gb = reinterpret_cast<const f32x4*>(a.g_base)[sc];
-        x.ga = reinterpret_cast<const f32x4*>(a.g_adapt)[sc];
-        return x;
-    };
-    const int stride = gridDim.x * HEAD_SLOTS;
-    In nxt = fetch(blockIdx.x * HEAD_SLOTS + slot);
-    for (int s = blockIdx.x * HEAD_SLOTS + slot; s < a.m; s += stride) {
-        const In cur = nxt;
-        nxt = fetch(s + stride);
-        const float gb4[4] = {cur.gb.x, cur.gb.y, cur.gb.z, cur.gb.w}, ga4[4] = {cur.ga.x, cur.ga.y, cur.ga.z, cur.ga.w};
-        const float hvv[4] = {cur.hv.x, cur.hv.y, cur.hv.z, cur.hv.w}, vvv[4] = {cur.vv.x, cur.vv.y, cur.vv.z, cur.vv.w};
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { accb[o][k] += gb4[o] * hvv[k]; acca[o][k] += ga4[o] * vvv[k]; }
-        if (c == 0) {
-#pragma unroll
-            for (int o = 0; o < 4; ++o) { bsum[o] += gb4[o]; bsum[4 + o] += ga4[o]; }
-        }
-    }
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { red[slot][c][4 * o + k] = accb[o][k]; red[slot][c][16 + 4 * o + k] = acca[o][k]; }
-    if (c == 0) {
-#pragma unroll
-        for (int o = 0; o < 8; ++o) redb[slot][o] = bsum[o];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 1024 / (32 * HEAD_SLOTS); ++q) {
-        const int e = threadIdx.x + 32 * HEAD_SLOTS * q;
-        const int cc = e >> 5, i = e & 31, o = (i & 15) >> 2, k = i & 3;
-        float v = 0.f;
-#pragma unroll
-        for (int sl = 0; sl < HEAD_SLOTS; ++sl) v += red[sl][cc][i];
-        float* dst = nullptr;
-        if (i < 16) dst = o < 3 ? a.gw_crgb + o * 128 + 4 * cc + k : a.gw_a1 + 4 * cc + k;
-        else if (cc < 16) { if (o < 3) dst = a.gw_rgb + o * 64 + 4 * cc + k; }
-        else if (o == 3) dst = a.gw_a + 4 * (cc - 16) + k;
-        if (dst) atomicAdd(dst, v);
-    }
-    if (threadIdx.x < 8) {
-        float v = 0.f;
-#pragma unroll
-        for (int sl = 0; sl < HEAD_SLOTS; ++sl) v += redb[sl][threadIdx.x];
-        const int o = threadIdx.x & 3;
-        float* dst = threadIdx.x < 4 ? (o < 3 ? a.gb_crgb + o : a.gb_a1) : (o < 3 ? a.gb_rgb + o : a.gb_a);
-        atomicAdd(dst, v);
-    }
-}
-
 // after feature_linear, down to the trunk's top layer in one pass over the activations (models.py:158-165 and the layer-5
 // relu / modulation backwards):  g_bc = g_g * h5;  g_h5 = g_g * bc + W_basehead^T g_base;  g_pre = g_h5 * [h5 > 0];
 // g_y = g_pre * bd (written over g_g in place);  g_bd = g_pre * (h5 / bd);  also gx = h5 * bc for feature_linear's weights

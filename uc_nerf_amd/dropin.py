@@ -24,7 +24,7 @@ import torch
 from . import ops
 
 _INFERENCE_PRECISION = "f32"
-_TRAINING_PRECISION = "f32"         # arithmetic of the training FORWARD (activations are kept in fp32 either way)
+_TRAINING_PRECISION = "f32"         # arithmetic of the training FORWARD (the kept activations have the format the backward mode reads either way)
 _INFERENCE_PRECISIONS = ("f32", "bf16x3", "bf16", "bf16x3_fused")
 _WEIGHT_CACHE = "verify"            # how an inference call gets its packed weight stream, see set_weight_cache
 _SOURCE_PRECISION = "f32"           # element type of the channel-last source copies the gather reads, see set_source_precision
