@@ -295,3 +295,28 @@ def test_bf16_source_copies_through_the_rendering_mirror_forward_and_backward(sd
     # ... and the rounding is really there: against the unrounded fp32 sources the render moves
     c = run(False, "f32")
     assert not torch.equal(a[0], c[0]) and (a[0] - c[0]).abs().max().item() < 2e-2
+
+
+# ---------------------------------------------------------------------------------------------- the 24-bit sets of the training step
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_kept_activation_sets_as_24_bit_floats_equal_the_fp32_sets_to_16_significant_bits(precision, sd_v7):
+    """ucnerf_mlp_fwd_train keeps the ten [m,128] activation sets as 24-bit floats for the gradient chain (bwd_mode 0) and as fp32 for the
+    layer-by-layer backward (bwd_mode 1): decoded, the former are the latter rounded to the top 24 bits (<= 2^-16 relative, half up) -- every
+    element, both forward kernels, a sample count that is not a multiple of the 32-sample tile."""
+    from uc_nerf_amd import ops
+    from uc_nerf_amd.pipeline import flat_params_of as flat_params
+    gen = torch.Generator().manual_seed(21)
+    m, S, F = 4100, 10, 97
+    pts, feats = torch.rand(m, 3, generator=gen), torch.randn(m, F, generator=gen)
+    feats[:, -1] = torch.rand(m, generator=gen)
+    dirs = torch.nn.functional.normalize(torch.randn(m // S, 3, generator=gen), dim=-1)
+    pw = ops.PackedWeights.get(6, 0, torch.device(DEV), precision)
+    ws = pw.pack(dev(flat_params(sd_v7)))
+    raw24, s24 = ops.mlp_fwd_train(pw, ws, dev(pts), dev(dirs), dev(feats), S, "chain")
+    raw32, s32 = ops.mlp_fwd_train(pw, ws, dev(pts), dev(dirs), dev(feats), S, "layerwise")
+    assert torch.equal(raw24, raw32)
+    for name in ops.KEPT_SETS:
+        a, b = s24[name], s32[name]
+        want = ((b.view(torch.int32) + 0x80) & ~0xff).view(torch.float32)          # the top 24 bits, dropped byte rounded half up
+        assert torch.equal(a, want), name
+        assert ((a - b).abs() <= b.abs() * 2.0 ** -16 + 1e-38).all(), name

@@ -44,6 +44,7 @@ const char* build_flags_mlp_bf16x3();
 const char* build_flags_mlp_bf16_plain();
 const char* build_flags_mlp_bwd();
 const char* build_flags_mlp_bwd_chain();
+const char* build_flags_mlp_wgrad();
 const char* build_flags_gather_cl();
 const char* build_flags_mlp_f32();
 

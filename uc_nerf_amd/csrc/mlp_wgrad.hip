@@ -29,6 +29,10 @@ typedef unsigned w_u32x4 __attribute__((ext_vector_type(4)));
 typedef w_u32x4 w_u32x4_a4 __attribute__((aligned(4)));
 #define WMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
+#ifndef UCNERF_WGRAD_EXP
+#define UCNERF_WGRAD_EXP 0      // timing experiments (wrong results), bit mask: 1 no unpack / split arithmetic (raw dwords into LDS), 2 no MFMAs,
+                                //   4 every operand load inside the first 1024 samples (cache resident), 8 no LDS fragment writes, 16 no fragment reads
+#endif
 constexpr int WG_STAGE = 64;              // samples per stage (four k16-steps)
 constexpr int WG_KS = WG_STAGE / 16;
 constexpr int WG_THREADS = 512;
@@ -124,12 +128,26 @@ __global__ void __launch_bounds__(WG_THREADS, 4) mlp_wgrad_kernel(WgArgs a) {
             }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r.d[e] = *reinterpret_cast<const w_u32x4_a4*>(base + off[e]);
+        for (int e = 0; e < 8; ++e) {
+#if UCNERF_WGRAD_EXP & 4
+            off[e] &= 0x3ffffu;
+#endif
+            r.d[e] = *reinterpret_cast<const w_u32x4_a4*>(base + off[e]);
+        }
     };
     float colsum[4] = {0.f, 0.f, 0.f, 0.f};                   // bias gradients of columns 4 grp .. 4 grp + 3: this thread's samples (G side only)
     // registers -> (hi, lo) fragments -> LDS: every value is split exactly once
     auto put_frag = [&](const float (&x)[8], int f, int o) {
+#if UCNERF_WGRAD_EXP & 1
+        WFrag fr;
+        fr.hi = __builtin_bit_cast(w_bf16x8, (w_f32x4){x[0], x[1], x[2], x[3]});
+        fr.lo = __builtin_bit_cast(w_bf16x8, (w_f32x4){x[4], x[5], x[6], x[7]});
+#else
         const WFrag fr = w_split8(x);
+#endif
+#if UCNERF_WGRAD_EXP & 8
+        if (x[0] != 12345.678f) return;
+#endif
         const int off = frag_off(f, o);
         *reinterpret_cast<w_bf16x8*>(Ol + off) = fr.hi;
         *reinterpret_cast<w_bf16x8*>(Ol + off + 4 * 64 * 16) = fr.lo;
@@ -190,9 +208,13 @@ __global__ void __launch_bounds__(WG_THREADS, 4) mlp_wgrad_kernel(WgArgs a) {
                     if (32 * kt < q.w) {
                         const w_bf16x8* xb = reinterpret_cast<const w_bf16x8*>(Xl) + (ks * 2 * 4 + kt) * 64 + (lane & 32) + swz(kt, lane >> 5, lane & 31);
                         const w_bf16x8 bhi = xb[0], blo = xb[4 * 64];
+#if UCNERF_WGRAD_EXP & 2
+                        acc[t][0] += __builtin_bit_cast(w_f32x4, ahi)[0] + __builtin_bit_cast(w_f32x4, bhi)[0] + __builtin_bit_cast(w_f32x4, alo)[1] + __builtin_bit_cast(w_f32x4, blo)[1];
+#else
                         acc[t] = WMFMA(ahi, bhi, acc[t]);
                         acc[t] = WMFMA(ahi, blo, acc[t]);
                         acc[t] = WMFMA(alo, bhi, acc[t]);
+#endif
                     }
                 }
             }
@@ -301,5 +323,7 @@ int wgrad_launch(const WgArgs* a, hipStream_t st) {
     hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(blocks), dim3(WG_THREADS), 2 * WG_OP_BYTES, st, *a);
     return check_launch("mlp_bwd wgrad");
 }
+
+const char* build_flags_mlp_wgrad() { return "mlp_wgrad: " UCNERF_FLAG(UCNERF_WGRAD_EXP); }
 
 }  // namespace ucnerf

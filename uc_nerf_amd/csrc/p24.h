@@ -8,7 +8,7 @@
 // (A TILED variant -- [tile of 32 samples][group][sample][12 bytes], 768 contiguous bytes per accumulator-layout access -- was built and measured:
 //  the training forward's stores gained 54 us per 131 k samples, the gradient chain nothing (its memory time is DRAM latency, not line requests),
 //  and the weight-gradient launch, whose lanes run over column groups, lost 90-290 us: profiles/r03_experiments.md.  Rows it is.)
-// Relative error of a stored value <= 2^-17 (the split-bf16 products themselves are good to 2^-16).
+// Relative error of a stored value <= 2^-16 (half an ulp of a 16-bit significand: what the split-bf16 products themselves are good to).
 #pragma once
 #include <hip/hip_runtime.h>
 

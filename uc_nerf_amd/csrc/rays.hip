@@ -310,8 +310,8 @@ const char* ucnerf_build_flags(void) {
     static char buf[2048];
     static bool done = false;          // (idempotent content: a race writes the same bytes)
     if (!done) {
-        snprintf(buf, sizeof(buf), "%s| %s| %s| %s| %s| %s", build_flags_mlp_bf16x3(), build_flags_mlp_bf16_plain(), build_flags_mlp_f32(), build_flags_mlp_bwd(),
-                 build_flags_mlp_bwd_chain(), build_flags_gather_cl());
+        snprintf(buf, sizeof(buf), "%s| %s| %s| %s| %s| %s| %s", build_flags_mlp_bf16x3(), build_flags_mlp_bf16_plain(), build_flags_mlp_f32(), build_flags_mlp_bwd(),
+                 build_flags_mlp_bwd_chain(), build_flags_mlp_wgrad(), build_flags_gather_cl());
         done = true;
     }
     return buf;

@@ -517,6 +517,42 @@ def mlp_fwd(pw, wstream, pts, dirs, feats, S, feats_tiled=False, max_blocks=0):
     return raw
 
 
+KEPT_SETS = ("bd", "h0", "h1", "h2", "h3", "h4", "h5", "bc", "ft", "vc")       # order of the activation sets at the head of the backward workspace
+
+
+def decode_p24(buf, m, cols=128):
+    """fp32 [m, cols] view-copy of a set kept in the 24-bit format of csrc/p24.h (rows of 3 * cols bytes: the top three bytes of every fp32)."""
+    b = buf.view(torch.uint8)[: m * cols * 3].view(m, cols, 3).to(torch.int32)
+    bits = (b[..., 0] << 8) | (b[..., 1] << 16) | (b[..., 2] << 24)
+    return bits.view(torch.float32)
+
+
+def mlp_fwd_train(pw, wstream, pts, dirs, feats, S, bwd_mode=None):
+    """ucnerf_mlp_fwd_train: the forward that keeps its activation sets for ucnerf_mlp_bwd (tests / diagnostics).  Returns (raw, sets): the ten
+    [m,128] sets decoded to fp32, whatever format the backward mode keeps them in (0 / "chain": 24-bit floats, 1 / "layerwise": fp32)."""
+    pts, dirs, feats = _f32(pts), _f32(dirs), _f32(feats)
+    mode = _backward_mode if bwd_mode is None else BACKWARD_MODES[bwd_mode] if isinstance(bwd_mode, str) else int(bwd_mode)
+    m = pts.numel() // 3
+    p = L.MlpParams()
+    p.cfg = pw.cfg
+    p.m, p.S = m, int(S)
+    n_dirs = dirs.numel() // 3
+    p.dirs_per_sample = int(n_dirs == m)
+    if not p.dirs_per_sample and n_dirs * int(S) != m:
+        raise RuntimeError("uc_nerf_amd.mlp_fwd_train: %d directions for %d samples (S=%d)" % (n_dirs, m, S))
+    raw = torch.empty(m, 4, device=pts.device)
+    ws = torch.zeros(L.lib().ucnerf_mlp_bwd_workspace_floats(C.addressof(pw.cfg), m), device=pts.device)
+    p.pts, p.dirs, p.feats, p.wstream, p.raw = _ptr(pts), _ptr(dirs), _ptr(feats), _ptr(wstream), _ptr(raw)
+    with _on(pts.device):
+        L.check(L.lib().ucnerf_mlp_fwd_train(C.addressof(p), _ptr(ws), mode, _stream()), "ucnerf_mlp_fwd_train")
+    per = (m * 128 + 3) // 4 * 4
+    sets = {}
+    for i, name in enumerate(KEPT_SETS):
+        chunk = ws[i * per:(i + 1) * per]
+        sets[name] = decode_p24(chunk, m) if mode == 0 else chunk[: m * 128].view(m, 128).clone()
+    return raw, sets
+
+
 def mlp_bwd(pw, wstream, flat, pts, dirs, feats, S, g_raw):
     """Gradients of sum(raw * g_raw) w.r.t. feats [m,F] and the flat parameter vector."""
     pts, dirs, feats, g_raw, flat = _f32(pts), _f32(dirs), _f32(feats), _f32(g_raw), _f32(flat)
