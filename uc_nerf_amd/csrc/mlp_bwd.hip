@@ -21,6 +21,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st);
 int launch_mlp_fwd_bf16x3_save(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st);      // mlp_bf16.hip
+int launch_embed_strided(int m, int n_freqs, int layout, const float* x, float* out, int out_stride, hipStream_t st);      // rays.hip
 
 // 4 consecutive parameters (parameter tensors are only 4-byte aligned inside the flat vector)
 __device__ __forceinline__ f32x4 ld4(const float* p) { return f32x4{p[0], p[1], p[2], p[3]}; }
@@ -594,7 +595,7 @@ static size_t carve_bwd(float* base, int m, int n_dirs, BwdWork* w) {
     w->sv.bd = take(M * 128);
     for (int l = 0; l < 6; ++l) w->sv.h[l] = take(M * 128);
     w->sv.bc = take(M * 128); w->sv.ft = take(M * 128); w->sv.vc = take(M * 128);
-    w->pep = take(M * 63); w->ped = take((size_t)n_dirs * 27);
+    w->pep = take(M * 64); w->ped = take((size_t)n_dirs * 32);      // encodings as matrices, rows padded to whole 16-byte pieces (64 / 32 floats)
     // (the sets the gradient chain writes have one spare row behind row m - 1 -- lanes without a sample store there, mlp_bwd_chain.hip --: as 24-bit
     //  rows they fill three quarters of M * 128 floats, which leaves it for M >= 3; the explicit tail covers smaller M)
     w->g1 = take(M * 128 + 96); w->g2 = take(M * 128 + 96); w->g3 = take(M * 128 + 96); w->gbd = take(M * 128 + 96); w->gx = take(M * 128 + 96);
@@ -727,18 +728,15 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
         RUN(launch_mlp_fwd(&fw, &w.sv, st));
     }
     const float *pep = w.pep, *ped = w.ped;      // encodings as matrices: [m,63] and [n_dirs,27]
-    int ld_pep = 63, ld_ped = 27;
+    int ld_pep = 64, ld_ped = 32;
     if (f.encoded) {                              // already in memory (UCNeRF.forward(x) of the reference)
         pep = f.pts; ld_pep = f.pts_stride ? f.pts_stride : 63;
         ped = f.dirs; ld_ped = f.dirs_stride ? f.dirs_stride : 27;
     } else {
         UCNERF_REQUIRE((f.pts_stride == 0 || f.pts_stride == 3) && (f.dirs_stride == 0 || f.dirs_stride == 3),
                        "mlp_bwd: strided raw pts/dirs are not supported");
-        ucnerf_embed_params e;
-        e.m = m; e.n_freqs = 10; e.layout = f.cfg.pe_layout; e.x = f.pts; e.out = w.pep;
-        RUN(ucnerf_embed(&e, st));
-        e.m = n_dirs; e.n_freqs = 4; e.x = f.dirs; e.out = w.ped;
-        RUN(ucnerf_embed(&e, st));
+        RUN(launch_embed_strided(m, 10, f.cfg.pe_layout, f.pts, w.pep, ld_pep, st));
+        RUN(launch_embed_strided(n_dirs, 4, f.cfg.pe_layout, f.dirs, w.ped, ld_ped, st));
     }
 
     const int KV = MLP_W + MLP_PE_DIR;

@@ -270,14 +270,14 @@ __global__ void ndc_project_kernel(ucnerf_ndc_project_params p) {
 }
 
 // ------------------------------------------------------------------------------------------- a5
-__global__ void embed_kernel(ucnerf_embed_params p) {
+// out_stride: floats between consecutive output rows (the public entry point: dense, 3 + 6 n_freqs)
+__global__ void embed_kernel(ucnerf_embed_params p, int out_stride) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (vector, freq slot)
     int L = p.n_freqs;
     if (idx >= (long long)p.m * (L + 1)) return;
     int v = (int)(idx / (L + 1)), k = (int)(idx % (L + 1));
-    int D = 3 + 6 * L;
     const float* x = p.x + 3 * (size_t)v;
-    float* o = p.out + (size_t)v * D;
+    float* o = p.out + (size_t)v * out_stride;
     if (k == L) {
         o[0] = x[0]; o[1] = x[1]; o[2] = x[2];
         return;
@@ -295,6 +295,16 @@ __global__ void embed_kernel(ucnerf_embed_params p) {
             o[3 + 6 * k + 3 + c] = co;
         }
     }
+}
+
+// rows `out_stride` floats apart (mlp_bwd.hip: the weight-gradient launch reads its fp32 operands in 16-byte pieces -- dense rows of 63 / 27
+// floats put every piece on an unaligned address)
+int launch_embed_strided(int m, int n_freqs, int layout, const float* x, float* out, int out_stride, hipStream_t st) {
+    if (m <= 0) return UCNERF_OK;
+    ucnerf_embed_params p;
+    p.m = m; p.n_freqs = n_freqs; p.layout = layout; p.x = x; p.out = out;
+    hipLaunchKernelGGL(embed_kernel, dim3(cdiv((long long)m * (n_freqs + 1), 256)), dim3(256), 0, st, p, out_stride);
+    return check_launch("embed");
 }
 
 }  // namespace ucnerf
@@ -448,7 +458,7 @@ int ucnerf_embed(const ucnerf_embed_params* p, void* stream) {
     UCNERF_REQUIRE(p->layout == 0 || p->layout == 1, "embed: layout %d", p->layout);
     if (p->m <= 0) return UCNERF_OK;
     hipLaunchKernelGGL(embed_kernel, dim3(cdiv((long long)p->m * (p->n_freqs + 1), 256)), dim3(256), 0,
-                       (hipStream_t)stream, *p);
+                       (hipStream_t)stream, *p, 3 + 6 * p->n_freqs);
     return check_launch("embed");
 }
 
