@@ -320,3 +320,44 @@ def test_kept_activation_sets_as_24_bit_floats_equal_the_fp32_sets_to_16_signifi
         want = ((b.view(torch.int32) + 0x80) & ~0xff).view(torch.float32)          # the top 24 bits, dropped byte rounded half up
         assert torch.equal(a, want), name
         assert ((a - b).abs() <= b.abs() * 2.0 ** -16 + 1e-38).all(), name
+
+
+# ---------------------------------------------------------------------------------------------- the gradient bucket over RCCL (one rank)
+def test_flat_grad_bucket_and_barrier_over_the_rccl_backend_with_one_rank():
+    """No multi-GPU node exists for the builder, so the data-parallel path has only crossed gloo.  This runs the same calls over the backend
+    the driver's scaling series will use (`nccl` = RCCL) with a world of ONE rank on this GPU: process-group creation bound to the device,
+    a device barrier, the max-over-ranks reduction of the bench and FlatGradBucket.allreduce on device tensors (a CPU tensor, a wrong dtype or a
+    missing device binding fails here and not in the first 8-GPU run)."""
+    import socket
+    import torch.distributed as dist
+    from uc_nerf_amd import parallel as P
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dev = torch.device(DEV)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+        dist.barrier()
+        t = torch.tensor([1.25], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert t.item() == 1.25
+        gen = torch.Generator().manual_seed(3)
+        params = [torch.nn.Parameter(torch.randn(n, generator=gen).to(dev)) for n in (7, 128 * 63, 1, 33)]
+        grads = [torch.randn(p.shape, generator=gen).to(dev) for p in params]
+        for p, g in zip(params[:3], grads[:3]):
+            p.grad = g.clone()                       # the last parameter gets no gradient (the reference leaves six tensors without one)
+        bucket = P.FlatGradBucket(params, n_scalars=2)
+        out = bucket.allreduce(1.0, scalars=(torch.tensor(2.0, device=dev), torch.tensor(-1.5, device=dev)))
+        torch.cuda.synchronize()
+        assert out.device.type == "cuda" and out.tolist() == [2.0, -1.5]
+        for p, g in zip(params[:3], grads[:3]):
+            assert torch.equal(p.grad, g)
+        assert params[3].grad is None
+        for p, g in zip(params[:3], grads[:3]):
+            p.grad = 2 * g
+        bucket.allreduce(0.5, scalars=(torch.tensor(0.0, device=dev), torch.tensor(0.0, device=dev)))      # steady state: no read-back
+        for p, g in zip(params[:3], grads[:3]):
+            assert torch.equal(p.grad, g)
+    finally:
+        dist.destroy_process_group()
