@@ -111,9 +111,16 @@ class Ctx:
         torch.cuda.set_device(local % n_dev)
         self.dev = torch.device("cuda", local % n_dev)
         self.dist = None
-        if self.world > 1:
+        # UCNERF_BENCH_GROUP_AT_1=1: create the process group with ONE rank too (and run `train_dp` through it): the only way to put the RCCL
+        # calls of the data-parallel step on a box with one GPU -- a rehearsal of the code path, not a scaling measurement
+        if self.world > 1 or os.environ.get("UCNERF_BENCH_GROUP_AT_1") == "1":
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                with socket.socket() as s_:
+                    s_.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
             if self.backend == "nccl":
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
             else:
@@ -591,6 +598,8 @@ def main():
                         "note": "NOT the headline: the same step under the other scaling rule (barrier + MAX over ranks as the headline)"}
             extra["weak" if args.scaling == "strong" else "strong"] = guarded(other_scaling)
             extra["train_dp"] = guarded(lambda: bench_train_dp(ctx, scene, sd, 2000 if args.scaling == "weak" else max(1, 2000 // world)))
+        if world == 1 and ctx.dist is not None:       # UCNERF_BENCH_GROUP_AT_1: the data-parallel step through a one-rank process group
+            extra["train_dp"] = guarded(lambda: bench_train_dp(ctx, scene, sd, 2000))
 
     psnr_vs_f32 = None
     if args.precision == "bf16":         # outside the parity bar by construction: report the distance to the exact render
