@@ -135,3 +135,62 @@ def test_cpu_tensors_are_refused_loudly():
         ops.embed(torch.zeros(4, 3), 10)
     with pytest.raises(RuntimeError, match="ROCm device"):
         ops.composite_fwd(torch.zeros(2, 8, 4), torch.zeros(2, 8))
+
+
+def test_gradient_chain_counted_waits_never_exceed_the_operations_actually_issued(tmp_path):
+    """mlp_bwd_chain_kernel waits for a slot of its LDS weight ring with `s_waitcnt vmcnt(6 + E)`, E = a compile-time count of the loads and
+    stores every wave has issued since the awaited copy (the compiler does not see the asm copies, so nothing else orders them).  An E larger
+    than what the compiled code really issues would let a wave read a slot before its copy has landed -- silently.  This compiles the
+    translation unit to ISA and replays the kernel's vector-memory stream: for every one of the 128 waits of the tile body, the number of
+    vector-memory instructions issued behind the awaited copy must be at least the count waited for."""
+    import shutil
+    import subprocess
+    from uc_nerf_amd import build as B
+    hipcc = B._hipcc()
+    if not (os.path.isabs(hipcc) and os.path.exists(hipcc)) and shutil.which(hipcc) is None:
+        pytest.skip("hipcc not available")
+    out = tmp_path / "chain.s"
+    cmd = [hipcc] + B.FLAGS + ["--cuda-device-only", "-S", os.path.join(B.CSRC, "mlp_bwd_chain.hip"), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = out.read_text().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN6ucnerf20mlp_bwd_chain_kernel"))
+    events = []                                   # ("dma" | "vm" | "adv", vmcnt)
+    pending_wait = None
+    for l in lines[start:]:
+        t = l.strip()
+        if t.startswith("s_endpgm"):
+            break
+        if t.startswith("s_waitcnt") and "vmcnt(" in t and "lgkmcnt(0)" in t:
+            pending_wait = int(t.split("vmcnt(")[1].split(")")[0])
+            continue
+        if t.startswith("s_barrier"):
+            if pending_wait is not None:
+                events.append(("adv", pending_wait))
+            pending_wait = None
+            continue
+        if not t or t.startswith(";") or t.startswith("."):
+            continue
+        pending_wait = None if not t.startswith("s_") and not t.startswith("v_") else pending_wait
+        if t.startswith("global_load_lds"):
+            events.append(("dma", 0))
+        elif t.startswith(("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "flat_load", "flat_store", "scratch_")):
+            events.append(("vm", 0))
+    n_adv = sum(1 for e in events if e[0] == "adv")
+    n_dma = sum(1 for e in events if e[0] == "dma")
+    assert n_adv == 128 and n_dma == 128 + 8, (n_adv, n_dma)          # 128 half-steps per tile; eight copies in the prologue
+    eighth = [i for i, e in enumerate(events) if e[0] == "dma"][7]     # the prologue's last copy: the tile loop's body starts behind it
+    body = events[eighth + 1:]
+    seq = body + body                                                  # two iterations of the tile loop
+    dma_idx = [i for i, e in enumerate(seq) if e[0] == "dma"]
+    adv_idx = [i for i, e in enumerate(seq) if e[0] == "adv"]
+    assert len(dma_idx) == 256 and len(adv_idx) == 256
+    checked = 0
+    for j in range(128):                                               # the advances of the second iteration
+        a_i = adv_idx[128 + j]
+        awaited = dma_idx[128 + j + 1 - 8]                             # the copy of half-step j + 1, issued seven advances earlier
+        younger = sum(1 for e in seq[awaited + 1:a_i] if e[0] in ("dma", "vm"))
+        assert seq[a_i][1] <= younger, "half-step %d waits for vmcnt(%d) but only %d operations follow the awaited copy" % (j, seq[a_i][1], younger)
+        assert seq[a_i][1] >= 6
+        checked += 1
+    assert checked == 128
