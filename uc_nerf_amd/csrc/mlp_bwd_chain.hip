@@ -139,6 +139,11 @@ __device__ __forceinline__ void c_split_tile(const c_f32x16& x, CFrag& f0, CFrag
 
 // ---- the weight ring: CHAIN_NB slots of one half-step (4 KB) each in LDS, shared by the block's four waves.  128 half-steps per tile
 // = 0 mod CHAIN_NB, so slot and source of every copy are compile-time constants of the unrolled tile body and the ring runs on across tiles.
+#ifndef UCNERF_CHAIN_WAVES
+#define UCNERF_CHAIN_WAVES 4      // waves per block = per CU: 4 (one per SIMD, 512 registers) or 8 (two per SIMD, 256 registers: b_d is then re-read per layer
+                                  //   instead of parked and the g_bd sum parked as 24-bit pieces -- experiment, profiles/r03_experiments.md)
+#endif
+constexpr int CHAIN_WAVES = UCNERF_CHAIN_WAVES;
 constexpr int CHAIN_NB = 8;
 struct CPipe {
     const char* gsrc;        // this lane's byte of half-step 0: stream + wave * 1024 + lane * 16 (laundered per section, see launder())
@@ -149,7 +154,10 @@ struct CPipe {
 __device__ __forceinline__ void c_dma(const CPipe& P, int hs_src, int slot) {
     const char* src = P.gsrc + (size_t)hs_src * BWD_HALF_BYTES;
     const unsigned dst = P.dst + slot * BWD_HALF_BYTES;
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+    if (CHAIN_WAVES == 8) {                // eight waves: 512 bytes each -- the lower 32 lanes copy
+        if ((threadIdx.x & 32) == 0) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+    } else
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
 }
 __device__ __forceinline__ CAF c_ldaf(const CPipe& P, int slot) {
     const c_bf16x8* a = reinterpret_cast<const c_bf16x8*>(P.rd + slot * BWD_HALF_BYTES);
@@ -251,15 +259,15 @@ __device__ __forceinline__ void c_zero(c_f32x16 (&acc)[4]) {
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 }
 
-constexpr int CHAIN_WAVES = 4;
+
 constexpr int CHAIN_HEAD_PAD = (BWD_HEAD_FLOATS + 3) & ~3;
 // LDS: [head table 4 KB][weight ring CHAIN_NB x 4 KB][per wave: b_d of its tile as 24-bit pieces (12 KB) | the running g_bd sum in fp32 (16 KB)]
 constexpr int CHAIN_RING_OFF = CHAIN_HEAD_PAD * 4;
 constexpr int CHAIN_PARK_OFF = CHAIN_RING_OFF + CHAIN_NB * BWD_HALF_BYTES;
-constexpr int CHAIN_PARK_BD = 16 * 64 * 12, CHAIN_PARK_GBD = 16 * 64 * 16;
+constexpr int CHAIN_PARK_BD = CHAIN_WAVES == 4 ? 16 * 64 * 12 : 0, CHAIN_PARK_GBD = CHAIN_WAVES == 4 ? 16 * 64 * 16 : 16 * 64 * 12;
 constexpr int CHAIN_LDS_BYTES = CHAIN_PARK_OFF + CHAIN_WAVES * (CHAIN_PARK_BD + CHAIN_PARK_GBD);      // 4 + 32 + 112 KB
 
-__global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(ChainArgs a) {
+__global__ void __launch_bounds__(64 * CHAIN_WAVES, CHAIN_WAVES / 4) mlp_bwd_chain_kernel(ChainArgs a) {
     // (b_d and the g_bd sum are parked in LDS rather than in 128 registers: with them resident the register allocator spilled ~200 values
     //  around every layer's MFMA section; b_d as the 24-bit pieces it was loaded as, which is what leaves room for the weight ring)
     extern __shared__ __attribute__((aligned(16))) float chain_lds[];
@@ -270,7 +278,8 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
     char* const lds = reinterpret_cast<char*>(chain_lds);
     char* const park_bd = lds + CHAIN_PARK_OFF + wave * (CHAIN_PARK_BD + CHAIN_PARK_GBD) + lane * 12;          // piece (nt, q) of this lane at + (4 nt + q) * 64 * 12
     c_f32x4* const park_gbd = reinterpret_cast<c_f32x4*>(lds + CHAIN_PARK_OFF + wave * (CHAIN_PARK_BD + CHAIN_PARK_GBD) + CHAIN_PARK_BD) + lane;
-    auto ld_bd = [&](int nt) {
+    auto ld_bd = [&](int nt, size_t ro_ = 0) {
+        if (CHAIN_WAVES != 4) return c_unpack(c_ld_tile(a.sv.bd, ro_, nt));       // (not parked: re-read, L2 resident)
         c_f32x16 x;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -283,31 +292,48 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
         return x;
     };
     auto st_bd = [&](int nt, const CRaw& x) {          // (the pieces as they were loaded)
+        if (CHAIN_WAVES != 4) return;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<p24_u32x3_a4*>(park_bd + (4 * nt + q) * 64 * 12) = (p24_u32x3){x.d[3 * q], x.d[3 * q + 1], x.d[3 * q + 2]};
     };
+    char* const park_g24 = lds + CHAIN_PARK_OFF + wave * (CHAIN_PARK_BD + CHAIN_PARK_GBD) + CHAIN_PARK_BD + lane * 12;      // (8 waves: g_bd as 24-bit pieces)
     auto ld_gbd = [&](int nt) {
         c_f32x16 x;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const c_f32x4 v = park_gbd[(nt * 4 + q) * 64];
-            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+            if (CHAIN_WAVES == 4) {
+                const c_f32x4 v = park_gbd[(nt * 4 + q) * 64];
+                x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+            } else {
+                const p24_u32x3 v = *reinterpret_cast<const p24_u32x3_a4*>(park_g24 + (4 * nt + q) * 64 * 12);
+                const P24Piece pc = {{v.x, v.y, v.z}};
+                float t0, t1, t2, t3;
+                p24_unpack4(pc, t0, t1, t2, t3);
+                x[4 * q] = t0; x[4 * q + 1] = t1; x[4 * q + 2] = t2; x[4 * q + 3] = t3;
+            }
         }
         return x;
     };
     auto st_gbd = [&](int nt, const c_f32x16& x) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) park_gbd[(nt * 4 + q) * 64] = (c_f32x4){x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+        for (int q = 0; q < 4; ++q) {
+            if (CHAIN_WAVES == 4) park_gbd[(nt * 4 + q) * 64] = (c_f32x4){x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+            else {
+                const P24Piece pc = p24_pack4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+                *reinterpret_cast<p24_u32x3_a4*>(park_g24 + (4 * nt + q) * 64 * 12) = (p24_u32x3){pc.d[0], pc.d[1], pc.d[2]};
+            }
+        }
     };
     const int j = lane & 31, h = lane >> 5;
     // (the stream does not depend on the tile: unless its address is laundered per section, every one of its 2048 fragment registers is
     //  hoisted out of the tile loop and spilled; the OFFSET is laundered -- a pointer passed through an integer asm operand comes back
     //  as a flat pointer)
     CPipe P;
-    P.gsrc = a.wstream + wave * 1024 + lane * 16;
-    P.dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + CHAIN_RING_OFF) + wave * 1024;
+    constexpr int SHARE = BWD_HALF_BYTES / CHAIN_WAVES;          // bytes of a half-step this wave copies
+    P.gsrc = a.wstream + wave * SHARE + (lane & (SHARE / 16 - 1)) * 16;
+    P.dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + CHAIN_RING_OFF) + wave * SHARE;
     P.rd = lds + CHAIN_RING_OFF + lane * 16;
-    auto launder = [&]() { unsigned o_ = (unsigned)(wave * 1024 + lane * 16); asm volatile("" : "+v"(o_)); P.gsrc = a.wstream + o_; };
+    auto launder = [&]() { unsigned o_ = (unsigned)(wave * SHARE + (lane & (SHARE / 16 - 1)) * 16); asm volatile("" : "+v"(o_)); P.gsrc = a.wstream + o_; };
 #pragma unroll
     for (int i = 0; i < CHAIN_NB; ++i) c_dma(P, i, i);        // half-steps 0 .. CHAIN_NB - 1 of the first tile
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CHAIN_NB - 1) : "memory");      // slot 0 has landed ...
@@ -479,7 +505,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const c_f32x16 hcur_ = c_unpack(hraw[nt]);
-                const c_f32x16 bdt = ld_bd(nt);
+                const c_f32x16 bdt = ld_bd(nt, ro);
                 c_f32x16 gb = ld_gbd(nt), gy;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -521,7 +547,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
         // ---- depth-bias net: g_bd = sum_l g_pre_l * y_l with y_l = h_l / b_d on the active units; then its transposed layer
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const c_f32x16 bdt = ld_bd(nt), gb = ld_gbd(nt);
+            const c_f32x16 bdt = ld_bd(nt, ro), gb = ld_gbd(nt);
             c_f32x16 g;
 #pragma unroll
             for (int r = 0; r < 16; ++r) g[r] = gb[r] != 0.f ? gb[r] / bdt[r] : 0.f;
@@ -605,6 +631,6 @@ int launch_mlp_bwd_chain(int n_src, int m, const float* raw, const float* g_raw,
     return check_launch("mlp_bwd chain");
 }
 
-const char* build_flags_mlp_bwd_chain() { return "mlp_bwd_chain: " UCNERF_FLAG(UCNERF_CHAIN_EXP); }
+const char* build_flags_mlp_bwd_chain() { return "mlp_bwd_chain: " UCNERF_FLAG(UCNERF_CHAIN_EXP) UCNERF_FLAG(UCNERF_CHAIN_WAVES); }
 
 }  // namespace ucnerf
