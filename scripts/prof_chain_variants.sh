@@ -11,7 +11,7 @@ for v in "$@"; do
   python3 - "$v" $R/gpurun_out/pcv/*/*kernel_stats.csv <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[2])):
-    if "chain" in r["Name"] or "wgrad" in r["Name"] or "mlp_fwd_kernel" in r["Name"]:
+    if any(k in r["Name"] for k in ("chain", "wgrad", "mlp_fwd_kernel", "gather_bwd", "add_transposed")):
         print("%-14s %-28s %8.1f us" % (sys.argv[1] or "production", r["Name"].split("(")[0][-28:], float(r["AverageNs"]) / 1e3))
 PY
 done
