@@ -5,16 +5,24 @@
 // Why not one gemm_tn launch per pair (mlp_bwd.hip, rounds 1-2): there every wave fetched its own operands from global
 // memory as dwords (features on lanes), 24 vector-memory instructions per nine MFMAs and every byte of G / X through the
 // CU's texture path four to eight times -- 57 us per 128 x 128 pair against 27 us for its bytes at HBM speed.  Here
-//   * a block stages 64 samples of G and X through LDS ONCE: waves 0-3 fetch G, waves 4-7 fetch X (the next stage's, in registers, while this
-//     one is multiplied).  Operands in the 24-bit format (p24.h: every G, and every X that is a kept activation set) arrive as 12-byte pieces
-//     -- thread (4-column group, sample octet) reads eight rows' pieces = four MFMA fragments; fp32 operands (encodings, gathered features)
-//     as coalesced dwords -- thread (column, sample octets hf, hf + 2, ...).  Either way every value is split into (hi, lo) bf16 ONCE and
-//     written in operand layout; the eight waves then read their fragments with one ds_read_b128 per plane;
+//   * one block per CU, eight waves in two ROLES.  Waves 0-3 (one per SIMD) are producers: they fetch 64 samples of G and X per stage into
+//     registers, two stages ahead in two register sets, split every value into (hi, lo) bf16 ONCE and write it in MFMA operand layout
+//     into one of TWO stage images in LDS.  Waves 4-7 are consumers: they read fragments (one ds_read_b128 per plane) from the other image and
+//     multiply -- nothing else.  One barrier per stage hands an image over in each direction, so the producers' vector arithmetic, their
+//     LDS writes and the wait for their loads all run beside the consumers' MFMAs on the same SIMD, and the next-but-one stage's loads are
+//     issued the moment a register set has been converted.
+//     (Before: two blocks per CU, every wave fetching, converting and multiplying in turn behind two barriers per stage, the next stage's loads
+//      issued only after the LDS writes: a stage cost its load round trip PLUS its arithmetic, 5.7 us per stage and block at 3.5 TB/s, where the
+//      fetch shape alone streams at 6.3 TB/s -- scripts/micro/load_shapes.hip.)
+//   * operands in the 24-bit format (p24.h: every G, and every X that is a kept activation set) arrive as 12-byte pieces -- thread
+//     (4-column group, sample octet) reads eight rows' pieces = four MFMA fragments; fp32 operands (encodings, gathered features) as
+//     16-byte pieces of rows or of the MLP tile layout;
 //   * products are hi*hi + hi*lo + lo*hi on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate: the forward's bf16x3
-//     scheme, 2^-16 relative), no vector arithmetic in the multiply loop;
-//   * the launch is persistent over the CONCATENATION of all pairs: the total cost (bytes per 64-sample stage, summed over
-//     pairs) is cut into equal ranges, one per block, two blocks per CU; a block flushes its 128 x 128 partial sum with float
-//     atomics on 128-byte row segments when its range leaves a pair -- ~530 flushes per step instead of ~3 300, no tail.
+//     scheme, 2^-16 relative);
+//   * the launch is persistent over the CONCATENATION of all pairs: the total cost (bytes per 64-sample stage plus a fixed part, summed over
+//     pairs) is cut into equal ranges, one per block; the producers' pipeline runs straight through the pair boundaries of a range; the consumers
+//     flush their 128 x 128 partial sum with float atomics on 128-byte row segments when the range leaves a pair.
+#include <type_traits>
 #include "common.h"
 #include "mlp_layout.h"
 #include "mlp_bwd_parts.h"
@@ -30,12 +38,12 @@ typedef w_u32x4 w_u32x4_a4 __attribute__((aligned(4)));
 #define WMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 #ifndef UCNERF_WGRAD_EXP
-#define UCNERF_WGRAD_EXP 0      // timing experiments (wrong results), bit mask: 1 no unpack / split arithmetic (raw dwords into LDS), 2 no MFMAs,
-                                //   4 every operand load inside the first 1024 samples (cache resident), 8 no LDS fragment writes, 16 no fragment reads
+#define UCNERF_WGRAD_EXP 0      // timing experiments (wrong results), bit mask: 1 no split arithmetic (raw dwords into LDS), 2 no MFMAs,
+                                //   4 every operand load inside its set's first 256 KB (cache resident), 8 no LDS fragment writes
 #endif
 constexpr int WG_STAGE = 64;              // samples per stage (four k16-steps)
 constexpr int WG_KS = WG_STAGE / 16;
-constexpr int WG_THREADS = 512;
+constexpr int WG_THREADS = 768;            // waves 0-3 produce the G operand, 4-7 the X operand, 8-11 multiply
 
 struct WFrag { w_bf16x8 hi, lo; };
 __device__ __forceinline__ WFrag w_split8(const float (&x)[8]) {
@@ -56,28 +64,44 @@ __device__ __forceinline__ WFrag w_split8(const float (&x)[8]) {
 // LDS image of one stage and operand: [k16-step][hi, lo][row tile 0..3][64 lanes][8 bf16] = 32 KB: the fragment of (k-step, tile) of
 // lane (feature i, half hh) = samples 16 ks + 8 hh + 0..7 of feature 32 tile + i, ready for one ds_read_b128 per plane
 constexpr int WG_OP_BYTES = WG_KS * 2 * 4 * 64 * 16;
+constexpr int WG_IMG_BYTES = 2 * WG_OP_BYTES;                 // a stage: [G operand | X operand]
+constexpr int WG_LDS_BYTES = 2 * WG_IMG_BYTES;                // two stages: one being written, one being multiplied
+constexpr int WG_UNROLL = 2;                                  // stages per trip of the producers' loop (see there)
 
-// The two sides' fetches have ONE shape whatever the operand's format: eight 16-byte loads at eight computed byte offsets.  (With a different
-// load sequence per format behind wave-uniform branches the compiler merged the branches' tails, kept the merged values in a stack slot and
-// waited for the loads right behind the fetch: nothing of the next stage was in flight during the multiply.)
+// A side's fetch has ONE shape whatever the operand's format: eight 16-byte loads at eight computed byte offsets.
 //   24-bit rows (every G; kept activation sets as X): thread (grp = 4-column group, oct = sample octet): the 12-byte pieces of eight rows
 //                (the load's fourth dword belongs to the next piece and is ignored) -> four fragments
 //   fp32 rows   (encodings, row-major features; one row per xdiv samples): the same with 16-byte pieces = four fp32 columns
 //   fp32 tiles  (features in the MLP tile layout [m / 32][F][32]): thread (column, tile of the stage): the 32 samples of its column = four fragments
 enum { WG_X24 = 0, WG_XROWS = 1, WG_XTILES = 2 };
-__global__ void __launch_bounds__(WG_THREADS, 4) mlp_wgrad_kernel(WgArgs a) {
+struct WgCur { int p, st, i; };                               // a stage of the block's range: pair, stage of the pair, index in the range
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }     // LDS traffic only: loads in flight stay in flight
+
+#ifndef UCNERF_WGRAD_STAMPS
+#define UCNERF_WGRAD_STAMPS 0   // 1 = diagnostic build: per-phase cycle totals of every wave, printed by wgrad_launch (which then synchronises)
+#endif
+#if UCNERF_WGRAD_STAMPS
+#define WG_T(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[k] += now_ - tlast; tlast = now_; }
+#define WG_STAMP_ARG , unsigned long long* stamps
+#else
+#define WG_T(k)
+#define WG_STAMP_ARG
+#endif
+__global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_STAMP_ARG) {
+#if UCNERF_WGRAD_STAMPS
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long rstart = __builtin_amdgcn_s_memrealtime(), tstart = tlast;
+#endif
     extern __shared__ __attribute__((aligned(16))) char wg_lds[];
-    char* const Gl = wg_lds;
-    char* const Xl = wg_lds + WG_OP_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = wave & 3, kg = wave >> 2;                  // this wave multiplies: row tile nt, column tiles kg and kg + 2
-    // ... and fetches: waves 0-3 the G operand, waves 4-7 the X operand (`xside`, wave-uniform), 256 threads per operand and stage
-    const int xside = __builtin_amdgcn_readfirstlane(wave >> 2);
+    const bool producer = wave < 8;                           // (wave-uniform)
     const int t8 = tid & 255;
+    int m_ = a.m, stages_ = a.stages;                        // (made opaque: the compiler otherwise re-reads kernel arguments wherever it is short of a register)
+    asm volatile("" : "+s"(m_), "+s"(stages_));
+    const int wg_m = m_, wg_stages = stages_;
     const int grp = t8 & 31, oct = t8 >> 5;                   // rows:  columns 4 grp .. 4 grp + 3, samples 8 oct .. 8 oct + 7 of the stage
     const int tcol = t8 & 127, ttile = t8 >> 7;               // tiles: column tcol, samples 32 ttile .. 32 ttile + 31 of the stage
-    char* const Ol = xside ? Xl : Gl;                         // the operand image this thread fills
     // fragment (column f, octet o) of a stage: k-step o >> 1, lane half o & 1, row tile f >> 5; hi plane here, lo plane 4 * 64 * 16 bytes on
     // (the slot of column i inside its 32-slot half is i ^ key, key = (tile + half + 2 (i >> 4)) & 3: a thread writes the fragments of columns 4 grp + c one c
     //  at a time -- 64-byte strides, four of the sixteen bank groups; with the key the 64 lanes of a write cover all sixteen.  Readers apply the same key.)
@@ -86,139 +110,288 @@ __global__ void __launch_bounds__(WG_THREADS, 4) mlp_wgrad_kernel(WgArgs a) {
 
     // this block's share of the concatenated pairs, in cost units -> (pair, stage) at both ends
     const long long total = a.prefix[a.n_pairs];
-    const long long c0 = total * blockIdx.x / gridDim.x, c1 = total * (blockIdx.x + 1) / gridDim.x;
+#ifndef UCNERF_WGRAD_XCD_MAP
+#define UCNERF_WGRAD_XCD_MAP 0
+#endif
+#if UCNERF_WGRAD_XCD_MAP
+    const int bid = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;     // XCD k (blocks k, k + 8, ...) takes the k-th eighth of the work
+#else
+    const int bid = blockIdx.x;
+#endif
+    const long long c0 = total * bid / gridDim.x, c1 = total * (bid + 1) / gridDim.x;
     auto locate = [&](long long c, int* pair, int* stage) {   // first stage whose start is >= c (so consecutive blocks tile exactly)
         int p = 0;
         for (int q = 1; q < a.n_pairs; ++q) p = c >= a.prefix[q] ? q : p;
         if (c >= total) { *pair = a.n_pairs; *stage = 0; return; }
         const long long off = c - a.prefix[p];
         int st = (int)((off + a.p[p].cost - 1) / a.p[p].cost);
-        if (st >= a.stages) { ++p; st = 0; }
+        if (st >= wg_stages) { ++p; st = 0; }
         *pair = p; *stage = st;
     };
-    int p, st, p_end, st_end;
-    locate(c0, &p, &st);
+    int p0, st0, p_end, st_end;
+    locate(c0, &p0, &st0);
     locate(c1, &p_end, &st_end);
-    if (p == p_end && st == st_end) return;
-
-    struct Regs { w_u32x4 d[8]; };
-    // global -> registers, and nothing else: rows / columns outside the matrix read a clamped (valid) piece that stage_lds replaces by zero
-    auto fetch = [&](Regs& r, int pr, int stg) {
-        const WgPair& q = a.p[pr];
-        const int mode = xside ? q.xmode : WG_X24;
-        const char* base = reinterpret_cast<const char*>(xside ? q.X : q.G);
-        unsigned off[8];                                      // byte offsets from the uniform base (wgrad_add checks that they fit 32 bits)
-        if (mode == WG_XTILES) {
-            const int s0 = stg * WG_STAGE + 32 * ttile;
-            const unsigned tl = (unsigned)((s0 < a.m ? s0 : a.m - 1) >> 5), c = (unsigned)(tcol < q.w ? tcol : q.w - 1);
-            const unsigned o0 = (tl * (unsigned)q.xtile_f + c) * 128u;
+    p0 = __builtin_amdgcn_readfirstlane(p0);                  // (block-uniform by construction; said so, the stage cursors below live in scalar registers)
+    st0 = __builtin_amdgcn_readfirstlane(st0);
+    const int N = __builtin_amdgcn_readfirstlane((p_end - p0) * wg_stages + st_end - st0);     // stages of this block
+    if (N <= 0) return;
+    const int trips = (N + WG_UNROLL - 1) / WG_UNROLL;       // both roles meet at trips * WG_UNROLL barriers; stages past N are converted from a re-read of the last one and never multiplied
+    // The pair descriptors live in the kernel-argument segment; read from there inside the stage loop (a.p[dynamic index] = scalar loads that
+    // go to the argument buffer in host-visible memory) every stage paid their round trip -- and the dies far from that memory paid 2-3x more
+    // of it than the near ones (in-kernel stamps: the "fetch" phase 0.5 k cycles on four XCDs, 1.4 k on the other four, with a static split
+    // of the work the launch waited for the slow four).  One copy into LDS, and the current pair of every cursor in scalar registers.
+    __shared__ WgPair lds_pairs[WG_MAX_PAIRS];
+    {
+        constexpr int words = (int)(sizeof(WgPair) / 4);
+        const unsigned* src = reinterpret_cast<const unsigned*>(&a.p[0]);
+        unsigned* dst = reinterpret_cast<unsigned*>(&lds_pairs[0]);
+        for (int i = tid; i < a.n_pairs * words; i += WG_THREADS) dst[i] = src[i];
+        __syncthreads();
+    }
+    auto load_pair = [&](WgPair& q, int pr) {
+        constexpr int words = (int)(sizeof(WgPair) / 4);
+        unsigned w[words];
+        const unsigned* src = reinterpret_cast<const unsigned*>(&lds_pairs[pr]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) off[e] = o0 + 16u * e;
-        } else {
-            const unsigned ld = (unsigned)(xside ? q.ldx : q.ldg);
-            const int width = xside ? q.w : q.nout;
-            const unsigned piece = mode == WG_X24 ? 12u : 16u;
-            const unsigned gc = piece * (unsigned)(4 * grp < width ? grp : (width - 1) >> 2);
-            const unsigned one = !xside || q.xdiv == 1 ? 0xffffffffu : 0u;          // (uniform) s / 1 without a branch
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int s = stg * WG_STAGE + 8 * oct + e;
-                const unsigned sc = (unsigned)(s < a.m ? s : a.m - 1);
-                off[e] = ((sc & one) | ((__umulhi(sc, q.div_m) >> q.div_sh) & ~one)) * ld + gc;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-#if UCNERF_WGRAD_EXP & 4
-            off[e] &= 0x3ffffu;
-#endif
-            r.d[e] = *reinterpret_cast<const w_u32x4_a4*>(base + off[e]);
-        }
+        for (int i = 0; i < words; ++i) w[i] = __builtin_amdgcn_readfirstlane(src[i]);
+        __builtin_memcpy(&q, w, sizeof(WgPair));
     };
-    float colsum[4] = {0.f, 0.f, 0.f, 0.f};                   // bias gradients of columns 4 grp .. 4 grp + 3: this thread's samples (G side only)
-    // registers -> (hi, lo) fragments -> LDS: every value is split exactly once
-    auto put_frag = [&](const float (&x)[8], int f, int o) {
-#if UCNERF_WGRAD_EXP & 1
-        WFrag fr;
-        fr.hi = __builtin_bit_cast(w_bf16x8, (w_f32x4){x[0], x[1], x[2], x[3]});
-        fr.lo = __builtin_bit_cast(w_bf16x8, (w_f32x4){x[4], x[5], x[6], x[7]});
-#else
-        const WFrag fr = w_split8(x);
-#endif
-#if UCNERF_WGRAD_EXP & 8
-        if (x[0] != 12345.678f) return;
-#endif
-        const int off = frag_off(f, o);
-        *reinterpret_cast<w_bf16x8*>(Ol + off) = fr.hi;
-        *reinterpret_cast<w_bf16x8*>(Ol + off + 4 * 64 * 16) = fr.lo;
-    };
-    auto stage_lds = [&](const Regs& r, int pr, int stg) {
-        const WgPair& q = a.p[pr];
-        const int mode = xside ? q.xmode : WG_X24;
-        const int width = xside ? q.w : q.nout;
-        if (mode == WG_XTILES) {                              // fragment k = samples 8 k .. 8 k + 7 of this thread's tile: loads 2 k, 2 k + 1
-            const bool fin = tcol < width;
-            const int s0 = stg * WG_STAGE + 32 * ttile;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float x[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = (s0 + 8 * k + e < a.m) && fin ? __uint_as_float(r.d[2 * k + (e >> 2)][e & 3]) : 0.f;
-                put_frag(x, tcol, 4 * ttile + k);
-            }
-        } else {                                              // fragment c = column 4 grp + c of the eight rows
-            const int s0 = stg * WG_STAGE + 8 * oct;
-            const bool is24 = mode == WG_X24;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int f = 4 * grp + c;
-                const bool fin = f < width;
-                float x[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float v24 = p24_unpack1(r.d[e][0], r.d[e][1], r.d[e][2], c);     // (one byte permute per value, straight from the piece)
-                    const float v = is24 ? v24 : __uint_as_float(r.d[e][c]);
-                    x[e] = (s0 + e < a.m) && fin ? v : 0.f;
-                    colsum[c] += x[e];                        // (the X side's sums are never read)
-                }
-                put_frag(x, f, oct);
-            }
-        }
+    // the next stage of the range (and its pair's descriptor); past the range's end (p, st) stay on the last stage and only the index moves on
+    auto advance = [&](WgCur& c, WgPair& q) {
+        if (c.i + 1 < N && ++c.st == wg_stages) { c.st = 0; ++c.p; load_pair(q, c.p); }
+        ++c.i;
     };
 
-    w_f32x16 acc[2];
-    auto zero = [&]() {
+    if (producer) {
+        struct Regs { w_u32x4 d[8]; };
+        // global -> registers, and nothing else: rows / columns outside the matrix read a clamped (valid) piece that `convert` replaces by zero
+        auto fetch_side = [&](auto XS, w_u32x4 (&d)[8], const WgPair& q, int stg) {
+            constexpr bool xs = decltype(XS)::value;
+            const int mode = xs ? q.xmode : WG_X24;
+            const char* base = reinterpret_cast<const char*>(xs ? q.X : q.G);
+            unsigned off[8];                                  // byte offsets from the uniform base (wgrad_add checks that they fit 32 bits)
+            if (xs && mode == WG_XTILES) {
+                const int s0 = stg * WG_STAGE + 32 * ttile;
+                const unsigned tl = (unsigned)((s0 < wg_m ? s0 : wg_m - 1) >> 5), c = (unsigned)(tcol < q.w ? tcol : q.w - 1);
+                const unsigned o0 = (tl * (unsigned)q.xtile_f + c) * 128u;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+                for (int e = 0; e < 8; ++e) off[e] = o0 + 16u * e;
+            } else {
+                const unsigned ld = (unsigned)(xs ? q.ldx : q.ldg);
+                const int width = xs ? q.w : q.nout;
+                const unsigned piece = mode == WG_X24 ? 12u : 16u;
+                const unsigned gc = piece * (unsigned)(4 * grp < width ? grp : (width - 1) >> 2);
+                if ((stg + 1) * WG_STAGE <= wg_m && (!xs || q.xdiv == 1)) {             // (uniform) the usual stage: whole, one row per sample
+                    const unsigned o0 = (unsigned)(stg * WG_STAGE + 8 * oct) * ld + gc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+                    for (int e = 0; e < 8; ++e) off[e] = o0 + (unsigned)e * ld;
+                } else {
+                    const unsigned one = !xs || q.xdiv == 1 ? 0xffffffffu : 0u;         // (uniform) s / 1 without a branch
 #pragma unroll
-        for (int c = 0; c < 4; ++c) colsum[c] = 0.f;
-    };
-    auto multiply = [&](const WgPair& q) {
-        if (32 * nt < q.nout) {                              // (wave-uniform) this wave's row tile exists
-#pragma unroll
-            for (int ks = 0; ks < WG_KS; ++ks) {
-                __builtin_amdgcn_sched_barrier(0);           // (one k-step's fragments at a time: read up front for all four they crowd the prefetched stage out of the registers)
-                const w_bf16x8* ga = reinterpret_cast<const w_bf16x8*>(Gl) + (ks * 2 * 4 + nt) * 64 + (lane & 32) + swz(nt, lane >> 5, lane & 31);
-                const w_bf16x8 ahi = ga[0], alo = ga[4 * 64];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int kt = kg + 2 * t;
-                    if (32 * kt < q.w) {
-                        const w_bf16x8* xb = reinterpret_cast<const w_bf16x8*>(Xl) + (ks * 2 * 4 + kt) * 64 + (lane & 32) + swz(kt, lane >> 5, lane & 31);
-                        const w_bf16x8 bhi = xb[0], blo = xb[4 * 64];
-#if UCNERF_WGRAD_EXP & 2
-                        acc[t][0] += __builtin_bit_cast(w_f32x4, ahi)[0] + __builtin_bit_cast(w_f32x4, bhi)[0] + __builtin_bit_cast(w_f32x4, alo)[1] + __builtin_bit_cast(w_f32x4, blo)[1];
-#else
-                        acc[t] = WMFMA(ahi, bhi, acc[t]);
-                        acc[t] = WMFMA(ahi, blo, acc[t]);
-                        acc[t] = WMFMA(alo, bhi, acc[t]);
-#endif
+                    for (int e = 0; e < 8; ++e) {
+                        const int s = stg * WG_STAGE + 8 * oct + e;
+                        const unsigned sc = (unsigned)(s < wg_m ? s : wg_m - 1);
+                        off[e] = ((sc & one) | ((__umulhi(sc, q.div_m) >> q.div_sh) & ~one)) * ld + gc;
                     }
                 }
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#if UCNERF_WGRAD_EXP & 4
+                off[e] &= 0x3ffffu;
+#endif
+                d[e] = *reinterpret_cast<const w_u32x4_a4*>(base + off[e]);
+            }
+        };
+        w_f32x2 colsum[2] = {{0.f, 0.f}, {0.f, 0.f}};        // bias gradients of columns 4 grp .. 4 grp + 3: this thread's samples
+        // registers -> (hi, lo) fragments -> LDS: every value is split exactly once
+        auto put_frag = [&](char* Ol, const float (&x)[8], int f, int o) {
+#if UCNERF_WGRAD_EXP & 1
+            WFrag fr;
+            fr.hi = __builtin_bit_cast(w_bf16x8, (w_f32x4){x[0], x[1], x[2], x[3]});
+            fr.lo = __builtin_bit_cast(w_bf16x8, (w_f32x4){x[4], x[5], x[6], x[7]});
+#else
+            const WFrag fr = w_split8(x);
+#endif
+#if UCNERF_WGRAD_EXP & 8
+            if (x[0] != 12345.678f) return;
+#endif
+            const int off = frag_off(f, o);
+            *reinterpret_cast<w_bf16x8*>(Ol + off) = fr.hi;
+            *reinterpret_cast<w_bf16x8*>(Ol + off + 4 * 64 * 16) = fr.lo;
+        };
+        // rows (24-bit or fp32 pieces): fragment c = column 4 grp + c of the thread's eight rows.  CLEAN (uniform: a whole stage of a 128-wide operand)
+        // = nothing to zero; otherwise clamped rows / columns are zeroed with one AND per value (a mask per column times a mask per row)
+        auto convert_rows = [&](auto XS, auto IS24, auto CLEAN, const w_u32x4 (&d)[8], int width, int stg, char* Ol, bool live) {
+            constexpr bool xs = decltype(XS)::value, is24 = decltype(IS24)::value, clean = decltype(CLEAN)::value;
+            const int s0 = stg * WG_STAGE + 8 * oct;
+            unsigned cm[4], rm[8];
+            if (!clean) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cm[c] = (4 * grp + c < width) && live ? 0xffffffffu : 0u;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rm[e] = s0 + e < wg_m ? 0xffffffffu : 0u;
+            }
+#pragma unroll
+            for (int cp = 0; cp < 4; cp += 2) {                // two columns at a time: their bias sums advance as one packed add per row
+                float x[2][8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        unsigned b = is24 ? __float_as_uint(p24_unpack1(d[e][0], d[e][1], d[e][2], cp + h)) : d[e][cp + h];      // (one byte permute per value, straight from the piece)
+                        if (!clean) b &= cm[cp + h] & rm[e];
+                        x[h][e] = __uint_as_float(b);
+                    }
+                if (!xs) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) colsum[cp >> 1] += (w_f32x2){x[0][e], x[1][e]};
+                }
+                put_frag(Ol, x[0], 4 * grp + cp, oct);
+                put_frag(Ol, x[1], 4 * grp + cp + 1, oct);
+            }
+            // (the fourth dword of a 24-bit piece's load is never read: left dead, the register allocator hands it to some temporary while
+            //  the load is still in flight, and the write to it waits for the load -- a stage's prefetch drained by a loop counter)
+            if (is24) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(d[e][3]));
+            }
+        };
+        auto convert_side = [&](auto XS, const w_u32x4 (&d)[8], const WgPair& q, int stg, char* Ol, bool live) {
+            constexpr bool xs = decltype(XS)::value;
+            const int mode = xs ? q.xmode : WG_X24;
+            const int width = xs ? q.w : q.nout;
+            const bool whole = (stg + 1) * WG_STAGE <= wg_m && width == 128 && live;     // (uniform)
+            constexpr std::true_type yes{};
+            constexpr std::false_type no{};
+            if (xs && mode == WG_XTILES) {                    // fragment k = samples 8 k .. 8 k + 7 of this thread's tile: loads 2 k, 2 k + 1
+                const unsigned cmask = tcol < width ? 0xffffffffu : 0u;
+                const int s0 = stg * WG_STAGE + 32 * ttile;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float x[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = __uint_as_float(d[2 * k + (e >> 2)][e & 3] & (s0 + 8 * k + e < wg_m ? cmask : 0u));
+                    put_frag(Ol, x, tcol, 4 * ttile + k);
+                }
+            } else if (xs && mode == WG_XROWS) {
+                if (whole) convert_rows(XS, no, yes, d, width, stg, Ol, live);
+                else convert_rows(XS, no, no, d, width, stg, Ol, live);
+            } else {
+                if (whole) convert_rows(XS, yes, yes, d, width, stg, Ol, live);
+                else convert_rows(XS, yes, no, d, width, stg, Ol, live);
+            }
+        };
+        auto flush_bias = [&](const WgPair& q) {
+            float* const gb = q.gb;
+            float* const gbh = q.gb_hi ? q.gb_hi : q.gb;
+            const int split = q.split, nout = q.nout;
+            const bool twob = q.gb_hi != nullptr;
+            if (gb) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int col = 4 * grp + c;
+                    const float v = colsum[c >> 1][c & 1];
+                    if (col < nout && v != 0.f) {
+                        const bool hi = twob && col >= split;
+                        atomicAdd((hi ? gbh : gb) + (hi ? col - split : col), v);
+                    }
+                }
+            }
+            colsum[0] = colsum[1] = (w_f32x2){0.f, 0.f};
+        };
+        WgCur fc = {p0, st0, 0}, cv = {p0, st0, 0};          // the stage fetched next, the stage converted next
+        WgPair fq, cq;                                        // ... and their pairs
+        load_pair(fq, p0);
+        load_pair(cq, p0);
+        // Two register sets, A and B, each a stage of this wave's operand: stage k + 2 is requested the moment stage k has left its set.  The loop's
+        // trip is two stages and starts BETWEEN a conversion and the fetch that refills its set, where only the other set is in flight; every
+        // wait is counted (the eight younger loads of the other set stay in flight).
+        auto run = [&](auto XS) {
+            constexpr bool xs = decltype(XS)::value;
+            auto fetch = [&](Regs& r) {
+                fetch_side(XS, r.d, fq, fc.st);
+                advance(fc, fq);
+            };
+            auto convert = [&](const Regs& r, int img) {
+                const WgPair& q = cq;
+                const bool live = cv.i < N;
+                convert_side(XS, r.d, q, cv.st, wg_lds + img * WG_IMG_BYTES + (xs ? WG_OP_BYTES : 0), live);
+                if (!xs && live && (cv.i == N - 1 || cv.st + 1 == wg_stages)) flush_bias(q);      // the range leaves this pair
+                advance(cv, cq);
+            };
+            Regs A, B;
+            fetch(A);
+            fetch(B);
+            convert(A, 0);
+            WG_T(0)
+#if UCNERF_WGRAD_STAMPS
+            unsigned long long tpair = __builtin_amdgcn_s_memtime();
+#endif
+            for (int t = 0; t < trips; ++t) {
+#if UCNERF_WGRAD_STAMPS
+#define WG_PAIR_T if (!xs && lane == 0 && cv.i < N) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (wave == 0) { atomicAdd(stamps + 32 + cv.p, n_ - tpair); atomicAdd(stamps + 48 + cv.p, 1ull); } tpair = n_; }
+                fetch(A); WG_T(1) wg_barrier(); WG_PAIR_T WG_T(2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); WG_T(3) convert(B, 1); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WG_T(4)
+                fetch(B); WG_T(1) wg_barrier(); WG_PAIR_T WG_T(2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); WG_T(3) convert(A, 0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WG_T(4)
+#else
+                fetch(A); wg_barrier(); convert(B, 1);
+                fetch(B); wg_barrier(); convert(A, 0);
+#endif
+            }
+#if UCNERF_WGRAD_STAMPS
+            if (lane == 0) for (int k = 0; k < 5; ++k) { atomicAdd(stamps + (xs ? 16 : 0) + k, tacc[k]); atomicAdd(stamps + 2048 + 32 * (blockIdx.x & 7) + (xs ? 8 : 0) + k, tacc[k]); }
+            if (!xs && tid == 0) atomicAdd(stamps + 2048 + 32 * (blockIdx.x & 7) + 30, (unsigned long long)N);
+            if (tid == 0) {
+                const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)), hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+                stamps[64 + 4 * blockIdx.x] = (unsigned long long)N | ((unsigned long long)xcc << 32) | ((unsigned long long)(hw & 0xffff00u) << 24);
+                stamps[65 + 4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - tstart; stamps[66 + 4 * blockIdx.x] = rstart; stamps[67 + 4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+            }
+            if (tid == 0) { atomicAdd(stamps + 12, (unsigned long long)N); atomicMax(stamps + 13, tacc[0] + tacc[1] + tacc[2] + tacc[3] + tacc[4]); atomicMin(stamps + 14, tacc[0] + tacc[1] + tacc[2] + tacc[3] + tacc[4]); }
+#endif
+        };
+        if (wave < 4) run(std::false_type{});
+        else run(std::true_type{});
+        return;
+    }
+
+    // ---- consumers: wave 8 + nt owns output rows 32 nt .. 32 nt + 31, all four column tiles
+    const int nt = wave - 8;
+    w_f32x16 acc[4];
+    auto zero = [&]() {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    };
+    // FULL: all four column tiles exist (w > 96): no branch between the fragment reads and the MFMAs of a k-step
+    auto multiply_as = [&](auto FULL, const WgPair& q, int img) {
+        constexpr bool full = decltype(FULL)::value;
+        const char* const Gl = wg_lds + img * WG_IMG_BYTES;
+        const char* const Xl = Gl + WG_OP_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < WG_KS; ++ks) {
+            const w_bf16x8* ga = reinterpret_cast<const w_bf16x8*>(Gl) + (ks * 2 * 4 + nt) * 64 + (lane & 32) + swz(nt, lane >> 5, lane & 31);
+            const w_bf16x8 ahi = ga[0], alo = ga[4 * 64];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                if (full || 32 * kt < q.w) {
+                    const w_bf16x8* xb = reinterpret_cast<const w_bf16x8*>(Xl) + (ks * 2 * 4 + kt) * 64 + (lane & 32) + swz(kt, lane >> 5, lane & 31);
+                    const w_bf16x8 bhi = xb[0], blo = xb[4 * 64];
+#if UCNERF_WGRAD_EXP & 2
+                    acc[kt][0] += __builtin_bit_cast(w_f32x4, ahi)[0] + __builtin_bit_cast(w_f32x4, bhi)[0] + __builtin_bit_cast(w_f32x4, alo)[1] + __builtin_bit_cast(w_f32x4, blo)[1];
+#else
+                    acc[kt] = WMFMA(ahi, bhi, acc[kt]);
+                    acc[kt] = WMFMA(ahi, blo, acc[kt]);
+                    acc[kt] = WMFMA(alo, bhi, acc[kt]);
+#endif
+                }
+            }
         }
+    };
+    auto multiply = [&](const WgPair& q, int img) {
+        if (32 * nt >= q.nout) return;                       // (wave-uniform) this wave's row tile does not exist
+        if (q.w > 96) multiply_as(std::true_type{}, q, img);
+        else multiply_as(std::false_type{}, q, img);
     };
     // leaving a pair: this block's partial sums go to the gradient (float atomics on 128-byte row segments)
     auto flush = [&](const WgPair& q) {
@@ -226,14 +399,12 @@ __global__ void __launch_bounds__(WG_THREADS, 4) mlp_wgrad_kernel(WgArgs a) {
         // (descriptor fields into scalars first: a select between two FIELDS became a per-lane load of the chosen one, with a vmcnt(0) per atomic)
         float* const gW = q.gW;
         float* const gWh = q.gW_hi ? q.gW_hi : q.gW;
-        float* const gb = q.gb;
-        float* const gbh = q.gb_hi ? q.gb_hi : q.gb;
         const int split = q.split, ldw = q.ldw, nout = q.nout, w = q.w;
-        const bool two = q.gW_hi != nullptr, twob = q.gb_hi != nullptr;
+        const bool two = q.gW_hi != nullptr;
         if (32 * nt < nout) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int kt = kg + 2 * t, k = 32 * kt + i;
+            for (int kt = 0; kt < 4; ++kt) {
+                const int k = 32 * kt + i;
                 if (32 * kt < w) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -241,44 +412,34 @@ __global__ void __launch_bounds__(WG_THREADS, 4) mlp_wgrad_kernel(WgArgs a) {
                         if (n < nout && k < w) {
                             const bool hi = two && n >= split;
                             float* base = hi ? gWh : gW;
-                            atomicAdd(base + (size_t)(hi ? n - split : n) * ldw + k, acc[t][r]);
+                            atomicAdd(base + (size_t)(hi ? n - split : n) * ldw + k, acc[kt][r]);
                         }
                     }
                 }
             }
         }
-        if (gb && !xside) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int col = 4 * grp + c;
-                if (col < nout && colsum[c] != 0.f) {
-                    const bool hi = twob && col >= split;
-                    atomicAdd((hi ? gbh : gb) + (hi ? col - split : col), colsum[c]);
-                }
-            }
-        }
         zero();
     };
-
     zero();
-    // One segment (the block's stages of ONE pair) at a time.  A stage's loads (64 KB per block, two blocks per CU) are in flight while the
-    // previous stage is multiplied.  (Two stages ahead in two register sets was built: the compiler's wait-count pass waits for vmcnt(0)
-    // at a loop header whatever the loop looks like -- conditional fetches, exits and the flush's atomics were all removed from it in
-    // turn -- so the second set never stayed in flight.  Bytes in flight come from the stage size instead.)
-    while (!(p == p_end && st == st_end)) {
-        const int seg_end = p == p_end ? st_end : a.stages;   // stages [st, seg_end) of pair p
-        Regs r;
-        fetch(r, p, st);
-        for (int t = st; t < seg_end; ++t) {
-            __syncthreads();                                 // every wave has read the previous stage
-            stage_lds(r, p, t);
-            __syncthreads();
-            fetch(r, p, t + 1 < seg_end ? t + 1 : t);        // (unconditional: the last stage is fetched again and ignored)
-            multiply(a.p[p]);
+    WgCur mu = {p0, st0, 0};                                  // the stage multiplied next
+    WgPair mq;
+    load_pair(mq, p0);
+    for (int k = 0; k < trips * WG_UNROLL; ++k) {
+        WG_T(0)
+        wg_barrier();                                        // image k & 1 holds stage k; everyone is done with the other one
+        WG_T(1)
+        if (k < N) {
+            const WgPair& q = mq;
+            multiply(q, k & 1);
+            WG_T(2)
+            if (k == N - 1 || mu.st + 1 == wg_stages) flush(q);
+            WG_T(3)
+            advance(mu, mq);
         }
-        flush(a.p[p]);
-        if (seg_end == a.stages) { ++p; st = 0; } else st = seg_end;
     }
+#if UCNERF_WGRAD_STAMPS
+    if (lane == 0) for (int k = 0; k < 6; ++k) { atomicAdd(stamps + 6 + k, tacc[k]); atomicAdd(stamps + 2048 + 32 * (blockIdx.x & 7) + 16 + k, tacc[k]); }
+#endif
 }
 
 // ---- host side: the pair list is built by ucnerf_mlp_bwd (mlp_bwd.hip)
@@ -317,13 +478,46 @@ int wgrad_launch(const WgArgs* a, hipStream_t st) {
     const int cus = device_cus();
     if (cus <= 0) return fail(UCNERF_EHIP, "mlp_bwd: no device");
     long long units = (long long)a->n_pairs * a->stages;
-    int blocks = 2 * cus;
+    int blocks = cus;                                        // one block per CU (128 KB of LDS)
     if (blocks > units) blocks = (int)units;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_wgrad_kernel), 2 * WG_OP_BYTES, "mlp_bwd wgrad")) return rc;
-    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(blocks), dim3(WG_THREADS), 2 * WG_OP_BYTES, st, *a);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_wgrad_kernel), WG_LDS_BYTES, "mlp_bwd wgrad")) return rc;
+#if UCNERF_WGRAD_STAMPS
+    static unsigned long long* stamps = nullptr;
+    if (!stamps) hipMalloc(&stamps, (64 + 4 * 1024) * 8);
+    unsigned long long init[64] = {0};
+    init[14] = ~0ull;
+    hipMemcpyAsync(stamps, init, sizeof(init), hipMemcpyHostToDevice, st);
+    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(blocks), dim3(WG_THREADS), WG_LDS_BYTES, st, *a, stamps);
+    static unsigned long long h[64 + 4 * 1024];
+    hipMemcpyAsync(h, stamps, sizeof(h), hipMemcpyDeviceToHost, st);
+    hipStreamSynchronize(st);
+    const double ns = (double)h[12], pw = 4.0 * ns, cw = 4.0 * ns;      // stage-visits summed over the four waves of a role
+    fprintf(stderr, "wgrad stamps (cycles per stage and wave; %d blocks, %.1f stages per block): G producer: prologue %.0f (per block), fetch %.0f, barrier %.0f, load wait %.0f, convert %.0f;  "
+            "X producer: fetch %.0f, barrier %.0f, load wait %.0f, convert %.0f;  consumer: loop %.0f, barrier %.0f, multiply %.0f, flush %.0f;  G producer total per block max %.0f min %.0f\n",
+            blocks, ns / blocks, h[0] / (4.0 * blocks), h[1] / pw, h[2] / pw, h[3] / pw, h[4] / pw, h[17] / pw, h[18] / pw, h[19] / pw, h[20] / pw, h[6] / cw, h[7] / cw, h[8] / cw, h[9] / cw,
+            (double)h[13], (double)h[14]);
+    {
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < blocks; ++b) t0 = h[66 + 4 * b] < t0 ? h[66 + 4 * b] : t0;
+        fprintf(stderr, "wgrad stamps, per block (N, first pair, start, end; cycles from the first start):");
+        for (int b = 0; b < blocks; ++b) fprintf(stderr, " %d:%d,%d,%llu,%llu,%d,%d", b, (int)(h[64 + 4 * b] & 0xffffffffu), (int)h[65 + 4 * b], h[66 + 4 * b] - t0, h[67 + 4 * b] - t0, (int)((h[64 + 4 * b] >> 32) & 15), (int)(h[64 + 4 * b] >> 40));
+        fprintf(stderr, "\n");
+    }
+    for (int x = 0; x < 8; ++x) {
+        const unsigned long long* q = h + 2048 + 32 * x;
+        const double w = 4.0 * (double)q[30];
+        fprintf(stderr, "wgrad stamps, blockIdx %% 8 = %d (cycles per stage and wave): G fetch %.0f barrier %.0f wait %.0f convert %.0f | X fetch %.0f barrier %.0f wait %.0f convert %.0f | consumer barrier %.0f multiply %.0f flush %.0f\n",
+                x, q[1] / w, q[2] / w, q[3] / w, q[4] / w, q[9] / w, q[10] / w, q[11] / w, q[12] / w, q[17] / w, q[18] / w, q[19] / w);
+    }
+    fprintf(stderr, "wgrad stamps, cycles per stage by pair (nout x w, X format, cost):");
+    for (int i = 0; i < a->n_pairs; ++i) fprintf(stderr, "  [%d x %d, %d, %d] %.0f", a->p[i].nout, a->p[i].w, a->p[i].xmode, a->p[i].cost, h[48 + i] ? (double)h[32 + i] / h[48 + i] : 0.0);
+    fprintf(stderr, "\n");
+#else
+    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(blocks), dim3(WG_THREADS), WG_LDS_BYTES, st, *a);
+#endif
     return check_launch("mlp_bwd wgrad");
 }
 
-const char* build_flags_mlp_wgrad() { return "mlp_wgrad: " UCNERF_FLAG(UCNERF_WGRAD_EXP); }
+const char* build_flags_mlp_wgrad() { return "mlp_wgrad: " UCNERF_FLAG(UCNERF_WGRAD_EXP) " " UCNERF_FLAG(UCNERF_WGRAD_STAMPS); }
 
 }  // namespace ucnerf
