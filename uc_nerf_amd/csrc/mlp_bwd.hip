@@ -585,6 +585,7 @@ struct BwdWork {
     float *pep, *ped, *g1, *g2, *g3, *gbd, *gx, *g_base, *g_adapt, *g_sigma, *raw;
     float* gy[6];           // bwd_mode 0: g_y of the six trunk layers (operands of their weight-gradient GEMMs)
     float* wstream_bwd;     // bwd_mode 0: transposed weights as split-bf16 fragments + head table (mlp_bwd_chain.hip)
+    unsigned* wg_counters;  // bwd_mode 0: the weight-gradient launch's chunk counters (mlp_wgrad.hip)
 };
 
 static size_t carve_bwd(float* base, int m, int n_dirs, BwdWork* w) {
@@ -602,6 +603,7 @@ static size_t carve_bwd(float* base, int m, int n_dirs, BwdWork* w) {
     w->g_base = take(M * 4 + 4); w->g_adapt = take(M * 4 + 4); w->g_sigma = take(M * 4 + 4); w->raw = take(M * 4);
     for (int l = 0; l < 6; ++l) w->gy[l] = take(M * 128 + 96);
     w->wstream_bwd = take(bwd_chain_stream_floats());
+    w->wg_counters = reinterpret_cast<unsigned*>(take(WG_MAX_PAIRS));
     return o;
 }
 
@@ -752,7 +754,7 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
         constexpr int R = P24_ROW_BYTES;
         const char* vc24 = reinterpret_cast<const char*>(w.sv.vc);
         WgArgs wg;
-        wgrad_begin(&wg, m);
+        wgrad_begin(&wg, m, w.wg_counters);
         RUN(wgrad_add(&wg, w.g1, R, 128, w.sv.ft, 1, R, 1, 128, G + L.p_vw, KV, G + L.p_vb, G + L.p_vcw, G + L.p_vcb, 64));       // [views | view_confi] x f
         RUN(wgrad_add(&wg, w.g1, R, 128, ped, 0, ld_ped, xdiv_dir, 27, G + L.p_vw + 128, KV, nullptr, G + L.p_vcw + 128, nullptr, 64));   // ... x dir encoding
         RUN(wgrad_add(&wg, w.g2, R, 128, w.gx, 1, R, 1, 128, G + L.p_fw, 128, G + L.p_fb, nullptr, nullptr, 0));                    // feature_linear

@@ -32,8 +32,9 @@ struct WgArgs {
     WgPair p[WG_MAX_PAIRS];
     long long prefix[WG_MAX_PAIRS + 1];   // cumulative cost: pair i covers [prefix[i], prefix[i + 1]) = stages * cost_i
     int n_pairs, m, stages;
+    unsigned* counters;                   // WG_MAX_PAIRS counters in global memory, zeroed by wgrad_launch: the next chunk of every pair (mlp_wgrad.hip)
 };
-void wgrad_begin(WgArgs* a, int m);
+void wgrad_begin(WgArgs* a, int m, unsigned* counters);
 int wgrad_add(WgArgs* a, const void* G, int ldg_bytes, int nout, const void* X, int x24, int ldx, int xdiv, int w, float* gW, int ldw, float* gb, float* gW_hi,
               float* gb_hi, int split, int xtile_f = 0);
 int wgrad_launch(const WgArgs* a, hipStream_t st);

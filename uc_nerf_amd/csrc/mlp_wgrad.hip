@@ -5,23 +5,25 @@
 // Why not one gemm_tn launch per pair (mlp_bwd.hip, rounds 1-2): there every wave fetched its own operands from global
 // memory as dwords (features on lanes), 24 vector-memory instructions per nine MFMAs and every byte of G / X through the
 // CU's texture path four to eight times -- 57 us per 128 x 128 pair against 27 us for its bytes at HBM speed.  Here
-//   * one block per CU, eight waves in two ROLES.  Waves 0-3 (one per SIMD) are producers: they fetch 64 samples of G and X per stage into
-//     registers, two stages ahead in two register sets, split every value into (hi, lo) bf16 ONCE and write it in MFMA operand layout
-//     into one of TWO stage images in LDS.  Waves 4-7 are consumers: they read fragments (one ds_read_b128 per plane) from the other image and
-//     multiply -- nothing else.  One barrier per stage hands an image over in each direction, so the producers' vector arithmetic, their
-//     LDS writes and the wait for their loads all run beside the consumers' MFMAs on the same SIMD, and the next-but-one stage's loads are
-//     issued the moment a register set has been converted.
+//   * one block per CU, twelve waves in three ROLES, three waves per SIMD.  Waves 0-3 produce the G operand, waves 4-7 the X operand: each
+//     fetches 64 samples of its operand per stage into registers, two stages ahead in two register sets, splits every value into (hi, lo)
+//     bf16 ONCE and writes it in MFMA operand layout into one of TWO stage images in LDS.  Waves 8-11 are consumers: they read fragments (one
+//     ds_read_b128 per plane) from the other image and multiply -- nothing else.  One barrier per stage hands an image over in each direction,
+//     so a producer's vector arithmetic, its LDS writes and the wait for its loads run beside the consumers' MFMAs on the same SIMD, and
+//     the next-but-one stage's loads are issued the moment a register set has been converted.
 //     (Before: two blocks per CU, every wave fetching, converting and multiplying in turn behind two barriers per stage, the next stage's loads
-//      issued only after the LDS writes: a stage cost its load round trip PLUS its arithmetic, 5.7 us per stage and block at 3.5 TB/s, where the
-//      fetch shape alone streams at 6.3 TB/s -- scripts/micro/load_shapes.hip.)
+//      issued only after the LDS writes: a stage cost its load round trip PLUS its arithmetic.)
 //   * operands in the 24-bit format (p24.h: every G, and every X that is a kept activation set) arrive as 12-byte pieces -- thread
 //     (4-column group, sample octet) reads eight rows' pieces = four MFMA fragments; fp32 operands (encodings, gathered features) as
 //     16-byte pieces of rows or of the MLP tile layout;
 //   * products are hi*hi + hi*lo + lo*hi on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate: the forward's bf16x3
 //     scheme, 2^-16 relative);
-//   * the launch is persistent over the CONCATENATION of all pairs: the total cost (bytes per 64-sample stage plus a fixed part, summed over
-//     pairs) is cut into equal ranges, one per block; the producers' pipeline runs straight through the pair boundaries of a range; the consumers
-//     flush their 128 x 128 partial sum with float atomics on 128-byte row segments when the range leaves a pair.
+//   * the launch is persistent over all pairs and hands its work out as it runs: chunks of eight stages through one counter per pair
+//     (see "the block's work" in the kernel); a block stays on one pair as long as that pair has chunks, and the consumers flush their
+//     128 x 128 partial sum with float atomics on 128-byte row segments only when the block moves to another pair.
+// What bounds it (in-kernel stamps of the diagnostic build, scripts/micro/load_shapes.hip, profiles/r03_experiments.md): the loads are never
+// waited for (17 cycles per stage) but their ISSUE is -- the memory system takes this traffic at 3.8-4.2 TB/s, because the sets were written
+// by the two launches before this one: the same streams read at 6.1 TB/s from data at rest and at 4.7 TB/s right after every byte was rewritten.
 #include <type_traits>
 #include "common.h"
 #include "mlp_layout.h"
@@ -66,7 +68,7 @@ __device__ __forceinline__ WFrag w_split8(const float (&x)[8]) {
 constexpr int WG_OP_BYTES = WG_KS * 2 * 4 * 64 * 16;
 constexpr int WG_IMG_BYTES = 2 * WG_OP_BYTES;                 // a stage: [G operand | X operand]
 constexpr int WG_LDS_BYTES = 2 * WG_IMG_BYTES;                // two stages: one being written, one being multiplied
-constexpr int WG_UNROLL = 2;                                  // stages per trip of the producers' loop (see there)
+constexpr int WG_UNROLL = 2;                                  // stages per trip of the stage loops (register sets A, B / images 0, 1)
 
 // A side's fetch has ONE shape whatever the operand's format: eight 16-byte loads at eight computed byte offsets.
 //   24-bit rows (every G; kept activation sets as X): thread (grp = 4-column group, oct = sample octet): the 12-byte pieces of eight rows
@@ -74,7 +76,16 @@ constexpr int WG_UNROLL = 2;                                  // stages per trip
 //   fp32 rows   (encodings, row-major features; one row per xdiv samples): the same with 16-byte pieces = four fp32 columns
 //   fp32 tiles  (features in the MLP tile layout [m / 32][F][32]): thread (column, tile of the stage): the 32 samples of its column = four fragments
 enum { WG_X24 = 0, WG_XROWS = 1, WG_XTILES = 2 };
-struct WgCur { int p, st, i; };                               // a stage of the block's range: pair, stage of the pair, index in the range
+struct WgCur { int j, p, st, left; };                         // a stage of the block's work: chunk number, pair, stage of the pair, stages left in the chunk (0 = END)
+struct WgChunk { int p, st, n; };                             // ring entry: pair, first stage, stages (0 = END)
+constexpr int WG_CHUNK = 8;                                   // stages per chunk
+constexpr int WG_RING = 8, WG_LEAD = 4;                       // ring entries; chunks asked for ahead of the one being multiplied (>= 4: chunks may be one stage long)
+// float atomic add on a pointer SAID to be global memory (the descriptors travel through LDS: a generic pointer would make it a FLAT atomic, and
+// every later wait of the wave vmcnt(0) lgkmcnt(0))
+__device__ __forceinline__ void wg_atomic_add(float* p, float v) {
+    typedef float __attribute__((address_space(1))) * gp_t;
+    __hip_atomic_fetch_add((gp_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }     // LDS traffic only: loads in flight stay in flight
 
 #ifndef UCNERF_WGRAD_STAMPS
@@ -91,6 +102,7 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
 #if UCNERF_WGRAD_STAMPS
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
     const unsigned long long rstart = __builtin_amdgcn_s_memrealtime(), tstart = tlast;
+    (void)rstart; (void)tstart;
 #endif
     extern __shared__ __attribute__((aligned(16))) char wg_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -108,38 +120,9 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
     auto swz = [](int tile, int hh, int i) { return i ^ ((tile + hh + 2 * (i >> 4)) & 3); };
     auto frag_off = [&](int f, int o) { return ((((o >> 1) * 2 * 4) + (f >> 5)) * 64 + (o & 1) * 32 + swz(f >> 5, o & 1, f & 31)) * 16; };
 
-    // this block's share of the concatenated pairs, in cost units -> (pair, stage) at both ends
-    const long long total = a.prefix[a.n_pairs];
-#ifndef UCNERF_WGRAD_XCD_MAP
-#define UCNERF_WGRAD_XCD_MAP 0
-#endif
-#if UCNERF_WGRAD_XCD_MAP
-    const int bid = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;     // XCD k (blocks k, k + 8, ...) takes the k-th eighth of the work
-#else
-    const int bid = blockIdx.x;
-#endif
-    const long long c0 = total * bid / gridDim.x, c1 = total * (bid + 1) / gridDim.x;
-    auto locate = [&](long long c, int* pair, int* stage) {   // first stage whose start is >= c (so consecutive blocks tile exactly)
-        int p = 0;
-        for (int q = 1; q < a.n_pairs; ++q) p = c >= a.prefix[q] ? q : p;
-        if (c >= total) { *pair = a.n_pairs; *stage = 0; return; }
-        const long long off = c - a.prefix[p];
-        int st = (int)((off + a.p[p].cost - 1) / a.p[p].cost);
-        if (st >= wg_stages) { ++p; st = 0; }
-        *pair = p; *stage = st;
-    };
-    int p0, st0, p_end, st_end;
-    locate(c0, &p0, &st0);
-    locate(c1, &p_end, &st_end);
-    p0 = __builtin_amdgcn_readfirstlane(p0);                  // (block-uniform by construction; said so, the stage cursors below live in scalar registers)
-    st0 = __builtin_amdgcn_readfirstlane(st0);
-    const int N = __builtin_amdgcn_readfirstlane((p_end - p0) * wg_stages + st_end - st0);     // stages of this block
-    if (N <= 0) return;
-    const int trips = (N + WG_UNROLL - 1) / WG_UNROLL;       // both roles meet at trips * WG_UNROLL barriers; stages past N are converted from a re-read of the last one and never multiplied
-    // The pair descriptors live in the kernel-argument segment; read from there inside the stage loop (a.p[dynamic index] = scalar loads that
-    // go to the argument buffer in host-visible memory) every stage paid their round trip -- and the dies far from that memory paid 2-3x more
-    // of it than the near ones (in-kernel stamps: the "fetch" phase 0.5 k cycles on four XCDs, 1.4 k on the other four, with a static split
-    // of the work the launch waited for the slow four).  One copy into LDS, and the current pair of every cursor in scalar registers.
+    // The pair descriptors live in the kernel-argument segment: a.p[dynamic index] inside the stage loop is a handful of scalar loads from that
+    // buffer per stage and wave.  One copy into LDS instead, and the current pair of every cursor in scalar registers (reloaded from LDS when
+    // a cursor changes pair): the stage loops have no scalar memory access at all.
     __shared__ WgPair lds_pairs[WG_MAX_PAIRS];
     {
         constexpr int words = (int)(sizeof(WgPair) / 4);
@@ -156,11 +139,113 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
         for (int i = 0; i < words; ++i) w[i] = __builtin_amdgcn_readfirstlane(src[i]);
         __builtin_memcpy(&q, w, sizeof(WgPair));
     };
-    // the next stage of the range (and its pair's descriptor); past the range's end (p, st) stay on the last stage and only the index moves on
-    auto advance = [&](WgCur& c, WgPair& q) {
-        if (c.i + 1 < N && ++c.st == wg_stages) { c.st = 0; ++c.p; load_pair(q, c.p); }
-        ++c.i;
+    // ---- the block's work: a sequence of CHUNKS (WG_CHUNK consecutive stages of one pair), decided as the launch runs.
+    // With a static split (equal modelled cost per block: rounds 1-3) the blocks finished between 0.6 and 1.3 of the mean: under this launch
+    // a stage took 2.1 us on four of the eight XCDs and 3.3 us on the other four (which four changed from box to box; in-kernel stamps,
+    // profiles/r03_experiments.md), and the split leaned on a cost model fitted to one kernel version.  Handing the work out as it is done
+    // leaves the launch's time where the memory system puts it (all eight XCDs then run at 2.9 us per stage) but takes the cost model and the
+    // dies' differences out of it.  Every pair's chunks are handed out through a counter in global memory.  A block starts on its
+    // HOME pair (blocks are spread over the pairs in proportion to their cost), whose first chunks it owns without asking (ns rows of the pair's
+    // chunks, one chunk per home block and row), then takes the pair's remaining chunks from the counter, then helps the pair with the most
+    // chunks left.  Consumer wave 8 does the asking, WG_LEAD chunks ahead of the stage being multiplied, and writes the answers into a ring in
+    // LDS that every cursor of every wave follows; the ring's END entry carries the block's total number of stages (lds_total).  Partial sums
+    // are flushed when a cursor's next chunk belongs to another pair.
+    __shared__ WgChunk ring[WG_RING];
+    __shared__ int lds_total;                                 // stages of this block, once its END is known (a huge number before)
+    __shared__ int sch_fb[WG_MAX_PAIRS + 1], sch_base[WG_MAX_PAIRS], sch_dyn[WG_MAX_PAIRS];      // first home block of a pair; chunks owned statically; chunks behind the counter
+    const int n_pairs = __builtin_amdgcn_readfirstlane(a.n_pairs);
+    const int chunks = (wg_stages + WG_CHUNK - 1) / WG_CHUNK;
+    if (tid <= n_pairs) {
+        const long long total = a.prefix[n_pairs];
+        sch_fb[tid] = tid == n_pairs ? (int)gridDim.x : (int)((a.prefix[tid] * (long long)gridDim.x + total - 1) / total);      // blocks b with prefix[p] <= total b / grid
+    }
+    if (tid == 0) lds_total = 0x3fffffff;                   // ("not known yet"; rounded up to even below)
+    __syncthreads();
+    if (tid < n_pairs) {
+        const int nb = sch_fb[tid + 1] - sch_fb[tid];
+        const int ns = nb > 0 ? (chunks / nb < WG_LEAD ? chunks / nb : WG_LEAD) : 0;
+        sch_base[tid] = ns * nb;
+        sch_dyn[tid] = chunks - ns * nb;
+    }
+    __syncthreads();
+    // producer of ring entries: wave 8 only (all 64 lanes run it: shuffles inside)
+    int g_next = 0, g_cum = 0, g_pref = 0;                    // entries written, their stages, the pair asked first
+    bool g_end = false;
+    auto ring_put = [&](int pr, int c) {
+        const int st = c * WG_CHUNK, n = wg_stages - st < WG_CHUNK ? wg_stages - st : WG_CHUNK;
+        if (lane == 0) ring[g_next & (WG_RING - 1)] = WgChunk{pr, st, n};
+        g_cum += n;
+        ++g_next;
     };
+    auto ring_end = [&]() {
+        if (lane == 0) { ring[g_next & (WG_RING - 1)] = WgChunk{0, 0, 0}; lds_total = g_cum; }
+        ++g_next;
+        g_end = true;
+    };
+    auto grab = [&]() {                                       // the next chunk behind a counter -> ring; END when every counter has run out
+        for (int tries = 0; tries < 4096 && !g_end; ++tries) {
+            const int dyn = __builtin_amdgcn_readfirstlane(sch_dyn[g_pref]);
+            if (dyn > 0) {
+                unsigned idx = 0;
+                if (lane == 0) idx = atomicAdd(a.counters + g_pref, 1u);
+                idx = __builtin_amdgcn_readfirstlane(idx);
+                if (idx < (unsigned)dyn) { ring_put(g_pref, __builtin_amdgcn_readfirstlane(sch_base[g_pref]) + (int)idx); return; }
+            }
+            // that pair is done: look at all counters, go where most is left
+            int key = 0;
+            if (lane < n_pairs) {
+                const unsigned cnt = __hip_atomic_load(a.counters + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int left = sch_dyn[lane] - (int)(cnt < (unsigned)sch_dyn[lane] ? cnt : (unsigned)sch_dyn[lane]);
+                key = left > 0 ? (left << 8) | lane : 0;
+            }
+#pragma unroll
+            for (int o = 32; o; o >>= 1) { const int other = __shfl_xor(key, o); key = other > key ? other : key; }
+            key = __builtin_amdgcn_readfirstlane(key);
+            if (key == 0) { ring_end(); return; }
+            g_pref = key & 255;
+        }
+        if (!g_end) ring_end();                              // (not reached: 4096 lost races in a row)
+    };
+    if (wave == 8) {
+        int hp = 0;
+        for (int q = 0; q < n_pairs; ++q) hp = sch_fb[q] <= (int)blockIdx.x && (int)blockIdx.x < sch_fb[q + 1] ? q : hp;
+        hp = __builtin_amdgcn_readfirstlane(hp);
+        const int nb = __builtin_amdgcn_readfirstlane(sch_fb[hp + 1] - sch_fb[hp]), rank = (int)blockIdx.x - __builtin_amdgcn_readfirstlane(sch_fb[hp]);
+        const int ns = nb > 0 ? __builtin_amdgcn_readfirstlane(sch_base[hp]) / nb : 0;
+        g_pref = hp;
+        for (int i = 0; i < ns; ++i) ring_put(hp, rank + i * nb);                   // (ns <= WG_LEAD)
+        while (g_next < WG_LEAD && !g_end) grab();
+    }
+    __syncthreads();
+    // a cursor: chunk number j, and inside it the pair, the stage, the stages left (0 = END; pair and stage then stay on the last real stage)
+    auto cur_init = [&](WgCur& c, WgPair& q) {
+        const WgChunk e = ring[0];
+        c.j = 0;
+        c.p = __builtin_amdgcn_readfirstlane(e.p); c.st = __builtin_amdgcn_readfirstlane(e.st); c.left = __builtin_amdgcn_readfirstlane(e.n);
+        load_pair(q, c.p);
+    };
+    auto advance = [&](WgCur& c, WgPair& q) {
+        if (c.left == 0) return;
+        if (--c.left > 0) { ++c.st; return; }
+        ++c.j;
+        const WgChunk e = ring[c.j & (WG_RING - 1)];
+        const int n = __builtin_amdgcn_readfirstlane(e.n);
+        if (n > 0) {
+            const int pr = __builtin_amdgcn_readfirstlane(e.p);
+            if (pr != c.p) load_pair(q, pr);
+            c.p = pr; c.st = __builtin_amdgcn_readfirstlane(e.st);
+        }
+        c.left = n;
+    };
+    // is this the cursor's last stage before another pair (or the end)?
+    auto leaving = [&](const WgCur& c) {
+        if (c.left != 1) return false;
+        const WgChunk e = ring[(c.j + 1) & (WG_RING - 1)];
+        return __builtin_amdgcn_readfirstlane(e.n) == 0 || __builtin_amdgcn_readfirstlane(e.p) != c.p;
+    };
+    // both roles run the stage indices 0 .. (total rounded up to even) - 1, one barrier each; the bound makes every loop finite whatever the ring says
+    const int k_max = n_pairs * wg_stages + 2;
+    auto total_even = [&]() { return (__builtin_amdgcn_readfirstlane(lds_total) + 1) & ~1; };
 
     if (producer) {
         struct Regs { w_u32x4 d[8]; };
@@ -168,7 +253,10 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
         auto fetch_side = [&](auto XS, w_u32x4 (&d)[8], const WgPair& q, int stg) {
             constexpr bool xs = decltype(XS)::value;
             const int mode = xs ? q.xmode : WG_X24;
-            const char* base = reinterpret_cast<const char*>(xs ? q.X : q.G);
+            // (the descriptor came through LDS: the compiler no longer knows that its pointers are global memory, and a FLAT load counts as an LDS
+            //  access too -- every wait behind one becomes vmcnt(0) lgkmcnt(0).  Said explicitly.)
+            typedef const char __attribute__((address_space(1))) * gptr_t;
+            const gptr_t base = (gptr_t)(xs ? q.X : q.G);
             unsigned off[8];                                  // byte offsets from the uniform base (wgrad_add checks that they fit 32 bits)
             if (xs && mode == WG_XTILES) {
                 const int s0 = stg * WG_STAGE + 32 * ttile;
@@ -200,7 +288,7 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
 #if UCNERF_WGRAD_EXP & 4
                 off[e] &= 0x3ffffu;
 #endif
-                d[e] = *reinterpret_cast<const w_u32x4_a4*>(base + off[e]);
+                d[e] = *(const w_u32x4_a4 __attribute__((address_space(1)))*)(base + off[e]);
             }
         };
         w_f32x2 colsum[2] = {{0.f, 0.f}, {0.f, 0.f}};        // bias gradients of columns 4 grp .. 4 grp + 3: this thread's samples
@@ -294,16 +382,16 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
                     const float v = colsum[c >> 1][c & 1];
                     if (col < nout && v != 0.f) {
                         const bool hi = twob && col >= split;
-                        atomicAdd((hi ? gbh : gb) + (hi ? col - split : col), v);
+                        wg_atomic_add((hi ? gbh : gb) + (hi ? col - split : col), v);
                     }
                 }
             }
             colsum[0] = colsum[1] = (w_f32x2){0.f, 0.f};
         };
-        WgCur fc = {p0, st0, 0}, cv = {p0, st0, 0};          // the stage fetched next, the stage converted next
+        WgCur fc, cv;                                         // the stage fetched next, the stage converted next
         WgPair fq, cq;                                        // ... and their pairs
-        load_pair(fq, p0);
-        load_pair(cq, p0);
+        cur_init(fc, fq);
+        cur_init(cv, cq);
         // Two register sets, A and B, each a stage of this wave's operand: stage k + 2 is requested the moment stage k has left its set.  The loop's
         // trip is two stages and starts BETWEEN a conversion and the fetch that refills its set, where only the other set is in flight; every
         // wait is counted (the eight younger loads of the other set stay in flight).
@@ -315,9 +403,9 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
             };
             auto convert = [&](const Regs& r, int img) {
                 const WgPair& q = cq;
-                const bool live = cv.i < N;
+                const bool live = cv.left > 0;                // (past the end: a re-read of the last stage, converted to zeros, never multiplied)
                 convert_side(XS, r.d, q, cv.st, wg_lds + img * WG_IMG_BYTES + (xs ? WG_OP_BYTES : 0), live);
-                if (!xs && live && (cv.i == N - 1 || cv.st + 1 == wg_stages)) flush_bias(q);      // the range leaves this pair
+                if (!xs && leaving(cv)) flush_bias(q);
                 advance(cv, cq);
             };
             Regs A, B;
@@ -325,14 +413,10 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
             fetch(B);
             convert(A, 0);
             WG_T(0)
+            for (int k = 0; k < k_max && k < total_even(); k += WG_UNROLL) {
 #if UCNERF_WGRAD_STAMPS
-            unsigned long long tpair = __builtin_amdgcn_s_memtime();
-#endif
-            for (int t = 0; t < trips; ++t) {
-#if UCNERF_WGRAD_STAMPS
-#define WG_PAIR_T if (!xs && lane == 0 && cv.i < N) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (wave == 0) { atomicAdd(stamps + 32 + cv.p, n_ - tpair); atomicAdd(stamps + 48 + cv.p, 1ull); } tpair = n_; }
-                fetch(A); WG_T(1) wg_barrier(); WG_PAIR_T WG_T(2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); WG_T(3) convert(B, 1); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WG_T(4)
-                fetch(B); WG_T(1) wg_barrier(); WG_PAIR_T WG_T(2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); WG_T(3) convert(A, 0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WG_T(4)
+                fetch(A); WG_T(1) wg_barrier(); WG_T(2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); WG_T(3) convert(B, 1); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WG_T(4)
+                fetch(B); WG_T(1) wg_barrier(); WG_T(2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); WG_T(3) convert(A, 0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WG_T(4)
 #else
                 fetch(A); wg_barrier(); convert(B, 1);
                 fetch(B); wg_barrier(); convert(A, 0);
@@ -340,13 +424,13 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
             }
 #if UCNERF_WGRAD_STAMPS
             if (lane == 0) for (int k = 0; k < 5; ++k) { atomicAdd(stamps + (xs ? 16 : 0) + k, tacc[k]); atomicAdd(stamps + 2048 + 32 * (blockIdx.x & 7) + (xs ? 8 : 0) + k, tacc[k]); }
-            if (!xs && tid == 0) atomicAdd(stamps + 2048 + 32 * (blockIdx.x & 7) + 30, (unsigned long long)N);
-            if (tid == 0) {
-                const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)), hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
-                stamps[64 + 4 * blockIdx.x] = (unsigned long long)N | ((unsigned long long)xcc << 32) | ((unsigned long long)(hw & 0xffff00u) << 24);
-                stamps[65 + 4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - tstart; stamps[66 + 4 * blockIdx.x] = rstart; stamps[67 + 4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+            if (!xs && tid == 0) {
+                const unsigned long long n_ = (unsigned long long)lds_total;
+                atomicAdd(stamps + 2048 + 32 * (blockIdx.x & 7) + 30, n_);
+                atomicAdd(stamps + 12, n_);
+                stamps[64 + 4 * blockIdx.x] = n_; stamps[65 + 4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - tstart;
+                stamps[66 + 4 * blockIdx.x] = rstart; stamps[67 + 4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
             }
-            if (tid == 0) { atomicAdd(stamps + 12, (unsigned long long)N); atomicMax(stamps + 13, tacc[0] + tacc[1] + tacc[2] + tacc[3] + tacc[4]); atomicMin(stamps + 14, tacc[0] + tacc[1] + tacc[2] + tacc[3] + tacc[4]); }
 #endif
         };
         if (wave < 4) run(std::false_type{});
@@ -412,7 +496,7 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
                         if (n < nout && k < w) {
                             const bool hi = two && n >= split;
                             float* base = hi ? gWh : gW;
-                            atomicAdd(base + (size_t)(hi ? n - split : n) * ldw + k, acc[kt][r]);
+                            wg_atomic_add(base + (size_t)(hi ? n - split : n) * ldw + k, acc[kt][r]);
                         }
                     }
                 }
@@ -421,19 +505,22 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
         zero();
     };
     zero();
-    WgCur mu = {p0, st0, 0};                                  // the stage multiplied next
+    WgCur mu;                                                 // the stage multiplied next
     WgPair mq;
-    load_pair(mq, p0);
-    for (int k = 0; k < trips * WG_UNROLL; ++k) {
-        WG_T(0)
-        wg_barrier();                                        // image k & 1 holds stage k; everyone is done with the other one
-        WG_T(1)
-        if (k < N) {
-            const WgPair& q = mq;
-            multiply(q, k & 1);
-            WG_T(2)
-            if (k == N - 1 || mu.st + 1 == wg_stages) flush(q);
-            WG_T(3)
+    cur_init(mu, mq);
+    for (int k = 0; k < k_max && k < total_even(); k += WG_UNROLL) {
+#pragma unroll
+        for (int h = 0; h < WG_UNROLL; ++h) {
+            if (wave == 8) while (!g_end && g_next < mu.j + 1 + WG_LEAD) grab();      // (before the barrier: visible to every wave from this stage index on)
+            WG_T(0)
+            wg_barrier();                                    // image h holds stage k + h; everyone is done with the other one
+            WG_T(1)
+            if (mu.left > 0) {
+                multiply(mq, h);
+                WG_T(2)
+                if (leaving(mu)) flush(mq);
+                WG_T(3)
+            }
             advance(mu, mq);
         }
     }
@@ -443,7 +530,7 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
 }
 
 // ---- host side: the pair list is built by ucnerf_mlp_bwd (mlp_bwd.hip)
-void wgrad_begin(WgArgs* a, int m) { memset(a, 0, sizeof(*a)); a->m = m; a->stages = cdiv(m, WG_STAGE); }
+void wgrad_begin(WgArgs* a, int m, unsigned* counters) { memset(a, 0, sizeof(*a)); a->m = m; a->stages = cdiv(m, WG_STAGE); a->counters = counters; }
 
 int wgrad_add(WgArgs* a, const void* G, int ldg_bytes, int nout, const void* X, int x24, int ldx, int xdiv, int wd, float* gW, int ldw, float* gb, float* gW_hi,
               float* gb_hi, int split, int xtile_f) {
@@ -477,7 +564,9 @@ int wgrad_launch(const WgArgs* a, hipStream_t st) {
     if (a->n_pairs == 0 || a->m <= 0) return UCNERF_OK;
     const int cus = device_cus();
     if (cus <= 0) return fail(UCNERF_EHIP, "mlp_bwd: no device");
-    long long units = (long long)a->n_pairs * a->stages;
+    if (!a->counters) return fail(UCNERF_EINVAL, "mlp_bwd: the weight-gradient launch needs its chunk counters");
+    long long units = (long long)a->n_pairs * cdiv(a->stages, WG_CHUNK);
+    if (hipMemsetAsync(a->counters, 0, WG_MAX_PAIRS * sizeof(unsigned), st) != hipSuccess) return fail(UCNERF_EHIP, "mlp_bwd: clearing the chunk counters failed");
     int blocks = cus;                                        // one block per CU (128 KB of LDS)
     if (blocks > units) blocks = (int)units;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_wgrad_kernel), WG_LDS_BYTES, "mlp_bwd wgrad")) return rc;
@@ -499,7 +588,7 @@ int wgrad_launch(const WgArgs* a, hipStream_t st) {
     {
         unsigned long long t0 = ~0ull;
         for (int b = 0; b < blocks; ++b) t0 = h[66 + 4 * b] < t0 ? h[66 + 4 * b] : t0;
-        fprintf(stderr, "wgrad stamps, per block (N, first pair, start, end; cycles from the first start):");
+        fprintf(stderr, "wgrad stamps, per block (stages, cycles, start, end in 10-ns ticks from the first start):");
         for (int b = 0; b < blocks; ++b) fprintf(stderr, " %d:%d,%d,%llu,%llu,%d,%d", b, (int)(h[64 + 4 * b] & 0xffffffffu), (int)h[65 + 4 * b], h[66 + 4 * b] - t0, h[67 + 4 * b] - t0, (int)((h[64 + 4 * b] >> 32) & 15), (int)(h[64 + 4 * b] >> 40));
         fprintf(stderr, "\n");
     }
@@ -509,9 +598,6 @@ int wgrad_launch(const WgArgs* a, hipStream_t st) {
         fprintf(stderr, "wgrad stamps, blockIdx %% 8 = %d (cycles per stage and wave): G fetch %.0f barrier %.0f wait %.0f convert %.0f | X fetch %.0f barrier %.0f wait %.0f convert %.0f | consumer barrier %.0f multiply %.0f flush %.0f\n",
                 x, q[1] / w, q[2] / w, q[3] / w, q[4] / w, q[9] / w, q[10] / w, q[11] / w, q[12] / w, q[17] / w, q[18] / w, q[19] / w);
     }
-    fprintf(stderr, "wgrad stamps, cycles per stage by pair (nout x w, X format, cost):");
-    for (int i = 0; i < a->n_pairs; ++i) fprintf(stderr, "  [%d x %d, %d, %d] %.0f", a->p[i].nout, a->p[i].w, a->p[i].xmode, a->p[i].cost, h[48 + i] ? (double)h[32 + i] / h[48 + i] : 0.0);
-    fprintf(stderr, "\n");
 #else
     hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(blocks), dim3(WG_THREADS), WG_LDS_BYTES, st, *a);
 #endif
