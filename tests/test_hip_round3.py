@@ -186,11 +186,16 @@ def test_given_coordinates_through_the_gather_fused_kernel_match_the_reference_f
 
 
 # ---------------------------------------------------------------------------------------------- the two backward modes
-def test_backward_modes_agree(sd_v7):
+@pytest.mark.parametrize("m", [10, 70, 640, 650, 5000, 20480, 45060])
+def test_backward_modes_agree(sd_v7, m):
+    """The one-launch backward (gradient chain + weight-gradient launch, bwd_mode 0) against the layer-by-layer backward (bwd_mode 1).  The sizes walk
+    the weight-gradient launch's scheduler through its corners: one stage per pair (fewer chunks than the look-ahead, END found before the first
+    barrier), a ragged last stage, fewer chunks than blocks, more blocks homed on a pair than it has chunks, and a size where the counters do
+    most of the hand-out."""
     from uc_nerf_amd import ops
     from uc_nerf_amd.pipeline import flat_params_of as flat_params
     gen = torch.Generator().manual_seed(12)
-    m, S, F = 5000, 10, 97
+    S, F = 10, 97
     pts, feats = torch.rand(m, 3, generator=gen), torch.randn(m, F, generator=gen)
     feats[:, -1] = torch.rand(m, generator=gen)
     dirs = torch.nn.functional.normalize(torch.randn(m // S, 3, generator=gen), dim=-1)
