@@ -146,9 +146,15 @@ static void run_geometry(const char* buf, size_t bytes, unsigned* out, int cus, 
 }
 
 // every byte of the buffer rewritten (what the forward and the gradient chain do to the sets before the weight-gradient launch reads them)
+template <int NT>
 __global__ void __launch_bounds__(256) rewrite_kernel(u32x4* buf, size_t n16, unsigned v) {
-    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) buf[i] = (u32x4){v, v + 1, v + 2, v + 3};
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const u32x4 x = (u32x4){v, v + 1, v + 2, v + 3};
+        if (NT) __builtin_nontemporal_store(x, buf + i);
+        else buf[i] = x;
+    }
 }
+template <int NT>
 static void run_geometry_after_rewrite(char* buf, size_t bytes, unsigned* out, int cus) {
     static unsigned long long* dur = nullptr;
     if (!dur) hipMalloc(&dur, 4096 * 8);
@@ -156,10 +162,14 @@ static void run_geometry_after_rewrite(char* buf, size_t bytes, unsigned* out, i
     const size_t spacing = (size_t)m * 384 + 384, used = (size_t)2 * pairs * spacing;
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    float tot = 0;
+    float tot = 0, wtot = 0;
     const int reps = 5;
     for (int w = 0; w < reps + 1; ++w) {
-        hipLaunchKernelGGL(rewrite_kernel, dim3(cus * 8), dim3(256), 0, 0, (u32x4*)buf, used / 16, (unsigned)w);
+        hipEvent_t c, d;
+        hipEventCreate(&c); hipEventCreate(&d);
+        hipEventRecord(c, 0);
+        hipLaunchKernelGGL(rewrite_kernel<NT>, dim3(cus * 8), dim3(256), 0, 0, (u32x4*)buf, used / 16, (unsigned)w);
+        hipEventRecord(d, 0);
         hipEventRecord(a, 0);
         hipLaunchKernelGGL(geometry_kernel, dim3(cus), dim3(512), 0, 0, buf, pairs, stages, spacing, out, dur);
         hipEventRecord(b, 0);
@@ -167,9 +177,12 @@ static void run_geometry_after_rewrite(char* buf, size_t bytes, unsigned* out, i
         float ms = 0;
         hipEventElapsedTime(&ms, a, b);
         if (w) tot += ms;
+        hipEventElapsedTime(&ms, c, d);
+        if (w) wtot += ms;
     }
     const double us = tot * 1e3 / reps, useful = (double)pairs * 2 * m * 384;
-    printf("geometry right after every byte was rewritten by another kernel, 1 block per CU: %8.1f us  %5.2f TB/s\n", us, useful / (us * 1e-6) / 1e12);
+    printf("geometry right after every byte was rewritten by another kernel (%s stores: %.1f us, %.2f TB/s), 1 block per CU: %8.1f us  %5.2f TB/s\n", NT ? "non-temporal" : "plain",
+           wtot * 1e3 / reps, (double)used / (wtot * 1e-3 / reps) / 1e12, us, useful / (us * 1e-6) / 1e12);
 }
 
 int main() {
@@ -197,6 +210,8 @@ int main() {
         run_geometry(buf, bytes, out, cus, set + 4096 + 384, bpc);
         run_geometry(buf, bytes, out, cus, set + (1 << 20) + 12288, bpc);
     }
-    run_geometry_after_rewrite(buf, bytes, out, cus);
+    run_geometry_after_rewrite<0>(buf, bytes, out, cus);
+    run_geometry_after_rewrite<1>(buf, bytes, out, cus);
+    run_geometry_after_rewrite<0>(buf, bytes, out, cus);
     return 0;
 }

@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported_and_bound(L):
 # FOOT_UNDER_GEMM, GATHER_RUN) is an experiment and must read 0
 PRODUCTION_FLAGS = {"UCNERF_BF16_BW": "8", "UCNERF_BF16_NBUF": "4", "UCNERF_BF16_WPS": "2", "UCNERF_BF16_HINT_V": "5", "UCNERF_BF16_IDLE_SKIP": "1",
                     "UCNERF_BF16_WAVE_MAJOR": "1", "UCNERF_MLP_WAVES": "8", "UCNERF_MLP_PRIO": "3", "UCNERF_MLP_RING": "4", "UCNERF_TN_BF16X3": "1",
-                    "UCNERF_TN_DEPTH2": "2", "UCNERF_GATHER_WAVES": "1", "UCNERF_CHAIN_WAVES": "4"}
+                    "UCNERF_TN_DEPTH2": "2", "UCNERF_GATHER_WAVES": "1", "UCNERF_CHAIN_WAVES": "4", "UCNERF_MLP_SAVE_NT": "1"}
 
 
 def test_library_was_built_with_production_switches(L):

@@ -321,6 +321,10 @@ __device__ __forceinline__ void load_encoded(const float* __restrict__ row, int 
 // Wave priority: the short VALU phases (encodings, epilogues, heads) run at high priority so that the partner
 // wave's back-to-back MFMAs (which otherwise hold the SIMD's vector issue almost continuously: measured ~100
 // cycles per VALU instruction, 35-65k cycles per phase) cannot stretch them; GEMM sections run at priority 0.
+#ifndef UCNERF_MLP_SAVE_NT
+#define UCNERF_MLP_SAVE_NT 1     // the kept 24-bit sets leave with non-temporal stores (whole 64-byte sectors per row here): the gradient chain reads them
+                                 // back 15-20 us faster per 131 k samples than sets left dirty in the caches (this launch +7 us); 0 = plain stores (A/B)
+#endif
 #ifndef UCNERF_MLP_PRIO
 #define UCNERF_MLP_PRIO 3
 #endif
@@ -370,7 +374,11 @@ __device__ __forceinline__ void save_rows(float* buf, int s, int h, bool valid, 
                 const int c = k * 64 + lane;                          // 16-byte chunk of the half set: row c / 12, chunk c % 12 of its 192 bytes
                 const int row = (c * 2731) >> 15, within = c - 12 * row;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(xbuf + row * XPOSE_ROW + 16 * within);
+#if UCNERF_MLP_SAVE_NT
+                if (row < rows) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(gtile + row * P24_ROW_BYTES + 192 * half + 16 * within));
+#else
                 if (row < rows) *reinterpret_cast<f32x4*>(gtile + row * P24_ROW_BYTES + 192 * half + 16 * within) = v;
+#endif
             }
         }
         return;
@@ -656,7 +664,7 @@ int launch_mlp_fwd_bf16_plain(const ucnerf_mlp_params* p, hipStream_t st);   // 
 #else
 #define UCNERF_MLP_DIAG_ON 0
 #endif
-const char* build_flags_mlp_f32() { return "mlp_f32: " UCNERF_FLAG(UCNERF_MLP_WAVES) UCNERF_FLAG(UCNERF_MLP_PRIO) UCNERF_FLAG(UCNERF_MLP_RING) UCNERF_FLAG(UCNERF_MLP_DIAG_ON); }
+const char* build_flags_mlp_f32() { return "mlp_f32: " UCNERF_FLAG(UCNERF_MLP_WAVES) UCNERF_FLAG(UCNERF_MLP_PRIO) UCNERF_FLAG(UCNERF_MLP_RING) UCNERF_FLAG(UCNERF_MLP_SAVE_NT) UCNERF_FLAG(UCNERF_MLP_DIAG_ON); }
 
 }  // namespace ucnerf
 
