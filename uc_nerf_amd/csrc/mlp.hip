@@ -321,6 +321,9 @@ __device__ __forceinline__ void load_encoded(const float* __restrict__ row, int 
 // Wave priority: the short VALU phases (encodings, epilogues, heads) run at high priority so that the partner
 // wave's back-to-back MFMAs (which otherwise hold the SIMD's vector issue almost continuously: measured ~100
 // cycles per VALU instruction, 35-65k cycles per phase) cannot stretch them; GEMM sections run at priority 0.
+#ifndef UCNERF_MLP_SAVE_EXP
+#define UCNERF_MLP_SAVE_EXP 0    // timing experiments (wrong results): 1 = the kept sets are packed and transposed but not stored; 2 = not even packed; 4 = packed and written to LDS, not read back
+#endif
 #ifndef UCNERF_MLP_SAVE_NT
 #define UCNERF_MLP_SAVE_NT 1     // the kept 24-bit sets leave with non-temporal stores (whole 64-byte sectors per row here): the gradient chain reads them
                                  // back 15-20 us faster per 131 k samples than sets left dirty in the caches (this launch +7 us); 0 = plain stores (A/B)
@@ -353,6 +356,9 @@ constexpr int XPOSE_BYTES = 32 * XPOSE_ROW;
 template <bool P24>
 __device__ __forceinline__ void save_rows(float* buf, int s, int h, bool valid, const f32x16 (&x)[4], char* xbuf = nullptr, int lane = 0, int tile = 0, int m = 0) {
     if (P24) {
+#if UCNERF_MLP_SAVE_EXP & 2
+        return;
+#endif
         asm volatile("" : "+v"(lane));                // (the chunk addresses below do not depend on the tile: unlaundered they are hoisted out of the tile loop -- 24 registers for the whole kernel)
         const int j = lane & 31;
         char* const gtile = reinterpret_cast<char*>(buf) + (size_t)tile * 32 * P24_ROW_BYTES;
@@ -368,13 +374,18 @@ __device__ __forceinline__ void save_rows(float* buf, int s, int h, bool valid, 
                     *reinterpret_cast<p24_u32x3_a4*>(xbuf + j * XPOSE_ROW + 12 * (8 * t + 2 * q + h)) = (p24_u32x3){pc.d[0], pc.d[1], pc.d[2]};
                 }
             // (LDS operations of a wave execute in order: the reads below see the writes above, and the next half's writes come after these reads)
+#if UCNERF_MLP_SAVE_EXP & 4
+            if (lane >= 0) continue;
+#endif
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 __builtin_amdgcn_sched_barrier(0);                    // (one chunk at a time: four registers, not twenty-four)
                 const int c = k * 64 + lane;                          // 16-byte chunk of the half set: row c / 12, chunk c % 12 of its 192 bytes
                 const int row = (c * 2731) >> 15, within = c - 12 * row;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(xbuf + row * XPOSE_ROW + 16 * within);
-#if UCNERF_MLP_SAVE_NT
+#if UCNERF_MLP_SAVE_EXP & 1
+                if (row < rows && v.x == 12345.678f) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(gtile + row * P24_ROW_BYTES + 192 * half + 16 * within));
+#elif UCNERF_MLP_SAVE_NT
                 if (row < rows) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(gtile + row * P24_ROW_BYTES + 192 * half + 16 * within));
 #else
                 if (row < rows) *reinterpret_cast<f32x4*>(gtile + row * P24_ROW_BYTES + 192 * half + 16 * within) = v;
@@ -664,7 +675,7 @@ int launch_mlp_fwd_bf16_plain(const ucnerf_mlp_params* p, hipStream_t st);   // 
 #else
 #define UCNERF_MLP_DIAG_ON 0
 #endif
-const char* build_flags_mlp_f32() { return "mlp_f32: " UCNERF_FLAG(UCNERF_MLP_WAVES) UCNERF_FLAG(UCNERF_MLP_PRIO) UCNERF_FLAG(UCNERF_MLP_RING) UCNERF_FLAG(UCNERF_MLP_SAVE_NT) UCNERF_FLAG(UCNERF_MLP_DIAG_ON); }
+const char* build_flags_mlp_f32() { return "mlp_f32: " UCNERF_FLAG(UCNERF_MLP_WAVES) UCNERF_FLAG(UCNERF_MLP_PRIO) UCNERF_FLAG(UCNERF_MLP_RING) UCNERF_FLAG(UCNERF_MLP_SAVE_NT) UCNERF_FLAG(UCNERF_MLP_SAVE_EXP) UCNERF_FLAG(UCNERF_MLP_DIAG_ON); }
 
 }  // namespace ucnerf
 
