@@ -183,7 +183,8 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
         g_end = true;
     };
     auto grab = [&]() {                                       // the next chunk behind a counter -> ring; END when every counter has run out
-        for (int tries = 0; tries < 4096 && !g_end; ++tries) {
+        // (every lost race is a chunk somebody else took: the bound cannot be reached while chunks are left; it makes the loop finite whatever memory says)
+        for (int tries = 0; tries < 2 * n_pairs * chunks + 64 && !g_end; ++tries) {
             const int dyn = __builtin_amdgcn_readfirstlane(sch_dyn[g_pref]);
             if (dyn > 0) {
                 unsigned idx = 0;
@@ -204,7 +205,7 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
             if (key == 0) { ring_end(); return; }
             g_pref = key & 255;
         }
-        if (!g_end) ring_end();                              // (not reached: 4096 lost races in a row)
+        if (!g_end) ring_end();                              // (not reached)
     };
     if (wave == 8) {
         int hp = 0;
