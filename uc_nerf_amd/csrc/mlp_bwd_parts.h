@@ -32,6 +32,7 @@ struct WgArgs {
     WgPair p[WG_MAX_PAIRS];
     long long prefix[WG_MAX_PAIRS + 1];   // cumulative cost: pair i covers [prefix[i], prefix[i + 1]) = stages * cost_i
     int n_pairs, m, stages;
+    int chunk;                            // stages per chunk of the hand-out (set by wgrad_launch)
     unsigned* counters;                   // WG_MAX_PAIRS counters in global memory, zeroed by wgrad_launch: the next chunk of every pair (mlp_wgrad.hip)
 };
 void wgrad_begin(WgArgs* a, int m, unsigned* counters);

@@ -18,7 +18,7 @@
 //     16-byte pieces of rows or of the MLP tile layout;
 //   * products are hi*hi + hi*lo + lo*hi on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate: the forward's bf16x3
 //     scheme, 2^-16 relative);
-//   * the launch is persistent over all pairs and hands its work out as it runs: chunks of eight stages through one counter per pair
+//   * the launch is persistent over all pairs and hands its work out as it runs: chunks of 2-16 stages through one counter per pair
 //     (see "the block's work" in the kernel); a block stays on one pair as long as that pair has chunks, and the consumers flush their
 //     128 x 128 partial sum with float atomics on 128-byte row segments only when the block moves to another pair.
 // What bounds it (in-kernel stamps of the diagnostic build, scripts/micro/load_shapes.hip, profiles/r03_experiments.md): the loads are never
@@ -78,7 +78,7 @@ constexpr int WG_UNROLL = 2;                                  // stages per trip
 enum { WG_X24 = 0, WG_XROWS = 1, WG_XTILES = 2 };
 struct WgCur { int j, p, st, left; };                         // a stage of the block's work: chunk number, pair, stage of the pair, stages left in the chunk (0 = END)
 struct WgChunk { int p, st, n; };                             // ring entry: pair, first stage, stages (0 = END)
-constexpr int WG_CHUNK = 8;                                   // stages per chunk
+constexpr int WG_CHUNK_MAX = 16;                              // stages per chunk: chosen per launch (wgrad_launch), 2 .. 16: 16 at the bench's sizes (4: +8 %, 8: +2 %, 32: +1.5 %)
 constexpr int WG_RING = 8, WG_LEAD = 4;                       // ring entries; chunks asked for ahead of the one being multiplied (>= 4: chunks may be one stage long)
 // float atomic add on a pointer SAID to be global memory (the descriptors travel through LDS: a generic pointer would make it a FLAT atomic, and
 // every later wait of the wave vmcnt(0) lgkmcnt(0))
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
         for (int i = 0; i < words; ++i) w[i] = __builtin_amdgcn_readfirstlane(src[i]);
         __builtin_memcpy(&q, w, sizeof(WgPair));
     };
-    // ---- the block's work: a sequence of CHUNKS (WG_CHUNK consecutive stages of one pair), decided as the launch runs.
+    // ---- the block's work: a sequence of CHUNKS (a.chunk consecutive stages of one pair), decided as the launch runs.
     // With a static split (equal modelled cost per block: rounds 1-3) the blocks finished between 0.6 and 1.3 of the mean: under this launch
     // a stage took 2.1 us on four of the eight XCDs and 3.3 us on the other four (which four changed from box to box; in-kernel stamps,
     // profiles/r03_experiments.md), and the split leaned on a cost model fitted to one kernel version.  Handing the work out as it is done
@@ -154,7 +154,8 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
     __shared__ int lds_total;                                 // stages of this block, once its END is known (a huge number before)
     __shared__ int sch_fb[WG_MAX_PAIRS + 1], sch_base[WG_MAX_PAIRS], sch_dyn[WG_MAX_PAIRS];      // first home block of a pair; chunks owned statically; chunks behind the counter
     const int n_pairs = __builtin_amdgcn_readfirstlane(a.n_pairs);
-    const int chunks = (wg_stages + WG_CHUNK - 1) / WG_CHUNK;
+    const int wg_chunk = __builtin_amdgcn_readfirstlane(a.chunk);
+    const int chunks = (wg_stages + wg_chunk - 1) / wg_chunk;
     if (tid <= n_pairs) {
         const long long total = a.prefix[n_pairs];
         sch_fb[tid] = tid == n_pairs ? (int)gridDim.x : (int)((a.prefix[tid] * (long long)gridDim.x + total - 1) / total);      // blocks b with prefix[p] <= total b / grid
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
     int g_next = 0, g_cum = 0, g_pref = 0;                    // entries written, their stages, the pair asked first
     bool g_end = false;
     auto ring_put = [&](int pr, int c) {
-        const int st = c * WG_CHUNK, n = wg_stages - st < WG_CHUNK ? wg_stages - st : WG_CHUNK;
+        const int st = c * wg_chunk, n = wg_stages - st < wg_chunk ? wg_stages - st : wg_chunk;
         if (lane == 0) ring[g_next & (WG_RING - 1)] = WgChunk{pr, st, n};
         g_cum += n;
         ++g_next;
@@ -566,7 +567,14 @@ int wgrad_launch(const WgArgs* a, hipStream_t st) {
     const int cus = device_cus();
     if (cus <= 0) return fail(UCNERF_EHIP, "mlp_bwd: no device");
     if (!a->counters) return fail(UCNERF_EINVAL, "mlp_bwd: the weight-gradient launch needs its chunk counters");
-    long long units = (long long)a->n_pairs * cdiv(a->stages, WG_CHUNK);
+    // chunk length: about eight chunks per block, 2 .. WG_CHUNK_MAX stages (the kernel reads it from the arguments)
+    WgArgs args = *a;
+    {
+        long long c = (long long)a->n_pairs * a->stages / (8ll * cus);
+        args.chunk = (int)(c < 2 ? 2 : c > WG_CHUNK_MAX ? WG_CHUNK_MAX : c);
+    }
+    a = &args;
+    long long units = (long long)a->n_pairs * cdiv(a->stages, a->chunk);
     if (hipMemsetAsync(a->counters, 0, WG_MAX_PAIRS * sizeof(unsigned), st) != hipSuccess) return fail(UCNERF_EHIP, "mlp_bwd: clearing the chunk counters failed");
     int blocks = cus;                                        // one block per CU (128 KB of LDS)
     if (blocks > units) blocks = (int)units;
