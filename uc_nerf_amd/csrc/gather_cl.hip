@@ -9,10 +9,6 @@
 #include "common.h"
 #include "gather_cl_device.h"
 
-#ifndef UCNERF_REPACK_NT
-#define UCNERF_REPACK_NT 0
-#endif
-#define REPACK_NT_STORE(v, p) { const float4 v_ = (v); typedef float nt_f4 __attribute__((ext_vector_type(4))); __builtin_nontemporal_store((nt_f4){v_.x, v_.y, v_.z, v_.w}, reinterpret_cast<nt_f4*>(p)); }
 namespace ucnerf {
 
 // ------------------------------------------------------------------------------------------------ repack
@@ -45,13 +41,8 @@ __global__ void __launch_bounds__(256) repack_sources_kernel(RepackArgs a) {
         if (S16) {
             reinterpret_cast<uint4*>(a.vol_dst[k])[i] = make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]), pack_bf16x2(c[6], c[7]));
         } else {
-#if UCNERF_REPACK_NT
-            REPACK_NT_STORE(make_float4(c[0], c[1], c[2], c[3]), &a.vol_dst[k][2 * i])
-            REPACK_NT_STORE(make_float4(c[4], c[5], c[6], c[7]), &a.vol_dst[k][2 * i + 1])
-#else
             a.vol_dst[k][2 * i] = make_float4(c[0], c[1], c[2], c[3]);
             a.vol_dst[k][2 * i + 1] = make_float4(c[4], c[5], c[6], c[7]);
-#endif
         }
     } else {
         const size_t hw = a.hw;
@@ -65,15 +56,9 @@ __global__ void __launch_bounds__(256) repack_sources_kernel(RepackArgs a) {
             d[1] = make_uint2(pack_bf16x2(ft[hw], ft[2 * hw]), pack_bf16x2(ft[3 * hw], ft[4 * hw]));
             d[2] = make_uint2(pack_bf16x2(ft[5 * hw], ft[6 * hw]), pack_bf16x2(ft[7 * hw], 0.f));
         } else {
-#if UCNERF_REPACK_NT
-            REPACK_NT_STORE(make_float4(im[0], im[hw], im[2 * hw], ft[0]), &a.img_dst[3 * i])
-            REPACK_NT_STORE(make_float4(ft[hw], ft[2 * hw], ft[3 * hw], ft[4 * hw]), &a.img_dst[3 * i + 1])
-            REPACK_NT_STORE(make_float4(ft[5 * hw], ft[6 * hw], ft[7 * hw], 0.f), &a.img_dst[3 * i + 2])
-#else
             a.img_dst[3 * i] = make_float4(im[0], im[hw], im[2 * hw], ft[0]);
             a.img_dst[3 * i + 1] = make_float4(ft[hw], ft[2 * hw], ft[3 * hw], ft[4 * hw]);
             a.img_dst[3 * i + 2] = make_float4(ft[5 * hw], ft[6 * hw], ft[7 * hw], 0.f);
-#endif
         }
     }
 }
