@@ -192,6 +192,54 @@ static void run_geometry_after_rewrite(char* buf, size_t bytes, unsigned* out, i
            wtot * 1e3 / reps, (double)used / (wtot * 1e-3 / reps) / 1e12, us, useful / (us * 1e-6) / 1e12);
 }
 
+// The gradient chain's memory side alone: one wave per SIMD (4-wave blocks, one per CU), a wave walks 32-sample tiles; per tile it reads NR sets
+// and writes NW sets of [m,128] 24-bit rows the way the chain does -- lane (sample j, half h) moves the 12-byte piece of column group 2 q + h of
+// its own row, sixteen instructions per set -- with nothing else to do.  Reads and writes go to different sets.
+template <int NR, int NW, int TILED>
+__global__ void __launch_bounds__(256, 1) chain_traffic_kernel(char* __restrict__ base, int n_tiles, size_t spacing, unsigned* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    unsigned acc = 0;
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        // rows: the lane's own row, piece 2 q + h;  TILED: [tile][group 2 q + h][sample j][12 bytes] -- 768 contiguous bytes per instruction
+        const size_t row = TILED ? (size_t)tile * 32 * 384 + (size_t)h * 384 + 12 * j : ((size_t)tile * 32 + j) * 384 + 12 * h;
+        constexpr int QS = TILED ? 768 : 24;
+#pragma unroll 1
+        for (int s = 0; s < NR; ++s) {
+            const char* set = base + (size_t)s * spacing + row;
+            u32x3 v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = *reinterpret_cast<const u32x3_a4*>(set + QS * q);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc ^= v[q][0] ^ v[q][1] ^ v[q][2];
+        }
+#pragma unroll 1
+        for (int s = 0; s < NW; ++s) {
+            char* set = base + (size_t)(NR + s) * spacing + row;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) *reinterpret_cast<u32x3_a4*>(set + QS * q) = (u32x3){acc + q, acc ^ (unsigned)s, acc};
+        }
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+template <int NR, int NW, int TILED>
+static void run_chain_traffic(char* buf, size_t bytes, unsigned* out, int cus) {
+    const int m = 131072, n_tiles = m / 32;
+    const size_t spacing = (size_t)m * 384 + 384;
+    if ((size_t)(NR + NW) * spacing > bytes) { printf("buffer too small\n"); return; }
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL((chain_traffic_kernel<NR, NW, TILED>), dim3(cus), dim3(256), 0, 0, buf, n_tiles, spacing, out);
+    hipEventRecord(a, 0);
+    const int reps = 5;
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL((chain_traffic_kernel<NR, NW, TILED>), dim3(cus), dim3(256), 0, 0, buf, n_tiles, spacing, out);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    const double us = ms * 1e3 / reps, moved = (double)(NR + NW) * m * 384;
+    printf("gradient chain's traffic alone (one wave per SIMD, %s): %d sets read, %d written: %8.1f us  %5.2f TB/s\n", TILED ? "tiled sets: 768 contiguous bytes per instruction" : "12-byte pieces of the lane's own row", NR, NW, us, moved / (us * 1e-6) / 1e12);
+}
+
 int main() {
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
@@ -221,5 +269,11 @@ int main() {
     run_geometry_after_rewrite<1, 0>(buf, bytes, out, cus);
     run_geometry_after_rewrite<0, 60000>(buf, bytes, out, cus);
     run_geometry_after_rewrite<0, 0>(buf, bytes, out, cus);
+    run_chain_traffic<9, 0, 0>(buf, bytes, out, cus);
+    run_chain_traffic<0, 12, 0>(buf, bytes, out, cus);
+    run_chain_traffic<9, 12, 0>(buf, bytes, out, cus);
+    run_chain_traffic<9, 0, 1>(buf, bytes, out, cus);
+    run_chain_traffic<0, 12, 1>(buf, bytes, out, cus);
+    run_chain_traffic<9, 12, 1>(buf, bytes, out, cus);
     return 0;
 }
