@@ -487,7 +487,15 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
         float* const gWh = q.gW_hi ? q.gW_hi : q.gW;
         const int split = q.split, ldw = q.ldw, nout = q.nout, w = q.w;
         const bool two = q.gW_hi != nullptr;
-        if (32 * nt < nout) {
+        if (nout == 128 && w == 128 && (!two || (split & 31) == 0)) {
+            // a whole 128 x 128 product (two thirds of all flushes): 64 atomics back to back, no per-element test (each test was a branch
+            // around its atomic); a wave's 32 rows lie on one side of a split that is a multiple of 32
+            float* const row0 = (two && 32 * nt >= split ? gWh + (size_t)(32 * nt - split) * ldw : gW + (size_t)(32 * nt) * ldw) + (size_t)(4 * hh) * ldw + i;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) wg_atomic_add(row0 + (size_t)((r & 3) + 8 * (r >> 2)) * ldw + 32 * kt, acc[kt][r]);
+        } else if (32 * nt < nout) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 const int k = 32 * kt + i;
