@@ -296,7 +296,9 @@ typedef struct {
     float* g_feats;            /* [m,F] out, rows g_feat_stride floats apart (every one of the F columns written) */
     int32_t g_feat_stride;     /* 0 = F */
     float* g_flat;             /* [param_count] accumulated */
-    float* workspace;          /* scratch, ucnerf_mlp_bwd_workspace_floats() floats, 16-byte aligned */
+    float* workspace;          /* scratch, ucnerf_mlp_bwd_workspace_floats() floats, 16-byte aligned (kept activations, gradient sets, and --
+                                  bwd_mode 0 -- the weight-gradient launch's 16 chunk counters, which the call zeroes itself: one workspace per
+                                  call in flight) */
     int32_t saved_valid;       /* 1: `workspace` already holds the activations of THIS forward, written by
                                   ucnerf_mlp_fwd_train with the same arguments -- the backward then skips its own forward */
     int32_t bwd_mode;          /* 0: register-resident gradient chain (ONE kernel walks the network backwards per 32-sample tile, data
