@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UCNERF_ABI_VERSION 3
+#define UCNERF_ABI_VERSION 4
 
 #define UCNERF_OK 0
 #define UCNERF_EINVAL (-1)   /* bad argument (null pointer, unsupported size/config) */
@@ -377,6 +377,13 @@ typedef struct {
 } ucnerf_sample_pdf_params;
 int ucnerf_sample_pdf(const ucnerf_sample_pdf_params* p, void* stream);
 
+/* a9 of the coarse pass + a8 in ONE launch -- network/renderer.py:109-140 followed by data/ray_utils.py:216-219, as the hierarchical renderer
+ * chains them (data/ray_utils.py:199-224): the wave that composites a ray re-samples it from the weights it has just computed.  `c` is the
+ * compositing call (live variant, no uncertainty inputs), `s` the re-sampling in its from_coarse form with n == c->n, n_merge == c->S,
+ * n_bins == c->S - 1; s->weights is ignored (the composite's weights, also written to c->weights when that is non-NULL) and s->z_merge, when
+ * given, must equal c->z.  Results are those of ucnerf_composite_fwd(c) followed by ucnerf_sample_pdf(s with weights = c->weights), bit for bit. */
+int ucnerf_composite_sample_pdf(const ucnerf_composite_params* c, const ucnerf_sample_pdf_params* s, void* stream);
+
 /* Applies the permutation of a sorted merge to per-sample rows: out[r][rank[r][i]] = cat(a[r], b[r])[i].
  * Lets the fine pass of the hierarchical renderer (data/ray_utils.py:199-224) evaluate the network on the NEW depths
  * only and take the coarse depths' outputs from the coarse pass: the merged rows are bit-identical to re-evaluating
@@ -512,6 +519,16 @@ typedef struct {
                                   accumulates source gradients in fp32 as before.  With cfg.precision == 3: derived coordinates only */
     int32_t train_bwd_mode;    /* with train_workspace: the bwd_mode of the coming ucnerf_render_fused_bwd call (it fixes the format the
                                   activations are kept in, see ucnerf_mlp_fwd_train) */
+    /* ABI v4: the launches around a coarse pass folded into it (data/ray_utils.py:199-224 chains them; at 512 rays per GPU each ~5-us launch
+     * is 4 % of the step) */
+    const ucnerf_sample_pdf_params* resample;   /* optional (HOST pointer): the pass's compositing launch also draws the NEXT pass's depths from its
+                                  weights -- ucnerf_composite_sample_pdf(this pass's compositing, *resample) instead of ucnerf_composite_fwd;
+                                  resample->weights / z_merge may be NULL (implied: this pass's weights and z) */
+    const ucnerf_ray_gen_params* gen_rays;      /* optional (HOST pointers, both or none; cfg.precision == 3, derived coordinates, xs / ys pixel lists): the */
+    const ucnerf_sample_stratified_params* gen_depths;  /* fused launch generates its own rays and stratified depths -- ucnerf_ray_gen_sample folded into the
+                                  kernel's per-tile prologue.  rays_d / z / dir_feat of THIS struct are then buffers the launch FILLS (they must
+                                  equal gen_rays->rays_d / gen_depths->z / gen_rays->angle; later passes and the compositing read them);
+                                  same values as ucnerf_ray_gen_sample, bit for bit */
 } ucnerf_render_params;
 int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream);

@@ -39,7 +39,13 @@ for k, o in out.items():
         o["frac_wait_inst_any"] = o.get("SQ_WAIT_INST_ANY", 0) / w
         o["frac_active_inst_any"] = o.get("SQ_ACTIVE_INST_ANY", 0) / w
     if "GRBM_GUI_ACTIVE" in o:
-        o["clock_ghz"] = o["GRBM_GUI_ACTIVE"] / 8 / o["_duration_ns_grbm"]
+        # GRBM_GUI_ACTIVE counts cycles of the whole dispatch window (queue pick-up, wave launch and drain included), so cycles / duration is a
+        # clock only for long launches: below 50 us it over-reads (5.4 "GHz" on a 3-us kernel) and is reported as invalid instead
+        if o["_duration_ns_grbm"] >= 50e3:
+            o["clock_ghz"] = o["GRBM_GUI_ACTIVE"] / 8 / o["_duration_ns_grbm"]
+        else:
+            o["clock_ghz"] = None
+            o["clock_ghz_note"] = "launch under 50 us: GRBM_GUI_ACTIVE / duration is not a clock"
     if "TCC_HIT_sum" in o:
         o["l2_hit_rate"] = o["TCC_HIT_sum"] / (o["TCC_HIT_sum"] + o["TCC_MISS_sum"])
 json.dump({"source": "scripts/pmc_mlp.sh (rocprofv3 --pmc, separate passes) on scripts/time_train_step.py (1024 rays x 128 samples)", "kernels": out},

@@ -33,8 +33,9 @@ for kind, o in out.items():
         if "SQ_INSTS_" + c in o:
             o[c.lower() + "_insts_per_tile"] = o["SQ_INSTS_" + c] / (samples / 32)
     if "GRBM_GUI_ACTIVE" in o:
-        o["clock_ghz"] = o["GRBM_GUI_ACTIVE"] / 8 / o["_duration_ns_grbm"]
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in o:
+        # (cycles of the whole dispatch window / duration: a clock only for long launches -- under 50 us it over-reads and is dropped)
+        o["clock_ghz"] = o["GRBM_GUI_ACTIVE"] / 8 / o["_duration_ns_grbm"] if o["_duration_ns_grbm"] >= 50e3 else None
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in o and o["clock_ghz"]:
             o["mfma_busy_frac"] = o["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (o["_duration_ns_sq1"] * o["clock_ghz"])
 res = {"source": "scripts/pmc_mlp.sh (rocprofv3 --pmc, separate passes) on python3 bench.py --steps 4 --warmup 1 --cpu-rays 0",
        "coarse": out.get("coarse"), "fine": out.get("fine")}

@@ -34,7 +34,7 @@ for prec in ("f32", "bf16x3"):
         L.check(L.lib().ucnerf_mlp_fwd(C.addressof(p), st), "fwd")
 
     def fwd_train():
-        L.check(L.lib().ucnerf_mlp_fwd_train(C.addressof(p), ops._ptr(work), st), "fwd_train")
+        L.check(L.lib().ucnerf_mlp_fwd_train(C.addressof(p), ops._ptr(work), ops._backward_mode, st), "fwd_train")
 
     for name, fn in (("forward", fwd), ("training forward (10 sets kept)", fwd_train)):
         for _ in range(3):

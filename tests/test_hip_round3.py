@@ -271,7 +271,8 @@ def test_bf16_source_copies_through_the_rendering_mirror_forward_and_backward(sd
     def run(rounded, prec):
         rnd = (lambda t: t.bfloat16().float()) if rounded else (lambda t: t)
         uc_nerf_amd.set_source_precision(prec)
-        try:
+        uc_nerf_amd.set_inference_precision("f32")      # one kernel for both runs (the default, bf16x3_fused, serves given coordinates from fp32 copies only
+        try:                                            #  and hands bf16 copies to the two-kernel bf16x3 pass: another summation order in the bias nets)
             net = models.UCNeRF(D=6, W=128, input_ch_pts=63, input_ch_views=27, input_ch_feat=97, view_num=V).to(DEV)
             net.load_state_dict({k: dev(v) for k, v in sd_v7.items()})
             vols = [dev(rnd(g["vol%d" % k])).requires_grad_(True) for k in (1, 2, 3)]
@@ -289,6 +290,7 @@ def test_bf16_source_copies_through_the_rendering_mirror_forward_and_backward(sd
                     [q.grad.clone() for q in net.parameters() if q.grad is not None] + [t.grad.clone() for t in vols + [img_feat, conf]])
         finally:
             uc_nerf_amd.set_source_precision("f32")
+            uc_nerf_amd.set_inference_precision("bf16x3_fused")
 
     a = run(False, "bf16")
     b = run(True, "f32")

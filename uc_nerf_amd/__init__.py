@@ -12,8 +12,8 @@ __version__ = "0.2.0"
 
 
 def set_inference_precision(precision):
-    """MLP arithmetic of the `rendering()` drop-in under torch.no_grad(): "f32" (default), "bf16x3", "bf16x3_fused" (the headline kernel: feature gather
-    inside the MLP kernel) or "bf16" (dropin.py)."""
+    """MLP arithmetic of the `rendering()` drop-in under torch.no_grad(): "bf16x3_fused" (default: the headline kernel, feature gather inside
+    the split-bf16 MLP kernel, within the 1e-4 parity bar), "bf16x3", "f32" (exact fp32 MFMA, the opt-out) or "bf16" (dropin.py)."""
     from . import dropin
     dropin.set_inference_precision(precision)
 
@@ -38,11 +38,17 @@ def set_training_precision(precision):
     dropin.set_training_precision(precision)
 
 
-def install_dropin():
+def install_dropin(precision=None, training_precision=None):
     """Registers this package's mirrors under the reference's module names (`network.renderer`,
     `network.models`, `utils.utils`, `utils.run_nerf_helpers`, `data.ray_utils`) so that the reference's
-    train.py imports resolve here unchanged.  See INTEGRATION.md."""
+    train.py imports resolve here unchanged.  See INTEGRATION.md.
+    precision: MLP arithmetic of `rendering()` under torch.no_grad() (None keeps the default, "bf16x3_fused"; "f32" = exact fp32 MFMA);
+    training_precision: of the training forward (None keeps "f32")."""
     import importlib
+    if precision is not None:
+        set_inference_precision(precision)
+    if training_precision is not None:
+        set_training_precision(training_precision)
     import sys
     import types
     for pkg in ("network", "utils", "data"):

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UCNERF_LIB") or os.path.join(_HERE, "libucnerf_hip.so")   # override: A/B builds
 
-ABI_VERSION = 3    # UCNERF_ABI_VERSION of include/ucnerf_hip.h this binding mirrors
+ABI_VERSION = 4    # UCNERF_ABI_VERSION of include/ucnerf_hip.h this binding mirrors
 
 fp = C.POINTER(C.c_float)
 i32 = C.c_int32
@@ -128,7 +128,8 @@ class RenderParams(C.Structure):
                 ("w2cs", vp), ("intrinsics", vp), ("wstream", vp), ("sources_cl", vp), ("workspace", vp), ("rgb_map", vp),
                 ("depth_map", vp), ("acc_map", vp), ("weights", vp), ("var", vp), ("raw", vp), ("feats", vp),
                 ("ev_mlp_start", vp), ("ev_mlp_stop", vp), ("train_workspace", vp), ("dir_feat", vp), ("u_sampled", vp),
-                ("wu_map", vp), ("pts_in", vp), ("ndc1_in", vp), ("ndc2_in", vp), ("ndc3_in", vp), ("ndc_in", vp), ("feats_tiled", i32), ("sources_cl_bf16", i32), ("train_bwd_mode", i32)]
+                ("wu_map", vp), ("pts_in", vp), ("ndc1_in", vp), ("ndc2_in", vp), ("ndc3_in", vp), ("ndc_in", vp), ("feats_tiled", i32), ("sources_cl_bf16", i32), ("train_bwd_mode", i32),
+                ("resample", vp), ("gen_rays", vp), ("gen_depths", vp)]
 
 
 class RenderBwdParams(C.Structure):
@@ -189,6 +190,7 @@ SYMBOLS = {
     "ucnerf_composite_fwd": (C.c_int, [_P, _P]),
     "ucnerf_composite_bwd": (C.c_int, [_P, _P]),
     "ucnerf_sample_pdf": (C.c_int, [_P, _P]),
+    "ucnerf_composite_sample_pdf": (C.c_int, [_P, _P, _P]),
     "ucnerf_merge_rows": (C.c_int, [_P, _P]),
     "ucnerf_cost_volume": (C.c_int, [_P, _P]),
     "ucnerf_depth_regress": (C.c_int, [_P, _P]),

@@ -6,120 +6,16 @@
 // (inclusive product scan, shifted by one lane), and the ray sums are shuffle reductions.  HBM-bound:
 // 20 B in + (4..8) B out per sample.
 #include "common.h"
+#include "composite_device.h"
 
 namespace ucnerf {
-
-__device__ __forceinline__ float wave_excl_prod(float v, int lane) {
-    // inclusive scan over 64 lanes, then shift: lane l gets prod_{k<l} v_k
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float o = __shfl_up(v, d);
-        if (lane >= d) v *= o;
-    }
-    float e = __shfl_up(v, 1);
-    return lane == 0 ? 1.f : e;
-}
-
-__device__ __forceinline__ float wave_excl_suffix_sum(float v, int lane) {
-    // lane l gets sum_{k>l} v_k
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float o = __shfl_down(v, d);
-        if (lane + d < 64) v += o;
-    }
-    float e = __shfl_down(v, 1);
-    return lane == 63 ? 0.f : e;
-}
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-    return v;
-}
-
-struct Sample {
-    float r, g, b, alpha, f, ex;   // activated colour, alpha, transmittance factor (1 - alpha + 1e-10), exp(-sigma)
-};
-
-// loads sample i of ray `ray` and applies the variant's activations; i >= S gives a neutral sample
-template <int VARIANT>
-__device__ __forceinline__ Sample load_sample(const ucnerf_composite_params& p, int ray, int i, float dnorm) {
-    Sample s;
-    if (i >= p.S) { s.r = s.g = s.b = s.alpha = s.ex = 0.f; s.f = 1.f; return s; }
-    const float4 raw = reinterpret_cast<const float4*>(p.raw)[(size_t)ray * p.S + i];
-    if (VARIANT == 0) {                       // renderer.py:29: alpha = 1 - exp(-sigma)
-        s.r = raw.x; s.g = raw.y; s.b = raw.z;
-        s.ex = expf(-raw.w);
-        s.alpha = 1.f - s.ex;
-    } else {                                  // run_nerf_helpers.py:356-375
-        const float* z = p.z + (size_t)ray * p.S;
-        float dist = (i + 1 < p.S ? z[i + 1] - z[i] : 1e10f) * dnorm;
-        float sg = raw.w + (p.noise ? p.noise[(size_t)ray * p.S + i] : 0.f);
-        s.r = 1.f / (1.f + expf(-raw.x)); s.g = 1.f / (1.f + expf(-raw.y)); s.b = 1.f / (1.f + expf(-raw.z));
-        s.ex = expf(-fmaxf(sg, 0.f) * dist);
-        s.alpha = 1.f - s.ex;
-    }
-    s.f = 1.f - s.alpha + 1e-10f;
-    return s;
-}
 
 template <int E, int VARIANT>
 __global__ void __launch_bounds__(256) composite_fwd_kernel(ucnerf_composite_params p) {
     const int lane = threadIdx.x & 63;
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= p.n) return;
-    float dnorm = 0.f;
-    if (VARIANT == 1) {
-        const float* d = p.rays_d + 3 * (size_t)ray;
-        dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-    }
-    Sample sm[E];
-    float T[E];
-    float prod = 1.f;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        sm[e] = load_sample<VARIANT>(p, ray, lane * E + e, dnorm);
-        T[e] = prod;
-        prod *= sm[e].f;
-    }
-    const float pre = wave_excl_prod(prod, lane);
-    float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f, su = 0.f;
-    float w[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = lane * E + e;
-        w[e] = sm[e].alpha * (pre * T[e]);
-        if (i < p.S) {
-            sr += w[e] * sm[e].r; sg += w[e] * sm[e].g; sb += w[e] * sm[e].b;
-            sd += w[e] * p.z[(size_t)ray * p.S + i];
-            sa += w[e];
-            if (p.wu) su += w[e] * p.u[(size_t)ray * p.S + i];      // composited uncertainty sum_i w_i u_i (u: network/models.py:149)
-            if (p.weights) p.weights[(size_t)ray * p.S + i] = w[e];
-        }
-    }
-    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
-    if (p.wu) su = wave_sum(su);
-    float var = 0.f;
-    if (p.var) {                                // torch.var_mean(weights, dim=1): unbiased
-        const float mean = sa / (float)p.S;
-        float q = 0.f;
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-            if (lane * E + e < p.S) { float d = w[e] - mean; q += d * d; }
-        var = wave_sum(q) / (float)(p.S - 1);
-    }
-    if (lane == 0) {
-        if (p.white_bkgd) { sr += 1.f - sa; sg += 1.f - sa; sb += 1.f - sa; }
-        p.rgb_map[3 * (size_t)ray] = sr; p.rgb_map[3 * (size_t)ray + 1] = sg; p.rgb_map[3 * (size_t)ray + 2] = sb;
-        p.depth_map[ray] = sd;
-        if (p.acc_map) p.acc_map[ray] = sa;
-        if (p.disp_map) {                       // 1 / max(1e-10, depth/acc); NaN (0/0) propagates as in torch.max
-            float q = sd / sa;
-            p.disp_map[ray] = q != q ? q : 1.f / fmaxf(1e-10f, q);
-        }
-        if (p.var) p.var[ray] = var;
-        if (p.wu) p.wu[ray] = su;
-    }
+    composite_ray<E, VARIANT>(p, ray, lane, nullptr);
 }
 
 // Backward of the live variant.  With gw_i = dL/dw_i:
@@ -202,7 +98,7 @@ int ucnerf_composite_fwd(const ucnerf_composite_params* p, void* stream) {
     UCNERF_REQUIRE(!p->wu || p->u, "composite_fwd: wu (sum of w*u) needs the per-sample uncertainty u");
     if (p->n <= 0) return UCNERF_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int E = cdiv(p->S, 64);
+    const int E = composite_lane_samples(p->S);      // (shared with the launch fused with the re-sampling: same lane split, same weights)
     if (E <= 1) launch_fwd<1>(*p, st);
     else if (E <= 2) launch_fwd<2>(*p, st);
     else if (E <= 3) launch_fwd<3>(*p, st);

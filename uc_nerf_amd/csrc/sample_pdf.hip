@@ -9,6 +9,7 @@
 //   * cumsum accumulates sequentially in float64 and rounds every output to float32.
 // This file must be compiled with -ffp-contract=off.
 #include "common.h"
+#include "composite_device.h"
 
 namespace ucnerf {
 
@@ -48,18 +49,26 @@ __device__ float aten_row_sum(int n, Item item) {
 // MAXB / MAXS size the per-ray LDS arrays: the common shapes (<= 128 bins, <= 512 merged depths) take 3.5 KB per ray, so
 // that a CU holds 32 rays at once; with the full-size arrays (20 KB) it holds 8 and 4096 rays need two rounds.
 template <int MAXB, int MAXS>
-__global__ void __launch_bounds__(64) sample_pdf_kernel(ucnerf_sample_pdf_params p) {
-    __shared__ float w[MAXB];               // weights + 1e-5, then pdf
-    __shared__ float cdf[MAXB];
-    __shared__ float srt[MAXS];
-    __shared__ float bins[MAXB];
-    __shared__ float lane_part[8];
-    __shared__ float total;
-    const int ray = blockIdx.x, lane = threadIdx.x;
+struct PdfShared {
+    float w[MAXB];               // weights + 1e-5, then pdf
+    float cdf[MAXB];
+    float srt[MAXS];
+    float bins[MAXB];
+    float lane_part[8];
+    float total;
+};
+
+// One ray by one 64-lane wave (= one block).  from_coarse: `w_coarse` / `z_coarse` are the ray's S coarse weights and depths -- rows of
+// p.weights / p.z_merge, or (the launch fused with the coarse pass's compositing) the weights the wave has just left in LDS.
+template <int MAXB, int MAXS>
+__device__ __forceinline__ void sample_pdf_ray(const ucnerf_sample_pdf_params& p, int ray, int lane, PdfShared<MAXB, MAXS>& sh,
+                                               const float* w_coarse, const float* z_coarse) {
+    float* const w = sh.w; float* const cdf = sh.cdf; float* const srt = sh.srt; float* const bins = sh.bins; float* const lane_part = sh.lane_part;
+    float& total = sh.total;
     const int L = p.n_bins, n = L - 1, M = p.n_samples;
     if (p.from_coarse) {        // bins = mid-points of the coarse depths, weights = w[1:-1]   (data/ray_utils.py:216-217)
-        const float* zc = p.z_merge + (size_t)ray * p.n_merge;
-        const float* wr = p.weights + (size_t)ray * p.n_merge + 1;
+        const float* zc = z_coarse;
+        const float* wr = w_coarse + 1;
         for (int i = lane; i < L; i += 64) bins[i] = .5f * (zc[i] + zc[i + 1]);
         for (int i = lane; i < n; i += 64) w[i] = wr[i] + 1e-5f;
     } else {
@@ -148,7 +157,8 @@ __global__ void __launch_bounds__(64) sample_pdf_kernel(ucnerf_sample_pdf_params
     // rank_i = #{x_j < x_i} + #{x_j == x_i, j < i} -- a permutation even with ties.
     if (p.z_sorted) {
         const int tot_n = M + p.n_merge;
-        for (int i = lane; i < p.n_merge; i += 64) srt[M + i] = p.z_merge[(size_t)ray * p.n_merge + i];
+        const float* zm = p.from_coarse ? z_coarse : p.z_merge + (size_t)ray * p.n_merge;
+        for (int i = lane; i < p.n_merge; i += 64) srt[M + i] = zm[i];
         __syncthreads();
         float* dst = p.z_sorted + (size_t)ray * tot_n;
         bool sorted = true;
@@ -195,6 +205,26 @@ __global__ void __launch_bounds__(64) sample_pdf_kernel(ucnerf_sample_pdf_params
     }
 }
 
+template <int MAXB, int MAXS>
+__global__ void __launch_bounds__(64) sample_pdf_kernel(ucnerf_sample_pdf_params p) {
+    __shared__ PdfShared<MAXB, MAXS> sh;
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    sample_pdf_ray<MAXB, MAXS>(p, ray, lane, sh, p.from_coarse ? p.weights + (size_t)ray * p.n_merge : nullptr,
+                               p.from_coarse ? p.z_merge + (size_t)ray * p.n_merge : nullptr);
+}
+
+// K7 of the coarse pass + K8 + K9 in ONE launch (both were one wave per ray already): the wave composites its ray (composite_device.h, the
+// arithmetic and lane split of composite_fwd_kernel: same weights bit for bit), leaves the S weights in LDS and re-samples from them.
+template <int MAXB, int MAXS, int E>
+__global__ void __launch_bounds__(64) composite_sample_pdf_kernel(ucnerf_composite_params c, ucnerf_sample_pdf_params p) {
+    __shared__ PdfShared<MAXB, MAXS> sh;
+    __shared__ float wl[MAXB + 2];
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    composite_ray<E, 0>(c, ray, lane, wl);
+    __syncthreads();
+    sample_pdf_ray<MAXB, MAXS>(p, ray, lane, sh, wl, c.z + (size_t)ray * c.S);
+}
+
 __global__ void merge_rows_kernel(ucnerf_merge_rows_params p) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int tot = p.na + p.nb;
@@ -231,6 +261,38 @@ extern "C" int ucnerf_sample_pdf(const ucnerf_sample_pdf_params* p, void* stream
     else
         hipLaunchKernelGGL((sample_pdf_kernel<PDF_MAX_BINS, PDF_MAX_SORT>), dim3(p->n), dim3(64), 0, (hipStream_t)stream, *p);
     return check_launch("sample_pdf");
+}
+
+extern "C" int ucnerf_composite_sample_pdf(const ucnerf_composite_params* c, const ucnerf_sample_pdf_params* s, void* stream) {
+    UCNERF_REQUIRE(c && s, "composite_sample_pdf: null params");
+    if (c->n <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(c->raw && c->z && c->rgb_map && c->depth_map, "composite_sample_pdf: null compositing pointer");
+    UCNERF_REQUIRE(c->variant == 0 && !c->u && !c->wu, "composite_sample_pdf: the live compositing variant without uncertainty inputs");
+    UCNERF_REQUIRE(!c->var || c->S >= 2, "composite_sample_pdf: var needs S >= 2");
+    UCNERF_REQUIRE(((uintptr_t)c->raw & 15) == 0, "composite_sample_pdf: raw must be 16-byte aligned");
+    UCNERF_REQUIRE(s->from_coarse && s->n == c->n && s->n_merge == c->S && s->n_bins == c->S - 1 && c->S >= 3 && c->S <= PDF_MAX_BINS + 1,
+                   "composite_sample_pdf: the re-sampling must be the from_coarse form over the composited pass (n %d / %d, n_merge %d, n_bins %d, S %d)",
+                   s->n, c->n, s->n_merge, s->n_bins, c->S);
+    UCNERF_REQUIRE(!s->z_merge || s->z_merge == c->z, "composite_sample_pdf: z_merge, when given, must be the composited pass's depths");
+    UCNERF_REQUIRE(s->u, "composite_sample_pdf: null draws");
+    UCNERF_REQUIRE(s->n_samples >= 1 && s->n_samples <= 1024, "composite_sample_pdf: n_samples = %d outside 1..1024", s->n_samples);
+    UCNERF_REQUIRE(s->u_stride == 0 || s->u_stride == s->n_samples, "composite_sample_pdf: u_stride must be 0 or n_samples");
+    UCNERF_REQUIRE(s->n_merge + s->n_samples <= PDF_MAX_SORT, "composite_sample_pdf: n_merge + n_samples > %d", PDF_MAX_SORT);
+    UCNERF_REQUIRE(s->samples || s->inds || s->cdf || s->z_sorted, "composite_sample_pdf: no re-sampling outputs requested");
+    UCNERF_REQUIRE(!s->merge_rank || s->z_sorted, "composite_sample_pdf: merge_rank needs z_sorted");
+    hipStream_t st = (hipStream_t)stream;
+    const int E = composite_lane_samples(c->S);
+    const bool small = s->n_bins <= 128 && s->n_merge + s->n_samples <= 512;
+#define UCNERF_CSP(MB, MS, EE) hipLaunchKernelGGL((composite_sample_pdf_kernel<MB, MS, EE>), dim3(c->n), dim3(64), 0, st, *c, *s)
+    if (small) {
+        if (E == 1) UCNERF_CSP(128, 512, 1); else if (E == 2) UCNERF_CSP(128, 512, 2); else UCNERF_CSP(128, 512, 3);
+    } else {
+        if (E == 1) UCNERF_CSP(PDF_MAX_BINS, PDF_MAX_SORT, 1); else if (E == 2) UCNERF_CSP(PDF_MAX_BINS, PDF_MAX_SORT, 2);
+        else if (E == 3) UCNERF_CSP(PDF_MAX_BINS, PDF_MAX_SORT, 3); else if (E == 4) UCNERF_CSP(PDF_MAX_BINS, PDF_MAX_SORT, 4);
+        else if (E == 8) UCNERF_CSP(PDF_MAX_BINS, PDF_MAX_SORT, 8); else UCNERF_CSP(PDF_MAX_BINS, PDF_MAX_SORT, 16);
+    }
+#undef UCNERF_CSP
+    return check_launch("composite_sample_pdf");
 }
 
 extern "C" int ucnerf_merge_rows(const ucnerf_merge_rows_params* p, void* stream) {

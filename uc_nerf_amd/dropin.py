@@ -22,8 +22,9 @@ import weakref
 import torch
 
 from . import ops
+from .flat import FlatStore
 
-_INFERENCE_PRECISION = "f32"
+_INFERENCE_PRECISION = "bf16x3_fused"     # what an unmodified train.py gets under torch.no_grad(): the kernel the headline benchmark is quoted on
 _TRAINING_PRECISION = "f32"         # arithmetic of the training FORWARD (the kept activations have the format the backward mode reads either way)
 _INFERENCE_PRECISIONS = ("f32", "bf16x3", "bf16", "bf16x3_fused")
 _WEIGHT_CACHE = "verify"            # how an inference call gets its packed weight stream, see set_weight_cache
@@ -32,10 +33,12 @@ _MAX_FEATURE_BYTES = (1 << 31) - (1 << 20)       # the MLP kernels address a pas
 
 
 def set_inference_precision(precision):
-    """MLP arithmetic of `rendering()` under torch.no_grad(): "f32" (exact fp32 MFMA, default), "bf16x3" (split-bf16 matrix
-    cores, within the 1e-4 parity bar), "bf16x3_fused" (the same arithmetic with the feature gather INSIDE the MLP kernel -- the
-    kernel the headline benchmark is quoted on, reading the coordinates rendering() was handed; per-sample uncertainty extras fall
-    back to "bf16x3") or "bf16" (plain bf16 operands, NOT within the bar).  Training always runs f32 (set_training_precision)."""
+    """MLP arithmetic of `rendering()` under torch.no_grad() (evaluation, train.py:254-272): "bf16x3_fused" (default since round 4:
+    split-bf16 matrix cores -- every product as hi*hi + hi*lo + lo*hi, fp32 accumulate, rendered outputs within 2e-5 of the exact ones,
+    the parity bar is 1e-4 -- with the feature gather INSIDE the MLP kernel: the kernel the headline benchmark is quoted on, reading the
+    coordinates rendering() was handed; per-sample uncertainty extras and bf16 source copies fall back to "bf16x3"), "bf16x3" (the same
+    arithmetic as gather -> feature buffer -> MLP), "f32" (exact fp32 MFMA: the opt-out, 2.7x slower) or "bf16" (plain bf16 operands, NOT
+    within the bar).  Training runs f32 unless set_training_precision says otherwise."""
     global _INFERENCE_PRECISION
     if precision not in _INFERENCE_PRECISIONS:
         raise ValueError("uc_nerf_amd: inference precision must be one of %s, got %r" % (", ".join(_INFERENCE_PRECISIONS), precision))
@@ -105,6 +108,7 @@ class FusedSession:
         nerf = getattr(net, "nerf", net)
         self.n_src = nerf.view_num
         named = list(net.named_parameters())
+        self.store = FlatStore.of(net)       # the parameters are views of ONE flat buffer (flat.py): no concatenation per step, one gradient buffer
         self.params = [p for _, p in named]
         self.grad_mask = [not any(tag in name for tag in _NO_GRAD) for name, _ in named]
         self.sizes = [p.numel() for p in self.params]
@@ -120,35 +124,33 @@ class FusedSession:
         self.src, self.src_sig, self.src_refs = None, None, None
 
     def packed(self, precision, layout, fresh=False):
-        """(flat parameter vector, packer, packed stream) of the network's CURRENT parameters.
-        fresh=True (calls under autograd): concatenated and packed now -- the flat vector is the one the backward will use.
-        Otherwise the stream follows the weight-cache policy (set_weight_cache) and `flat` is only a placeholder of the right size."""
-        dev = self.params[0].device
+        """(flat parameter vector, packer, packed stream) of the network's CURRENT parameters.  The parameters live in one flat buffer
+        (flat.FlatStore), so nothing is ever concatenated.
+        fresh=True (calls under autograd): packed now, and `flat` is a SNAPSHOT of the buffer (one 0.7-MB copy) -- the backward takes its
+        weight gradients against the parameters of this very forward, whatever an optimizer does in between.
+        Otherwise the stream follows the weight-cache policy (set_weight_cache) and `flat` is the live buffer."""
         key = (precision, layout)
+        live = self.store.sync()
+        dev = live.device
+        if live.dtype != torch.float32:
+            raise RuntimeError("uc_nerf_amd: network parameters must be float32")
         pw = ops.PackedWeights.get(self.n_src, layout, dev, precision)
         ent = self.weights.get(key)
         if fresh:
-            flat = torch.cat([p.detach().reshape(-1) for p in self.params]).float()
-            ent = self.weights[key] = {"sig": None, "flat": flat, "ws": pw.pack(flat), "table": None}
+            flat = live.clone()
+            ent = self.weights[key] = {"sig": None, "ws": pw.pack(flat)}
             return flat, pw, ent["ws"]
         if _WEIGHT_CACHE == "versions":
-            sig = tuple((p._version, p.data_ptr()) for p in self.params)
+            sig = (live.data_ptr(),) + tuple(p._version for p in self.params)
             if ent is None or ent["sig"] != sig:
-                flat = torch.cat([p.detach().reshape(-1) for p in self.params]).float()
-                ent = self.weights[key] = {"sig": sig, "flat": flat, "ws": pw.pack(flat), "table": None}
-            return ent["flat"], pw, ent["ws"]
-        # "verify": one launch re-packs the stream IN PLACE from the live tensors (no concatenation); the pointer table is rebuilt only
-        # when a parameter's storage moved
-        ptrs = tuple(p.data_ptr() for p in self.params)
-        if ent is None or ent["table"] is None or ent["table"].key != ptrs:
-            if any(p.dtype != torch.float32 or not p.is_contiguous() for p in self.params):
-                raise RuntimeError("uc_nerf_amd: network parameters must be contiguous float32 tensors")
-            flat = ent["flat"] if ent is not None else torch.empty(sum(self.sizes), device=dev)
-            ws = ent["ws"] if ent is not None else torch.empty(pw.n_stream, device=dev)
-            ent = self.weights[key] = {"sig": None, "flat": flat, "ws": ws, "table": ops.TensorTable(self.params)}
-        pw.pack_table(ent["table"], ent["ws"])
+                ent = self.weights[key] = {"sig": sig, "ws": pw.pack(live)}
+            return live, pw, ent["ws"]
+        # "verify": one launch re-packs the stream IN PLACE from the live buffer
+        if ent is None or ent["ws"].device != dev:
+            ent = self.weights[key] = {"sig": None, "ws": torch.empty(pw.n_stream, device=dev)}
+        pw.pack(live, out=ent["ws"])
         ent["sig"] = None
-        return ent["flat"], pw, ent["ws"]
+        return live, pw, ent["ws"]
 
     def sources(self, vols, conf, imgs, img_feat, w2cs, intrinsics):
         """GatherSources for these tensors.  Two signatures: the HEAVY sources (volumes, images, image features -- what the
@@ -222,17 +224,18 @@ class _FusedRender(torch.autograd.Function):
         need = tuple(ctx.needs_input_grad[10:15])                            # vol1, vol2, vol3, conf, img_feat
         need = (need[0], need[1], need[2], need[3], need[4])
         f32w = None
-        if rp.pw.cfg.precision != 0 and getattr(rp, "_saved_for", None) != (z.shape[0], z.shape[1], ctx.kept["raw"].data_ptr()):
+        if rp.pw.cfg.precision != 0 and not rp.saved_matches(z.shape[0], z.shape[1], ctx.kept["raw"]):
             # another forward overwrote the kept activations: recompute them exactly -- from the parameters of THIS call's forward
             # (ctx.flat, which the weight gradients below are taken against), not from whatever the parameters hold by now
             pw32 = ops.PackedWeights.get(sess.n_src, ctx.layout, z.device, "f32")
             f32w = (pw32, pw32.pack(ctx.flat))
+        store = sess.store
         g_flat, gv1, gv2, gv3, gc, gi = rp.backward(rays_dir, z, ctx.kept, g_rgb.contiguous(), g_depth, ctx.flat, need=need,
-                                                    coords=ctx.coords, dir_feat=angle, f32_weights=f32w)
+                                                    coords=ctx.coords, dir_feat=angle, f32_weights=f32w, flat_room=store.grad_room)
         grads = [g.reshape(s) if g is not None else None for g, s in zip((gv1, gv2, gv3, gc, gi), ctx.shapes)]
-        g_params = []
-        for piece, p, has, req in zip(torch.split(g_flat, sess.sizes), sess.params, sess.grad_mask, ctx.needs_input_grad[15:]):
-            g_params.append(piece.view_as(p) if (has and req) else None)
+        # views of the ONE flat gradient vector the kernels wrote: autograd installs them as p.grad without a copy (flat.py), so the
+        # step's gradients stay one buffer -- what FlatGradBucket all-reduces in place and FlatAdam steps in one launch
+        g_params = store.grad_views(g_flat, [has and req for has, req in zip(sess.grad_mask, ctx.needs_input_grad[15:])])
         # (ctx.kept stays: a second backward over the same graph -- retain_graph=True -- finds the kept activations overwritten and
         #  recomputes them through the route above)
         return (None,) * 10 + tuple(grads) + tuple(g_params)
@@ -265,8 +268,10 @@ def fused_rendering(net, layout, args, w2c_dir, rays_pts, rays_ndc, z, rays_dir,
                                   vols[0], vols[1], vols[2], conf, img_feat, *sess.params)
     src = sess.sources(vols, conf, imgs, img_feat, w2cs, intrinsics)
     prec = inference_precision(args)
-    if prec == "bf16x3_fused" and ("u" in extras or "wu" in extras):
-        prec = "bf16x3"                              # the gather-fused kernel keeps nothing per sample: same arithmetic on the two-kernel pass
+    if prec == "bf16x3_fused" and ("u" in extras or "wu" in extras or _SOURCE_PRECISION == "bf16" or not src.full):
+        # the gather-fused kernel keeps nothing per sample, reads fp32 copies when it is handed coordinates and gathers every unit:
+        # the same arithmetic on the two-kernel pass otherwise
+        prec = "bf16x3"
     rp, _ = sess.render_pass(prec, layout, src, white_bkgd)
     out = rp(rays_dir, z, want=tuple(extras), dir_feat=angle, coords=coords)
     if extras:

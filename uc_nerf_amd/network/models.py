@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..flat import FlatStore
 
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
@@ -90,6 +91,7 @@ class BaseAdapt_Renderer(nn.Module):
                     self.alpha_linear, self.rgb_linear, self.confi_rgb_linear):
             mod.apply(weights_init)
         self._check_supported()
+        FlatStore.of(self)                     # the parameters become views of ONE flat buffer (uc_nerf_amd/flat.py); names and shapes unchanged
 
     def _check_supported(self):
         ok = (self.D == 6 and self.W == 128 and list(self.skips) == [4] and self.input_ch == 63 and self.input_ch_views == 27
@@ -100,6 +102,13 @@ class BaseAdapt_Renderer(nn.Module):
                 "skip [4], multires 10/4 -> 63/27 inputs, feat_dim = 24 + 12*(view_num-1) + 1, view_num 2..9); got "
                 "D=%d W=%d skips=%s in=(%d,%d,%d) view_num=%d" % (self.D, self.W, self.skips, self.input_ch,
                                                                  self.in_ch_feat, self.input_ch_views, self.view_num + 1))
+
+    def _apply(self, fn, *args, **kwargs):
+        """`.to()` / `.cuda()` / `.float()` re-point every parameter at a converted copy: gather them into one flat buffer again."""
+        out = super()._apply(fn, *args, **kwargs)
+        if "_ucnerf_flat_store" in self.__dict__:
+            self.__dict__["_ucnerf_flat_store"].sync()
+        return out
 
     # ---- helpers shared with the fused render path
     def flat_parameters(self):
@@ -118,10 +127,14 @@ class BaseAdapt_Renderer(nn.Module):
         """(flat parameter vector for autograd, packer, packed stream).  The stream -- and, when no gradient is wanted, the
         flat vector too -- comes from the per-network cache, rebuilt only when a parameter changed (dropin.FusedSession)."""
         from .. import dropin
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            flat = self.flat_parameters()                     # autograd-aware; the stream is packed from this very vector
-            pw = self.packer(pe_layout)
-            return flat, pw, pw.pack(flat.detach().float())
+        if torch.is_grad_enabled():
+            if any(p.requires_grad for p in self.parameters()):
+                flat = self.flat_parameters()                 # autograd-aware; the stream is packed from this very vector
+                pw = self.packer(pe_layout)
+                return flat, pw, pw.pack(flat.detach().float())
+            # frozen network, gradients wanted for the inputs: the backward takes its data gradients from `flat`, so it must be the REAL
+            # parameters of this forward -- a snapshot of the flat buffer, packed now
+            return dropin.session_of(self).packed("f32", pe_layout, fresh=True)
         return dropin.session_of(self).packed("f32", pe_layout)
 
     def forward(self, x, pe_layout=0):

@@ -447,12 +447,16 @@ class PackedWeights:
             cls._cache[key] = cls(n_src, pe_layout, device, precision)
         return cls._cache[key]
 
-    def pack(self, flat):
+    def pack(self, flat, out=None):
+        """The packed stream of a flat parameter vector; into `out` (a stream buffer of this packer) when given."""
         flat = _f32(flat, "flat parameters")
         if flat.numel() != self.n_params:
             raise RuntimeError("uc_nerf_amd: flat parameter vector has %d floats, expected %d"
                                % (flat.numel(), self.n_params))
-        out = torch.empty(self.n_stream, device=flat.device)
+        if out is None:
+            out = torch.empty(self.n_stream, device=flat.device)
+        elif out.numel() != self.n_stream or out.dtype != torch.float32 or not out.is_contiguous() or out.device != flat.device:
+            raise RuntimeError("uc_nerf_amd: stream buffer must be %d contiguous float32 on the parameters' device" % self.n_stream)
         with _on(flat.device):
             L.check(L.lib().ucnerf_mlp_pack(C.addressof(self.cfg), _ptr(flat), _ptr(self.idx), _ptr(out), _stream()), "ucnerf_mlp_pack")
         return out
@@ -1023,10 +1027,16 @@ class RenderPass:
         _launch("ucnerf_render_fused_fwd", p, dev)
         return out
 
+    def saved_matches(self, n, S, raw):
+        """True when the backward workspace still holds the activations the training forward kept for THIS (n, S, raw) -- no later forward
+        overwrote them -- in the format of the current backward mode."""
+        return getattr(self, "_saved_for", None) == (n, S, raw.data_ptr(), _backward_mode)
+
     def backward(self, rays_d, z, kept, g_rgb, g_depth, flat, near_far=None, need=(True, True, True, True, True), coords=None,
-                 dir_feat=None, f32_weights=None):
+                 dir_feat=None, f32_weights=None, flat_room=0):
         """Backward of the last-style forward call: `kept` = its outputs with keep=("raw", "feats").
-        Returns (g_flat, g_vol1, g_vol2, g_vol3, g_conf, g_img_feat).  A pass bound to bf16x3 weights runs its backward from
+        Returns (g_flat, g_vol1, g_vol2, g_vol3, g_conf, g_img_feat).  flat_room > n_params: g_flat is returned with that many floats (the
+        rest zero) -- room a gradient bucket uses for its scalars and flags without another buffer (flat.FlatStore.grad_room).  A pass bound to bf16x3 weights runs its backward from
         the activations the training forward kept; should another forward have overwritten them, the network forward is
         repeated in f32 and needs `f32_weights` = (PackedWeights, stream) packed from the same parameters."""
         rays_d, z, flat, g_rgb = _f32(rays_d), _f32(z), _f32(flat), _f32(g_rgb)
@@ -1047,7 +1057,7 @@ class RenderPass:
         dir_feat = _f32(dir_feat, "dir_feat") if dir_feat is not None else None
         p.dir_feat = _ptr(dir_feat)
         p.ev_mlp_start = p.ev_mlp_stop = None
-        saved = getattr(self, "_saved_for", None) == (n, S, kept["raw"].data_ptr(), _backward_mode)
+        saved = self.saved_matches(n, S, kept["raw"])
         ws = self._bwd_ws if saved else torch.empty(L.lib().ucnerf_render_bwd_workspace_floats(n, S, self.src.V), device=dev)
         bp.saved_valid = int(saved)
         bp.bwd_mode = _backward_mode
@@ -1059,7 +1069,7 @@ class RenderPass:
         self._saved_for = None
         # ONE zero fill for all accumulated outputs (six separate torch.zeros were six 5-us launches per step): views of a flat buffer,
         # every segment padded to 16 bytes
-        shapes = [(self.pw.n_params,)] + [tuple(v.shape) if need[k] else None for k, v in enumerate(self.src.vols)] + \
+        shapes = [(max(int(flat_room), self.pw.n_params),)] + [tuple(v.shape) if need[k] else None for k, v in enumerate(self.src.vols)] + \
                  [tuple(self.src.conf.shape) if need[3] else None, tuple(self.src.img_feat.shape) if need[4] else None]
         sizes = [0 if sh is None else (int(torch.Size(sh).numel()) + 3) // 4 * 4 for sh in shapes]
         pool = torch.zeros(sum(sizes), device=dev)

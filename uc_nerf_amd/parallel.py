@@ -73,66 +73,113 @@ class FlatGradBucket:
     rays, so the global mean-loss gradient is sum_r (n_r / n) g_r -- pass `weight = n_r / n` (1/world for equal
     shards, which reproduces plain gradient averaging).
 
+    **No pack, no unpack for the renderer network.**  Its parameters live in one flat buffer and the backward of `rendering()` writes one
+    flat gradient vector that the `p.grad`s are views of (flat.FlatStore); the bucket IS that vector -- layout
+    `[network gradients (in place) | other parameters' gradients | scalars | has-gradient flags]`, the last three in the room the backward
+    left behind the gradients -- so a step costs: one multi-tensor copy for parameters of other modules (none when only the renderer
+    trains), one copy per scalar, one for the flags, one scale, ONE all-reduce, and nothing afterwards.  Gradients that are not views of one
+    buffer (the op-by-op route, accumulation over several backward passes) take the generic path: the same bucket filled and emptied
+    with two multi-tensor copies.
+
     Which parameters receive a gradient is a property of the model and the loss, not of the step (the reference leaves
     six tensors without one) -- except on a rank whose shard is empty, where NO parameter gets one.  Every
     rank must still end up with the same gradients, so the bucket also carries one has-gradient flag per parameter; the
-    reduced flags are read back ONCE (the only host synchronisation this class ever makes) and cached: parameters some
+    reduced flags are read back (the only host synchronisation this class makes) and cached: parameters some
     rank differentiated get their p.grad materialised from the reduced segment on every rank, parameters no rank touched
     keep grad = None as in the reference.  Nothing else reads device memory: scalars are written into the bucket with a
     device-side copy.
 
-    The cached flags are refreshed (one more read-back) whenever they could have changed: when THIS rank's own pattern of
-    None / not-None gradients differs from the previous step's (a loss term switched on by a schedule, layers unfrozen -- every
-    rank runs the same model and loss, so every rank with rays sees the change and refreshes in the same step), and in every
-    step on a rank that differentiated nothing at all (an empty shard: it cannot see such a change locally, and its step time
-    does not matter)."""
+    The cached flags are refreshed (one more read-back) when THIS rank's own pattern of None / not-None gradients differs from the
+    previous step's (a loss term switched on by a schedule, layers unfrozen), in every step on a rank that differentiated nothing at all
+    (an empty shard cannot see such a change locally, and its step time does not matter), and -- because a change on ANOTHER rank alone
+    (a data-dependent branch, a per-rank loss term) is invisible locally -- every `verify_every` steps on every rank (default 16: one
+    read-back per 16 steps): replicas can then disagree about a gradient's existence for at most that many steps, not silently for ever."""
 
-    def __init__(self, params, n_scalars=0):
+    def __init__(self, params, n_scalars=0, verify_every=16):
+        from .flat import store_of_param
         self.params = [p for p in params if p.requires_grad]
         self.sizes = [p.numel() for p in self.params]
         self.n_scalars = n_scalars
-        self.n_grads = sum(self.sizes)
+        self.verify_every = int(verify_every)
+        # parameters that live in a flat store (the renderer network) keep their place in the store's gradient vector; the others are
+        # packed behind it
+        self.store, self.seg = None, []                # seg[i] = offset of parameter i inside the bucket
+        placed = [store_of_param(p) for p in self.params]
+        stores = {id(st): st for st, _ in placed if st is not None}
+        if len(stores) == 1:
+            self.store = next(iter(stores.values()))
+        base = self.store.n if self.store is not None else 0
+        off = base
+        for p, n, (st, i) in zip(self.params, self.sizes, placed):
+            if st is not None and st is self.store:
+                self.seg.append(st.offsets[i])
+            else:
+                self.seg.append(off)
+                off += n
+        self.n_grads = off                             # floats in front of the scalars
         self.numel = self.n_grads + n_scalars + len(self.params)
-        self.flat = None
+        self.in_store = [st is not None and st is self.store for st, _ in placed]
+        if self.store is not None:
+            from .flat import TAIL_FLOATS
+            self.store.reserve(max(0, self.numel - self.store.n - TAIL_FLOATS))
+        self.flat = None             # the generic path's own buffer
         self.has_grad = None         # cached reduced flags: list of bool, one per parameter
         self.local_flags = None      # this rank's own None / not-None pattern at the step has_grad was read
+        self._flag_cache = {}        # local pattern -> device tensor of 0 / 1 flags
+        self._step = 0
+        self.last_path = None        # "in_place" / "generic": which route the last allreduce took (tests, bench)
+
+    def _flags_tensor(self, local, dev):
+        t = self._flag_cache.get((local, dev))
+        if t is None:
+            t = self._flag_cache[(local, dev)] = torch.tensor([1.0 if f else 0.0 for f in local], dtype=torch.float32, device=dev)
+        return t
 
     def allreduce(self, weight, scalars=(), group=None):
         """In place on p.grad.  Returns the reduced scalars (e.g. global loss terms) as a device tensor."""
         if len(scalars) != self.n_scalars:
             raise ValueError("expected %d scalars, got %d" % (self.n_scalars, len(scalars)))
         dev = self.params[0].device
-        if self.flat is None or self.flat.device != dev:
-            self.flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
-        off = 0
-        for p, n in zip(self.params, self.sizes):
-            seg = self.flat[off:off + n]
-            if p.grad is None:
-                seg.zero_()
-            else:
-                torch.mul(p.grad.reshape(-1), weight, out=seg)
-            off += n
-        if self.n_scalars:
-            vals = torch.stack([torch.as_tensor(s, dtype=torch.float32, device=dev).reshape(()) for s in scalars])
-            torch.mul(vals, weight, out=self.flat[off:off + self.n_scalars])
-        off += self.n_scalars
         local = tuple(p.grad is not None for p in self.params)                     # (host-side: no device access)
-        refresh = self.has_grad is None or local != self.local_flags or not any(local)
+        # ---- the bucket: the store's own gradient vector when this step's gradients are views of one, else our buffer
+        buf = self.store.flat_grad(room=self.numel) if self.store is not None else None
+        in_place = buf is not None
+        if not in_place:
+            if self.flat is None or self.flat.device != dev:
+                self.flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
+            buf = self.flat
+            buf[:self.n_grads].zero_()
+        self.last_path = "in_place" if in_place else "generic"
+        views = [buf[o:o + n] for o, n in zip(self.seg, self.sizes)]
+        fill = [(v, p.grad.reshape(-1)) for v, p, ins in zip(views, self.params, self.in_store) if p.grad is not None and not (in_place and ins)]
+        if fill:
+            torch._foreach_copy_([a for a, _ in fill], [b for _, b in fill])
+        off = self.n_grads
+        for k, sc in enumerate(scalars):
+            buf[off + k].copy_(torch.as_tensor(sc, dtype=torch.float32).reshape(()), non_blocking=True)
+        off += self.n_scalars
         # the flags always travel (every rank must contribute the same bucket layout); they are only READ when a refresh is due
-        self.flat[off:].copy_(torch.tensor([1.0 if f else 0.0 for f in local]), non_blocking=True)
+        buf[off:off + len(self.params)].copy_(self._flags_tensor(local, dev), non_blocking=True)
+        if weight != 1.0:
+            buf[:self.numel].mul_(weight)
         if dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(buf[:self.numel], op=dist.ReduceOp.SUM, group=group)
+        self._step += 1
+        refresh = (self.has_grad is None or local != self.local_flags or not any(local)
+                   or (self.verify_every > 0 and self._step % self.verify_every == 0))
         if refresh:
-            self.has_grad = [bool(v > 0) for v in self.flat[off:].tolist()]       # the read-back: first step, pattern change, empty shard
+            self.has_grad = [bool(v > 0) for v in buf[off:off + len(self.params)].tolist()]       # the read-back
             self.local_flags = local
-        off = 0
-        for p, n, has in zip(self.params, self.sizes, self.has_grad):
+        back = []
+        for p, v, has, ins in zip(self.params, views, self.has_grad, self.in_store):
             if p.grad is not None:
-                p.grad.copy_(self.flat[off:off + n].view_as(p.grad))
+                if not (in_place and ins):
+                    back.append((p.grad, v.view_as(p.grad)))
             elif has:                                                              # e.g. an empty shard on this rank
-                p.grad = self.flat[off:off + n].view_as(p).clone()
-            off += n
-        return self.flat[self.n_grads:self.n_grads + self.n_scalars].clone()
+                p.grad = v.view_as(p).clone()
+        if back:
+            torch._foreach_copy_([a for a, _ in back], [b for _, b in back])
+        return buf[self.n_grads:self.n_grads + self.n_scalars].clone()
 
 
 def all_gather_rays(local, n_total, rank, world, group=None):
