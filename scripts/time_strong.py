@@ -22,6 +22,8 @@ r = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), 64, 128, precision=os.
 xs, ys = random_pixels(4096, scene_cpu["H"], scene_cpu["W"], seed=0)
 xs, ys = xs[:n].to(dev).contiguous(), ys[:n].to(dev).contiguous()
 noise = torch.rand(4096, 64, generator=torch.Generator().manual_seed(100))[:n].to(dev).contiguous()
+fold = int(os.environ.get("FOLD", "3"))      # bit 0: coarse compositing + re-sampling in one launch; bit 1: rays generated inside the coarse MLP launch; 0: the launch structure of rounds 1-3
+r.fold_launches, r.fold_rays = bool(fold & 1), bool(fold & 2)
 r.pass_.repack_sources()
 for _ in range(max(150, steps // 2)):
     r.render(xs, ys, perturb=1.0, noise=noise, repack=repack)
@@ -31,4 +33,4 @@ for _ in range(steps):
     r.render(xs, ys, perturb=1.0, noise=noise, repack=repack)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / steps * 1e3
-print("render step %d rays x (64+128), repack=%d: %.4f ms = %.3f M rays/s" % (n, repack, ms, n / ms / 1e3))
+print("render step %d rays x (64+128), repack=%d fold=%d: %.4f ms = %.3f M rays/s" % (n, repack, fold, ms, n / ms / 1e3))

@@ -193,3 +193,59 @@ def test_frozen_network_with_differentiable_features_matches_oracle_autograd(sd_
         gs = fo.grad.abs().max().item()
         close(fd.grad, fo.grad, 2e-4 * gs, 2e-3)
         assert all(p.grad is None for p in net.parameters())
+
+
+# ---------------------------------------------------------------------------------------------- the launches folded into the coarse pass
+@pytest.mark.parametrize("S,M,u_kind", [(64, 128, "linspace"), (64, 128, "random"), (90, 45, "random"), (3, 7, "random"), (129, 300, "linspace"),
+                                        (200, 128, "random"), (300, 1024, "linspace")])
+def test_compositing_fused_with_the_resampling_equals_the_two_launches_bit_for_bit(S, M, u_kind, sd_v7):
+    """ABI v4 `ucnerf_render_params.resample` / `ucnerf_composite_sample_pdf`: network/renderer.py:109-140 followed by data/ray_utils.py:216-219 in ONE
+    launch.  Same weights (the lane split of the compositing kernel), hence the same cdf, the same searchsorted indices, the same depths."""
+    from uc_nerf_amd import ops
+    from test_hip_configs import render_pass_for
+    g = load_golden("g10_rendering")
+    rp, _ = render_pass_for(g, sd_v7, precision="bf16x3_fused")
+    rp.repack_sources()
+    gen = torch.Generator().manual_seed(S * 1000 + M)
+    n = 37
+    rays_d = dev(g["rays_d"][:n])
+    z = dev(torch.sort(1.0 + 3.0 * torch.rand(n, S, generator=gen), -1)[0])
+    u = torch.linspace(0., 1., M) if u_kind == "linspace" else torch.rand(n, M, generator=gen)
+    u = dev(u)
+    for want_rank in (False, True):
+        two = rp(rays_d, z, want=("acc", "weights", "var"))
+        hs = ops.sample_pdf(None, two["weights"], u, z_merge=z, want_inds=False, from_coarse=True, want_rank=want_rank)
+        one = rp(rays_d, z, want=("acc", "weights", "var"), resample={"u": u, "want_rank": want_rank})
+        for k in ("rgb", "depth", "acc", "weights", "var"):
+            assert torch.equal(one[k], two[k]), k
+        for k in ("samples", "z_sorted") + (("merge_rank",) if want_rank else ()):
+            assert torch.equal(one[k], hs[k]), k
+    assert one["z_sorted"].shape == (n, S + M) and bool((one["z_sorted"][:, 1:] >= one["z_sorted"][:, :-1]).all())
+
+
+@pytest.mark.parametrize("n,perturb", [(512, 1.0), (4096, 1.0), (37, 0.0), (1, 1.0)])
+def test_step_with_the_small_launches_folded_in_equals_the_old_launch_structure_bit_for_bit(n, perturb):
+    """ABI v4 gen_rays / gen_depths + resample: the 64 + 128 step as four launches (the gather-fused coarse launch generates its own rays, depths and
+    view-direction features; its compositing launch re-samples) against ray_gen_sample -> coarse -> composite -> sample_pdf -> fine -> composite."""
+    from uc_nerf_amd.pipeline import CoarseFineRenderer, flat_params_of
+    from uc_nerf_amd.synthetic import init_ucnerf_state_dict, make_scene, random_pixels, scene_to
+    scene = scene_to(make_scene(seed=0), torch.device(DEV))
+    sd = init_ucnerf_state_dict(seed=0, n_src=6, sigma_scale=0.05, sigma_bias=0.05)
+    r = CoarseFineRenderer(scene, flat_params_of(sd).to(DEV), 64, 128, precision="bf16x3_fused")
+    xs, ys = random_pixels(4096, 256, 320, seed=0)
+    xs, ys = dev(xs[:n].contiguous()), dev(ys[:n].contiguous())
+    noise = dev(torch.rand(n, 64, generator=torch.Generator().manual_seed(100)))
+    assert r.fold_launches and not r.fold_rays             # the default: compositing + re-sampling folded; rays still a launch (measured faster)
+    r.fold_launches = r.fold_rays = False
+    old = r.render(xs, ys, perturb=perturb, noise=noise if perturb > 0 else None)
+    old = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in old.items()}
+    for fl, fr in ((True, False), (False, True), (True, True)):
+        r.fold_launches, r.fold_rays = fl, fr
+        new = r.render(xs, ys, perturb=perturb, noise=noise if perturb > 0 else None)
+        for k in ("rays_d", "z_coarse", "z_samples", "z_fine", "rgb", "depth", "acc", "weights", "var"):
+            assert torch.equal(new[k], old[k]), (fl, fr, k)
+        for k in ("rgb", "depth", "weights"):
+            assert torch.equal(new["coarse"][k], old["coarse"][k]), (fl, fr, "coarse " + k)
+        # reuse_coarse goes through the same folded launches (merge_rank from the fused compositing launch)
+        ru = r.render(xs, ys, perturb=perturb, noise=noise if perturb > 0 else None, reuse_coarse=True)
+        assert torch.equal(ru["rgb"], old["rgb"]) and torch.equal(ru["depth"], old["depth"])

@@ -33,6 +33,7 @@
 #include "mlp_layout.h"
 #include "sincos_cw.h"
 #include "gather_cl_device.h"
+#include "raygen_device.h"
 #include "p24.h"
 
 // the LDS-DMA asm below names m0 as a clobber on purpose (it loads the LDS base into it)
@@ -570,11 +571,24 @@ struct FusedGather {
     const float* ndc_in[3];
     const float* ndc_enc;
     int s16;                 // the channel-last copies hold bf16 (ucnerf_render_params.sources_cl_bf16): 16-byte voxels, 24-byte pixels
+    // RAYGEN instantiation (ABI v4 gen_rays / gen_depths: ucnerf_ray_gen_sample folded into this launch): pixels and jitter draws in, and the rays,
+    // depths and view-direction features the launch generates are WRITTEN for the launches behind it (compositing, re-sampling, the fine pass)
+    const float* gen_xs;     // [n] pixel columns / rows
+    const float* gen_ys;
+    const float* gen_noise;  // [n,S] or NULL (perturb == 0)
+    float gen_K[4];          // K00, K02, K11, K12 of the target camera
+    float gen_R[12];         // its c2w, row-major 3x4
+    float gen_Q[12];         // rotation of the view-direction feature (w2c_dir)
+    float gen_perturb;
+    int gen_lindisp;
+    float* gen_rays_d;       // [n,3] out
+    float* gen_z;            // [n,S] out
+    float* gen_angle;        // [n,3] out
 };
 [[maybe_unused]] constexpr int FUSED_MAX_V = 8;    // (seven and eight views: with a two-slot weight ring, fused_ring_slots)
 constexpr int VIEW_TAB = 24;      // floats per source view in the LDS table: w2c (12), K (9), pad
 
-template <bool TILED, int NSRC, int TERMS, int SAVE, bool FUSED = false, bool COORDS = false, bool S16 = false>       // TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only); SAVE: training forward keeping the activation sets (1: fp32, 2: the 24-bit format of p24.h); COORDS (FUSED only): sample coordinates given; S16 (FUSED only): bf16 channel-last sources
+template <bool TILED, int NSRC, int TERMS, int SAVE, bool FUSED = false, bool COORDS = false, bool S16 = false, bool RAYGEN = false>       // RAYGEN (FUSED only): rays and stratified depths generated in the tile prologue; TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only); SAVE: training forward keeping the activation sets (1: fp32, 2: the 24-bit format of p24.h); COORDS (FUSED only): sample coordinates given; S16 (FUSED only): bf16 channel-last sources
 #ifndef UCNERF_BF16_WPS
 #define UCNERF_BF16_WPS 2      // waves per SIMD: 2 -> 256 VGPRs per wave, 1 -> 512
 #endif
@@ -725,6 +739,12 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             return;
         }
         const unsigned r = fg.S == 1 ? s : (__umulhi(s, fg.div_m) >> fg.div_sh);
+        if (RAYGEN) {                                        // pixel and jitter draw of the sample: g_gen() turns them into ray and depth
+            grd[0] = fg.gen_xs[r]; grd[1] = fg.gen_ys[r];
+            gz = fg.gen_noise ? fg.gen_noise[s] : 0.f;
+            gnf[0] = gnf[2] = fg.near; gnf[1] = gnf[3] = fg.far;
+            return;
+        }
         gz = fg.z[s];
         const float* rd = fg.rays_d + 3 * (size_t)r;
         grd[0] = rd[0]; grd[1] = rd[1]; grd[2] = rd[2];
@@ -803,7 +823,24 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             fi[pr].mask = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.f : 0.f;
         }
     };
-    auto g_foot = [&]() {
+    // RAYGEN: ray, depth and view-direction feature of this lane's sample from its pixel and jitter draw (raygen_device.h: the arithmetic of
+    // ray_gen_sample_kernel, same bits), stored for the launches behind this one; the feature also goes to the sample's own slot of a scratch
+    // row -- the lane pair reads it back in layer 5 instead of carrying three registers through the trunk
+    // RAYGEN: ray and depth of this lane's sample from its pixel and jitter draw (raygen_device.h: the arithmetic of ray_gen_sample_kernel, same
+    // bits).  Nothing is stored here: vector-memory operations retire in issue order, so a store in FRONT of the gather's corner loads puts its
+    // write acknowledgement (~4 us at 512 rays) in front of every one of them, and values kept across the gather spill (208 bytes per lane for
+    // five views and more).  The launch's side outputs -- z, rays_d, the view-direction feature -- are produced once more in layer 5, where the
+    // non-generating kernel loads its direction row (see RAYGEN there).
+    auto g_gen = [&](int tile) {
+        const unsigned s = (unsigned)sample_of(tile);
+        const unsigned r = fg.S == 1 ? s : (__umulhi(s, fg.div_m) >> fg.div_sh);
+        float wx, wy, wz;
+        pinhole_ray(grd[0], grd[1], fg.gen_K[0], fg.gen_K[1], fg.gen_K[2], fg.gen_K[3], fg.gen_R, &wx, &wy, &wz);
+        gz = stratified_depth(fg.near, fg.far, (int)(s - r * (unsigned)fg.S), fg.S, fg.gen_lindisp, fg.gen_perturb, gz);
+        grd[0] = wx; grd[1] = wy; grd[2] = wz;
+    };
+    auto g_foot = [&](int tile) {
+        if (RAYGEN) g_gen(tile);
 #pragma unroll
         for (int part = 0; part < 3 + NP; ++part) g_part(part);
     };
@@ -899,7 +936,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     };
     if (FUSED) {                                            // (the gather itself opens every iteration of the tile loop)
         g_pre(tile0);
-        if (UCNERF_FUSED_FOOT_UNDER_GEMM) g_foot();
+        if (UCNERF_FUSED_FOOT_UNDER_GEMM) g_foot(tile0);
     } else fetch(tile0);
 
 #ifdef UCNERF_MLP_DIAG
@@ -919,7 +956,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         if (FUSED) {
             // this tile's gather (its depth / ray / depth range came in under the previous tile's last GEMM phase); the point encoding
             // runs while the first loads are in flight.  ONE copy of this code: as a prologue before the loop it spilled 208 bytes per lane
-            if (!UCNERF_FUSED_FOOT_UNDER_GEMM) g_foot();
+            if (!UCNERF_FUSED_FOOT_UNDER_GEMM) g_foot(tile);
             g_issue_first();
             encode_point(); g_finish();
             cur = read_half(P.buf, lane, 0);               // the fragments the last half-step left in `cur`, read again: sixteen registers the gather can use
@@ -1108,11 +1145,35 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
 #endif
                            }
                        }
+                       if (RAYGEN) {                           // pixel and jitter draw again (the ray's row of xs / ys, the sample's draw): three loads where the
+                           const unsigned r_ = fg.S == 1 ? (unsigned)s_here : (__umulhi((unsigned)s_here, fg.div_m) >> fg.div_sh);     // direction row would be loaded
+                           dv[0] = fg.gen_xs[r_]; dv[1] = fg.gen_ys[r_]; dv[2] = fg.gen_noise ? fg.gen_noise[s_here] : 0.f;
+                       } else {
                        int ray = s_here;
                        if (!p.dirs_per_sample) { int S = p.S; asm volatile("" : "+s"(S)); ray = s_here / S; }   // (opaque: no reciprocal hoisted into a loop-long VGPR)
                        const float* drow = p.dirs + (size_t)ray * 3;
                        dv[0] = drow[0]; dv[1] = drow[1]; dv[2] = drow[2];
+                       }
                        if (FUSED && UCNERF_FUSED_FOOT_UNDER_GEMM) g_pre(tile + tiles_per_round);      // depth, ray, depth range of the NEXT tile's sample (clamped past the end: harmless)
+                   }
+                   if (RAYGEN && q == 10) {                // the launch's side outputs, beside the MFMAs: depth of every sample, ray and feature once per ray
+                       const unsigned r_ = fg.S == 1 ? (unsigned)s_here : (__umulhi((unsigned)s_here, fg.div_m) >> fg.div_sh);
+                       const bool first = (unsigned)s_here == r_ * (unsigned)fg.S;
+                       float wx, wy, wz, ax, ay, az;
+                       pinhole_ray(dv[0], dv[1], fg.gen_K[0], fg.gen_K[1], fg.gen_K[2], fg.gen_K[3], fg.gen_R, &wx, &wy, &wz);
+                       const float zz = stratified_depth(fg.near, fg.far, (int)((unsigned)s_here - r_ * (unsigned)fg.S), fg.S, fg.gen_lindisp, fg.gen_perturb, dv[2]);
+                       view_dir_feature(wx, wy, wz, fg.gen_Q, &ax, &ay, &az);
+                       if (opaque(h) == 0 && tile * 32 + (opaque(lane) & 31) < p.m) {
+                           fg.gen_z[s_here] = zz;
+                           if (first) {
+                               float* rd = fg.gen_rays_d + 3 * (size_t)r_;
+                               rd[0] = wx; rd[1] = wy; rd[2] = wz;
+                               float* ao = fg.gen_angle + 3 * (size_t)r_;
+                               ao[0] = ax; ao[1] = ay; ao[2] = az;
+                           }
+                       }
+                       dv[0] = ax; dv[1] = ay; dv[2] = az;
+                       pin(dv[0]); pin(dv[1]); pin(dv[2]);
                    }
                    if (FUSED && UCNERF_FUSED_FOOT_UNDER_GEMM && q == 10) {     // every plain load of the tile is waited for HERE, in one place
                        pin(dv[0]); pin(dv[1]); pin(dv[2]);
@@ -1298,6 +1359,8 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
         fg = *fuse;
         UCNERF_REQUIRE(!(fg.s16 && fg.pts_in), "mlp_fwd (gather fused): bf16 channel-last sources are served on derived coordinates only (given coordinates: fp32 copies, "
                        "or the two-kernel pass)");
+        UCNERF_REQUIRE(!fg.gen_xs || (!fg.s16 && !fg.pts_in && !fg.near_far && B.v <= 6), "mlp_fwd (gather fused): generated rays go with fp32 source copies, derived "
+                       "coordinates, the scene's depth range and at most six source views");
         const size_t smem_f = bf16_smem_bytes_fused(B.v);
 #define X(N)                                                                                                                   \
         if (B.v == N && !fg.pts_in && fg.s16) {                                                                                \
@@ -1305,7 +1368,7 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
             if (int rc = ensure_dynamic_lds(fn, (int)smem_f, "mlp_fwd (bf16x3, gather fused, bf16 sources)")) return rc;      \
             hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, 3, false, true, false, true>), grid, block, smem_f, st, *p, g, n_tiles, sv, fg); \
         }                                                                                                                      \
-        if (B.v == N && !fg.pts_in && !fg.s16) {                                                                               \
+        if (B.v == N && !fg.pts_in && !fg.s16 && !fg.gen_xs) {                                                                 \
             const void* fn = (const void*)mlp_fwd_bf16_kernel<true, N, 3, false, true>;                                        \
             if (int rc = ensure_dynamic_lds(fn, (int)smem_f, "mlp_fwd (bf16x3, gather fused)")) return rc;                    \
             hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, 3, false, true>), grid, block, smem_f, st, *p, g, n_tiles, sv, fg); \
@@ -1316,6 +1379,15 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
             hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, 3, false, true, true>), grid, block, smem_f, st, *p, g, n_tiles, sv, fg); \
         }
         UCNERF_BF16_FOR_ALL(X)
+#undef X
+        // rays generated inside the launch (ABI v4 gen_rays / gen_depths): one to six source views (seven and eight spill 24 bytes per lane)
+#define X(N)                                                                                                                   \
+        if (B.v == N && fg.gen_xs) {                                                                                           \
+            const void* fn = (const void*)mlp_fwd_bf16_kernel<true, N, 3, false, true, false, false, true>;                    \
+            if (int rc = ensure_dynamic_lds(fn, (int)smem_f, "mlp_fwd (bf16x3, gather fused, rays generated)")) return rc;    \
+            hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, 3, false, true, false, false, true>), grid, block, smem_f, st, *p, g, n_tiles, sv, fg); \
+        }
+        X(1) X(2) X(3) X(4) X(5) X(6)
 #undef X
         return check_launch("mlp_fwd (bf16x3, gather fused)");
     }
@@ -1404,6 +1476,16 @@ int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* re
     memcpy(f.K_ref, rp->K_ref, sizeof(f.K_ref));
     f.w2cs = rp->w2cs; f.Ks = rp->intrinsics;
     f.pts_in = rp->pts_in; f.ndc_in[0] = rp->ndc1_in; f.ndc_in[1] = rp->ndc2_in; f.ndc_in[2] = rp->ndc3_in; f.ndc_enc = rp->ndc_in;
+    if (rp->gen_rays) {          // ABI v4: the launch generates rays and stratified depths itself (validated by ucnerf_render_fused_fwd)
+        const ucnerf_ray_gen_params* gr = rp->gen_rays;
+        const ucnerf_sample_stratified_params* gs = rp->gen_depths;
+        f.gen_xs = gr->xs; f.gen_ys = gr->ys; f.gen_noise = gs->perturb > 0.f ? gs->noise : nullptr;
+        f.gen_K[0] = gr->K[0]; f.gen_K[1] = gr->K[2]; f.gen_K[2] = gr->K[4]; f.gen_K[3] = gr->K[5];
+        memcpy(f.gen_R, gr->c2w, sizeof(f.gen_R));
+        memcpy(f.gen_Q, gr->w2c_dir, sizeof(f.gen_Q));
+        f.gen_perturb = gs->perturb; f.gen_lindisp = gs->lindisp;
+        f.gen_rays_d = gr->rays_d; f.gen_z = gs->z; f.gen_angle = gr->angle;      // (`dirs` is not read: every lane derives its ray's feature itself)
+    }
     {   // magic for idx / S (gather_cl.hip)
         unsigned l = 1;
         while ((1u << l) < (unsigned)rp->S) ++l;

@@ -1,6 +1,7 @@
 // K1/K2/K3 + a2/a5 small per-ray / per-sample kernels (HBM-bound, one thread per element).
 #include "common.h"
 #include "sincos_cw.h"
+#include "raygen_device.h"
 
 #include <atomic>
 #include <mutex>
@@ -52,30 +53,20 @@ __device__ __forceinline__ void ray_gen_one(const ucnerf_ray_gen_params& p, int 
         y = (float)(idx / p.W);
         x = (float)(idx % p.W);
     }
-    float dx, dy, dz;
+    const float* R = p.c2w;
+    float wx, wy, wz;
     if (p.opengl) {                            // utils/run_nerf_helpers.py:252
         float f = p.K[0];
-        dx = (x - p.W * .5f) / f;
-        dy = -(y - p.H * .5f) / f;
-        dz = -1.0f;
+        const float dx = (x - p.W * .5f) / f, dy = -(y - p.H * .5f) / f, dz = -1.0f;
+        wx = dx * R[0] + dy * R[1] + dz * R[2]; wy = dx * R[4] + dy * R[5] + dz * R[6]; wz = dx * R[8] + dy * R[9] + dz * R[10];
     } else {                                   // data/ray_utils.py:27, utils/utils.py:259-261
-        dx = (x - p.K[2]) / p.K[0];
-        dy = (y - p.K[5]) / p.K[4];
-        dz = 1.0f;
+        pinhole_ray(x, y, p.K[0], p.K[2], p.K[4], p.K[5], R, &wx, &wy, &wz);
     }
-    const float* R = p.c2w;
-    const float wx = dx * R[0] + dy * R[1] + dz * R[2], wy = dx * R[4] + dy * R[5] + dz * R[6], wz = dx * R[8] + dy * R[9] + dz * R[10];
     p.rays_d[3 * i + 0] = wx;
     p.rays_d[3 * i + 1] = wy;
     p.rays_d[3 * i + 2] = wz;
-    if (p.angle) {                             // the arithmetic of dir_feature_kernel on the values just stored
-        const float c = sqrtf(wx * wx + wy * wy + wz * wz);
-        const float ux = wx / c, uy = wy / c, uz = wz / c;
-        const float* Q = p.w2c_dir;
-        p.angle[3 * i + 0] = ux * Q[0] + uy * Q[1] + uz * Q[2];
-        p.angle[3 * i + 1] = ux * Q[4] + uy * Q[5] + uz * Q[6];
-        p.angle[3 * i + 2] = ux * Q[8] + uy * Q[9] + uz * Q[10];
-    }
+    if (p.angle)                               // the arithmetic of dir_feature_kernel on the values just stored
+        view_dir_feature(wx, wy, wz, p.w2c_dir, &p.angle[3 * i + 0], &p.angle[3 * i + 1], &p.angle[3 * i + 2]);
     if (p.rays_o) {
         p.rays_o[3 * i + 0] = R[3];
         p.rays_o[3 * i + 1] = R[7];
@@ -134,30 +125,11 @@ __global__ void dir_feature_kernel(ucnerf_dir_feature_params p) {
 }
 
 // ------------------------------------------------------------------------------------------- a3
-// torch.linspace(0, 1, S)[i]: ATen computes start + step*i below the midpoint and end - step*(S-1-i) above.
-__device__ __forceinline__ float linspace01(int i, int S) {
-    if (S == 1) return 0.f;
-    float step = 1.0f / (float)(S - 1);
-    return i < S / 2 ? step * (float)i : 1.0f - step * (float)(S - 1 - i);
-}
-
-__device__ __forceinline__ float z_at(float near, float far, int i, int S, int lindisp) {
-    float t = linspace01(i, S);
-    return lindisp ? 1.f / (1.f / near * (1.f - t) + 1.f / far * t) : near * (1.f - t) + far * t;
-}
-
 __device__ __forceinline__ void sample_stratified_one(const ucnerf_sample_stratified_params& p, long long idx) {
     int r = (int)(idx / p.S), s = (int)(idx % p.S);
     const float* ray = p.rays ? p.rays + 8 * (size_t)r : nullptr;
     const float near = ray ? ray[6] : p.near, far = ray ? ray[7] : p.far;
-    float z = z_at(near, far, s, p.S, p.lindisp);
-    if (p.perturb > 0.f) {
-        float zl = s > 0 ? z_at(near, far, s - 1, p.S, p.lindisp) : z;
-        float zu = s + 1 < p.S ? z_at(near, far, s + 1, p.S, p.lindisp) : z;
-        float lower = s > 0 ? .5f * (zl + z) : z;         // mids = .5*(z[:-1] + z[1:])
-        float upper = s + 1 < p.S ? .5f * (z + zu) : z;
-        z = lower + (upper - lower) * (p.perturb * p.noise[idx]);
-    }
+    const float z = stratified_depth(near, far, s, p.S, p.lindisp, p.perturb, p.perturb > 0.f ? p.noise[idx] : 0.f);
     p.z[idx] = z;
     if (p.pts) {
         p.pts[3 * idx] = ray[0] + ray[3] * z;

@@ -135,10 +135,11 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
         UCNERF_REQUIRE(p->sources_cl && !keep_feats && !p->u_sampled && !p->train_workspace,
                        "render_fused_fwd: precision 3 (gather fused into the MLP kernel) needs the channel-last sources; it keeps no features "
                        "and returns no per-sample uncertainty");
-        if (!p->dir_feat && (rc = launch_dirs(p, st, w))) return rc;
+        const bool gen = p->gen_rays != nullptr;          // rays, depths and direction features are generated inside the launch (w->angle: its per-sample scratch)
+        if (!gen && !p->dir_feat && (rc = launch_dirs(p, st, w))) return rc;
         raw_fused = p->raw ? p->raw : w->raw;
         if (p->ev_mlp_start && (rc = ucnerf_event_record(p->ev_mlp_start, st))) return rc;
-        if ((rc = launch_mlp_fwd_bf16x3_gather(p, p->sources_cl, p->dir_feat ? p->dir_feat : w->angle, raw_fused, st))) return rc;
+        if ((rc = launch_mlp_fwd_bf16x3_gather(p, p->sources_cl, gen ? w->angle : p->dir_feat ? p->dir_feat : w->angle, raw_fused, st))) return rc;
         if (p->ev_mlp_stop && (rc = ucnerf_event_record(p->ev_mlp_stop, st))) return rc;
     } else if (p->sources_cl) {                                // fast path: channel-last sources, coordinates derived in-kernel
         g.out_tiled = keep_feats ? (p->feats_tiled ? 1 : 0) : 1;
@@ -175,6 +176,12 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
     c.raw = m.raw; c.z = p->z;
     c.rgb_map = p->rgb_map; c.depth_map = p->depth_map; c.acc_map = p->acc_map; c.weights = p->weights; c.var = p->var;
     c.u = p->u_sampled; c.wu = p->wu_map;
+    if (p->resample) {                                   // ABI v4: this pass's compositing and the next pass's depths from ONE launch
+        UCNERF_REQUIRE(!p->u_sampled, "render_fused_fwd: resample and the per-sample uncertainty outputs exclude each other");
+        ucnerf_sample_pdf_params s = *p->resample;
+        s.weights = nullptr; s.z_merge = p->z;
+        return ucnerf_composite_sample_pdf(&c, &s, st);
+    }
     return ucnerf_composite_fwd(&c, st);
 }
 
@@ -257,7 +264,20 @@ int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream) {
     UCNERF_REQUIRE(!p->wu_map || p->u_sampled, "render_fused_fwd: wu_map needs u_sampled");
     const int n_given = !!p->pts_in + !!p->ndc1_in + !!p->ndc2_in + !!p->ndc3_in + !!p->ndc_in;
     UCNERF_REQUIRE(n_given == 0 || n_given == 5, "render_fused_fwd: pts_in / ndc1_in / ndc2_in / ndc3_in / ndc_in must be given together");
-    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE((p->gen_rays != nullptr) == (p->gen_depths != nullptr), "render_fused_fwd: gen_rays and gen_depths go together");
+    if (p->gen_rays) {
+        const ucnerf_ray_gen_params* gr = p->gen_rays;
+        const ucnerf_sample_stratified_params* gs = p->gen_depths;
+        UCNERF_REQUIRE(p->cfg.precision == 3 && n_given == 0 && !p->near_far && !p->sources_cl_bf16,
+                       "render_fused_fwd: generated rays are served by the gather-fused kernel (cfg.precision 3) on derived coordinates, the scene's depth range and fp32 source copies");
+        UCNERF_REQUIRE(gr->n == p->n && gs->n == p->n && gs->S == p->S, "render_fused_fwd: gen_rays / gen_depths sizes (%d, %d x %d) differ from the pass's (%d x %d)",
+                       gr->n, gs->n, gs->S, p->n, p->S);
+        UCNERF_REQUIRE(gr->xs && gr->ys && !gr->opengl && !gr->rays_o && !gr->pix, "render_fused_fwd: gen_rays takes pixel lists in the intrinsic-matrix convention (no origin / pixel outputs)");
+        UCNERF_REQUIRE(!gs->rays && !gs->pts && (!(gs->perturb > 0.f) || gs->noise), "render_fused_fwd: gen_depths uses the scalar near / far form (and needs noise draws when perturb > 0)");
+        UCNERF_REQUIRE(gs->near == p->near && gs->far == p->far, "render_fused_fwd: gen_depths samples [%g, %g] but the pass's scene range is [%g, %g]", gs->near, gs->far, p->near, p->far);
+        UCNERF_REQUIRE(gr->rays_d && gr->angle && gs->z && gr->rays_d == p->rays_d && gs->z == p->z && gr->angle == p->dir_feat,
+                       "render_fused_fwd: rays_d / z / dir_feat must be the buffers gen_rays / gen_depths fill");
+    }
     Workspace w;
     return run_forward(p, (hipStream_t)stream, &w);
 }

@@ -118,7 +118,10 @@ class RaySampler:
             _mat(self.rg.w2c_dir, w2c_dir, 3, 4)
         self.ss.S, self.ss.lindisp, self.ss.near, self.ss.far = int(S), int(lindisp), float(near), float(far)
 
-    def __call__(self, xs, ys, perturb=0.0, noise=None):
+    def prepare(self, xs, ys, perturb=0.0, noise=None):
+        """Binds inputs and freshly allocated outputs WITHOUT launching: (rays_d, angle, z) are filled by whoever runs the bound structs --
+        `__call__` (ucnerf_ray_gen_sample) or a render pass handed this sampler as `gen=` (ABI v4: the gather-fused MLP launch of the coarse pass
+        generates rays and depths in its own prologue)."""
         xs, ys = _f32(xs, "xs"), _f32(ys, "ys")
         n, device = xs.numel(), xs.device
         rg, ss = self.rg, self.ss
@@ -130,9 +133,14 @@ class RaySampler:
         if perturb > 0:
             noise = _f32(noise if noise is not None else torch.rand(n, ss.S, device=device), "noise")
         ss.noise = _ptr(noise if perturb > 0 else None)
-        with _on(device):
-            L.check(L.lib().ucnerf_ray_gen_sample(C.addressof(rg), C.addressof(ss), _stream()), "ucnerf_ray_gen_sample")
+        self._alive = (xs, ys, noise)              # (until the launch that reads them is enqueued)
         return rays_d, angle, z
+
+    def __call__(self, xs, ys, perturb=0.0, noise=None):
+        out = self.prepare(xs, ys, perturb, noise)
+        with _on(out[0].device):
+            L.check(L.lib().ucnerf_ray_gen_sample(C.addressof(self.rg), C.addressof(self.ss), _stream()), "ucnerf_ray_gen_sample")
+        return out
 
 
 def ray_gen_sample(K, c2w, xs, ys, S, near, far, perturb=0.0, noise=None, lindisp=False, w2c_dir=None):
@@ -972,9 +980,14 @@ class RenderPass:
         p.pts_in, p.ndc1_in, p.ndc2_in, p.ndc3_in, p.ndc_in = (_ptr(t) for t in keep)
         return keep
 
-    def __call__(self, rays_d, z, near_far=None, want=("acc", "weights", "var"), keep=(), events=None, dir_feat=None, coords=None):
+    def __call__(self, rays_d, z, near_far=None, want=("acc", "weights", "var"), keep=(), events=None, dir_feat=None, coords=None, resample=None, gen=None):
         """want may also name "u" (per-sample uncertainty u = 1 - sampled confidence [n,S], network/models.py:149) and
-        "wu" (its composite sum_i w_i u_i [n]) -- the opt-in uncertainty outputs of SURVEY.md 8(a)."""
+        "wu" (its composite sum_i w_i u_i [n]) -- the opt-in uncertainty outputs of SURVEY.md 8(a).
+        resample: dict(u=draws [n,M] or [M], want_rank=False) -- the pass's compositing launch also draws the NEXT pass's depths from this pass's
+        weights (data/ray_utils.py:216-219: mid-point bins, w[1:-1], sorted merge with z): adds out["samples"] [n,M], out["z_sorted"] [n,S+M]
+        (and out["merge_rank"]), the results of sample_pdf(None, out["weights"], u, z_merge=z, from_coarse=True) bit for bit, with no launch of its own.
+        gen: a RaySampler whose prepare() returned this call's (rays_d, dir_feat, z): the pass generates them itself (gather-fused kernel only) -- the
+        values of RaySampler.__call__, bit for bit, with no launch of its own."""
         rays_d, z = _f32(rays_d, "rays_d"), _f32(z, "z")
         dir_feat = _f32(dir_feat, "dir_feat") if dir_feat is not None else None
         n, S = z.shape
@@ -1014,6 +1027,31 @@ class RenderPass:
         p.ev_mlp_start, p.ev_mlp_stop = events if events is not None else (None, None)
         p.train_workspace = None
         p.dir_feat = _ptr(dir_feat)
+        p.gen_rays = p.gen_depths = None
+        if gen is not None:
+            if self.pw.cfg.precision != 3 or coords is not None or near_far is not None or dir_feat is None:
+                raise RuntimeError("uc_nerf_amd.RenderPass: gen= needs the gather-fused kernel (precision 'bf16x3_fused'), derived coordinates and the sampler's dir_feat")
+            p.gen_rays, p.gen_depths = C.addressof(gen.rg), C.addressof(gen.ss)
+        p.resample = None
+        if resample is not None:
+            u = _f32(resample["u"], "u")
+            M = u.shape[-1]
+            sp = self._resample_p = getattr(self, "_resample_p", None) or L.SamplePdfParams()
+            sp.n, sp.n_bins, sp.n_samples, sp.n_merge, sp.from_coarse = n, S - 1, M, S, 1
+            if u.numel() == n * M:
+                sp.u_stride = M
+            elif u.numel() == M:
+                sp.u_stride = 0
+            else:
+                raise RuntimeError("uc_nerf_amd.RenderPass: resample draws must be [n, M] or [M]")
+            out["samples"] = torch.empty(n, M, device=dev)
+            out["z_sorted"] = torch.empty(n, S + M, device=dev)
+            sp.merge_rank = None
+            if resample.get("want_rank"):
+                out["merge_rank"] = torch.empty(n, S + M, dtype=torch.int32, device=dev)
+                sp.merge_rank = _ptr(out["merge_rank"])
+            sp.u, sp.samples, sp.z_sorted = _ptr(u), _ptr(out["samples"]), _ptr(out["z_sorted"])
+            p.resample = C.addressof(sp)
         self._saved_for = None
         if training:
             # training forward (exact f32 or split-bf16): keep the MLP activations in the backward's workspace so that

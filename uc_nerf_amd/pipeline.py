@@ -1,8 +1,10 @@
 """The 64 coarse + 128 fine hierarchical renderer composed from the library's entry points
 (ray_marcher -> render -> sample_pdf on mid-points with w[1:-1] -> sorted merge -> render).
 
-Five library calls per batch (+ the source repack when asked), all on the caller's stream:
-  ray_gen_sample (rays + coarse depths) -> render_fused_fwd (coarse) -> sample_pdf(+merge) -> render_fused_fwd (fine)
+Library calls per batch (+ the source repack when asked), all on the caller's stream:
+  ray_gen_sample (rays + coarse depths) -> render_fused_fwd (coarse; its compositing launch also runs sample_pdf + merge) -> render_fused_fwd (fine).
+  Five kernel launches per step on the gather-fused route (rays, MLP, composite + re-sample, MLP, composite); `fold_rays` moves the first into the
+  coarse MLP launch (four launches; measured slower, off by default).
 """
 import torch
 
@@ -52,6 +54,13 @@ class CoarseFineRenderer:
         self.w2c_dir_host = w2c_ref.detach().cpu()
         self.near_host, self.far_host = float(scene["near"]), float(scene["far"])
         self.sampler = ops.RaySampler(self.K_host, self.c2w_host, n_coarse, self.near_host, self.far_host, self.w2c_dir_host)
+        # round 4: the small launches around the coarse pass are folded into it -- ray_gen_sample into the gather-fused kernel's prologue, the coarse
+        # compositing + sample_pdf + merge into one launch (a 512-ray shard's step is five launches instead of seven); False restores the old structure
+        self.fold_launches = True     # coarse compositing + sample_pdf + merge: one launch (-2.5 us per step at 512 and at 4096 rays, same box)
+        # ray_gen_sample inside the gather-fused coarse launch (ABI v4 gen_rays / gen_depths): built, bit-identical, and measured SLOWER than the
+        # 4.8-us launch it removes -- +1.2 us per step at 512 rays, +8 us at 4096 (profiles/r04_experiments.md: five correctly rounded divisions and
+        # a square root per lane and tile, twice, are ~200 vector instructions in a kernel where none is free).  Off by default.
+        self.fold_rays = False
 
     def set_params(self, flat_params):
         self.wstream.copy_(self.pw.pack(flat_params))
@@ -78,12 +87,22 @@ class CoarseFineRenderer:
         if repack:
             self.pass_.repack_sources()
         # rays and their view-direction feature from one launch; both passes take the feature as an input
-        rays_d, angle, z_c = self.sampler(xs, ys, perturb, noise)
-        ev = [(a.h, b.h) for a, b in events] if events else (None, None)
         n = int(xs.shape[0])
-        coarse = self._pass_for(n * self.n_coarse)(rays_d, z_c, want=("weights",), events=ev[0], keep=("raw",) if reuse_coarse else (), dir_feat=angle)
-        hs = ops.sample_pdf(None, coarse["weights"], self.u_det if u is None else u, z_merge=z_c, want_inds=False,
-                            from_coarse=True, want_rank=reuse_coarse)
+        cpass = self._pass_for(n * self.n_coarse)
+        # fold_rays (gather-fused kernel, up to six source views): the coarse launch generates rays, coarse depths and direction features itself
+        # (ABI v4 gen_rays / gen_depths) -- no ray_gen_sample launch
+        gen = self.sampler if (self.fold_rays and cpass.pw.cfg.precision == 3 and cpass.use_cl and self.src.V <= 6) else None
+        rays_d, angle, z_c = self.sampler.prepare(xs, ys, perturb, noise) if gen is not None else self.sampler(xs, ys, perturb, noise)
+        ev = [(a.h, b.h) for a, b in events] if events else (None, None)
+        # the coarse pass's compositing launch draws the fine depths as well (composite + sample_pdf + sorted merge: one launch, ABI v4)
+        if self.fold_launches:
+            coarse = cpass(rays_d, z_c, want=("weights",), events=ev[0], keep=("raw",) if reuse_coarse else (), dir_feat=angle, gen=gen,
+                           resample={"u": self.u_det if u is None else u, "want_rank": reuse_coarse})
+            hs = coarse
+        else:                                                   # (the launch structure of rounds 1-3, kept for A/B and the bit-identity tests)
+            coarse = cpass(rays_d, z_c, want=("weights",), events=ev[0], keep=("raw",) if reuse_coarse else (), dir_feat=angle, gen=gen)
+            hs = ops.sample_pdf(None, coarse["weights"], self.u_det if u is None else u, z_merge=z_c, want_inds=False,
+                                from_coarse=True, want_rank=reuse_coarse)
         if reuse_coarse:
             new = self._pass_for(n * self.n_fine)(rays_d, hs["samples"], want=(), events=ev[1], keep=("raw",), dir_feat=angle)
             raw = ops.merge_rows(new["raw"], coarse["raw"], hs["merge_rank"])      # cat(samples, z_coarse) order
