@@ -218,6 +218,11 @@ typedef struct {
                                         lanes add the 32 contiguous bytes of one corner instead of eight scattered
                                         cache lines) and added to g_vol / g_img_feat by a transposing pass.  Contents
                                         are overwritten.  NULL: atomics go straight to the channel-major outputs. */
+    float* g_sources_cl;             /* ABI v4, optional: a gradient buffer in the CHANNEL-LAST SOURCE LAYOUT (that of ucnerf_gather_repack, fp32:
+                                        [D,h,w,8] per volume, then [V,H,W,12] pixels = (r,g,b,f0..f7,pad)), 16-byte aligned.  The volume and
+                                        image-feature gradients are ACCUMULATED there (zero it first; the r,g,b,pad slots are never written) and
+                                        g_vol / g_img_feat / scratch are ignored: no scratch, no memset, no transposing pass -- for callers whose
+                                        sources already live channel-last (ucnerf_render_params.sources_cl handed over zero-copy) */
 } ucnerf_feat_gather_bwd_params;
 int ucnerf_feat_gather_bwd(const ucnerf_feat_gather_bwd_params* p, void* stream);
 int64_t ucnerf_feat_gather_bwd_scratch_floats(const ucnerf_feat_gather_params* p);
@@ -477,7 +482,8 @@ typedef struct {
     const float* w2cs;         /* [V,12] source views */
     const float* intrinsics;   /* [V,9] */
     const float* wstream;
-    const float* sources_cl;   /* optional: channel-last copies of the sources (ucnerf_gather_repack).  When given and
+    const float* sources_cl;   /* optional: channel-last copies of the sources (ucnerf_gather_repack) -- or the sources THEMSELVES, for a producer
+                                  that writes that layout (zero copy: vol / imgs / img_feat may then be NULL).  When given and
                                   `feats` is NULL, the pass uses the fast gather that reads them and derives the
                                   sample coordinates itself; vol/imgs/img_feat are then not touched.  REQUIRED when
                                   cfg.precision == 3 (the gather then runs inside the MLP kernel: no feature buffer) */
@@ -555,6 +561,8 @@ typedef struct {
     int32_t saved_valid;           /* 1: the forward call was given this `workspace` as fwd.train_workspace (it kept the
                                       MLP activations there), so the backward does not repeat the network forward */
     int32_t bwd_mode;              /* ucnerf_mlp_bwd_params.bwd_mode */
+    float* g_sources_cl;           /* ABI v4, optional: ucnerf_feat_gather_bwd_params.g_sources_cl -- source gradients accumulated in the channel-last
+                                      source layout (g_vol / g_img_feat / gather_scratch are then ignored; g_conf as before) */
 } ucnerf_render_bwd_params;
 int64_t ucnerf_render_bwd_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* p, void* stream);

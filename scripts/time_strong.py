@@ -18,6 +18,10 @@ steps = int(os.environ.get("STEPS", "300"))
 scene_cpu = make_scene(seed=0)
 scene = scene_to(scene_cpu, dev)
 sd = init_ucnerf_state_dict(seed=0, n_src=6, sigma_scale=0.05, sigma_bias=0.05)
+if os.environ.get("ZC", "0") == "1":       # sources handed over channel-last: read in place, no repack to hoist
+    from uc_nerf_amd import ops
+    cl = ops.ChannelLastSources.from_reference_layout(scene["vols"], scene["imgs"], scene["img_feat"])
+    scene = dict(scene, vols=cl.vols, imgs=cl.imgs, img_feat=cl.img_feat)
 r = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), 64, 128, precision=os.environ.get("PREC", "bf16x3_fused"))
 xs, ys = random_pixels(4096, scene_cpu["H"], scene_cpu["W"], seed=0)
 xs, ys = xs[:n].to(dev).contiguous(), ys[:n].to(dev).contiguous()

@@ -16,6 +16,10 @@ n, S = int(os.environ.get("RAYS", "1024")), int(os.environ.get("SAMPLES", "128")
 scene = scene_to(make_scene(seed=0), dev)
 sd = init_ucnerf_state_dict(seed=0, n_src=6, sigma_scale=0.05, sigma_bias=0.05)
 flat = flat_params_of(sd).to(dev)
+zc = os.environ.get("ZC", "0") == "1"      # sources handed over channel-last (ops.ChannelLastSources): no repack, channel-last source gradients
+if zc:
+    cl = ops.ChannelLastSources.from_reference_layout(scene["vols"], scene["imgs"], scene["img_feat"])
+    scene = dict(scene, vols=cl.vols, imgs=cl.imgs, img_feat=cl.img_feat)
 r = CoarseFineRenderer(scene, flat, 64, 128)          # f32: the training path
 xs, ys = random_pixels(n, scene["H"], scene["W"], seed=0)
 rays_d, _, _ = ops.ray_gen(r.K_host, r.c2w_host, xs=xs.to(dev), ys=ys.to(dev))
@@ -38,4 +42,4 @@ for _ in range(K):
     step()
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / K * 1e3
-print("train-style step (fwd + bwd), %d rays x %d samples: %.3f ms = %.0f rays/s" % (n, S, ms, n / ms * 1e3))
+print("train-style step (fwd + bwd), %d rays x %d samples, channel-last sources=%d: %.3f ms = %.0f rays/s" % (n, S, zc, ms, n / ms * 1e3))

@@ -249,3 +249,109 @@ def test_step_with_the_small_launches_folded_in_equals_the_old_launch_structure_
         # reuse_coarse goes through the same folded launches (merge_rank from the fused compositing launch)
         ru = r.render(xs, ys, perturb=perturb, noise=noise if perturb > 0 else None, reuse_coarse=True)
         assert torch.equal(ru["rgb"], old["rgb"]) and torch.equal(ru["depth"], old["depth"])
+
+
+# ---------------------------------------------------------------------------------------------- sources handed over channel-last, zero copy
+def _bench_scene_channel_last(seed=0):
+    from uc_nerf_amd import ops
+    from uc_nerf_amd.synthetic import make_scene, scene_to
+    scene = scene_to(make_scene(seed=seed), torch.device(DEV))
+    cl = ops.ChannelLastSources.from_reference_layout(scene["vols"], scene["imgs"], scene["img_feat"])
+    scene_cl = dict(scene, vols=cl.vols, imgs=cl.imgs, img_feat=cl.img_feat)
+    return scene, scene_cl, cl
+
+
+def test_channel_last_sources_are_read_zero_copy_and_render_bit_identically():
+    """ops.ChannelLastSources: the three cascade volumes as [1,8,D,h,w] views of [D,h,w,8] memory (torch's channels_last_3d) and the source images /
+    image features as views of [V,H,W,12] pixels, all in ONE buffer of the layout ucnerf_gather_repack writes.  A pass bound to them reads the buffer
+    in place (utils/utils.py:742-799,833-893 sample the same values): no repack launch, bit-identical renders."""
+    from uc_nerf_amd import ops
+    from uc_nerf_amd.pipeline import CoarseFineRenderer, flat_params_of
+    from uc_nerf_amd.synthetic import init_ucnerf_state_dict, random_pixels
+    scene, scene_cl, cl = _bench_scene_channel_last()
+    for a, b in zip(cl.vols + [cl.imgs, cl.img_feat], scene["vols"] + [scene["imgs"], scene["img_feat"]]):
+        assert a.shape == b.reshape(a.shape).shape and torch.equal(a, b.reshape(a.shape))
+    assert cl.vols[0].is_contiguous(memory_format=torch.channels_last_3d)
+    sd = init_ucnerf_state_dict(seed=0, n_src=6, sigma_scale=0.05, sigma_bias=0.05)
+    flat = flat_params_of(sd).to(DEV)
+    xs, ys = random_pixels(700, 256, 320, seed=0)
+    noise = dev(torch.rand(700, 64, generator=torch.Generator().manual_seed(100)))
+    for prec in ("bf16x3_fused", "bf16x3", "f32"):
+        ra = CoarseFineRenderer(scene, flat, 64, 128, precision=prec)
+        rb = CoarseFineRenderer(scene_cl, flat, 64, 128, precision=prec)
+        assert rb.src.zero_copy and not ra.src.zero_copy and rb.src._cl.data_ptr() == cl.buf.data_ptr()
+        before = cl.buf.clone()
+        a = ra.render(dev(xs), dev(ys), perturb=1.0, noise=noise)
+        b = rb.render(dev(xs), dev(ys), perturb=1.0, noise=noise, repack=True)       # (repack=True is a no-op for them: the buffer is the caller's)
+        assert torch.equal(cl.buf, before)
+        for k in ("rgb", "depth", "acc", "weights", "z_fine"):
+            assert torch.equal(a[k], b[k]), (prec, k)
+    # an entry point that reads the reference's channel-major layout refuses them (their pointers are withheld) instead of reading the wrong layout
+    src = ops.GatherSources(cl.vols, scene["confidence"], cl.imgs, cl.img_feat, scene["w2cs"][1:], scene["intrinsics"][1:])
+    assert src.zero_copy
+    pts = torch.rand(8, 4, 3, device=DEV)
+    with pytest.raises(RuntimeError, match="null"):
+        ops.feat_gather_fwd(src, pts, pts, pts, pts)
+    # views that are NOT one buffer of that layout take the repack route (here: the image stack moved elsewhere)
+    moved = ops.GatherSources(cl.vols, scene["confidence"], cl.imgs.clone(), cl.img_feat, scene["w2cs"][1:], scene["intrinsics"][1:])
+    assert not moved.zero_copy
+
+
+def test_training_through_channel_last_sources_returns_gradients_in_their_layout(sd_v7):
+    """rendering() under autograd with the sources handed over as ChannelLastSources views: the forward equals the repack route bit for bit, and the
+    gradients of the volumes / image features arrive as views (the inputs' shapes AND strides) of one buffer in the same channel-last layout --
+    accumulated there by the gather backward, no scratch, no transposing pass -- equal to the channel-major route's (float-atomic order aside)."""
+    from uc_nerf_amd import ops
+    mods = _mods()
+    g = load_golden("g10_rendering")
+    qfn = _qfn(mods)
+    gen = torch.Generator().manual_seed(7)
+    r3, r1 = dev(torch.randn(g["z"].shape[0], 3, generator=gen)), dev(torch.randn(g["z"].shape[0], generator=gen))
+    vols_ref = [dev(g["vol%d" % k]) for k in (1, 2, 3)]
+    cl = ops.ChannelLastSources.from_reference_layout(vols_ref, dev(g["imgs"]), dev(g["img_feat"]))
+
+    seen = {}
+
+    def run(zero_copy):
+        net = _net(mods, 7, sd_v7)
+        if zero_copy:
+            vols = [v.detach().requires_grad_(True) for v in cl.vols]
+            img_feat = cl.img_feat.detach().requires_grad_(True)
+            img_feat.register_hook(lambda gr: seen.update(stride=gr.stride(), ptr=gr.data_ptr()))      # the gradient as the backward hands it upstream
+            imgs = cl.imgs
+        else:
+            vols = [v.clone().requires_grad_(True) for v in vols_ref]
+            img_feat = dev(g["img_feat"]).requires_grad_(True)
+            imgs = dev(g["imgs"])
+        conf = dev(g["conf"]).requires_grad_(True)
+        V = g["V"]
+        args = types.SimpleNamespace(view_num=V, feat_dim=97, img_downscale=1.0, use_color_volume=False, net_type="v2")
+        vf = {"stage%d" % (i + 1): {"volume_feature_no_ref": vols[i]} for i in range(3)}
+        pose = {"w2cs": dev(g["w2cs"]).clone(), "intrinsics": dev(g["K"]).repeat(V, 1, 1)}
+        ndc = {"stage1": dev(g["ndc1"]), "stage2": dev(g["ndc2"]), "stage3": dev(g["ndc3"]), "ndc": dev(g["ndc"])}
+        rgb, depth = mods.renderer.rendering(args, pose, dev(g["pts"]), ndc, dev(g["z"]), dev(g["rays_d"]), vf, imgs, network_fn=net,
+                                             img_feat=img_feat, network_query_fn=qfn, confidence=conf)
+        ((rgb * r3).sum() + (depth * r1).sum()).backward()
+        from uc_nerf_amd import dropin
+        return rgb.detach(), depth.detach(), vols, img_feat, conf, net, dropin.session_of(net)
+
+    rgb_a, d_a, vols_a, if_a, conf_a, net_a, _ = run(False)
+    rgb_b, d_b, vols_b, if_b, conf_b, net_b, sess = run(True)
+    assert sess.src.zero_copy and sess.src._cl.data_ptr() == cl.buf.data_ptr()
+    assert torch.equal(rgb_a, rgb_b) and torch.equal(d_a, d_b)
+    # gradients: same shapes AND strides as the inputs, all inside one buffer laid out like the sources' own
+    base = vols_b[0].grad.data_ptr()
+    for k, (v, w) in enumerate(zip(vols_b, vols_a)):
+        assert v.grad.shape == v.shape and v.grad.stride() == v.stride(), k
+        assert v.grad.data_ptr() - base == v.data_ptr() - vols_b[0].data_ptr(), k
+        torch.testing.assert_close(v.grad, w.grad.reshape(v.shape), atol=2e-5 * max(w.grad.abs().max().item(), 1e-6), rtol=1e-4)
+    # the image features are 8 of a pixel's 12 floats: their gradient goes upstream (to the feature network's backward) as a view with the input's
+    # strides inside the same buffer; only a LEAF of that non-dense layout gets autograd's own contiguous copy as its .grad (torch's layout contract)
+    assert seen["stride"] == if_b.stride() and seen["ptr"] - base == if_b.data_ptr() - vols_b[0].data_ptr()
+    torch.testing.assert_close(if_b.grad, if_a.grad.reshape(if_b.shape), atol=2e-5 * max(if_a.grad.abs().max().item(), 1e-6), rtol=1e-4)
+    torch.testing.assert_close(conf_b.grad, conf_a.grad, atol=2e-5 * max(conf_a.grad.abs().max().item(), 1e-6), rtol=1e-4)
+    for (name, p), q in zip(net_a.named_parameters(), net_b.parameters()):
+        if p.grad is None:
+            assert q.grad is None, name
+        else:
+            torch.testing.assert_close(q.grad, p.grad, atol=2e-5 * max(p.grad.abs().max().item(), 1e-6), rtol=1e-4, msg=lambda s_: name + ": " + s_)

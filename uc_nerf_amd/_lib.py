@@ -62,7 +62,7 @@ class FeatGatherParams(C.Structure):
 
 class FeatGatherBwdParams(C.Structure):
     _fields_ = [("fwd", FeatGatherParams), ("g_feats", vp), ("g_vol", vp * 3), ("g_conf", vp), ("g_img_feat", vp),
-                ("scratch", vp)]
+                ("scratch", vp), ("g_sources_cl", vp)]
 
 
 class MlpConfig(C.Structure):
@@ -135,7 +135,7 @@ class RenderParams(C.Structure):
 class RenderBwdParams(C.Structure):
     _fields_ = [("fwd", RenderParams), ("g_rgb", vp), ("g_depth", vp), ("flat_params", vp), ("g_flat", vp),
                 ("g_vol", vp * 3), ("g_conf", vp), ("g_img_feat", vp), ("workspace", vp), ("gather_scratch", vp),
-                ("saved_valid", i32), ("bwd_mode", i32)]
+                ("saved_valid", i32), ("bwd_mode", i32), ("g_sources_cl", vp)]
 
 
 STRUCTS = {

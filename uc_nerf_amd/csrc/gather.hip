@@ -193,12 +193,15 @@ __global__ void __launch_bounds__(256) feat_gather_bwd_kernel(ucnerf_feat_gather
 
 // ---- channel-last accumulation (scratch given): thread = (sample, channel); the eight lanes of a sample add the 32
 // contiguous bytes of one corner, so an atomic wave-instruction touches 8 cache lines instead of 64.
-struct ScratchLayout { size_t vol[3], img, total; };
-__host__ __device__ inline ScratchLayout scratch_layout(const ucnerf_feat_gather_params& p) {
+// `pix`: floats per pixel of the image-feature region, `pix0`: where a pixel's eight feature gradients start -- (8, 0) in the scratch buffer,
+// (12, 3) in a gradient buffer that has the channel-last SOURCE layout (pixels = r,g,b,f0..f7,pad: ucnerf_feat_gather_bwd_params.g_sources_cl)
+struct ScratchLayout { size_t vol[3], img, total; int pix, pix0; };
+__host__ __device__ inline ScratchLayout scratch_layout(const ucnerf_feat_gather_params& p, bool source_layout = false) {
     ScratchLayout L;
     size_t o = 0;
     for (int k = 0; k < 3; ++k) { L.vol[k] = o; o += 8 * (size_t)p.vol_d[k] * p.vol_h[k] * p.vol_w[k]; }
-    L.img = o; o += 8 * (size_t)p.V * p.H * p.W;
+    L.pix = source_layout ? 12 : 8; L.pix0 = source_layout ? 3 : 0;
+    L.img = o; o += (size_t)L.pix * p.V * p.H * p.W;
     L.total = o;
     return L;
 }
@@ -237,10 +240,12 @@ __global__ void __launch_bounds__(256) feat_gather_bwd_cl_kernel(ucnerf_feat_gat
     const int F = 24 + 12 * p.V + 1;
     if (p.unit_mask && !((p.unit_mask >> unit) & 1)) return;            // (uniform per block)
     const float* gf = bp.g_feats + (size_t)s * F;
-    const ScratchLayout L = scratch_layout(p);
+    const bool to_sources = bp.g_sources_cl != nullptr;                 // accumulate straight into a gradient buffer in the channel-last source layout
+    float* const acc_buf = to_sources ? bp.g_sources_cl : bp.scratch;
+    const ScratchLayout L = scratch_layout(p, to_sources);
     if (unit < 3) {
-        if (!bp.g_vol[unit]) return;
-        float* gv = bp.scratch + L.vol[unit] + c;
+        if (!to_sources && !bp.g_vol[unit]) return;
+        float* gv = acc_buf + L.vol[unit] + c;
         const float* g = (unit == 0 ? p.ndc1 : unit == 1 ? p.ndc2 : p.ndc3) + 3 * (size_t)s;
         const int D = p.vol_d[unit], h = p.vol_h[unit], w = p.vol_w[unit];
         const Lerp ax = axis(g[0] * 2.f - 1.0f, w, false), ay = axis(g[1] * 2.f - 1.0f, h, false),
@@ -260,18 +265,19 @@ __global__ void __launch_bounds__(256) feat_gather_bwd_cl_kernel(ucnerf_feat_gat
         run_atomic_add<8>(gv, dead | (8 * (o11 + ax.i0)), gc * (w11 * ax.w0), sl);
         run_atomic_add<8>(gv, dead | (8 * (o11 + ax.i1)), gc * (w11 * ax.w1), sl);
     } else {
-        if (!bp.g_img_feat) return;
+        if (!to_sources && !bp.g_img_feat) return;
         const int v = unit - 4;
         float gx, gy;
         project_view(p, v, s, &gx, &gy);
         const Lerp ax = axis(gx, p.W, true), ay = axis(gy, p.H, true);
         const size_t hw = (size_t)p.H * p.W;
         const int o00 = ay.i0 * p.W + ax.i0, o01 = ay.i0 * p.W + ax.i1, o10 = ay.i1 * p.W + ax.i0, o11 = ay.i1 * p.W + ax.i1;
-        float* ft = bp.scratch + L.img + 8 * (size_t)v * hw + c;
+        const int ps = L.pix;
+        float* ft = acc_buf + L.img + (size_t)ps * v * hw + L.pix0 + c;
         const float gc = live ? gf[24 + 4 * p.V + 8 * v + c] : 0.f;
         const int dead = live ? 0 : -1;
-        run_atomic_add<8>(ft, dead | (8 * o00), gc * (ay.w0 * ax.w0), sl); run_atomic_add<8>(ft, dead | (8 * o01), gc * (ay.w0 * ax.w1), sl);
-        run_atomic_add<8>(ft, dead | (8 * o10), gc * (ay.w1 * ax.w0), sl); run_atomic_add<8>(ft, dead | (8 * o11), gc * (ay.w1 * ax.w1), sl);
+        run_atomic_add<8>(ft, dead | (ps * o00), gc * (ay.w0 * ax.w0), sl); run_atomic_add<8>(ft, dead | (ps * o01), gc * (ay.w0 * ax.w1), sl);
+        run_atomic_add<8>(ft, dead | (ps * o10), gc * (ay.w1 * ax.w0), sl); run_atomic_add<8>(ft, dead | (ps * o11), gc * (ay.w1 * ax.w1), sl);
     }
 }
 
@@ -340,6 +346,13 @@ int ucnerf_feat_gather_bwd(const ucnerf_feat_gather_bwd_params* bp, void* stream
     if (bp->fwd.m <= 0) return UCNERF_OK;
     hipStream_t st = (hipStream_t)stream;
     const ucnerf_feat_gather_params& f = bp->fwd;
+    if (bp->g_sources_cl) {      // ABI v4: the caller's gradients live in the channel-last source layout -- accumulate there, nothing else to do
+        UCNERF_REQUIRE(((uintptr_t)bp->g_sources_cl & 15) == 0, "feat_gather_bwd: g_sources_cl must be 16-byte aligned");
+        hipLaunchKernelGGL(feat_gather_bwd_cl_kernel, dim3(cdiv((long long)f.m * 8, 256), 3 + f.V), dim3(256), 0, st, *bp);
+        if (bp->g_conf && (8 & (f.unit_mask ? f.unit_mask : ~0)))
+            hipLaunchKernelGGL(conf_bwd_kernel, dim3(cdiv(f.m, 256)), dim3(256), 0, st, *bp);
+        return check_launch("feat_gather_bwd (channel-last gradients)");
+    }
     if (!bp->scratch) {
         hipLaunchKernelGGL(feat_gather_bwd_kernel, dim3(cdiv(f.m, 256), 4 + f.V), dim3(256), 0, st, *bp);
         return check_launch("feat_gather_bwd");

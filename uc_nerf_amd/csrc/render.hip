@@ -241,13 +241,13 @@ int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* bp, void* stream) {
     mb.saved_valid = bp->saved_valid; mb.bwd_mode = bp->bwd_mode;
     if ((rc = ucnerf_mlp_bwd(&mb, st))) return rc;
 
-    if (bp->g_vol[0] || bp->g_vol[1] || bp->g_vol[2] || bp->g_conf || bp->g_img_feat) {
+    if (bp->g_vol[0] || bp->g_vol[1] || bp->g_vol[2] || bp->g_conf || bp->g_img_feat || bp->g_sources_cl) {
         ucnerf_feat_gather_bwd_params gb;
         memset(&gb, 0, sizeof(gb));
         gather_geometry(&q, &w, &gb.fwd);
         gb.g_feats = g_feats;
         for (int k = 0; k < 3; ++k) gb.g_vol[k] = bp->g_vol[k];
-        gb.g_conf = bp->g_conf; gb.g_img_feat = bp->g_img_feat; gb.scratch = bp->gather_scratch;
+        gb.g_conf = bp->g_conf; gb.g_img_feat = bp->g_img_feat; gb.scratch = bp->gather_scratch; gb.g_sources_cl = bp->g_sources_cl;
         if ((rc = ucnerf_feat_gather_bwd(&gb, st))) return rc;
     }
     return UCNERF_OK;

@@ -272,6 +272,94 @@ def embed(x, n_freqs, layout=0):
 
 
 # ------------------------------------------------------------------------------------------------ a7
+def _cl_layout(vol_dhw, V, H, W):
+    """Float offsets of the channel-last source buffer the fast gather reads (ucnerf_gather_repack's layout, fp32): three volumes as
+    [D,h,w,8] voxels, then the source views as [V,H,W,12] pixels = (r, g, b, f0..f7, pad).  Returns ([vol offsets], pixel offset, total)."""
+    off, o = [], 0
+    for d, h, w in vol_dhw:
+        off.append(o)
+        o += 8 * d * h * w
+    return off, o, o + 12 * V * H * W
+
+
+class ChannelLastSources:
+    """ONE device buffer in the layout the gather kernels read, plus torch VIEWS of it in the reference's shapes -- for a producer that can write
+    its outputs there (or for sources that stay fixed over many steps):
+
+        vols[k]   [1, 8, D, h, w]   (memory [D,h,w,8]: what torch calls channels_last_3d)       <- volume_feature_no_ref of stage k + 1
+        imgs      [1, V, 3, H, W]   (channels 0..2 of the [V,H,W,12] pixels)                    <- imgs[:, 1:]
+        img_feat  [V, 1, 8, H, W]   (channels 3..10)                                            <- img_feat
+
+    Handed to `rendering()` / `GatherSources` (as they are, or `.detach().requires_grad_()` of them), these views are recognised by their
+    pointers and strides: the pass reads the buffer ZERO-COPY -- no per-step repack (25 us, 150 MB of traffic) -- and returns the source
+    gradients in the same layout (views with the inputs' strides: no transposing pass either).  Anything else takes the repack route."""
+
+    def __init__(self, vol_dhw, V, H, W, device):
+        self.vol_dhw, self.V, self.H, self.W = [tuple(int(x) for x in t) for t in vol_dhw], int(V), int(H), int(W)
+        voff, poff, total = _cl_layout(self.vol_dhw, V, H, W)
+        self.buf = torch.zeros(total, device=device)
+        self.vols, self.imgs, self.img_feat = self.views_of(self.buf)
+
+    def views_of(self, buf):
+        """The (vols, imgs, img_feat) views of a flat buffer of this geometry (the sources' buffer, or a gradient buffer of the same layout)."""
+        voff, poff, total = _cl_layout(self.vol_dhw, self.V, self.H, self.W)
+        vols = [buf[o:o + 8 * d * h * w].view(d, h, w, 8).permute(3, 0, 1, 2).unsqueeze(0) for o, (d, h, w) in zip(voff, self.vol_dhw)]
+        pix = buf[poff:total].view(self.V, self.H, self.W, 12)
+        return vols, pix[..., 0:3].permute(0, 3, 1, 2).unsqueeze(0), pix[..., 3:11].permute(0, 3, 1, 2).unsqueeze(1)
+
+    @classmethod
+    def from_reference_layout(cls, vols, imgs, img_feat):
+        """Allocates the buffer for these sources (reference layouts: volumes [1,8,D,h,w], imgs [1,V,3,H,W], img_feat [V,1,8,H,W]) and copies
+        them in -- once; afterwards the views ARE the sources."""
+        dhw = [tuple(v.shape[-3:]) for v in vols]
+        imgs4 = imgs.reshape(-1, 3, *imgs.shape[-2:])
+        c = cls(dhw, imgs4.shape[0], imgs.shape[-2], imgs.shape[-1], imgs.device)
+        with torch.no_grad():
+            for dst, src in zip(c.vols, vols):
+                dst.copy_(src.reshape(dst.shape))
+            c.imgs.copy_(imgs.reshape(c.imgs.shape))
+            c.img_feat.copy_(img_feat.reshape(c.img_feat.shape))
+        return c
+
+
+def _channel_last_alias(vols, imgs, img_feat):
+    """The flat fp32 tensor aliasing ONE buffer that `vols`, `imgs` and `img_feat` are the channel-last views of (ChannelLastSources), or None."""
+    try:
+        if vols is None or imgs is None or img_feat is None or any(v is None for v in vols):
+            return None
+        ts = list(vols) + [imgs, img_feat]
+        if any((not torch.is_tensor(t)) or t.dtype != torch.float32 or not t.is_cuda for t in ts):
+            return None
+        v4 = [t[0] if t.dim() == 5 else t for t in vols]
+        if any(t.dim() != 4 or t.shape[0] != 8 for t in v4):
+            return None
+        im = imgs[0] if imgs.dim() == 5 else imgs
+        ft = img_feat[:, 0] if img_feat.dim() == 5 else img_feat
+        if im.dim() != 4 or ft.dim() != 4 or im.shape[1] != 3 or ft.shape[1] != 8 or im.shape[0] != ft.shape[0] or im.shape[2:] != ft.shape[2:]:
+            return None
+        V, H, W = im.shape[0], im.shape[2], im.shape[3]
+        dhw = [tuple(t.shape[1:]) for t in v4]
+        voff, poff, total = _cl_layout(dhw, V, H, W)
+        base = v4[0].data_ptr()
+        if base % 16:
+            return None
+        for t, o, (d, h, w) in zip(v4, voff, dhw):
+            if t.data_ptr() != base + 4 * o or tuple(t.stride()) != (1, h * w * 8, w * 8, 8):
+                return None
+        pst = (H * W * 12, 1, W * 12, 12)
+        if im.data_ptr() != base + 4 * poff or ft.data_ptr() != base + 4 * (poff + 3) or tuple(im.stride()) != pst or tuple(ft.stride()) != pst:
+            return None
+        stg = v4[0].untyped_storage()
+        if any(t.untyped_storage().data_ptr() != stg.data_ptr() for t in ts):
+            return None
+        off = v4[0].storage_offset()
+        if (off + total) * 4 > stg.nbytes():
+            return None
+        return torch.empty(0, dtype=torch.float32, device=v4[0].device).set_(stg, off, (total,))
+    except (RuntimeError, IndexError, AttributeError):
+        return None
+
+
 class GatherSources:
     """The gather's read-only geometry + source tensors, normalised to the layouts the kernels read.
     Any of `vols`, `conf`, `imgs` may be None: the corresponding units are masked out (their feature columns are
@@ -285,7 +373,16 @@ class GatherSources:
         self.mask = 0
         dev = None
         self.vols = [None, None, None]
-        if vols is not None:
+        # Sources that already live channel-last in ONE buffer of the kernels' layout (ChannelLastSources views): read in place -- no repack,
+        # ever -- and their gradients come back in the same layout.  The reference-layout pointers are then withheld (fill()): an entry
+        # point that reads channel-major sources fails loudly instead of reading the wrong layout.
+        alias = None if cl_bf16 else _channel_last_alias(vols, imgs, img_feat)
+        self.zero_copy = alias is not None
+        if self.zero_copy:
+            self.vols = [(v[0] if v.dim() == 5 else v) for v in vols]                  # [8,D,h,w] views, channel-last in memory
+            self.mask |= 0b111
+            dev = alias.device
+        elif vols is not None:
             self.vols = [_f32(v, "volume").reshape(v.shape[-4:]) for v in vols]       # [8,D,h,w]
             for v in self.vols:
                 if v.shape[0] != 8:
@@ -302,11 +399,16 @@ class GatherSources:
         self.V = 1
         if imgs is not None:
             hw = tuple(imgs.shape[-2:])
-            self.imgs = _f32(imgs, "imgs").reshape(-1, 3, *hw)                         # [V,3,H,W]
+            if self.zero_copy:
+                self.imgs = imgs[0] if imgs.dim() == 5 else imgs                       # [V,3,H,W] / [V,8,H,W] views of the [V,H,W,12] pixels
+                self.img_feat = img_feat[:, 0] if img_feat.dim() == 5 else img_feat
+            else:
+                self.imgs = _f32(imgs, "imgs").reshape(-1, 3, *hw)                     # [V,3,H,W]
             self.V = self.imgs.shape[0]
             dev = self.imgs.device
-            self.img_feat = (_f32(img_feat, "img_feat").reshape(self.V, 8, *hw) if img_feat is not None
-                             else torch.zeros(self.V, 8, *hw, device=dev))
+            if not self.zero_copy:
+                self.img_feat = (_f32(img_feat, "img_feat").reshape(self.V, 8, *hw) if img_feat is not None
+                                 else torch.zeros(self.V, 8, *hw, device=dev))
             self.w2cs = torch.as_tensor(w2cs, dtype=torch.float32)[:, :3, :4].reshape(-1, 12).to(dev).contiguous()
             self.intrinsics = torch.as_tensor(intrinsics, dtype=torch.float32).reshape(-1, 9).to(dev).contiguous()
             if self.w2cs.shape[0] != self.V or self.intrinsics.shape[0] != self.V:
@@ -319,8 +421,8 @@ class GatherSources:
         self.F = 24 + 12 * self.V + 1
         self.device = dev
         self.full = self.mask == (0b1111 | (((1 << self.V) - 1) << 4))
-        self._cl = None              # channel-last copies read by the fast gather (RenderPass.repack_sources), shared by
-                                     # every RenderPass bound to these sources
+        self._cl = alias             # channel-last copies read by the fast gather (RenderPass.repack_sources), shared by
+                                     # every RenderPass bound to these sources; zero_copy: the sources' own buffer
 
     def fill(self, p):
         p.V, p.H, p.W = self.V, self.H, self.W
@@ -330,8 +432,9 @@ class GatherSources:
                 p.vol_d[k], p.vol_h[k], p.vol_w[k] = v.shape[1], v.shape[2], v.shape[3]
             else:
                 p.vol_d[k] = p.vol_h[k] = p.vol_w[k] = 1
-            p.vol[k] = _ptr(v)
-        p.conf, p.imgs, p.img_feat = _ptr(self.conf), _ptr(self.imgs), _ptr(self.img_feat)
+            p.vol[k] = None if self.zero_copy else _ptr(v)
+        p.conf = _ptr(self.conf)
+        p.imgs, p.img_feat = (None, None) if self.zero_copy else (_ptr(self.imgs), _ptr(self.img_feat))
         p.w2cs, p.intrinsics = _ptr(self.w2cs), _ptr(self.intrinsics)
 
 
@@ -943,6 +1046,9 @@ class RenderPass:
         self.use_cl = False
         self.p.sources_cl = None
         self.p.sources_cl_bf16 = int(src.cl_bf16)
+        if src.zero_copy:                            # the sources ARE channel-last: nothing to repack, now or later
+            self.p.sources_cl = _ptr(src._cl)
+            self.use_cl = True
 
     def set_weights(self, pw, wstream):
         self.pw, self.wstream = pw, wstream
@@ -956,6 +1062,10 @@ class RenderPass:
         """(Re)builds the channel-last copies the fast gather reads; call whenever the sources changed.  The copies belong
         to the sources object: with force=False an existing copy (made through any RenderPass bound to them) is reused."""
         src = self.src
+        if src.zero_copy:                            # (never written: the buffer is the caller's)
+            self.p.sources_cl = _ptr(src._cl)
+            self.use_cl = True
+            return
         n = L.lib().ucnerf_gather_repack_floats(C.addressof(self.p))
         fresh = src._cl is None or src._cl.numel() != n
         if fresh:
@@ -1107,8 +1217,10 @@ class RenderPass:
         self._saved_for = None
         # ONE zero fill for all accumulated outputs (six separate torch.zeros were six 5-us launches per step): views of a flat buffer,
         # every segment padded to 16 bytes
-        shapes = [(max(int(flat_room), self.pw.n_params),)] + [tuple(v.shape) if need[k] else None for k, v in enumerate(self.src.vols)] + \
-                 [tuple(self.src.conf.shape) if need[3] else None, tuple(self.src.img_feat.shape) if need[4] else None]
+        zc = self.src.zero_copy       # sources handed over channel-last: their gradients are accumulated in ONE buffer of the same layout
+        shapes = [(max(int(flat_room), self.pw.n_params),)] + \
+                 ([(self.src._cl.numel(),), None, None] if zc else [tuple(v.shape) if need[k] else None for k, v in enumerate(self.src.vols)]) + \
+                 [tuple(self.src.conf.shape) if need[3] else None, None if zc else (tuple(self.src.img_feat.shape) if need[4] else None)]
         sizes = [0 if sh is None else (int(torch.Size(sh).numel()) + 3) // 4 * 4 for sh in shapes]
         pool = torch.zeros(sum(sizes), device=dev)
         outs, off = [], 0
@@ -1118,9 +1230,21 @@ class RenderPass:
         g_flat, gv, gc, gi = outs[0], outs[1:4], outs[4], outs[5]
         g_depth = _f32(g_depth) if g_depth is not None else None
         bp.g_rgb, bp.g_depth, bp.flat_params, bp.g_flat, bp.workspace = _ptr(g_rgb), _ptr(g_depth), _ptr(flat), _ptr(g_flat), _ptr(ws)
-        for k in range(3):
-            bp.g_vol[k] = _ptr(gv[k])
-        bp.g_conf, bp.g_img_feat = _ptr(gc), _ptr(gi)
+        bp.g_sources_cl = None
+        if zc:
+            # views of the gradient buffer with the SOURCES' shapes and strides (what autograd's layout contract asks for: installed without a copy)
+            g_cl = gv[0]
+            bp.g_sources_cl = _ptr(g_cl)
+            voff, poff, total = _cl_layout([tuple(v.shape[1:]) for v in self.src.vols], self.src.V, self.src.H, self.src.W)
+            gv = [g_cl[o:o + v.numel()].view(*v.shape[1:], 8).permute(3, 0, 1, 2) if need[k] else None for k, (o, v) in enumerate(zip(voff, self.src.vols))]
+            gi = g_cl[poff:total].view(self.src.V, self.src.H, self.src.W, 12)[..., 3:11].permute(0, 3, 1, 2) if need[4] else None
+            for k in range(3):
+                bp.g_vol[k] = None
+            bp.g_conf, bp.g_img_feat = _ptr(gc), None
+        else:
+            for k in range(3):
+                bp.g_vol[k] = _ptr(gv[k])
+            bp.g_conf, bp.g_img_feat = _ptr(gc), _ptr(gi)
         gfwd = L.FeatGatherParams()
         self.src.fill(gfwd)
         bp.gather_scratch = _ptr(_gather_scratch(self.src, gfwd, dev))
