@@ -276,9 +276,13 @@ def bench_dropin(ctx, scene, sd, steps=40, warmup=10):
     out["strong_train_250"] = {"ms_per_step": dt250 * 1e3, "rays": 250, "samples_per_ray": 90, "ms_per_step_2000": dt * 1e3,
                                "projected_speedup_at_8_gpus": dt / dt250,
                                "note": "the rendering() training step on 250 rays x 90 (the per-GPU share of the 2000-ray batch at 8 GPUs) against the "
-                                       "2000-ray step of the same run; both rebuild the channel-last source copies (new volumes every step, "
-                                       "train.py:136-163); the gradient all-reduce (0.73 MB) is NOT in either figure; NOT a scaling measurement"}
-    # the same 2000-ray step with the flat optimizer (uc_nerf_amd.flat.FlatAdam: one fused launch over the flat buffer and the flat gradient)
+                                       "2000-ray step of the same run (source tensors unchanged between steps: their channel-last copies are reused; "
+                                       "a producer that writes new volumes every step, train.py:136-163, adds the 25-us repack to both, or nothing "
+                                       "with ops.ChannelLastSources); the gradient all-reduce (0.73 MB; 0.02 ms through a one-rank RCCL group) is NOT "
+                                       "in either figure; the 250-ray step is HOST-bound (Python issue time), see ms_per_step_flat_adam; NOT a scaling measurement"}
+    # the same steps with the flat optimizer (uc_nerf_amd.flat.FlatAdam: one fused launch over the flat buffer and the flat gradient).  The
+    # 250-ray step is HOST-bound with torch's multi-tensor Adam over 30 tensors (~0.25 ms of Python per step against ~0.55 ms of GPU work,
+    # profiles/r04_experiments.md): the optimizer is what the shard's step time hangs on
     from uc_nerf_amd.flat import FlatAdam
     net2 = kw["network_fn"]
     optf = FlatAdam(net2, lr=5e-4, betas=(0.9, 0.999))
@@ -288,6 +292,10 @@ def bench_dropin(ctx, scene, sd, steps=40, warmup=10):
     out["dropin_train_flat_adam"] = {"ms_per_step": dtf * 1e3, "value": 2000 / dtf, "unit": "rays/s",
                                      "note": "the same step with uc_nerf_amd.flat.FlatAdam(network_fn) in place of torch.optim.Adam(grad_vars): an opt-in, "
                                              "element-wise the same update"}
+    stepf250 = make_step(250, optf, 5)
+    dtf250 = ctx.timed(stepf250, steps * 2, warmup * 2)
+    out["strong_train_250"].update(ms_per_step_flat_adam=dtf250 * 1e3, ms_per_step_2000_flat_adam=dtf * 1e3,
+                                   projected_speedup_at_8_gpus_flat_adam=dtf / dtf250)
     return out
 
 
@@ -301,7 +309,7 @@ def bench_train_dp(ctx, scene, sd, rays_per_rank, steps=30, warmup=8):
     tr = live_path_batch(scene, outputs, rays_per_rank, 90, seed=10 + ctx.rank)
     target = torch.rand(rays_per_rank, 3, device=dev)
     opt = torch.optim.Adam(grad_vars, lr=5e-4, betas=(0.9, 0.999))
-    bucket = P.FlatGradBucket(grad_vars, n_scalars=1)
+    bucket = P.FlatGradBucket(grad_vars, n_scalars=1, collective_at_one=True)      # (one-rank rehearsal: the RCCL call is issued all the same)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     k = [-warmup]
 

@@ -95,12 +95,13 @@ class FlatGradBucket:
     (a data-dependent branch, a per-rank loss term) is invisible locally -- every `verify_every` steps on every rank (default 16: one
     read-back per 16 steps): replicas can then disagree about a gradient's existence for at most that many steps, not silently for ever."""
 
-    def __init__(self, params, n_scalars=0, verify_every=16):
+    def __init__(self, params, n_scalars=0, verify_every=16, collective_at_one=False):
         from .flat import store_of_param
         self.params = [p for p in params if p.requires_grad]
         self.sizes = [p.numel() for p in self.params]
         self.n_scalars = n_scalars
         self.verify_every = int(verify_every)
+        self.collective_at_one = bool(collective_at_one)      # issue the all-reduce through a ONE-rank group too (rehearsal of the RCCL call on a one-GPU box)
         # parameters that live in a flat store (the renderer network) keep their place in the store's gradient vector; the others are
         # packed behind it
         self.store, self.seg = None, []                # seg[i] = offset of parameter i inside the bucket
@@ -162,7 +163,7 @@ class FlatGradBucket:
         buf[off:off + len(self.params)].copy_(self._flags_tensor(local, dev), non_blocking=True)
         if weight != 1.0:
             buf[:self.numel].mul_(weight)
-        if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_initialized() and (dist.get_world_size(group) > 1 or self.collective_at_one):
             dist.all_reduce(buf[:self.numel], op=dist.ReduceOp.SUM, group=group)
         self._step += 1
         refresh = (self.has_grad is None or local != self.local_flags or not any(local)
