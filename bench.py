@@ -296,6 +296,22 @@ def bench_dropin(ctx, scene, sd, steps=40, warmup=10):
     dtf250 = ctx.timed(stepf250, steps * 2, warmup * 2)
     out["strong_train_250"].update(ms_per_step_flat_adam=dtf250 * 1e3, ms_per_step_2000_flat_adam=dtf * 1e3,
                                    projected_speedup_at_8_gpus_flat_adam=dtf / dtf250)
+
+    # ... and as ONE HIP-graph replay per step (train_step.GraphedStep: zero_grad + rendering() + loss + backward + FlatAdam captured once): what is
+    # left is the GPU time of the step
+    def graphed():
+        from uc_nerf_amd.train_step import GraphedStep
+        res = {}
+        for n_rays, seed in ((2000, 4), (250, 5)):
+            optg = FlatAdam(net2, lr=5e-4, betas=(0.9, 0.999), capturable=True)
+            g = GraphedStep(make_step(n_rays, optg, seed))
+            dtg = ctx.timed(g.replay, steps * 2, warmup * 2)
+            assert torch.isfinite(g.replay()).all()
+            res[n_rays] = dtg
+        return {"ms_per_step_2000": res[2000] * 1e3, "ms_per_step_250": res[250] * 1e3, "projected_speedup_at_8_gpus": res[2000] / res[250],
+                "note": "the rendering() training step (forward + loss + backward + FlatAdam) captured into one HIP graph and replayed "
+                        "(uc_nerf_amd.train_step.GraphedStep): an opt-in for static batch shapes; NOT a scaling measurement"}
+    out["dropin_train_graphed"] = guarded(graphed)
     return out
 
 

@@ -355,3 +355,49 @@ def test_training_through_channel_last_sources_returns_gradients_in_their_layout
             assert q.grad is None, name
         else:
             torch.testing.assert_close(q.grad, p.grad, atol=2e-5 * max(p.grad.abs().max().item(), 1e-6), rtol=1e-4, msg=lambda s_: name + ": " + s_)
+
+
+# ---------------------------------------------------------------------------------------------- the training step as one HIP-graph replay
+def test_graphed_training_step_follows_the_eager_one(sd_v7):
+    """train_step.GraphedStep: zero_grad + rendering() + loss + backward + FlatAdam captured once, replayed per step -- the parameters follow the
+    eager step's (train.py:147-188 issues the same work launch by launch) up to the order of the gradients' float atomics."""
+    from uc_nerf_amd.flat import FlatAdam
+    from uc_nerf_amd.train_step import GraphedStep
+    mods = _mods()
+    g = load_golden("g10_rendering")
+    qfn = _qfn(mods)
+    gen = torch.Generator().manual_seed(5)
+    target = dev(torch.rand(g["z"].shape[0], 3, generator=gen))
+
+    # everything the step reads is on the device already: a capture admits no host-to-device copy
+    V = g["V"]
+    args = types.SimpleNamespace(view_num=V, feat_dim=24 + 12 * (V - 1) + 1, img_downscale=1.0, use_color_volume=False, net_type="v2")
+    vf = {"stage%d" % k: {"volume_feature_no_ref": dev(g["vol%d" % k])} for k in (1, 2, 3)}
+    w2cs, Ks = dev(g["w2cs"]), dev(g["K"]).repeat(V, 1, 1)
+    ndc = {"stage1": dev(g["ndc1"]), "stage2": dev(g["ndc2"]), "stage3": dev(g["ndc3"]), "ndc": dev(g["ndc"])}
+    pts, z, rays_d, imgs, img_feat, conf = dev(g["pts"]), dev(g["z"]), dev(g["rays_d"]), dev(g["imgs"]), dev(g["img_feat"]), dev(g["conf"])
+
+    def make(net, opt):
+        def step():
+            opt.zero_grad(set_to_none=True)
+            rgb, depth = mods.renderer.rendering(args, {"w2cs": w2cs, "intrinsics": Ks}, pts, ndc, z, rays_d, vf, imgs, network_fn=net, img_feat=img_feat,
+                                                 network_query_fn=qfn, confidence=conf)
+            loss = torch.mean((rgb - target) ** 2) * 5.0 + 0.05 * torch.mean((depth - 2.0) ** 2)
+            loss.backward()
+            opt.step()
+            return loss
+        return step
+
+    net_e, net_g = _net(mods, 7, sd_v7), _net(mods, 7, sd_v7)
+    step_e = make(net_e, FlatAdam(net_e, lr=5e-4))
+    graphed = GraphedStep(make(net_g, FlatAdam(net_g, lr=5e-4, capturable=True)), warmup=2)     # (the 2 warm-up steps have stepped net_g; the capture itself executes nothing)
+    for _ in range(2):
+        loss_e = step_e()
+    losses = [loss_e.item()]
+    for _ in range(4):
+        losses.append(step_e().item())
+        lg = graphed.replay()
+        for (name, a), b in zip(net_e.named_parameters(), net_g.parameters()):
+            torch.testing.assert_close(a, b, atol=2e-5, rtol=0, msg=lambda s_: name + ": " + s_)
+        assert abs(lg.item() - losses[-1]) < 1e-4 * max(1.0, abs(losses[-1]))
+    assert losses[-1] < losses[0]                            # (and it trains)

@@ -157,7 +157,7 @@ class FlatAdam(torch.optim.Adam):
             raise ValueError("uc_nerf_amd.FlatAdam: weight decay would also decay the tensors the reference leaves without a gradient")
         self.store = FlatStore.of(module)
         self.fp = torch.nn.Parameter(self.store.sync())
-        kw.setdefault("fused", self.fp.is_cuda)
+        kw.setdefault("fused", self.fp.is_cuda)               # (capturable=True: usable inside a HIP-graph capture, train_step.GraphedStep)
         super().__init__([self.fp], lr=lr, betas=betas, eps=eps, weight_decay=0, **kw)
 
     def _bind(self):

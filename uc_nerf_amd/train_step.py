@@ -104,3 +104,35 @@ class TrainStep:
         out["img_mse"] = out["img_loss"]
         out["psnr"] = -10.0 * np.log(max(float(out["img_loss"]), 1e-20)) / np.log(10.0)        # mse2psnr2 (utils/utils.py:14)
         return out
+
+
+class GraphedStep:
+    """One optimisation step as ONE HIP-graph replay (SURVEY.md 8(f) f1 "HIP-graph capture", for the regime it pays in: a data-parallel shard of a few
+    hundred rays, where the step is bound by the host -- the rendering() training step on 250 rays x 90 issues ~70 launches in ~0.8-1.0 ms of Python
+    against ~0.5 ms of GPU work; profiles/r04_experiments.md).
+
+    `fn()` is the whole step on STATIC tensors -- `optimizer.zero_grad(set_to_none=True)`, `rendering()`, the loss, `backward()`, optionally
+    `FlatGradBucket.allreduce(...)` (RCCL collectives capture), `optimizer.step()` -- and returns a tensor or tuple of tensors (e.g. the loss).
+    Every library launch goes to torch's current stream and every allocation through torch's caching allocator, so the capture is a plain stream
+    capture.  What the caller owes: the optimizer must be capturable (`torch.optim.Adam(..., capturable=True)` or `flat.FlatAdam(...,
+    capturable=True)`); a new batch is COPIED INTO the tensors `fn` reads (same shapes) before `replay()`; nothing inside `fn` may read device
+    memory back (`.item()`, `float()`; a FlatGradBucket must be built with `verify_every=0`)."""
+
+    def __init__(self, fn, warmup=3):
+        import torch
+        dev = torch.cuda.current_device()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                        # warm-up on a side stream: one-time attribute calls, workspaces, optimizer state
+            for _ in range(max(1, warmup)):
+                fn()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = fn()
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
+
+    __call__ = replay
