@@ -26,7 +26,7 @@ r = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), 64, 128, precision=os.
 xs, ys = random_pixels(4096, scene_cpu["H"], scene_cpu["W"], seed=0)
 xs, ys = xs[:n].to(dev).contiguous(), ys[:n].to(dev).contiguous()
 noise = torch.rand(4096, 64, generator=torch.Generator().manual_seed(100))[:n].to(dev).contiguous()
-fold = int(os.environ.get("FOLD", "3"))      # bit 0: coarse compositing + re-sampling in one launch; bit 1: rays generated inside the coarse MLP launch; 0: the launch structure of rounds 1-3
+fold = int(os.environ.get("FOLD", "1"))      # bit 0: coarse compositing + re-sampling in one launch; bit 1: rays generated inside the coarse MLP launch; 0: the launch structure of rounds 1-3
 r.fold_launches, r.fold_rays = bool(fold & 1), bool(fold & 2)
 r.pass_.repack_sources()
 for _ in range(max(150, steps // 2)):

@@ -112,11 +112,7 @@ __device__ __forceinline__ void gather_cl_unit(const GatherClArgs& a, unsigned i
     constexpr int fs = TILED ? 32 : 1;                                      // feature f at out[f * fs]
     // Tiled rows are full 128-byte lines written once and read once by the MLP: stream them past the L2 so that the sources
     // stay there (-19 us per step).  Row-major rows are completed piecewise by one thread and want the L2.
-#if UCNERF_GATHER_EXP & 1      // timing experiment: loads and arithmetic only (a store no value ever takes)
-#define PUT(IDX, VAL) do { const float v_ = (VAL); if (v_ == 12345.678f) out[(IDX)] = v_; } while (0)
-#else
 #define PUT(IDX, VAL) do { if (TILED) __builtin_nontemporal_store((float)(VAL), &out[(IDX)]); else out[(IDX)] = (VAL); } while (0)
-#endif
     float* out = TILED ? a.feats + ((size_t)(idx >> 5) * F) * 32 + (idx & 31) : a.feats + (size_t)idx * F;
     if (unit < 4) {
         float u, v, qz = 0.f, zn_given = 0.f;
@@ -386,6 +382,6 @@ int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float
     return check_launch("feat_gather_cl");
 }
 
-const char* build_flags_gather_cl() { return "gather_cl: " UCNERF_FLAG(UCNERF_GATHER_EXP) UCNERF_FLAG(UCNERF_GATHER_RUN) UCNERF_FLAG(UCNERF_GATHER_WAVES); }
+const char* build_flags_gather_cl() { return "gather_cl: " UCNERF_FLAG(UCNERF_GATHER_RUN) UCNERF_FLAG(UCNERF_GATHER_WAVES); }
 
 }  // namespace ucnerf

@@ -3,9 +3,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#ifndef UCNERF_GATHER_EXP
-#define UCNERF_GATHER_EXP 0     // timing experiments (wrong results), bit mask: 1 no stores, 2 all source loads within 32 KB, 4 no source loads
-#endif
 
 namespace ucnerf {
 
@@ -43,24 +40,10 @@ typedef float gf2 __attribute__((ext_vector_type(2)));
 // 16 bytes at a 32-bit byte offset from a block-uniform base: the address is one scalar pair + one VGPR (no 64-bit
 // vector arithmetic per corner); every repacked source is far below 4 GB.
 __device__ __forceinline__ float4 ld16(const char* base, unsigned off) {
-#if UCNERF_GATHER_EXP & 2
-    off &= 0x7ff0u;
-#endif
-#if UCNERF_GATHER_EXP & 4
-    const float f_ = __uint_as_float(off | 0x3f000000u);
-    return make_float4(f_, f_, f_, f_);
-#endif
     return *(const float4*)(base + off);
 }
 
 __device__ __forceinline__ float2 ld8(const char* base, unsigned off) {
-#if UCNERF_GATHER_EXP & 2
-    off &= 0x7ff8u;
-#endif
-#if UCNERF_GATHER_EXP & 4
-    const float f_ = __uint_as_float(off | 0x3f000000u);
-    return make_float2(f_, f_);
-#endif
     return *(const float2*)(base + off);
 }
 // bf16 channel-last copies: eight bf16 in 16 bytes -> the first / second four as floats (a bf16 is the upper half of its float)

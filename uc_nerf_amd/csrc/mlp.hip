@@ -154,7 +154,6 @@ struct MlpGeom {      // MlpLayout subset the kernel needs (32-bit is plenty: th
     int stream_bytes;     // size of the packed weight stream
     unsigned feat_bytes;  // size of the feature buffer
     int stagger;          // start-up delay of waves 4..7 in units of s_sleep(127) (= 8128 cycles)
-    unsigned long long* diag;   // diagnostic builds only (UCNERF_MLP_DIAG): per-wave tile start/end clocks
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -321,9 +320,6 @@ __device__ __forceinline__ void load_encoded(const float* __restrict__ row, int 
 // Wave priority: the short VALU phases (encodings, epilogues, heads) run at high priority so that the partner
 // wave's back-to-back MFMAs (which otherwise hold the SIMD's vector issue almost continuously: measured ~100
 // cycles per VALU instruction, 35-65k cycles per phase) cannot stretch them; GEMM sections run at priority 0.
-#ifndef UCNERF_MLP_SAVE_EXP
-#define UCNERF_MLP_SAVE_EXP 0    // timing experiments (wrong results): 1 = the kept sets are packed and transposed but not stored; 2 = not even packed; 4 = packed and written to LDS, not read back
-#endif
 #ifndef UCNERF_MLP_SAVE_NT
 #define UCNERF_MLP_SAVE_NT 1     // the kept 24-bit sets leave with non-temporal stores (whole 64-byte sectors per row here): the gradient chain reads them
                                  // back 15-20 us faster per 131 k samples than sets left dirty in the caches (this launch +7 us); 0 = plain stores (A/B)
@@ -356,9 +352,6 @@ constexpr int XPOSE_BYTES = 32 * XPOSE_ROW;
 template <bool P24>
 __device__ __forceinline__ void save_rows(float* buf, int s, int h, bool valid, const f32x16 (&x)[4], char* xbuf = nullptr, int lane = 0, int tile = 0, int m = 0) {
     if (P24) {
-#if UCNERF_MLP_SAVE_EXP & 2
-        return;
-#endif
         asm volatile("" : "+v"(lane));                // (the chunk addresses below do not depend on the tile: unlaundered they are hoisted out of the tile loop -- 24 registers for the whole kernel)
         const int j = lane & 31;
         char* const gtile = reinterpret_cast<char*>(buf) + (size_t)tile * 32 * P24_ROW_BYTES;
@@ -374,18 +367,13 @@ __device__ __forceinline__ void save_rows(float* buf, int s, int h, bool valid, 
                     *reinterpret_cast<p24_u32x3_a4*>(xbuf + j * XPOSE_ROW + 12 * (8 * t + 2 * q + h)) = (p24_u32x3){pc.d[0], pc.d[1], pc.d[2]};
                 }
             // (LDS operations of a wave execute in order: the reads below see the writes above, and the next half's writes come after these reads)
-#if UCNERF_MLP_SAVE_EXP & 4
-            if (lane >= 0) continue;
-#endif
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 __builtin_amdgcn_sched_barrier(0);                    // (one chunk at a time: four registers, not twenty-four)
                 const int c = k * 64 + lane;                          // 16-byte chunk of the half set: row c / 12, chunk c % 12 of its 192 bytes
                 const int row = (c * 2731) >> 15, within = c - 12 * row;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(xbuf + row * XPOSE_ROW + 16 * within);
-#if UCNERF_MLP_SAVE_EXP & 1
-                if (row < rows && v.x == 12345.678f) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(gtile + row * P24_ROW_BYTES + 192 * half + 16 * within));
-#elif UCNERF_MLP_SAVE_NT
+#if UCNERF_MLP_SAVE_NT
                 if (row < rows) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(gtile + row * P24_ROW_BYTES + 192 * half + 16 * within));
 #else
                 if (row < rows) *reinterpret_cast<f32x4*>(gtile + row * P24_ROW_BYTES + 192 * half + 16 * within) = v;
@@ -455,18 +443,9 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         }
     }
 
-#ifdef UCNERF_MLP_DIAG
-    int diag_k = 0;
-#endif
     // Wave-major inside a round of n_waves tiles: a partly filled last round keeps the same number of waves busy in every block (one per
     // SIMD while it is at most half full) instead of running some blocks with two waves per SIMD and leaving others empty.
     for (int tile = wave * (int)gridDim.x + lblock; tile < n_tiles; tile += n_waves) {
-#ifdef UCNERF_MLP_DIAG
-#define DIAG_STAMP(K) { __builtin_amdgcn_sched_barrier(0); if (g.diag && lane == 0 && diag_k == 5) g.diag[(size_t)(blockIdx.x * MLP_WAVES + wave) * 16 + (K)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
-#else
-#define DIAG_STAMP(K)
-#endif
-        DIAG_STAMP(0)
         PRIO_VALU();
         S.soff = 0;
         const int s_raw = tile * 32 + j;
@@ -502,20 +481,16 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         for (int t = 0; t < KS_PE_PTS; ++t) stash[t * 64 + lane] = pe[t];
 
         // ---- depth-bias net: bd = W_d [volume feats | colours+masks] + b      (models.py:150)
-        DIAG_STAMP(1)
         init_bias(cst, SEC_BD, h, bd);
         PRIO_GEMM(); gemm_feats(S, fsec, kd, bd); PRIO_VALU();
-        DIAG_STAMP(2)
         if (SAVE) save_rows<SAVE == 2>(sv.bd, s, h, valid, bd, xpose[SAVE == 2 ? wave : 0], lane, tile, p.m);
         const float u = 1.f - conf, omu = 1.f - u;          // models.py:149,177-178 (consumed at the very end)
 
         // ---- layer 0
         init_bias(cst, SEC_L0, h, acc);
         PRIO_GEMM(); gemm_regs<KS_PE_PTS>(S, pe, acc); PRIO_VALU();
-        DIAG_STAMP(3)
         EPILOGUE_RELU_MOD(hin, acc, bd)
         if (SAVE) save_rows<SAVE == 2>(sv.h[0], s, h, valid, hin, xpose[SAVE == 2 ? wave : 0], lane, tile, p.m);
-        DIAG_STAMP(4)
 
         // ---- layers 1..4                                                        (models.py:153-155)
 #pragma unroll 1
@@ -527,11 +502,9 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         }
 
         // ---- layer 5 on [pe | h]                                                (models.py:156-157)
-        DIAG_STAMP(5)
         init_bias(cst, SEC_L0 + 5, h, acc);
         PRIO_GEMM(); gemm_stash<KS_PE_PTS>(S, stash, lane, acc); PRIO_VALU();
         PRIO_GEMM(); gemm_hidden(S, hin, acc); PRIO_VALU();
-        DIAG_STAMP(6)
         EPILOGUE_RELU_MOD(hin, acc, bd)
         // operands of the confidence-bias net: issued now (b_d's registers are free), they land during the base heads
         load_section_feats<TILED>(FS, (g.f_img + h) * fstride * 4, 2 * fstride * 4, kc, fsec);
@@ -539,12 +512,10 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
 
         // ---- base heads: confi_rgb_linear, alpha_linear_1                       (models.py:161-162)
         const f32x4 base = head4(hb, h, hin);
-        DIAG_STAMP(7)
 
         // ---- confidence-bias net, feature_linear(h * b_c)                       (models.py:151,164)
         init_bias(cst, SEC_BC, h, bd);
         PRIO_GEMM(); gemm_feats(S, fsec, kc, bd); PRIO_VALU();
-        DIAG_STAMP(8)
         if (SAVE) save_rows<SAVE == 2>(sv.bc, s, h, valid, bd, xpose[SAVE == 2 ? wave : 0], lane, tile, p.m);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -557,10 +528,8 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         const float* drow = p.dirs + ray * g.dirs_stride;
         float dv[3] = {0.f, 0.f, 0.f};
         if (!ENC) { dv[0] = drow[0]; dv[1] = drow[1]; dv[2] = drow[2]; }
-        DIAG_STAMP(9)
         init_bias(cst, SEC_FT, h, acc);
         PRIO_GEMM(); gemm_hidden(S, hin, acc); PRIO_VALU();
-        DIAG_STAMP(10)
         if (SAVE) save_rows<SAVE == 2>(sv.ft, s, h, valid, acc, xpose[SAVE == 2 ? wave : 0], lane, tile, p.m);
 
         // ---- views_linears | view_confi_linears on [feature | dir encoding], relu   (models.py:166-173)
@@ -572,7 +541,6 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
             else encode<4, KS_PE_DIR>(dv, h, pd);
             PRIO_GEMM(); gemm_regs<KS_PE_DIR>(S, pd, hin); PRIO_VALU();
         }
-        DIAG_STAMP(11)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -581,7 +549,6 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
 
         // ---- adapt heads (rgb_linear on rows 0..63, alpha_linear on rows 64..127), uncertainty blend
         const f32x4 adapt = head4(ha, h, hin);
-        DIAG_STAMP(12)
         f32x4 out;
         out.x = 1.f / (1.f + expf(-(base.x * omu + adapt.x * u)));
         out.y = 1.f / (1.f + expf(-(base.y * omu + adapt.y * u)));
@@ -589,17 +556,13 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         out.w = fmaxf(adapt.w * omu + base.w * u, 0.f);
         if (h == 0 && valid) reinterpret_cast<f32x4*>(p.raw)[s_raw] = out;
         px[0] = pn[0]; px[1] = pn[1]; px[2] = pn[2];
-        DIAG_STAMP(13)
-#ifdef UCNERF_MLP_DIAG
-        ++diag_k;
-#endif
     }
 }
 
 static MlpGeom geom_of(const MlpLayout& L) {
     MlpGeom g;
     g.F = L.F; g.kd = L.kd; g.kc = L.kc; g.f_img = 24 + 4 * L.v; g.off_const = (int)L.off_const;
-    g.pts_stride = g.dirs_stride = 3; g.feat_stride = L.F; g.pe_layout = 0; g.stream_bytes = 0; g.feat_bytes = 0; g.stagger = 0; g.diag = nullptr;
+    g.pts_stride = g.dirs_stride = 3; g.feat_stride = L.F; g.pe_layout = 0; g.stream_bytes = 0; g.feat_bytes = 0; g.stagger = 0;
     return g;
 }
 
@@ -633,9 +596,6 @@ int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t
         if (stagger < 0) { const char* e = getenv("UCNERF_MLP_STAGGER"); stagger = e ? atoi(e) : 0; }   // measured on MI355X: 0 is best (A/B in DESIGN.md)
         g.stagger = n_tiles > blocks * 4 ? stagger : 0;          // nothing to hide when waves 4..7 have no partner work
     }
-#ifdef UCNERF_MLP_DIAG
-    { const char* e = getenv("UCNERF_MLP_DIAG_PTR"); g.diag = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
-#endif
     UCNERF_REQUIRE(p->cfg.pe_layout == 0 || p->cfg.pe_layout == 1, "mlp_fwd: pe_layout %d", p->cfg.pe_layout);
     UCNERF_REQUIRE(!p->encoded || (p->dirs_per_sample && !p->feats_tiled), "mlp_fwd: encoded inputs need per-sample dirs and row-major feats");
     UCNERF_REQUIRE(p->pts_stride >= 0 && p->dirs_stride >= 0 && p->feat_stride >= 0, "mlp_fwd: negative stride");
@@ -670,12 +630,7 @@ int launch_pack_bf16_tab(const ucnerf_mlp_config* cfg, const ParamTable& t, cons
 int launch_mlp_fwd_bf16x3(const ucnerf_mlp_params* p, hipStream_t st);      // mlp_bf16.hip built with TERMS = 3
 int launch_mlp_fwd_bf16_plain(const ucnerf_mlp_params* p, hipStream_t st);   // ... and with TERMS = 1
 
-#ifdef UCNERF_MLP_DIAG
-#define UCNERF_MLP_DIAG_ON 1
-#else
-#define UCNERF_MLP_DIAG_ON 0
-#endif
-const char* build_flags_mlp_f32() { return "mlp_f32: " UCNERF_FLAG(UCNERF_MLP_WAVES) UCNERF_FLAG(UCNERF_MLP_PRIO) UCNERF_FLAG(UCNERF_MLP_RING) UCNERF_FLAG(UCNERF_MLP_SAVE_NT) UCNERF_FLAG(UCNERF_MLP_SAVE_EXP) UCNERF_FLAG(UCNERF_MLP_DIAG_ON); }
+const char* build_flags_mlp_f32() { return "mlp_f32: " UCNERF_FLAG(UCNERF_MLP_WAVES) UCNERF_FLAG(UCNERF_MLP_PRIO) UCNERF_FLAG(UCNERF_MLP_RING) UCNERF_FLAG(UCNERF_MLP_SAVE_NT); }
 
 }  // namespace ucnerf
 

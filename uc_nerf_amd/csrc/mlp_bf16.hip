@@ -55,9 +55,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#ifndef UCNERF_BF16_EXP
-#define UCNERF_BF16_EXP 0      // timing experiments only (results are wrong): 1 no DMA wait, 2 no barrier, 4 no DMA, 64 no interleave hints, 128 no epilogue arithmetic, 256 half the LDS fragment reads, 512 no point-encoding arithmetic, 1024 no feature / point loads: zeros instead (compare with a launch on all-zero inputs: same values, same power draw), 8192 one more VALU per split value, 2048 every feature load issued TWICE (the second from another tile's rows, weighted 0: same values, same power -- what the loads cost is what the copy adds)
-#endif
 #ifndef UCNERF_BF16_HINT_V
 #define UCNERF_BF16_HINT_V 5   // VALU instructions the scheduler may place after each MFMA of a half-step (7 would fill an MFMA's 32 cycles; measured
                                // over 1..9: 3..6 read 0.5 % faster than 7, 9 is 1.5 % slower -- profiles/r02_logs/r02_hint_v_sweep.log)
@@ -68,10 +65,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef UCNERF_BF16_PRIO_GEMM
 #define UCNERF_BF16_PRIO_GEMM 0     // ... and during the GEMM phases
 #endif
-#ifndef UCNERF_BF16_NO_PK
-#define UCNERF_BF16_NO_PK 0    // 1: element-wise work beside the MFMAs in scalar fp32 instructions (v_mul / v_sub / v_fma), never the packed
-                               //    v_pk_* forms: MI355X_MICROARCH.md prices a packed fp32 op at +22..26 cycles per MFMA gap over its two scalar ones
-#endif
 // scalar fp32 ops the SLP vectoriser cannot re-pack (one empty asm per result keeps every op its own instruction)
 __device__ __forceinline__ float sc_mul(float a, float b) { float r = a * b; asm volatile("" : "+v"(r)); return r; }
 __device__ __forceinline__ float sc_sub(float a, float b) { float r = a - b; asm volatile("" : "+v"(r)); return r; }
@@ -79,12 +72,6 @@ __device__ __forceinline__ float sc_fma(float a, float b, float c) { float r = _
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define SB0 __builtin_amdgcn_sched_barrier(0)
 
-#ifndef UCNERF_FUSED_FOOT_UNDER_GEMM
-#define UCNERF_FUSED_FOOT_UNDER_GEMM 0    // gather-fused kernel: 1 = the NEXT tile's footprints (projection, corner offsets and weights of every unit: ~500 vector
-                                         //   instructions, no loads) are computed in otherwise empty fills of the last GEMM phase, beside the MFMAs; 0 = at the top of
-                                         //   the tile loop with the rest of the gather.  Measured: 1 is SLOWER (step 0.857 against 0.845-0.847 ms, same box) -- beside
-                                         //   the MFMAs of a power-limited kernel the instructions cost at least what they cost alone (profiles/r02_mlp_bf16_experiments.md)
-#endif
 #ifndef UCNERF_BF16_IDLE_SKIP
 #define UCNERF_BF16_IDLE_SKIP 1          // a wave whose tile lies past the end only turns the weight ring (0: it computes a clamped tile and discards it)
 #endif
@@ -243,51 +230,18 @@ struct Frag { bf16x8 hi, lo; };
 // 7 for a round-to-nearest hi.  |lo| < 2^-7 |x| (not 2^-8), so the dropped lo*lo term is 2^-16 relative.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-#ifndef UCNERF_BF16_SPLIT_DOT
-#define UCNERF_BF16_SPLIT_DOT 0     // 1: residual by v_dot2c_f32_bf16 against the packed hi pair (4 VALU per pair instead of 5;
-                                    //    bit-identical, scripts/micro/dot2_split.hip) -- measured 0.6 % SLOWER: the dot is not a full-rate op
-#endif
 __device__ __forceinline__ Frag split8(const float (&x)[8]) {
     u32x4 hi;
     Frag f;
-#if UCNERF_BF16_SPLIT_DOT
-    unsigned sel_lo = 0x0000bf80u, sel_hi = 0xbf800000u;
-    asm volatile("" : "+s"(sel_lo), "+s"(sel_hi));
-#endif
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
-#if UCNERF_BF16_EXP & 8192      // timing experiment: ONE MORE vector instruction per split value (an AND with an opaque all-ones mask: same values, same
-                                // operand toggling) -- the inverse of removing one, to price the split's instruction count
-        unsigned ones_ = 0xffffffffu;
-        asm volatile("" : "+v"(ones_));
-        const unsigned b0 = __builtin_bit_cast(unsigned, x[j]) & ones_, b1 = __builtin_bit_cast(unsigned, x[j + 1]) & ones_;
-#else
         const unsigned b0 = __builtin_bit_cast(unsigned, x[j]), b1 = __builtin_bit_cast(unsigned, x[j + 1]);
-#endif
         const unsigned packed = __builtin_amdgcn_perm(b1, b0, 0x07060302u);      // [hi(x[j+1]) | hi(x[j])]
         hi[j >> 1] = packed;
-#if UCNERF_BF16_SPLIT_DOT
-        // x - hi = x + (-1) * hi + 0 * (the other hi): one dot2c per value, exact (the products are exact, the sum is
-        // representable), the hi pair read straight from its packed form -- no fp32 copy of hi is ever made
-        // (the two selectors (-1, 0) / (0, -1) are laundered into scalar registers: as literals the compiler turns them into
-        //  16-bit inline constants of the wrong format)
-        const bf16x2 hp = __builtin_bit_cast(bf16x2, packed);
-        const float l0 = __builtin_amdgcn_fdot2_f32_bf16(hp, __builtin_bit_cast(bf16x2, sel_lo), x[j], false);
-        const float l1 = __builtin_amdgcn_fdot2_f32_bf16(hp, __builtin_bit_cast(bf16x2, sel_hi), x[j + 1], false);
-        f.lo[j] = (__bf16)l0;
-        f.lo[j + 1] = (__bf16)l1;
-#else
-#if UCNERF_BF16_NO_PK
-        const float l0_ = sc_sub(x[j], __builtin_bit_cast(float, b0 & 0xffff0000u)), l1_ = sc_sub(x[j + 1], __builtin_bit_cast(float, b1 & 0xffff0000u));
-        f.lo[j] = (__bf16)l0_;
-        f.lo[j + 1] = (__bf16)l1_;
-#else
         const f32x2 h = {__builtin_bit_cast(float, b0 & 0xffff0000u), __builtin_bit_cast(float, b1 & 0xffff0000u)};
         const f32x2 l = (f32x2){x[j], x[j + 1]} - h;
         f.lo[j] = (__bf16)l.x;
         f.lo[j + 1] = (__bf16)l.y;
-#endif
-#endif
     }
     f.hi = __builtin_bit_cast(bf16x8, hi);
     return f;
@@ -334,22 +288,11 @@ __device__ __forceinline__ void save_tile(float* row, int nt, const f32x16& x) {
 // SV: the eight fp32 values also go to `srow` (this lane's row of an activation set, NULL past the last sample) as row-tile nt
 template <int MODE, int SV = 0>       // SV: the kernel's SAVE (0 none, 1 fp32 sets, 2 24-bit sets)
 __device__ __forceinline__ Frag frag_of(const f32x16& a, const f32x16& m, int s, float* srow = nullptr, int nt = 0) {
-#if UCNERF_BF16_EXP & 128      // timing experiment: no epilogue arithmetic at all (wrong results)
-    Frag e;
-    e.hi = __builtin_bit_cast(bf16x8, (f32x4){a[8 * s], a[8 * s + 1], a[8 * s + 2], a[8 * s + 3]});
-    e.lo = __builtin_bit_cast(bf16x8, (f32x4){a[8 * s + 4], a[8 * s + 5], a[8 * s + 6], a[8 * s + 7]});
-    return e;
-#endif
     float t[8];
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
-#if UCNERF_BF16_NO_PK
-        f32x2 v = {a[8 * s + j], a[8 * s + j + 1]};
-        if (MODE >= 1) { v.x = sc_mul(v.x, m[8 * s + j]); v.y = sc_mul(v.y, m[8 * s + j + 1]); }
-#else
         f32x2 v = {a[8 * s + j], a[8 * s + j + 1]};
         if (MODE >= 1) v = v * (f32x2){m[8 * s + j], m[8 * s + j + 1]};
-#endif
         t[j] = MODE == 2 ? fmaxf(v.x, 0.f) : v.x;
         t[j + 1] = MODE == 2 ? fmaxf(v.y, 0.f) : v.y;
     }
@@ -362,7 +305,6 @@ __device__ __forceinline__ Frag frag_of(const f32x16& a, const f32x16& m, int s,
 struct BGeom {
     int F, kd16, kc16, f_img, slots, feat_stride;
     int const_off_bytes;
-    unsigned long long* diag;          // diagnostic builds only (UCNERF_MLP_DIAG): per-wave phase clocks of one tile
 };
 
 // A fragments of one half-step (row-tile pair)
@@ -405,15 +347,9 @@ __device__ __forceinline__ AF read_half(const char* buf, int lane, int half) {
 // vmcnt: the DMAs younger than the awaited slot are those of the NBUF - 2 slots after it.
 template <int NB = NBUF>
 __device__ __forceinline__ void advance(Pipe& P) {
-#if !(UCNERF_BF16_EXP & 1)
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NB - 2) * DMA_PER_SLOT) : "memory");
-#endif
-#if !(UCNERF_BF16_EXP & 2)
     __builtin_amdgcn_s_barrier();
-#endif
-#if !(UCNERF_BF16_EXP & 4)
     issue_dma<NB>(P, P.gpos);                               // position gpos + NB into the slot of position gpos
-#endif
     ++P.gpos;
     P.buf = P.ring + (P.gpos & (NB - 1)) * SLOT_BYTES;
 }
@@ -421,13 +357,11 @@ __device__ __forceinline__ void advance(Pipe& P) {
 // scheduling hint for a half-step region: one MFMA, then up to `V` VALU, six times (LDS reads stay with their users)
 template <int V>
 __device__ __forceinline__ void interleave_hint() {
-#if !(UCNERF_BF16_EXP & 64)
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
     }
-#endif
 }
 
 // One half-step: (c0, c1) += A_hi*B_hi + A_hi*B_lo + A_lo*B_hi for one row-tile pair, with `fill()` -- element-wise work
@@ -437,11 +371,7 @@ template <int TERMS, int NB = NBUF, class F>
 __device__ __forceinline__ void half_step(const int ODD, Pipe& P, AF& cur, int lane, const Frag& b, f32x16& c0, f32x16& c1, F&& fill) {
     if (ODD) advance<NB>(P);                                   // (a constant once the caller's loop is unrolled)
     AF nxt;
-#if UCNERF_BF16_EXP & 256       // timing experiment: half the fragment reads (lo := hi, wrong results)
-    if (false) {}
-#else
     if (TERMS == 3) nxt = read_half(P.buf, lane, ODD ? 0 : 1);
-#endif
     else {                                                 // plain bf16: the lo halves are never read
         const bf16x8* a = reinterpret_cast<const bf16x8*>(P.buf + (ODD ? 0 : 1) * HALF_BYTES) + lane;
         nxt.h0 = a[0]; nxt.h1 = a[128]; nxt.l0 = nxt.h0; nxt.l1 = nxt.h1;
@@ -475,22 +405,14 @@ struct HeadAcc { f32x2 s01, s23; };
 template <class Map>
 __device__ __forceinline__ void head_part(HeadAcc& a, const float* hd, int h, const f32x16& x, int nt, int r0, int n, Map map) {
     const f32x4* w = reinterpret_cast<const f32x4*>(hd) + opaque(h * 64) + nt * 16;
-#if UCNERF_BF16_EXP & 128
-    a.s01.x += x[r0]; return;
-#endif
 #pragma unroll
     for (int i = 0; i < 16; ++i)
         if (i >= r0 && i < r0 + n) {
             const f32x4 wv = w[i];
             const float xv = map(x[i]);
-#if UCNERF_BF16_NO_PK
-            a.s01.x = sc_fma(xv, wv.x, a.s01.x); a.s01.y = sc_fma(xv, wv.y, a.s01.y);
-            a.s23.x = sc_fma(xv, wv.z, a.s23.x); a.s23.y = sc_fma(xv, wv.w, a.s23.y);
-#else
             const f32x2 xx = {xv, xv};
             a.s01 = __builtin_elementwise_fma(xx, (f32x2){wv.x, wv.y}, a.s01);
             a.s23 = __builtin_elementwise_fma(xx, (f32x2){wv.z, wv.w}, a.s23);
-#endif
         }
     pin(a.s01); pin(a.s23);
 }
@@ -504,12 +426,7 @@ __device__ __forceinline__ f32x4 head_finish(const HeadAcc& a, const float* hd) 
         asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
         return a + b;
     };
-#ifdef UCNERF_BF16_SHFL
-    f32x4 s = {a.s01.x, a.s01.y, a.s23.x, a.s23.y};
-    s.x += __shfl_xor(s.x, 32); s.y += __shfl_xor(s.y, 32); s.z += __shfl_xor(s.z, 32); s.w += __shfl_xor(s.w, 32);
-#else
     f32x4 s = {fold(a.s01.x), fold(a.s01.y), fold(a.s23.x), fold(a.s23.y)};
-#endif
     const f32x4 b = *reinterpret_cast<const f32x4*>(hd + 512);
     s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
     return s;
@@ -659,12 +576,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     float nfs[4][8], nconf, npx[3];
     // (j and the parked-scalar address are re-derived from `lane` at each use: as loop-long values they get spilled)
     auto sample_of = [&](int tile) { const int s_raw = tile * 32 + (opaque(lane) & 31); return s_raw < p.m ? s_raw : p.m - 1; };
-#if UCNERF_BF16_EXP & 4096      // timing experiment: every feature load falls into the rows of eight tiles (cache resident): instruction and wait
-                                // cost of the loads without their HBM traffic (compare on all-zero inputs)
-    auto feat_base = [&](int s) { return TILED ? p.feats + ((size_t)((s >> 5) & 7) * F * 32 + (s & 31)) : p.feats + (size_t)(s & 255) * g.feat_stride; };
-#else
     auto feat_base = [&](int s) { return TILED ? p.feats + ((size_t)(s >> 5) * F * 32 + (s & 31)) : p.feats + (size_t)s * g.feat_stride; };
-#endif
     constexpr int fstride = TILED ? 32 : 1;
     auto fetch = [&](int tile) {
         const int s = sample_of(tile);
@@ -678,29 +590,11 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                 // (tiled layout: streaming loads -- every 128-byte line is consumed by one load; kept out of the L2 they leave the
                 //  gather's sources there.  Row-major rows are read four bytes at a time and need the cache.)
                 const float* src_ = (NSRC && c + 8 < F) ? &fh[c * fstride] : &fb[(size_t)min(c, F - 1) * fstride];
-#if UCNERF_BF16_EXP & 1024
-                { float z_ = 0.f; asm volatile("" : "+v"(z_)); nfs[q][e] = z_; }      // (opaque zero: keeps the split arithmetic)
-                (void)src_;
-#elif UCNERF_BF16_EXP & 2048
-                {
-                    const float* src2_ = src_ + (tile + 1 < n_tiles / 2 ? (size_t)(n_tiles / 2) * F * 32 : 0);      // the same row of a tile half a buffer away
-                    float a_ = q >= kd16 ? 0.f : TILED ? __builtin_nontemporal_load(src_) : *src_;
-                    const float b_ = q >= kd16 ? 0.f : TILED ? __builtin_nontemporal_load(src2_) : *src2_;
-                    float zero_ = 0.f;
-                    asm volatile("" : "+v"(zero_));
-                    nfs[q][e] = a_ + zero_ * b_;
-                }
-#else
                 nfs[q][e] = q >= kd16 ? 0.f : TILED ? __builtin_nontemporal_load(src_) : *src_;
-#endif
             }
-#if UCNERF_BF16_EXP & 1024
-        { float z_ = 0.f; asm volatile("" : "+v"(z_)); nconf = z_; npx[0] = z_; npx[1] = z_; npx[2] = z_; }
-#else
         nconf = fb[(size_t)(F - 1) * fstride];
         const float* prow = p.pts + (size_t)s * 3;
         npx[0] = prow[0]; npx[1] = prow[1]; npx[2] = prow[2];
-#endif
     };
     // FUSED: the same values, gathered from the sources (see FusedGather)
     // The in-kernel gather runs with eight waves per CU (the stand-alone kernel has 28) and all of them reach it together, so it is
@@ -768,7 +662,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     // footprints of the gather, in parts (so that they can be spread over several fills): 0 reference projection (+ the point the
     // encoding takes), 1 this lane's first volume, 2 stage-3 volume + confidence, 3 + pr view pair pr
     auto g_part = [&](int part) {
-        constexpr bool so_ = !UCNERF_FUSED_FOOT_UNDER_GEMM;
+        constexpr bool so_ = true;
         const int gW = sopaque(fg.W, so_), gH = sopaque(fg.H, so_);
         const float x = COORDS ? grd[0] : ro[0] + gz * grd[0], y = COORDS ? grd[1] : ro[1] + gz * grd[1], w = COORDS ? grd[2] : ro[2] + gz * grd[2];
         const int hl = opaque(h);
@@ -936,14 +830,8 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     };
     if (FUSED) {                                            // (the gather itself opens every iteration of the tile loop)
         g_pre(tile0);
-        if (UCNERF_FUSED_FOOT_UNDER_GEMM) g_foot(tile0);
     } else fetch(tile0);
 
-#ifdef UCNERF_MLP_DIAG
-#define DIAG_STAMP(K) { SB0; if (g.diag && lane == 0 && round == 5) g.diag[(size_t)(blockIdx.x * BW + wave) * 16 + (K)] = __builtin_readcyclecounter(); SB0; }
-#else
-#define DIAG_STAMP(K)
-#endif
     for (int round = 0; round < n_rounds; ++round) {                          // block-uniform trip count: every wave joins every barrier
         const int tile = round * tiles_per_round + tile0;
 #if UCNERF_BF16_IDLE_SKIP
@@ -956,7 +844,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         if (FUSED) {
             // this tile's gather (its depth / ray / depth range came in under the previous tile's last GEMM phase); the point encoding
             // runs while the first loads are in flight.  ONE copy of this code: as a prologue before the loop it spilled 208 bytes per lane
-            if (!UCNERF_FUSED_FOOT_UNDER_GEMM) g_foot(tile);
+            g_foot(tile);
             g_issue_first();
             encode_point(); g_finish();
             cur = read_half(P.buf, lane, 0);               // the fragments the last half-step left in `cur`, read again: sixteen registers the gather can use
@@ -971,7 +859,6 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         const size_t hstride = SAVE ? (size_t)(sv.h[1] - sv.h[0]) : 0;      // the six trunk sets are carved back to back
         // (few scalars are carried through the trunk -- every VGPR there is spoken for: sample index, feature base
         //  and view direction are re-derived / loaded where they are needed)
-        DIAG_STAMP(0)
         __builtin_amdgcn_s_setprio(UCNERF_BF16_PRIO_VALU);
         f32x16 bd[4], acc[4];
         Frag X[8], Y[8];
@@ -981,45 +868,20 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
 #pragma unroll
             for (int e = 0; e < 8; ++e) fsec[q][e] = nfs[q][e];
         ustash_w[opaque(lane)] = 1.f - nconf;                             // u: only needed again at the very end of the tile
-#ifdef UCNERF_MLP_DIAG
-        pin(npx[2]);
-        DIAG_STAMP(4)
-#endif
 
         // ---- point encoding -> fragments in LDS (layer 0 and the skip connection read them from there); FUSED: done at the previous tail
         if (!FUSED) {
             const float px[3] = {npx[0], npx[1], npx[2]};
             float pe[KS_PE_PTS];
-#if UCNERF_BF16_EXP & 512       // timing experiment: no point encoding arithmetic (wrong results) -- what moving it out of the kernel could buy
-#pragma unroll
-            for (int e = 0; e < KS_PE_PTS; ++e) pe[e] = px[e % 3];
-#else
             encode16<10, KS_PE_PTS>(px, h, pe);
-#endif
-#ifdef UCNERF_MLP_DIAG
-            pin(pe[0]); pin(pe[14]); pin(pe[29]);
-            DIAG_STAMP(14)
-#endif
 #pragma unroll
             for (int q = 0; q < KS16_PE_PTS; ++q) {
                 float t[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t[e] = pe[8 * q + e];
-#if UCNERF_BF16_EXP & 512
-                u32x4 uh_, ul_;                                               // finite bf16 pairs at one instruction each
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    uh_[e] = (__builtin_bit_cast(unsigned, t[e]) & 0x007f007fu) | 0x3c003c00u;
-                    ul_[e] = (__builtin_bit_cast(unsigned, t[4 + e]) & 0x007f007fu) | 0x38003800u;
-                }
-                Frag f_; f_.hi = __builtin_bit_cast(bf16x8, uh_); f_.lo = __builtin_bit_cast(bf16x8, ul_);
-                stash[q * 64] = f_;
-#else
                 stash[q * 64] = split8(t);
-#endif
             }
         }
-        DIAG_STAMP(1)
         __builtin_amdgcn_s_setprio(UCNERF_BF16_PRIO_GEMM);
 
         // ---- depth-bias net (step-major): bd = W_bd feats + b
@@ -1036,7 +898,6 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                     if (q + 1 < 4 && q + 1 < kd16) fc = fn;
                 }
         }
-        DIAG_STAMP(2)
         if (SAVE) {
             float* r_ = srow(sv.bd);
             if (r_) { save_tile<false, SAVE == 2>(r_, 0, bd[0]); save_tile<false, SAVE == 2>(r_, 1, bd[1]); save_tile<false, SAVE == 2>(r_, 2, bd[2]); save_tile<false, SAVE == 2>(r_, 3, bd[3]); }
@@ -1059,7 +920,6 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                    if (q == 3) init_bias_pair(cst, SEC_L0 + 1, h, 0, acc));
             }
         }
-        DIAG_STAMP(3)
 
         // ---- layers 1..4 (pair-split, fragments ping-pong between X and Y).  In: in[0..3] + acc[2], acc[3] of the
         // previous layer (their epilogue -> in[4..7] runs under phase A); out: out[0..3] + acc[2], acc[3].
@@ -1082,7 +942,6 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             layer128(X, Y, SEC_L0 + l);
             layer128(Y, X, SEC_L0 + l + 1);
         }
-        DIAG_STAMP(5)
 
         // ---- layer 5 on [h | pe] in k order h 0..3, pe 0..3, h 4..7; its output h5 = relu(. * bd) stays fp32 in acc
         // One batch of plain loads per tile (confidence-net operands + view direction, issued under phase B below):
@@ -1128,21 +987,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                            for (int e = 0; e < 8; ++e) {
                                const int c = f_img + 16 * qq + e;
                                const float* src_ = (NSRC && c + 8 < F) ? &fhb[c * fstride] : &fb[(size_t)min(c, F - 1) * fstride];
-#if UCNERF_BF16_EXP & 1024
-                               { float z_ = 0.f; asm volatile("" : "+v"(z_)); fsec[qq][e] = z_; }
-                               (void)src_;
-#elif UCNERF_BF16_EXP & 2048
-                               {
-                                   const float* src2_ = src_ + (tile + 1 < n_tiles / 2 ? (size_t)(n_tiles / 2) * F * 32 : 0);
-                                   const float a_ = qq >= kc16 ? 0.f : TILED ? __builtin_nontemporal_load(src_) : *src_;
-                                   const float b_ = qq >= kc16 ? 0.f : TILED ? __builtin_nontemporal_load(src2_) : *src2_;
-                                   float zero_ = 0.f;
-                                   asm volatile("" : "+v"(zero_));
-                                   fsec[qq][e] = a_ + zero_ * b_;
-                               }
-#else
                                fsec[qq][e] = qq >= kc16 ? 0.f : TILED ? __builtin_nontemporal_load(src_) : *src_;
-#endif
                            }
                        }
                        if (RAYGEN) {                           // pixel and jitter draw again (the ray's row of xs / ys, the sample's draw): three loads where the
@@ -1154,7 +999,6 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                        const float* drow = p.dirs + (size_t)ray * 3;
                        dv[0] = drow[0]; dv[1] = drow[1]; dv[2] = drow[2];
                        }
-                       if (FUSED && UCNERF_FUSED_FOOT_UNDER_GEMM) g_pre(tile + tiles_per_round);      // depth, ray, depth range of the NEXT tile's sample (clamped past the end: harmless)
                    }
                    if (RAYGEN && q == 10) {                // the launch's side outputs, beside the MFMAs: depth of every sample, ray and feature once per ray
                        const unsigned r_ = fg.S == 1 ? (unsigned)s_here : (__umulhi((unsigned)s_here, fg.div_m) >> fg.div_sh);
@@ -1174,19 +1018,13 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                        }
                        dv[0] = ax; dv[1] = ay; dv[2] = az;
                        pin(dv[0]); pin(dv[1]); pin(dv[2]);
-                   }
-                   if (FUSED && UCNERF_FUSED_FOOT_UNDER_GEMM && q == 10) {     // every plain load of the tile is waited for HERE, in one place
-                       pin(dv[0]); pin(dv[1]); pin(dv[2]);
-                       pin(gz); pin(grd[0]); pin(grd[1]); pin(grd[2]); pin(gnf[0]); pin(gnf[1]); pin(gnf[2]); pin(gnf[3]);
                    });
             }
         }
-        DIAG_STAMP(6)
 #pragma unroll
         for (int nt = 2; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = fmaxf(acc[nt][r] * bd[nt][r], 0.f);
-        DIAG_STAMP(7)
         if (SAVE) {
             float* r_ = srow(sv.h[5]);
             if (r_) { save_tile<false, SAVE == 2>(r_, 0, acc[0]); save_tile<false, SAVE == 2>(r_, 1, acc[1]); save_tile<false, SAVE == 2>(r_, 2, acc[2]); save_tile<false, SAVE == 2>(r_, 3, acc[3]); }
@@ -1212,7 +1050,6 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                 }
         }
         if (kc16 < 2) head_part(hbase, hb, h, acc[1], 1, 0, 16, ident);        // (one-step bias net: the rest is exposed)
-        DIAG_STAMP(8)
         if (SAVE) {
             float* r_ = srow(sv.bc);
             if (r_) { save_tile<false, SAVE == 2>(r_, 0, bd[0]); save_tile<false, SAVE == 2>(r_, 1, bd[1]); save_tile<false, SAVE == 2>(r_, 2, bd[2]); save_tile<false, SAVE == 2>(r_, 3, bd[3]); }
@@ -1221,7 +1058,6 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
 #pragma unroll
         for (int q = 0; q < 4; ++q) X[q] = frag_of<1>(acc[q >> 1], bd[q >> 1], q & 1);
         init_bias_pair(cst, SEC_FT, h, 0, acc);
-        DIAG_STAMP(9)
 
         // ---- feature_linear (pair-split); base heads of row tiles 2,3 underneath
 #pragma unroll
@@ -1249,7 +1085,6 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         pd[12] = h ? dv[2] : dv[0];
         pd[13] = h ? 0.f : dv[1];
         pd[14] = 0.f; pd[15] = 0.f;
-        DIAG_STAMP(10)
 
         // ---- views_linears | view_confi_linears on [feature | dir encoding] (pair-split), relu
         Frag D[2];
@@ -1265,7 +1100,6 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                    for (int e = 0; e < 8; ++e) t[e] = pd[8 * (q - 5) + e];
                    D[q - 5] = split8(t); pin(D[q - 5].hi); pin(D[q - 5].lo);
                }
-               if (FUSED && UCNERF_FUSED_FOOT_UNDER_GEMM && q >= 7) g_part(q - 7);          // next tile: reference projection, the two volumes + confidence
                );
         }
         HeadAcc hadapt = {{0.f, 0.f}, {0.f, 0.f}};
@@ -1275,11 +1109,9 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             const Frag b = q < 8 ? Y[q] : D[q - 8];
             HS(q & 1, b, acc[2], acc[3],
                if (q < 4) head_part(hadapt, ha, h, acc[q >> 1], q >> 1, (q & 1) * 8, 8, relu);
-               if (FUSED && UCNERF_FUSED_FOOT_UNDER_GEMM && q >= 4 && q - 4 < NP) g_part(3 + q - 4);      // ... its view pairs
-               if (FUSED && !UCNERF_FUSED_FOOT_UNDER_GEMM && q == 9) g_pre(tile + tiles_per_round);              // (after the tile's last advance(): its counted wait would sit on these loads too; clamped past the end: harmless)
+               if (FUSED && q == 9) g_pre(tile + tiles_per_round);              // (after the tile's last advance(): its counted wait would sit on these loads too; clamped past the end: harmless)
                if (SAVE && (q == 4 || q == 5)) { float* r_ = srow(sv.vc); if (r_) save_tile<true, SAVE == 2>(r_, q - 4, acc[q - 4]); });
         }
-        DIAG_STAMP(11)
         __builtin_amdgcn_s_setprio(UCNERF_BF16_PRIO_VALU);
         if (!FUSED) fetch(tile + tiles_per_round);         // next tile's inputs (clamped past the end: harmless)
         if (SAVE) {
@@ -1290,7 +1122,6 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         head_part(hadapt, ha, h, acc[2], 2, 0, 16, relu);
         head_part(hadapt, ha, h, acc[3], 3, 0, 16, relu);
         const f32x4 adapt = head_finish(hadapt, ha);
-        DIAG_STAMP(12)
         const float u = ustash_w[opaque(lane)], omu = 1.f - u;
         const int s_raw = tile * 32 + (opaque(lane) & 31);
         f32x4 out;
@@ -1299,7 +1130,6 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         out.z = 1.f / (1.f + expf(-(base.z * omu + adapt.z * u)));
         out.w = fmaxf(adapt.w * omu + base.w * u, 0.f);
         if (h == 0 && s_raw < p.m) reinterpret_cast<f32x4*>(p.raw)[s_raw] = out;
-        DIAG_STAMP(13)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
 }
@@ -1337,10 +1167,6 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
     g.F = B.F; g.kd16 = B.kd16; g.kc16 = B.kc16; g.f_img = 24 + 4 * B.v; g.slots = B.slots;
     g.feat_stride = p->feat_stride ? p->feat_stride : B.F;
     g.const_off_bytes = (int)B.const_off_bytes;
-    g.diag = nullptr;
-#ifdef UCNERF_MLP_DIAG
-    { const char* e = getenv("UCNERF_MLP_DIAG_PTR"); g.diag = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
-#endif
     // One instantiation per source-view count (1..8: SCARED scripts 6, Hamlyn 3, the reference's opt.py default 4, ...):
     // with the section lengths known at compile time no instantiation carries the spills of a runtime-length version.
     // This translation unit is compiled twice (uc_nerf_amd/build.py): -DUCNERF_BF16_BUILD_TERMS=3 (bf16x3) and =1 (bf16).
@@ -1430,14 +1256,10 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
     return check_launch("mlp_fwd_bf16");
 }
 
-#ifdef UCNERF_MLP_DIAG
-#define UCNERF_MLP_DIAG_ON 1
-#else
-#define UCNERF_MLP_DIAG_ON 0
-#endif
-#define UCNERF_BF16_FLAGS UCNERF_FLAG(UCNERF_BF16_EXP) UCNERF_FLAG(UCNERF_BF16_NO_PK) UCNERF_FLAG(UCNERF_BF16_SPLIT_DOT) UCNERF_FLAG(UCNERF_BF16_BW) \
-    UCNERF_FLAG(UCNERF_BF16_NBUF) UCNERF_FLAG(UCNERF_BF16_WPS) UCNERF_FLAG(UCNERF_BF16_HINT_V) UCNERF_FLAG(UCNERF_BF16_PRIO_VALU) UCNERF_FLAG(UCNERF_BF16_PRIO_GEMM) \
-    UCNERF_FLAG(UCNERF_BF16_IDLE_SKIP) UCNERF_FLAG(UCNERF_BF16_WAVE_MAJOR) UCNERF_FLAG(UCNERF_FUSED_FOOT_UNDER_GEMM) UCNERF_FLAG(UCNERF_GATHER_EXP) UCNERF_FLAG(UCNERF_MLP_DIAG_ON)
+// (the timing-experiment switches of rounds 1-3 -- UCNERF_BF16_EXP, NO_PK, SPLIT_DOT, FUSED_FOOT_UNDER_GEMM, the DIAG stamps -- were taken out of
+//  this file in round 4, their numbers are in profiles/r0N_experiments.md and DESIGN.md; what is left are structural parameters)
+#define UCNERF_BF16_FLAGS UCNERF_FLAG(UCNERF_BF16_BW) UCNERF_FLAG(UCNERF_BF16_NBUF) UCNERF_FLAG(UCNERF_BF16_WPS) UCNERF_FLAG(UCNERF_BF16_HINT_V) \
+    UCNERF_FLAG(UCNERF_BF16_PRIO_VALU) UCNERF_FLAG(UCNERF_BF16_PRIO_GEMM) UCNERF_FLAG(UCNERF_BF16_IDLE_SKIP) UCNERF_FLAG(UCNERF_BF16_WAVE_MAJOR)
 #if UCNERF_BF16_BUILD_TERMS == 3
 const char* build_flags_mlp_bf16x3() { return "mlp_bf16x3: " UCNERF_BF16_FLAGS; }
 #else

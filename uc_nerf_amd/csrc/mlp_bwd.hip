@@ -191,17 +191,11 @@ struct TnArgs {
     float* gW_hi; float* gb_hi;   // optional: rows n >= 64 belong to a second layer (row n - 64 of these)
 };
 
-#ifndef UCNERF_TN_EXP
-#define UCNERF_TN_EXP 0
-#endif
 #ifndef UCNERF_TN_BF16X3
 #define UCNERF_TN_BF16X3 1        // weight-gradient contraction on the bf16 matrix cores with split operands (0: exact fp32 MFMA)
 #endif
 #ifndef UCNERF_TN_DEPTH2
 #define UCNERF_TN_DEPTH2 2      // stages (8 samples each) of loads in flight (measured: 1, 2 and 3 time the same -- the loop is not latency-bound)
-#endif
-#ifndef UCNERF_TN_EXP
-#define UCNERF_TN_EXP 0
 #endif
 
 template <int KT, int NE>
@@ -277,19 +271,11 @@ __global__ void __launch_bounds__(1024) gemm_tn_kernel(TnArgs a) {
             const unsigned go = g_lane + (unsigned)(SPS * it) * g_row;
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-#if UCNERF_TN_EXP == 4              // (timing experiment: no G loads)
-                st.g[e] = __builtin_bit_cast(float, go);
-#else
                 st.g[e] = ldf(Gu[e], go);
-#endif
                 const unsigned xo = DIV ? (unsigned)((ws0 + SPS * it + ES * e + HS * h) / a.xdiv) * x_row : (unsigned)(SPS * it) * x_row;
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt)
-#if UCNERF_TN_EXP == 5              // (timing experiment: no X loads)
-                    st.x[e][kt] = __builtin_bit_cast(float, xo + kt);
-#else
                     st.x[e][kt] = ldf(Xu[e], x_lane[kt] + xo);
-#endif
             }
         };
         auto load_tail = [&](int it, TnStage<KT, NE>& st) {      // ragged last stage: clamped row, zeroed operands
@@ -339,11 +325,7 @@ __global__ void __launch_bounds__(1024) gemm_tn_kernel(TnArgs a) {
 #pragma unroll
             for (int b = 0; b < NB; ++b)
                 if (it + b < n_full) {
-#if UCNERF_TN_EXP != 2              // (2 = timing experiment: MFMAs only)
                     if (it + b + DEPTH < n_full) load(it + b + DEPTH, sb[(b + DEPTH) % NB]);
-#else
-                    asm volatile("" : "+v"(sb[b].g[0]));
-#endif
                     mma(sb[b]);
                 }
         }
@@ -373,11 +355,7 @@ __global__ void __launch_bounds__(1024) gemm_tn_kernel(TnArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h, k = 32 * (ks * KT + kt) + i;
                 float* drow = a.gW_hi && n >= 64 ? a.gW_hi + (size_t)(n - 64) * a.ldw : a.gW + (size_t)n * a.ldw;
-#if UCNERF_TN_EXP == 3              // (timing experiment: no atomics)
-                if (n < a.Nout && k < a.Kin && acc[kt][r] == 1234.5f) drow[k] = 0.f;
-#else
                 if (n < a.Nout && k < a.Kin) atomicAdd(drow + k, acc[kt][r]);
-#endif
             }
         }
         __syncthreads();
@@ -662,7 +640,7 @@ static int run_tn(hipStream_t st, int m, const float* G, int ldg, int Nout, cons
 
 #define RUN(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
-const char* build_flags_mlp_bwd() { return "mlp_bwd: " UCNERF_FLAG(UCNERF_TN_EXP) UCNERF_FLAG(UCNERF_TN_BF16X3) UCNERF_FLAG(UCNERF_TN_DEPTH2); }
+const char* build_flags_mlp_bwd() { return "mlp_bwd: " UCNERF_FLAG(UCNERF_TN_BF16X3) UCNERF_FLAG(UCNERF_TN_DEPTH2); }
 
 }  // namespace ucnerf
 

@@ -28,10 +28,6 @@ typedef float c_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 c_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned c_u32x4 __attribute__((ext_vector_type(4)));
 #define CSB __builtin_amdgcn_sched_barrier(0)
-#ifndef UCNERF_CHAIN_EXP
-#define UCNERF_CHAIN_EXP 0      // timing experiments (wrong results), bit mask: 1 no activation-set loads, 2 no set stores, 4 no wait for the weight copies,
-                                //   8 no barrier, 16 no weight copies, 64 / 128 all set loads / stores inside the sets' first 1024 samples (cache resident)
-#endif
 #define CMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 constexpr int BWD_HALF_STEPS = 128;            // VC 16 | FT 16 | BC 8 | L5 16 | L4 16 | L3 16 | L2 16 | L1 16 | BD 8
@@ -175,16 +171,10 @@ __device__ __forceinline__ CAF c_ldaf(const CPipe& P, int slot) {
 // (hs: a constant once the caller's loops are unrolled)
 template <int YOUNGER>
 __device__ __forceinline__ CAF c_advance(const CPipe& P, int hs) {
-#if !(UCNERF_CHAIN_EXP & 4)
     static_assert(YOUNGER >= CHAIN_NB - 2 && YOUNGER <= 63, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(YOUNGER) : "memory");
-#endif
-#if !(UCNERF_CHAIN_EXP & 8)
     __builtin_amdgcn_s_barrier();
-#endif
-#if !(UCNERF_CHAIN_EXP & 16)
     c_dma(P, (hs + CHAIN_NB) % BWD_HALF_STEPS, hs % CHAIN_NB);
-#endif
     return c_ldaf(P, (hs + 1) % CHAIN_NB);
 }
 
@@ -198,13 +188,7 @@ __device__ __forceinline__ CRaw c_ld_tile(const float* set, size_t rb, int nt) {
     CRaw x;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-#if UCNERF_CHAIN_EXP & 1
-        unsigned z_ = 0x3f000000u + (unsigned)rb;
-        asm volatile("" : "+v"(z_));
-        const P24Piece v = {{z_, z_, z_}};
-#else
         const P24Piece v = p24_load(row + P24_GROUP_BYTES * (8 * nt + 2 * q));
-#endif
         x.d[3 * q] = v.d[0]; x.d[3 * q + 1] = v.d[1]; x.d[3 * q + 2] = v.d[2];
     }
     return x;
@@ -223,9 +207,6 @@ __device__ __forceinline__ c_f32x16 c_unpack(const CRaw& r) {
 // (no predicate: the stores of a lane without a sample go to the spare row behind the set's last one -- `rb` then points there -- so that every
 //  wave issues the same number of vector-memory operations, which c_advance's counted waits rely on)
 __device__ __forceinline__ void c_st_tile(float* set, size_t rb, int nt, const c_f32x16& x) {
-#if UCNERF_CHAIN_EXP & 2
-    if (x[0] != 12345.678f) return;
-#endif
     char* row = reinterpret_cast<char*>(set) + rb;
 #pragma unroll
     for (int q = 0; q < 4; ++q) p24_store(row + P24_GROUP_BYTES * (8 * nt + 2 * q), p24_pack4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]));
@@ -348,16 +329,8 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, CHAIN_WAVES / 4) mlp_bwd_cha
         const int s_raw = tile * 32 + j;
         const bool valid = s_raw < a.m;
         const int s = valid ? s_raw : a.m - 1;
-#if UCNERF_CHAIN_EXP & 64        // timing experiment: every load falls into the first 1024 samples of its set (cache resident)
-        const size_t ro = p24_offset((size_t)(s & 1023), h, 32);
-#else
         const size_t ro = p24_offset((size_t)s, h, 32);        // this lane's piece of column group h of a [m,128] set, in bytes
-#endif
-#if UCNERF_CHAIN_EXP & 128       // ... every store
-        const size_t ro_st = p24_offset((size_t)((valid ? s_raw : a.m) & 1023), h, 32);
-#else
         const size_t ro_st = p24_offset((size_t)(valid ? s_raw : a.m), h, 32);      // ... for stores: sample m is the spare row of every set written here
-#endif
 
         // ---- output stage (models.py:177-178 backwards)
         const c_f32x4 raw = reinterpret_cast<const c_f32x4*>(a.raw)[s];
@@ -631,6 +604,6 @@ int launch_mlp_bwd_chain(int n_src, int m, const float* raw, const float* g_raw,
     return check_launch("mlp_bwd chain");
 }
 
-const char* build_flags_mlp_bwd_chain() { return "mlp_bwd_chain: " UCNERF_FLAG(UCNERF_CHAIN_EXP) UCNERF_FLAG(UCNERF_CHAIN_WAVES); }
+const char* build_flags_mlp_bwd_chain() { return "mlp_bwd_chain: " UCNERF_FLAG(UCNERF_CHAIN_WAVES); }
 
 }  // namespace ucnerf

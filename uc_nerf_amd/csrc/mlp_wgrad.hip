@@ -39,10 +39,6 @@ typedef unsigned w_u32x4 __attribute__((ext_vector_type(4)));
 typedef w_u32x4 w_u32x4_a4 __attribute__((aligned(4)));
 #define WMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-#ifndef UCNERF_WGRAD_EXP
-#define UCNERF_WGRAD_EXP 0      // timing experiments (wrong results), bit mask: 1 no split arithmetic (raw dwords into LDS), 2 no MFMAs,
-                                //   4 every operand load inside its set's first 256 KB (cache resident), 8 no LDS fragment writes
-#endif
 constexpr int WG_STAGE = 64;              // samples per stage (four k16-steps)
 constexpr int WG_KS = WG_STAGE / 16;
 constexpr int WG_THREADS = 768;            // waves 0-3 produce the X operand, 4-7 the G operand, 8-11 multiply
@@ -88,22 +84,9 @@ __device__ __forceinline__ void wg_atomic_add(float* p, float v) {
 }
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }     // LDS traffic only: loads in flight stay in flight
 
-#ifndef UCNERF_WGRAD_STAMPS
-#define UCNERF_WGRAD_STAMPS 0   // 1 = diagnostic build: per-phase cycle totals of every wave, printed by wgrad_launch (which then synchronises)
-#endif
-#if UCNERF_WGRAD_STAMPS
-#define WG_T(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[k] += now_ - tlast; tlast = now_; }
-#define WG_STAMP_ARG , unsigned long long* stamps
-#else
 #define WG_T(k)
 #define WG_STAMP_ARG
-#endif
 __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_STAMP_ARG) {
-#if UCNERF_WGRAD_STAMPS
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-    const unsigned long long rstart = __builtin_amdgcn_s_memrealtime(), tstart = tlast;
-    (void)rstart; (void)tstart;
-#endif
     extern __shared__ __attribute__((aligned(16))) char wg_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -287,25 +270,13 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-#if UCNERF_WGRAD_EXP & 4
-                off[e] &= 0x3ffffu;
-#endif
                 d[e] = *(const w_u32x4_a4 __attribute__((address_space(1)))*)(base + off[e]);
             }
         };
         w_f32x2 colsum[2] = {{0.f, 0.f}, {0.f, 0.f}};        // bias gradients of columns 4 grp .. 4 grp + 3: this thread's samples
         // registers -> (hi, lo) fragments -> LDS: every value is split exactly once
         auto put_frag = [&](char* Ol, const float (&x)[8], int f, int o) {
-#if UCNERF_WGRAD_EXP & 1
-            WFrag fr;
-            fr.hi = __builtin_bit_cast(w_bf16x8, (w_f32x4){x[0], x[1], x[2], x[3]});
-            fr.lo = __builtin_bit_cast(w_bf16x8, (w_f32x4){x[4], x[5], x[6], x[7]});
-#else
             const WFrag fr = w_split8(x);
-#endif
-#if UCNERF_WGRAD_EXP & 8
-            if (x[0] != 12345.678f) return;
-#endif
             const int off = frag_off(f, o);
             *reinterpret_cast<w_bf16x8*>(Ol + off) = fr.hi;
             *reinterpret_cast<w_bf16x8*>(Ol + off + 4 * 64 * 16) = fr.lo;
@@ -416,24 +387,9 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
             convert(A, 0);
             WG_T(0)
             for (int k = 0; k < k_max && k < total_even(); k += WG_UNROLL) {
-#if UCNERF_WGRAD_STAMPS
-                fetch(A); WG_T(1) wg_barrier(); WG_T(2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); WG_T(3) convert(B, 1); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WG_T(4)
-                fetch(B); WG_T(1) wg_barrier(); WG_T(2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); WG_T(3) convert(A, 0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WG_T(4)
-#else
                 fetch(A); wg_barrier(); convert(B, 1);
                 fetch(B); wg_barrier(); convert(A, 0);
-#endif
             }
-#if UCNERF_WGRAD_STAMPS
-            if (lane == 0) for (int k = 0; k < 5; ++k) { atomicAdd(stamps + (xs ? 16 : 0) + k, tacc[k]); atomicAdd(stamps + 2048 + 32 * (blockIdx.x & 7) + (xs ? 8 : 0) + k, tacc[k]); }
-            if (!xs && (tid & 255) == 0) {
-                const unsigned long long n_ = (unsigned long long)lds_total;
-                atomicAdd(stamps + 2048 + 32 * (blockIdx.x & 7) + 30, n_);
-                atomicAdd(stamps + 12, n_);
-                stamps[64 + 4 * blockIdx.x] = n_; stamps[65 + 4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - tstart;
-                stamps[66 + 4 * blockIdx.x] = rstart; stamps[67 + 4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-            }
-#endif
         };
         // (the X producers are the block's first four waves: their stage is the longer one -- fetch + conversion 4.5 k cycles against the G side's
         //  2.9 k -- and the older waves' loads go first: 304 -> 294 us per 131 k samples against the other order)
@@ -465,13 +421,9 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
                 if (full || 32 * kt < q.w) {
                     const w_bf16x8* xb = reinterpret_cast<const w_bf16x8*>(Xl) + (ks * 2 * 4 + kt) * 64 + (lane & 32) + swz(kt, lane >> 5, lane & 31);
                     const w_bf16x8 bhi = xb[0], blo = xb[4 * 64];
-#if UCNERF_WGRAD_EXP & 2
-                    acc[kt][0] += __builtin_bit_cast(w_f32x4, ahi)[0] + __builtin_bit_cast(w_f32x4, bhi)[0] + __builtin_bit_cast(w_f32x4, alo)[1] + __builtin_bit_cast(w_f32x4, blo)[1];
-#else
                     acc[kt] = WMFMA(ahi, bhi, acc[kt]);
                     acc[kt] = WMFMA(ahi, blo, acc[kt]);
                     acc[kt] = WMFMA(alo, bhi, acc[kt]);
-#endif
                 }
             }
         }
@@ -536,9 +488,6 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
             advance(mu, mq);
         }
     }
-#if UCNERF_WGRAD_STAMPS
-    if (lane == 0) for (int k = 0; k < 6; ++k) { atomicAdd(stamps + 6 + k, tacc[k]); atomicAdd(stamps + 2048 + 32 * (blockIdx.x & 7) + 16 + k, tacc[k]); }
-#endif
 }
 
 // ---- host side: the pair list is built by ucnerf_mlp_bwd (mlp_bwd.hip)
@@ -589,40 +538,10 @@ int wgrad_launch(const WgArgs* a, hipStream_t st) {
     int blocks = cus;                                        // one block per CU (128 KB of LDS)
     if (blocks > units) blocks = (int)units;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp_wgrad_kernel), WG_LDS_BYTES, "mlp_bwd wgrad")) return rc;
-#if UCNERF_WGRAD_STAMPS
-    static unsigned long long* stamps = nullptr;
-    if (!stamps) hipMalloc(&stamps, (64 + 4 * 1024) * 8);
-    unsigned long long init[64] = {0};
-    init[14] = ~0ull;
-    hipMemcpyAsync(stamps, init, sizeof(init), hipMemcpyHostToDevice, st);
-    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(blocks), dim3(WG_THREADS), WG_LDS_BYTES, st, *a, stamps);
-    static unsigned long long h[64 + 4 * 1024];
-    hipMemcpyAsync(h, stamps, sizeof(h), hipMemcpyDeviceToHost, st);
-    hipStreamSynchronize(st);
-    const double ns = (double)h[12], pw = 4.0 * ns, cw = 4.0 * ns;      // stage-visits summed over the four waves of a role
-    fprintf(stderr, "wgrad stamps (cycles per stage and wave; %d blocks, %.1f stages per block): G producer: prologue %.0f (per block), fetch %.0f, barrier %.0f, load wait %.0f, convert %.0f;  "
-            "X producer: fetch %.0f, barrier %.0f, load wait %.0f, convert %.0f;  consumer: loop %.0f, barrier %.0f, multiply %.0f, flush %.0f;  G producer total per block max %.0f min %.0f\n",
-            blocks, ns / blocks, h[0] / (4.0 * blocks), h[1] / pw, h[2] / pw, h[3] / pw, h[4] / pw, h[17] / pw, h[18] / pw, h[19] / pw, h[20] / pw, h[6] / cw, h[7] / cw, h[8] / cw, h[9] / cw,
-            (double)h[13], (double)h[14]);
-    {
-        unsigned long long t0 = ~0ull;
-        for (int b = 0; b < blocks; ++b) t0 = h[66 + 4 * b] < t0 ? h[66 + 4 * b] : t0;
-        fprintf(stderr, "wgrad stamps, per block (stages, cycles, start, end in 10-ns ticks from the first start):");
-        for (int b = 0; b < blocks; ++b) fprintf(stderr, " %d:%d,%d,%llu,%llu,%d,%d", b, (int)(h[64 + 4 * b] & 0xffffffffu), (int)h[65 + 4 * b], h[66 + 4 * b] - t0, h[67 + 4 * b] - t0, (int)((h[64 + 4 * b] >> 32) & 15), (int)(h[64 + 4 * b] >> 40));
-        fprintf(stderr, "\n");
-    }
-    for (int x = 0; x < 8; ++x) {
-        const unsigned long long* q = h + 2048 + 32 * x;
-        const double w = 4.0 * (double)q[30];
-        fprintf(stderr, "wgrad stamps, blockIdx %% 8 = %d (cycles per stage and wave): G fetch %.0f barrier %.0f wait %.0f convert %.0f | X fetch %.0f barrier %.0f wait %.0f convert %.0f | consumer barrier %.0f multiply %.0f flush %.0f\n",
-                x, q[1] / w, q[2] / w, q[3] / w, q[4] / w, q[9] / w, q[10] / w, q[11] / w, q[12] / w, q[17] / w, q[18] / w, q[19] / w);
-    }
-#else
     hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(blocks), dim3(WG_THREADS), WG_LDS_BYTES, st, *a);
-#endif
     return check_launch("mlp_bwd wgrad");
 }
 
-const char* build_flags_mlp_wgrad() { return "mlp_wgrad: " UCNERF_FLAG(UCNERF_WGRAD_EXP) " " UCNERF_FLAG(UCNERF_WGRAD_STAMPS); }
+const char* build_flags_mlp_wgrad() { return "mlp_wgrad: (no compile-time switches) "; }
 
 }  // namespace ucnerf
