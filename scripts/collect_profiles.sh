@@ -52,5 +52,15 @@ json.dump({"source": "scripts/pmc_mlp.sh (rocprofv3 --pmc, separate passes) on s
           open(sys.argv[2], "w"), indent=1, sort_keys=True)
 PY
 [ -s $G/final_n2_gloo.json ] && cp $G/final_n2_gloo.json $R/profiles/${P}_bench_n2_gloo_rehearsal.json
+[ -s $G/final_n4_gloo.json ] && cp $G/final_n4_gloo.json $R/profiles/${P}_bench_n4_gloo_rehearsal.json
+[ -s $G/final_rccl1.json ] && cp $G/final_rccl1.json $R/profiles/${P}_bench_rccl_one_rank_group.json
+for v in repack hoisted; do
+  [ -s $G/strong_final_$v.kernel_stats.csv ] && cp $G/strong_final_$v.kernel_stats.csv $R/profiles/${P}_strong512_kernel_stats_$v.csv
+  [ -s $G/strong_final_$v.gaps.json ] && cp $G/strong_final_$v.gaps.json $R/profiles/${P}_strong512_launch_gaps_$v.json
+done
+for n in 2000 250; do
+  [ -s $G/dropin_train_final_$n.kernel_stats.csv ] && cp $G/dropin_train_final_$n.kernel_stats.csv $R/profiles/${P}_dropin_train_kernel_stats_$n.csv
+  [ -s $G/dropin_train_final_$n.gaps.json ] && cp $G/dropin_train_final_$n.gaps.json $R/profiles/${P}_dropin_train_launch_gaps_$n.json
+done
 [ -f $G/parity_errors.json ] && cp $G/parity_errors.json $R/profiles/${P}_parity_errors.json
 echo collected into profiles/${P}_*

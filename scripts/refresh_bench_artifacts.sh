@@ -23,6 +23,11 @@ PREC=bf16x3_fused KERNEL=mlp_fwd_bf16 bash scripts/pmc_mlp.sh final_pmc_fused > 
 python scripts/pmc_summary.py gpurun_out/final_pmc_fused gpurun_out/final_mlp_bf16_fused_hbm_traffic.json > gpurun_out/final_pmc_fused_summary.log 2>&1 || true
 KERNEL="mlp_bwd_chain|mlp_wgrad|mlp_fwd_kernel|feat_gather" SCRIPT=scripts/time_train_step.py bash scripts/pmc_mlp.sh final_pmc_train > gpurun_out/final_pmc_train.log 2>&1
 python scripts/pmc_by_kernel.py gpurun_out/final_pmc_train gpurun_out/final_train_step_hbm_traffic.json > gpurun_out/final_pmc_train_summary.log 2>&1 || true
-# the self-launched two-rank line (both ranks on this GPU, gloo for the collective): only the JSON line is kept
-UCNERF_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 30 --warmup 5 2> gpurun_out/final_n2_gloo.err | grep '^{' > gpurun_out/final_n2_gloo.json || true
+# round 4: the strong-scaling shard's step (512 rays) as a kernel trace with the gaps between launches, and the rendering() training step at 2000 / 250 rays
+bash scripts/prof_strong.sh final > gpurun_out/final_strong512.log 2>&1 || true
+bash scripts/prof_dropin_train.sh final > gpurun_out/final_dropin_train_trace.log 2>&1 || true
+# the data-parallel step through a ONE-rank RCCL group (the collective's code path on one GPU)
+UCNERF_BENCH_GROUP_AT_1=1 python bench.py --cpu-rays 0 2> gpurun_out/final_rccl1.err | grep '^{' > gpurun_out/final_rccl1.json || true
+# the self-launched four-rank line (all ranks on this GPU, gloo for the collective; six processes at most may share the card): only the JSON line is kept
+UCNERF_BENCH_BACKEND=gloo python bench.py --gpus 4 --steps 20 --warmup 5 2> gpurun_out/final_n4_gloo.err | grep '^{' > gpurun_out/final_n4_gloo.json || true
 tail -c 300 $R/gpurun_out/final_bf16x3_fused.json

@@ -8,7 +8,7 @@ Layers:
 
 GPU only: there is no CPU or PyTorch fallback; calls on CPU tensors raise.
 """
-__version__ = "0.2.0"
+__version__ = "0.4.0"
 
 
 def set_inference_precision(precision):
@@ -36,6 +36,13 @@ def set_training_precision(precision):
     """MLP arithmetic of the training forward of the `rendering()` drop-in: "f32" (default) or "bf16x3" (dropin.py)."""
     from . import dropin
     dropin.set_training_precision(precision)
+
+
+def set_backward_mode(mode):
+    """Backward of the network: "chain" (default: one register-resident gradient-chain launch + one weight-gradient launch) or "layerwise" (the
+    exact-fp32 layer-by-layer kernels of rounds 1-2, kept as the cross-check) -- ops.set_backward_mode."""
+    from . import ops
+    ops.set_backward_mode(mode)
 
 
 def install_dropin(precision=None, training_precision=None):
