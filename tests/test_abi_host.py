@@ -78,6 +78,29 @@ def test_argument_validation_reports_instead_of_launching(L):
     assert lib.ucnerf_ray_gen(C.addressof(e), None) == 0
     assert lib.ucnerf_render_workspace_floats(4096, 192, 6) > 4096 * 192 * 97
     assert lib.ucnerf_render_workspace_floats(1, 0, 6) < 0
+    # ABI v4 entry points and fields: arguments are checked before anything is launched
+    assert lib.ucnerf_composite_sample_pdf(None, None, None) == -1 and b"null params" in lib.ucnerf_last_error()
+    c = L.CompositeParams()
+    c.n, c.S, c.raw, c.z, c.rgb_map, c.depth_map = 4, 64, 16, 16, 16, 16
+    s = L.SamplePdfParams()
+    s.n, s.n_bins, s.n_samples, s.n_merge, s.from_coarse, s.u, s.samples = 4, 62, 128, 64, 1, 16, 16            # n_bins must be S - 1
+    assert lib.ucnerf_composite_sample_pdf(C.addressof(c), C.addressof(s), None) == -1 and b"from_coarse form over the composited pass" in lib.ucnerf_last_error()
+    s.n_bins, s.from_coarse = 63, 0
+    assert lib.ucnerf_composite_sample_pdf(C.addressof(c), C.addressof(s), None) == -1
+    s.from_coarse, s.z_merge = 1, 32                                                                              # z_merge, when given, must be the pass's own depths
+    assert lib.ucnerf_composite_sample_pdf(C.addressof(c), C.addressof(s), None) == -1 and b"z_merge" in lib.ucnerf_last_error()
+    r = L.RenderParams()
+    r.n, r.S, r.cfg = 4, 64, L.MlpConfig(6, 0, 3)
+    r.rays_o = r.rays_d = r.z = r.workspace = r.wstream = r.rgb_map = r.depth_map = 16
+    rg = L.RayGenParams()
+    r.gen_rays = C.addressof(rg)                                                                                  # gen_rays without gen_depths
+    assert lib.ucnerf_render_fused_fwd(C.addressof(r), None) == -1 and b"go together" in lib.ucnerf_last_error()
+    ss = L.SampleStratifiedParams()
+    r.gen_depths = C.addressof(ss)
+    rg.n, ss.n, ss.S = 4, 4, 32                                                                                   # depths for another S
+    assert lib.ucnerf_render_fused_fwd(C.addressof(r), None) == -1 and b"differ from the pass" in lib.ucnerf_last_error()
+    r.cfg = L.MlpConfig(6, 0, 1)                                                                                   # generated rays need the gather-fused kernel
+    assert lib.ucnerf_render_fused_fwd(C.addressof(r), None) == -1 and b"gather-fused kernel" in lib.ucnerf_last_error()
 
 
 @pytest.mark.parametrize("n_src,layout", [(6, 0), (3, 0), (6, 1), (1, 0), (8, 1)])
