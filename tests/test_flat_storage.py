@@ -182,6 +182,60 @@ def test_flat_adam_steps_like_adam_over_the_parameter_list():
     assert st.is_flat()
 
 
+def test_bucket_over_a_partly_frozen_network_and_flat_adam_state_round_trip(tmp_path):
+    """Layers frozen by the caller (requires_grad False) drop out of the bucket but keep their place in the flat vector; FlatAdam's state
+    survives state_dict() / load_state_dict() like any torch optimizer's."""
+    net = _net()
+    st, mask = FlatStore.of(net), _mask(net)
+    for name, p in net.named_parameters():
+        if name.startswith("nerf.pts_linears.0.") or name.startswith("nerf.rgb_linear."):
+            p.requires_grad_(False)
+    live = [m and p.requires_grad for m, p in zip(mask, net.parameters())]
+    bucket = P.FlatGradBucket(list(net.parameters()), n_scalars=1)
+    assert len(bucket.params) == 32 and bucket.numel == st.n + 1 + 32          # the frozen tensors' segments stay inside the reduced vector (zeros)
+
+    class Render(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, *params):
+            return params[2].sum() * 0
+
+        @staticmethod
+        def backward(ctx, g):
+            pool = torch.zeros(st.grad_room + 8)
+            gf = pool[:st.grad_room]
+            gf[:st.n] = _grad_values(st, live)
+            return tuple(st.grad_views(gf, [w and n for w, n in zip(live, ctx.needs_input_grad)]))
+
+    Render.apply(*net.parameters()).backward()
+    red = bucket.allreduce(0.5, [3.0])
+    assert bucket.last_path == "in_place" and red.tolist() == [1.5]
+    for (name, p), o, n, w in zip(net.named_parameters(), st.offsets, st.sizes, live):
+        if w:
+            assert torch.equal(p.grad.reshape(-1), (_grad_values(st, live) * 0.5)[o:o + n]), name
+        else:
+            assert p.grad is None, name
+    # optimizer state round trip
+    net2 = _net(seed=2)
+    net2.load_state_dict(net.state_dict())
+    for p in net.parameters():
+        p.requires_grad_(True)
+    opt = FlatAdam(net, lr=1e-3)
+    _FakeRender.apply(st, mask, 1.0, *net.parameters()).backward()
+    opt.step()
+    path = str(tmp_path / "opt.pt")
+    torch.save(opt.state_dict(), path)
+    st2 = FlatStore.of(net2)
+    net2.load_state_dict(net.state_dict())
+    opt2 = FlatAdam(net2, lr=1e-3)
+    opt2.load_state_dict(torch.load(path))
+    for o_, n_ in ((opt, net), (opt2, net2)):
+        o_.zero_grad()
+        s_ = FlatStore.of(n_)
+        _FakeRender.apply(s_, mask, 2.0, *n_.parameters()).backward()
+        o_.step()
+    assert torch.equal(st.flat, st2.flat)
+
+
 # ---- world size 2 over gloo: the in-place route through a real collective, one rank with an empty shard in the second step
 def _two_rank_in_place(rank, world):
     net = _net()
