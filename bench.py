@@ -65,6 +65,23 @@ def cpu_baseline(scene_cpu, sd, n_rays, n_coarse, n_fine, budget_s=45.0):
                       "median of %d runs" % (n_rays, n_coarse, n_fine, len(times))}
 
 
+def parity_vs_oracle(scene_cpu, sd, out, xs_cpu, ys_cpu, noise_cpu, n_coarse, n_fine, n_check=256):
+    """"PSNR vs ref" of the metric, on a bounded sample: the first `n_check` rays of the timed batch re-rendered by the CPU oracle (the pinned
+    restatement of the reference path) teacher-forced on the device's own fine depths (the free-running hierarchy is only statistically
+    comparable: a draw landing in the neighbouring cdf bin moves a fine depth), against the device's render.  The checker, never the product."""
+    from oracle import ucnerf_oracle as O
+    n = min(n_check, int(xs_cpu.shape[0]))
+    with torch.no_grad():
+        ref = O.render_coarse_fine(sd, scene_cpu, xs_cpu[:n], ys_cpu[:n], n_coarse, n_fine, noise=noise_cpu[:n], perturb=1.0,
+                                   z_fine_override=out["z_fine"][:n].cpu())
+    d_rgb, d_depth = out["rgb"][:n].cpu() - ref["rgb"], out["depth"][:n].cpu() - ref["depth"]
+    mse = torch.mean(d_rgb ** 2).item()
+    return {"rays": n, "psnr_db": -10.0 * math.log10(max(mse, 1e-20)), "max_abs_rgb": d_rgb.abs().max().item(), "max_abs_depth": d_depth.abs().max().item(),
+            "max_abs_coarse_weight": (out["coarse"]["weights"][:n].cpu() - ref["coarse"]["weights"]).abs().max().item(),
+            "bar": 1e-4, "note": "the device's render of the first %d rays of the timed batch against the CPU oracle (fp32, the pinned restatement of the reference "
+                                 "path) teacher-forced on the device's own fine depths; all rays counted (the batch's knife-edge rays included)" % n}
+
+
 def self_launch_command(gpus, argv, env, port=None):
     """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE / RANK unset): the command that starts the N ranks --
     one process per GPU through torch.distributed.run, rendezvous on 127.0.0.1 -- or None when this process IS a rank (or N = 1).
@@ -756,6 +773,7 @@ def main():
             line["parity_vs_f32"] = psnr_vs_f32
         line.update(extra)
         if args.cpu_rays > 0:           # (rank 0 only; at N > 1 the other ranks wait at the closing barrier)
+            line["parity_vs_oracle"] = guarded(lambda: parity_vs_oracle(scene_cpu, sd, out, xs_all[:rays], ys_all[:rays], noise.cpu(), args.coarse, args.fine))
             line["cpu_baseline"] = cpu_baseline(scene_cpu, sd, args.cpu_rays, args.coarse, args.fine)
         print(json.dumps(line), flush=True)
     if ctx.dist is not None:
