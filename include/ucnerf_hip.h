@@ -247,11 +247,7 @@ typedef struct {
                              3: bf16x3 with the feature gather INSIDE the MLP kernel: the stream is packed in the
                                 order that kernel's lane halves produce the bias nets' operands and serves ucnerf_render_fused_fwd
                                 only (channel-last sources, coordinates derived from (ray, depth) or handed over -- pts_in ... ndc_in --,
-                                no kept features, no per-sample uncertainty); ucnerf_mlp_fwd refuses it.  Same arithmetic as 1.
-                             4: (ABI v4) precision 3 on 16-SAMPLE tiles (v_mfma_f32_16x16x32_bf16; its own stream layout): half the work per wave,
-                                twice the waves -- for passes that fill the chip's wave slots less than twice (a data-parallel shard of a few
-                                hundred rays), where one tile's latency bounds the launch; derived coordinates, fp32 source copies.  Same
-                                arithmetic as 1 / 3 up to summation order. */
+                                no kept features, no per-sample uncertainty); ucnerf_mlp_fwd refuses it.  Same arithmetic as 1. */
 } ucnerf_mlp_config;
 
 /* Sizes: floats in the flat parameter vector, floats (4-byte units) of the packed stream, int32 entries of the pack

@@ -629,10 +629,6 @@ int launch_pack_bf16(const ucnerf_mlp_config* cfg, const float* flat, const int3
 int launch_pack_bf16_tab(const ucnerf_mlp_config* cfg, const ParamTable& t, const int32_t* idx, float* out, hipStream_t st);
 int launch_mlp_fwd_bf16x3(const ucnerf_mlp_params* p, hipStream_t st);      // mlp_bf16.hip built with TERMS = 3
 int launch_mlp_fwd_bf16_plain(const ucnerf_mlp_params* p, hipStream_t st);   // ... and with TERMS = 1
-// mlp_bf16_w16.hip (cfg.precision 4: the gather-fused kernel on 16-sample tiles, its own stream layout)
-int build_pack_index_bf16_w16(const ucnerf_mlp_config* cfg, int32_t* idx);
-int64_t bf16_w16_index_count(const ucnerf_mlp_config* cfg);
-int64_t bf16_w16_stream_floats(const ucnerf_mlp_config* cfg);
 
 const char* build_flags_mlp_f32() { return "mlp_f32: " UCNERF_FLAG(UCNERF_MLP_WAVES) UCNERF_FLAG(UCNERF_MLP_PRIO) UCNERF_FLAG(UCNERF_MLP_RING) UCNERF_FLAG(UCNERF_MLP_SAVE_NT); }
 
@@ -652,25 +648,20 @@ int64_t ucnerf_mlp_stream_count(const ucnerf_mlp_config* cfg) {
     MlpLayout L;
     if (!cfg || !mlp_layout(cfg->n_src, &L)) return fail(UCNERF_EINVAL, "mlp: n_src must be in 1..8");
     if (cfg->precision >= 1 && cfg->precision <= 3) return bf16_stream_floats(cfg);
-    if (cfg->precision == 4) return bf16_w16_stream_floats(cfg);
-    if (cfg->precision != 0) return fail(UCNERF_EINVAL, "mlp: precision %d (0 = f32, 1 = bf16x3, 2 = bf16, 3 = bf16x3 with the gather fused, 4 = the same on 16-sample tiles)", cfg->precision);
+    if (cfg->precision != 0) return fail(UCNERF_EINVAL, "mlp: precision %d (0 = f32, 1 = bf16x3, 2 = bf16, 3 = bf16x3 with the gather fused)", cfg->precision);
     return L.total;
 }
 
 int64_t ucnerf_mlp_index_count(const ucnerf_mlp_config* cfg) {
     const int64_t n = ucnerf_mlp_stream_count(cfg);
     if (n < 0) return n;
-    return cfg->precision == 4 ? bf16_w16_index_count(cfg) : cfg->precision != 0 ? bf16_index_count(cfg) : n;
+    return cfg->precision != 0 ? bf16_index_count(cfg) : n;
 }
 
 int ucnerf_mlp_pack_index(const ucnerf_mlp_config* cfg, int32_t* idx_host) {
     UCNERF_REQUIRE(cfg && idx_host, "mlp_pack_index: null pointer");
     UCNERF_REQUIRE(cfg->pe_layout == 0 || cfg->pe_layout == 1, "mlp_pack_index: pe_layout %d", cfg->pe_layout);
-    UCNERF_REQUIRE(cfg->precision >= 0 && cfg->precision <= 4, "mlp_pack_index: precision %d", cfg->precision);
-    if (cfg->precision == 4) {               // (its constants come in the 16-sample kernel's own register order)
-        UCNERF_REQUIRE(build_pack_index_bf16_w16(cfg, idx_host) == 0, "mlp_pack_index: n_src %d outside 1..8", cfg->n_src);
-        return UCNERF_OK;
-    }
+    UCNERF_REQUIRE(cfg->precision >= 0 && cfg->precision <= 3, "mlp_pack_index: precision %d", cfg->precision);
     if (cfg->precision == 0) {
         UCNERF_REQUIRE(build_pack_index(cfg, idx_host) == 0, "mlp_pack_index: n_src %d outside 1..8", cfg->n_src);
         return UCNERF_OK;
@@ -726,7 +717,6 @@ int ucnerf_mlp_unpack_grad(const float* g, const int32_t* idx, float* gflat, int
 }
 
 int ucnerf_mlp_fwd(const ucnerf_mlp_params* p, void* stream) {
-    UCNERF_REQUIRE(!p || p->cfg.precision != 4, "mlp_fwd: a weight stream packed with precision 4 serves the render pass on 16-sample tiles and nothing else (ucnerf_render_fused_fwd)");
     if (p && (p->cfg.precision == 1 || p->cfg.precision == 3)) return launch_mlp_fwd_bf16x3(p, (hipStream_t)stream);      // (3: refused there with the reason)
     if (p && p->cfg.precision == 2) return launch_mlp_fwd_bf16_plain(p, (hipStream_t)stream);
     return launch_mlp_fwd(p, nullptr, (hipStream_t)stream);

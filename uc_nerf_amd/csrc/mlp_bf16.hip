@@ -1338,14 +1338,10 @@ __global__ void pack_f32_kernel(const float* __restrict__ flat, const int32_t* _
     if (i < n) { const int32_t k = idx[i]; out[i] = k >= 0 ? flat[k] : 0.f; }
 }
 
-int64_t bf16_w16_index_count(const ucnerf_mlp_config* cfg);       // mlp_bf16_w16.hip (cfg.precision 4: another stream length, same element format)
-int64_t bf16_w16_const_off_bytes(const ucnerf_mlp_config* cfg);
-
 int launch_pack_bf16(const ucnerf_mlp_config* cfg, const float* flat, const int32_t* idx, float* out, hipStream_t st) {
     Bf16Layout B;
     UCNERF_REQUIRE(bf16_layout(cfg->n_src, &B), "mlp_pack: n_src %d outside 1..8", cfg->n_src);
-    if (cfg->precision == 4) B.const_off_bytes = bf16_w16_const_off_bytes(cfg);
-    const int64_t n16 = cfg->precision == 4 ? bf16_w16_index_count(cfg) - CONST_FLOATS : (int64_t)B.slots * (SLOT_BYTES / 2);
+    const int64_t n16 = (int64_t)B.slots * (SLOT_BYTES / 2);
     hipLaunchKernelGGL(pack_bf16_kernel, dim3(cdiv(n16, 256)), dim3(256), 0, st, flat, idx, reinterpret_cast<unsigned short*>(out), n16);
     hipLaunchKernelGGL(pack_f32_kernel, dim3(cdiv(CONST_FLOATS, 256)), dim3(256), 0, st, flat, idx + n16,
                        reinterpret_cast<float*>(reinterpret_cast<char*>(out) + B.const_off_bytes), CONST_FLOATS);
@@ -1377,8 +1373,7 @@ __global__ void pack_all_tab_kernel(ParamTable t, const int32_t* __restrict__ id
 int launch_pack_bf16_tab(const ucnerf_mlp_config* cfg, const ParamTable& t, const int32_t* idx, float* out, hipStream_t st) {
     Bf16Layout B;
     UCNERF_REQUIRE(bf16_layout(cfg->n_src, &B), "mlp_pack: n_src %d outside 1..8", cfg->n_src);
-    if (cfg->precision == 4) B.const_off_bytes = bf16_w16_const_off_bytes(cfg);
-    const int64_t n16 = cfg->precision == 4 ? bf16_w16_index_count(cfg) - CONST_FLOATS : (int64_t)B.slots * (SLOT_BYTES / 2);
+    const int64_t n16 = (int64_t)B.slots * (SLOT_BYTES / 2);
     const int nb16 = cdiv(n16, 256), nbc = cdiv(CONST_FLOATS, 256);
     hipLaunchKernelGGL(pack_all_tab_kernel, dim3(nb16 + nbc), dim3(256), 0, st, t, idx, reinterpret_cast<unsigned short*>(out), n16,
                        reinterpret_cast<float*>(reinterpret_cast<char*>(out) + B.const_off_bytes), CONST_FLOATS, nb16);

@@ -56,7 +56,6 @@ __global__ void __launch_bounds__(256) render_points_kernel(PointsArgs a) {
 
 int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float* feats, int tiled, float* ndc, hipStream_t st);
 int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* repacked, const float* dirs, float* raw, hipStream_t st);   // mlp_bf16.hip
-int launch_mlp_fwd_bf16x3_gather_w16(const ucnerf_render_params* rp, const float* repacked, const float* dirs, float* raw, hipStream_t st);   // mlp_bf16_w16.hip
 
 struct Workspace {
     float *pts, *ndc1, *ndc2, *ndc3, *ndc, *angle, *feats, *raw;
@@ -132,17 +131,15 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
     const bool keep_feats = p->feats != nullptr;        // caller wants row-major features (for the backward)
     ucnerf_feat_gather_params g;
     float* raw_fused = nullptr;
-    if (p->cfg.precision == 3 || p->cfg.precision == 4) {   // row f1: gather + PE + MLP in one launch, no feature buffer at all (4: on 16-sample tiles, for partly filled rounds)
+    if (p->cfg.precision == 3) {                        // row f1: gather + PE + MLP in one launch, no feature buffer at all
         UCNERF_REQUIRE(p->sources_cl && !keep_feats && !p->u_sampled && !p->train_workspace,
-                       "render_fused_fwd: precision 3 / 4 (gather fused into the MLP kernel) needs the channel-last sources; it keeps no features "
+                       "render_fused_fwd: precision 3 (gather fused into the MLP kernel) needs the channel-last sources; it keeps no features "
                        "and returns no per-sample uncertainty");
         const bool gen = p->gen_rays != nullptr;          // rays, depths and direction features are generated inside the launch (w->angle: its per-sample scratch)
         if (!gen && !p->dir_feat && (rc = launch_dirs(p, st, w))) return rc;
         raw_fused = p->raw ? p->raw : w->raw;
         if (p->ev_mlp_start && (rc = ucnerf_event_record(p->ev_mlp_start, st))) return rc;
-        if (p->cfg.precision == 4) {
-            if ((rc = launch_mlp_fwd_bf16x3_gather_w16(p, p->sources_cl, p->dir_feat ? p->dir_feat : w->angle, raw_fused, st))) return rc;
-        } else if ((rc = launch_mlp_fwd_bf16x3_gather(p, p->sources_cl, gen ? w->angle : p->dir_feat ? p->dir_feat : w->angle, raw_fused, st))) return rc;
+        if ((rc = launch_mlp_fwd_bf16x3_gather(p, p->sources_cl, gen ? w->angle : p->dir_feat ? p->dir_feat : w->angle, raw_fused, st))) return rc;
         if (p->ev_mlp_stop && (rc = ucnerf_event_record(p->ev_mlp_stop, st))) return rc;
     } else if (p->sources_cl) {                                // fast path: channel-last sources, coordinates derived in-kernel
         g.out_tiled = keep_feats ? (p->feats_tiled ? 1 : 0) : 1;

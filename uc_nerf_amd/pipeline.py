@@ -22,7 +22,7 @@ class CoarseFineRenderer:
     confidence [H,W]; tensors already on the device.  flat_params: the MLP's flat parameter vector (device)."""
 
     def __init__(self, scene, flat_params, n_coarse=64, n_fine=128, white_bkgd=False, pe_layout=0, max_blocks=0,
-                 precision="f32", fused_min_rounds=0, sources_bf16=False, small_route="bf16x3_fused_w16"):
+                 precision="f32", fused_min_rounds=0, sources_bf16=False):
         dev = scene["confidence"].device
         self.scene, self.dev = scene, dev
         self.n_coarse, self.n_fine, self.white_bkgd = n_coarse, n_fine, white_bkgd
@@ -36,15 +36,14 @@ class CoarseFineRenderer:
         w2c_ref = scene["w2cs"][0]
         self.pass_ = ops.RenderPass(self.src, self.pw, self.wstream, scene["c2w"][:3, 3].to(dev), w2c_ref,
                                     scene["intrinsics"][0], w2c_ref, scene["near"], scene["far"], white_bkgd, max_blocks)
-        # Passes that fill the chip's wave slots fewer than `fused_min_rounds` times (32-sample tiles) run on the SAME fused kernel with
-        # 16-sample tiles (precision "bf16x3_fused_w16", csrc/mlp_bf16_w16.hip: half the work per wave, twice the waves -- such a pass is bound by
-        # one tile's latency, not by throughput): a second packed stream of the same parameters.  `small_route` = "bf16x3" restores round 2's
-        # alternative for small passes, the two-kernel route.
+        # fused_min_rounds > 0: passes with fewer tiles per wave than that take the two-kernel route (a second stream of the same
+        # parameters).  Measured (scripts/ab_rounds.sh, 512 .. 2048 rays x 64 + 128): the fused kernel wins or ties at every size,
+        # so the default is 0 -- always fused; the option stays for devices / shapes where a launch-bound shard might prefer otherwise.
         self.pass_small, self.fused_min_samples = None, 0
         if precision == "bf16x3_fused" and fused_min_rounds > 0:
             cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
-            self.fused_min_samples = int(fused_min_rounds * cus * 8 * 32)
-            self.pw_small = ops.PackedWeights.get(self.src.V, pe_layout, dev, small_route)
+            self.fused_min_samples = int(fused_min_rounds) * cus * 8 * 32
+            self.pw_small = ops.PackedWeights.get(self.src.V, pe_layout, dev, "bf16x3")
             self.wstream_small = self.pw_small.pack(flat_params)
             self.pass_small = ops.RenderPass(self.src, self.pw_small, self.wstream_small, scene["c2w"][:3, 3].to(dev), w2c_ref,
                                              scene["intrinsics"][0], w2c_ref, scene["near"], scene["far"], white_bkgd, max_blocks)
