@@ -38,7 +38,7 @@ int ucnerf_sizeof(const char* struct_name);
 /* Number of compute units of the current device (grid sizing for persistent kernels); <0 on error. */
 int ucnerf_device_cus(void);
 /* The compile-time parameters this binary was built with, as "NAME=value NAME=value ..." (structural parameters of the kernels:
- * UCNERF_BF16_BW, UCNERF_BF16_NBUF, UCNERF_MLP_WAVES, UCNERF_MLP_RING, ...; the wrong-result timing switches of rounds 1-3 were taken out of
+ * UCNERF_BF16_BW, UCNERF_BF16_NBUF, UCNERF_MLP_WAVES, UCNERF_CHAIN_WAVES, ...; the wrong-result timing switches of rounds 1-3 were taken out of
  * the sources in round 4).  The host side checks the production values (tests/test_abi_host.py). */
 const char* ucnerf_build_flags(void);
 /* Digest of the sources, headers and flags this binary was linked from (uc_nerf_amd/build.py: source_hash()): a host can tell a library

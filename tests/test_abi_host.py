@@ -40,14 +40,14 @@ def test_every_declared_symbol_is_exported_and_bound(L):
 # FOOT_UNDER_GEMM, GATHER_RUN) is an experiment and must read 0
 PRODUCTION_FLAGS = {"UCNERF_BF16_BW": "8", "UCNERF_BF16_NBUF": "4", "UCNERF_BF16_WPS": "2", "UCNERF_BF16_HINT_V": "5", "UCNERF_BF16_IDLE_SKIP": "1",
                     "UCNERF_BF16_WAVE_MAJOR": "1", "UCNERF_MLP_WAVES": "8", "UCNERF_MLP_PRIO": "3", "UCNERF_MLP_RING": "4", "UCNERF_TN_BF16X3": "1",
-                    "UCNERF_TN_DEPTH2": "2", "UCNERF_GATHER_WAVES": "1", "UCNERF_MLP_SAVE_NT": "1"}
+                    "UCNERF_TN_DEPTH2": "2", "UCNERF_GATHER_WAVES": "1", "UCNERF_CHAIN_WAVES": "4", "UCNERF_MLP_SAVE_NT": "1"}
 
 
 def test_library_was_built_with_production_switches(L):
     """ucnerf_build_flags() names every compile-time switch of the kernels: no wrong-result experiment may be live in the shipped binary."""
     flags = L.lib().ucnerf_build_flags().decode()
     pairs = re.findall(r"(UCNERF_[A-Z0-9_]+)=(\S+)", flags)
-    assert len(pairs) >= 17 and {"mlp_bf16x3", "mlp_bf16_plain", "mlp_f32", "mlp_bwd", "gather_cl"} <= set(re.findall(r"(\w+):", flags)), flags
+    assert len(pairs) >= 18 and {"mlp_bf16x3", "mlp_bf16_plain", "mlp_f32", "mlp_bwd", "gather_cl"} <= set(re.findall(r"(\w+):", flags)), flags
     for name, value in pairs:
         assert value == PRODUCTION_FLAGS.get(name, "0"), "%s=%s in the shipped library (%s)" % (name, value, flags)
 
@@ -164,9 +164,8 @@ def test_gradient_chain_counted_waits_never_exceed_the_operations_actually_issue
     """mlp_bwd_chain_kernel waits for a slot of its LDS weight ring with `s_waitcnt vmcnt(6 + E)`, E = a compile-time count of the loads and
     stores every wave has issued since the awaited copy (the compiler does not see the asm copies, so nothing else orders them).  An E larger
     than what the compiled code really issues would let a wave read a slot before its copy has landed -- silently.  This compiles the
-    translation unit to ISA and replays the kernel's vector-memory stream: for every one of the 136 waits of the tile body, the number of
+    translation unit to ISA and replays the kernel's vector-memory stream: for every one of the 128 waits of the tile body, the number of
     vector-memory instructions issued behind the awaited copy must be at least the count waited for."""
-    HS = 136                                       # BWD_HALF_STEPS (mlp_bwd_chain.hip)
     import shutil
     import subprocess
     from uc_nerf_amd import build as B
@@ -202,19 +201,19 @@ def test_gradient_chain_counted_waits_never_exceed_the_operations_actually_issue
             events.append(("vm", 0))
     n_adv = sum(1 for e in events if e[0] == "adv")
     n_dma = sum(1 for e in events if e[0] == "dma")
-    assert n_adv == HS and n_dma == HS + 8, (n_adv, n_dma)            # 136 half-steps per tile; eight copies in the prologue
+    assert n_adv == 128 and n_dma == 128 + 8, (n_adv, n_dma)          # 128 half-steps per tile; eight copies in the prologue
     eighth = [i for i, e in enumerate(events) if e[0] == "dma"][7]     # the prologue's last copy: the tile loop's body starts behind it
     body = events[eighth + 1:]
     seq = body + body                                                  # two iterations of the tile loop
     dma_idx = [i for i, e in enumerate(seq) if e[0] == "dma"]
     adv_idx = [i for i, e in enumerate(seq) if e[0] == "adv"]
-    assert len(dma_idx) == 2 * HS and len(adv_idx) == 2 * HS
+    assert len(dma_idx) == 256 and len(adv_idx) == 256
     checked = 0
-    for j in range(HS):                                                # the advances of the second iteration
-        a_i = adv_idx[HS + j]
-        awaited = dma_idx[HS + j + 1 - 8]                             # the copy of half-step j + 1, issued seven advances earlier
+    for j in range(128):                                               # the advances of the second iteration
+        a_i = adv_idx[128 + j]
+        awaited = dma_idx[128 + j + 1 - 8]                             # the copy of half-step j + 1, issued seven advances earlier
         younger = sum(1 for e in seq[awaited + 1:a_i] if e[0] in ("dma", "vm"))
         assert seq[a_i][1] <= younger, "half-step %d waits for vmcnt(%d) but only %d operations follow the awaited copy" % (j, seq[a_i][1], younger)
         assert seq[a_i][1] >= 6
         checked += 1
-    assert checked == HS
+    assert checked == 128

@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         // ---- depth-bias net: bd = W_d [volume feats | colours+masks] + b      (models.py:150)
         init_bias(cst, SEC_BD, h, bd);
         PRIO_GEMM(); gemm_feats(S, fsec, kd, bd); PRIO_VALU();
-        if (SAVE && sv.bd) save_rows<SAVE == 2>(sv.bd, s, h, valid, bd, xpose[SAVE == 2 ? wave : 0], lane, tile, p.m);
+        if (SAVE) save_rows<SAVE == 2>(sv.bd, s, h, valid, bd, xpose[SAVE == 2 ? wave : 0], lane, tile, p.m);
         const float u = 1.f - conf, omu = 1.f - u;          // models.py:149,177-178 (consumed at the very end)
 
         // ---- layer 0
@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES, MLP_WAVES / 4) mlp_fwd_kernel(
         // ---- confidence-bias net, feature_linear(h * b_c)                       (models.py:151,164)
         init_bias(cst, SEC_BC, h, bd);
         PRIO_GEMM(); gemm_feats(S, fsec, kc, bd); PRIO_VALU();
-        if (SAVE && sv.bc) save_rows<SAVE == 2>(sv.bc, s, h, valid, bd, xpose[SAVE == 2 ? wave : 0], lane, tile, p.m);
+        if (SAVE) save_rows<SAVE == 2>(sv.bc, s, h, valid, bd, xpose[SAVE == 2 ? wave : 0], lane, tile, p.m);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll

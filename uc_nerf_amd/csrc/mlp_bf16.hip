@@ -899,7 +899,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
                 }
         }
         if (SAVE) {
-            float* r_ = sv.bd ? srow(sv.bd) : nullptr;      // (not kept for the gradient chain: it computes the bias nets again)
+            float* r_ = srow(sv.bd);
             if (r_) { save_tile<false, SAVE == 2>(r_, 0, bd[0]); save_tile<false, SAVE == 2>(r_, 1, bd[1]); save_tile<false, SAVE == 2>(r_, 2, bd[2]); save_tile<false, SAVE == 2>(r_, 3, bd[3]); }
         }
 
@@ -1051,7 +1051,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         }
         if (kc16 < 2) head_part(hbase, hb, h, acc[1], 1, 0, 16, ident);        // (one-step bias net: the rest is exposed)
         if (SAVE) {
-            float* r_ = sv.bc ? srow(sv.bc) : nullptr;      // (not kept for the gradient chain: it computes the bias nets again)
+            float* r_ = srow(sv.bc);
             if (r_) { save_tile<false, SAVE == 2>(r_, 0, bd[0]); save_tile<false, SAVE == 2>(r_, 1, bd[1]); save_tile<false, SAVE == 2>(r_, 2, bd[2]); save_tile<false, SAVE == 2>(r_, 3, bd[3]); }
         }
         // g = h5 * b_c: fragments of row tiles 0,1 now, of 2,3 under feature_linear's phase A

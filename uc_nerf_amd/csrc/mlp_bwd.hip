@@ -665,7 +665,6 @@ int ucnerf_mlp_fwd_train(const ucnerf_mlp_params* p, float* bwd_workspace, int32
     carve_bwd(bwd_workspace, p->m, p->dirs_per_sample ? p->m : p->m / (p->S > 0 ? p->S : 1), &w);
     hipStream_t st = (hipStream_t)stream;
     w.sv.p24 = bwd_mode == 0;                       // the gradient chain reads the sets as 24-bit floats, the layer-by-layer backward as fp32
-    if (bwd_mode == 0) w.sv.bc = nullptr;           // ... and computes b_c again from the gathered features: not kept
     if (p->cfg.precision == 1) { RUN(launch_mlp_fwd_bf16x3_save(p, &w.sv, st)); }      // split-bf16 matrix cores
     else RUN(launch_mlp_fwd(p, &w.sv, st));
     // the backward reads the forward's output from its own slot
@@ -706,7 +705,6 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
         ucnerf_mlp_params fw = f;
         fw.raw = w.raw;
         w.sv.p24 = bp->bwd_mode == 0;
-        if (bp->bwd_mode == 0) w.sv.bc = nullptr;
         RUN(launch_mlp_fwd(&fw, &w.sv, st));
     }
     const float *pep = w.pep, *ped = w.ped;      // encodings as matrices: [m,63] and [n_dirs,27]

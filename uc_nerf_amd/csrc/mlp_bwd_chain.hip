@@ -10,12 +10,12 @@
 // re-split into (hi, lo), as the B operand: three v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate (the forward's bf16x3
 // scheme, 2^-16 relative).  Per layer the kernel reads the kept activation it needs for the relu mask and the b_d product (h_{l-1},
 // once) and writes g_y (once) for the weight-gradient GEMMs: nothing else touches HBM.
-// The confidence-bias net's output b_c is NOT kept by the training forward (round 4): the chain computes it again from the image features
-// (a forward-oriented section of the stream, 48 MFMAs per tile on a matrix pipe that is ~85 % idle here; 192 bytes of features per sample
-// instead of 384 bytes of kept set, and one set less for the forward to write).  b_d IS kept: the depth-bias net's gradient divides by it
-// (g_bd = sum_l g_pre_l h_l / b_d recovers y_l = h_l / b_d), which is exact only with the very b_d the forward multiplied by -- a recomputed one
-// differs by the rounding of its terms, and where b_d cancels to nearly zero that is a per-cent error of the quotient (built with three bf16
-// pieces per operand, 2^-24: 14 of 485 000 feature gradients still off by up to 9 %, profiles/r04_experiments.md).
+//
+// One wave per SIMD with 512 registers (the resident state is the accumulators, the B fragments and two activation sets; b_d and the
+// running g_bd sum are parked in LDS).  The 512-KB stream of W^T fragments reaches the four waves of a block through ONE ring in LDS,
+// filled by global_load_lds (each wave copies a quarter of every half-step, eight half-steps ahead) -- round 3's first version had every
+// wave read the stream for itself from L2, three half-steps ahead: 2 GB of L2 traffic per launch and an L2 round trip (~1 000 cycles
+// under that load) in front of most half-steps: 183 k cycles per tile against 25 k of MFMA work (SQ_WAIT_INST_ANY 0.61).
 #include "common.h"
 #include "mlp_layout.h"
 #include "mlp_bwd_parts.h"
@@ -30,22 +30,18 @@ typedef unsigned c_u32x4 __attribute__((ext_vector_type(4)));
 #define CSB __builtin_amdgcn_sched_barrier(0)
 #define CMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-constexpr int BWD_HALF_STEPS = 136;            // VC 16 | FT 16 | BC 8 | BCF 8 | L5 16 | L4 16 | L3 16 | L2 16 | L1 16 | BD 8   (BCF: the confidence-bias net FORWARD)
+constexpr int BWD_HALF_STEPS = 128;            // VC 16 | FT 16 | BC 8 | L5 16 | L4 16 | L3 16 | L2 16 | L1 16 | BD 8
 constexpr int BWD_HALF_BYTES = 4096;           // [t 0..1][hi, lo][64 lanes][8 bf16]
-constexpr int BWD_HEAD_BIAS = 8 * 128 + 8;     // ... where the confidence-bias net's bias vector starts
-constexpr int BWD_HEAD_FLOATS = BWD_HEAD_BIAS + 128;   // head table [o][feature] (base rgb x3, base sigma, adapt rgb x3, adapt sigma) + 8 biases + b of the confidence-bias net
-constexpr int BWD_N_SEC = 10;
+constexpr int BWD_HEAD_FLOATS = 8 * 128 + 8;   // head table [o][feature] (base rgb x3, base sigma, adapt rgb x3, adapt sigma) + 8 biases
 
-// one layer of the stream, `ks` k16-steps per pair of row tiles.
-//   transposed (fwd = 0): rows = input features of the layer (padded to 32 * 2 * pairs), contraction over its 128 outputs (ks = 8)
-//   forward    (fwd = 1): rows = the layer's 128 outputs, contraction over its `rows` inputs in their natural order, padded to 16 ks
-struct BwdSec { int hs0, pairs, ld, col0, rows, ks, fwd; long long base, base_hi; };
+// one transposed layer of the stream: rows = input features of the layer (padded to 32 * 2 * pairs), contraction over its outputs
+struct BwdSec { int hs0, pairs, ld, col0, rows; long long base, base_hi; };
 struct BwdPackArgs {
-    BwdSec sec[BWD_N_SEC];
+    BwdSec sec[9];
     const float* flat;
     unsigned short* out;           // [128][2048] bf16
     float* head;                   // [BWD_HEAD_FLOATS]
-    long long p_crw, p_a1w, p_rw, p_aw, p_crb, p_a1b, p_rb, p_ab, p_bcb;
+    long long p_crw, p_a1w, p_rw, p_aw, p_crb, p_a1b, p_rb, p_ab;
 };
 
 // feature held by element j of lane-half hh in k16-step q = (kt, s): accumulator register 8 s + j of row tile kt (as mlp_bf16.hip)
@@ -59,18 +55,16 @@ __global__ void __launch_bounds__(256) pack_bwd_kernel(BwdPackArgs a) {
         const int hs = f >> 8, t = (f >> 7) & 1, part = (f >> 6) & 1, lane = f & 63;
         int si = 0;
 #pragma unroll
-        for (int i = 1; i < BWD_N_SEC; ++i) si = hs >= a.sec[i].hs0 ? i : si;
+        for (int i = 1; i < 9; ++i) si = hs >= a.sec[i].hs0 ? i : si;
         const BwdSec sc = a.sec[si];
-        const int lhs = hs - sc.hs0, pair = lhs / sc.ks, q = lhs % sc.ks;
+        const int lhs = hs - sc.hs0, pair = lhs >> 3, q = lhs & 7;
         const int row = 32 * (2 * pair + t) + (lane & 31);
         unsigned short v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int n = c_hid_feature16(q >> 1, q & 1, e, lane >> 5);
-            const int k = 16 * q + 8 * (lane >> 5) + e;             // (forward sections: the B operand is loaded in this order, c_ld_feats)
             float w = 0.f;
-            if (sc.fwd) { if (k < sc.rows) w = a.flat[sc.base + (long long)row * sc.ld + sc.col0 + k]; }
-            else if (row < sc.rows) w = (sc.base_hi >= 0 && n >= 64) ? a.flat[sc.base_hi + (long long)(n - 64) * sc.ld + sc.col0 + row] : a.flat[sc.base + (long long)n * sc.ld + sc.col0 + row];
+            if (row < sc.rows) w = (sc.base_hi >= 0 && n >= 64) ? a.flat[sc.base_hi + (long long)(n - 64) * sc.ld + sc.col0 + row] : a.flat[sc.base + (long long)n * sc.ld + sc.col0 + row];
             const __bf16 hi = (__bf16)w;
             const __bf16 val = part ? (__bf16)(w - (float)hi) : hi;
             v[e] = __builtin_bit_cast(unsigned short, val);
@@ -86,11 +80,9 @@ __global__ void __launch_bounds__(256) pack_bwd_kernel(BwdPackArgs a) {
             else if (o == 3) w = a.flat[a.p_a1w + k];
             else if (o < 7) w = k < 64 ? a.flat[a.p_rw + (o - 4) * 64 + k] : 0.f;       // rgb_linear reads the views half of vc
             else w = k >= 64 ? a.flat[a.p_aw + k - 64] : 0.f;                           // alpha_linear the view_confi half
-        } else if (f < BWD_HEAD_BIAS) {
+        } else {
             const int o = f - 1024;
             w = o < 3 ? a.flat[a.p_crb + o] : o == 3 ? a.flat[a.p_a1b] : o < 7 ? a.flat[a.p_rb + o - 4] : a.flat[a.p_ab];
-        } else {
-            w = a.flat[a.p_bcb + f - BWD_HEAD_BIAS];
         }
         a.head[f] = w;
     }
@@ -143,8 +135,11 @@ __device__ __forceinline__ void c_split_tile(const c_f32x16& x, CFrag& f0, CFrag
 
 // ---- the weight ring: CHAIN_NB slots of one half-step (4 KB) each in LDS, shared by the block's four waves.  128 half-steps per tile
 // = 0 mod CHAIN_NB, so slot and source of every copy are compile-time constants of the unrolled tile body and the ring runs on across tiles.
-constexpr int CHAIN_WAVES = 4;    // waves per block = per CU: one per SIMD, 512 registers (two per SIMD with 256 registers each: built and measured in round 3,
-                                  //   353-361 us against 322-336: profiles/r03_experiments.md)
+#ifndef UCNERF_CHAIN_WAVES
+#define UCNERF_CHAIN_WAVES 4      // waves per block = per CU: 4 (one per SIMD, 512 registers) or 8 (two per SIMD, 256 registers: b_d is then re-read per layer
+                                  //   instead of parked and the g_bd sum parked as 24-bit pieces -- experiment, profiles/r03_experiments.md)
+#endif
+constexpr int CHAIN_WAVES = UCNERF_CHAIN_WAVES;
 constexpr int CHAIN_NB = 8;
 struct CPipe {
     const char* gsrc;        // this lane's byte of half-step 0: stream + wave * 1024 + lane * 16 (laundered per section, see launder())
@@ -155,7 +150,10 @@ struct CPipe {
 __device__ __forceinline__ void c_dma(const CPipe& P, int hs_src, int slot) {
     const char* src = P.gsrc + (size_t)hs_src * BWD_HALF_BYTES;
     const unsigned dst = P.dst + slot * BWD_HALF_BYTES;
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+    if (CHAIN_WAVES == 8) {                // eight waves: 512 bytes each -- the lower 32 lanes copy
+        if ((threadIdx.x & 32) == 0) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+    } else
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
 }
 __device__ __forceinline__ CAF c_ldaf(const CPipe& P, int slot) {
     const c_bf16x8* a = reinterpret_cast<const c_bf16x8*>(P.rd + slot * BWD_HALF_BYTES);
@@ -214,17 +212,17 @@ __device__ __forceinline__ void c_st_tile(float* set, size_t rb, int nt, const c
     for (int q = 0; q < 4; ++q) p24_store(row + P24_GROUP_BYTES * (8 * nt + 2 * q), p24_pack4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]));
 }
 
-// PAIRS row-tile pairs x KS k16-steps of one layer (8: a transposed 128-wide layer; 4: a bias net forward), starting at half-step HS0 of the stream;
-// EPI = vector-memory operations every wave has issued between the previous section and this one (see c_advance)
+// PAIRS row-tile pairs x 8 k16-steps of one transposed layer, starting at half-step HS0 of the stream; EPI = vector-memory operations every wave
+// has issued between the previous section and this one (see c_advance)
 constexpr int c_younger(int epi) { return CHAIN_NB - 2 + epi > 63 ? 63 : CHAIN_NB - 2 + epi; }
-template <int HS0, int PAIRS, int EPI, int KS = 8>
-__device__ __forceinline__ void c_section(const CPipe& P, CAF& cur, const CFrag (&B)[KS], c_f32x16 (&acc)[4]) {
+template <int HS0, int PAIRS, int EPI>
+__device__ __forceinline__ void c_section(const CPipe& P, CAF& cur, const CFrag (&B)[8], c_f32x16 (&acc)[4]) {
 #pragma unroll
     for (int p = 0; p < PAIRS; ++p)
 #pragma unroll
-        for (int q = 0; q < KS; ++q) {
+        for (int q = 0; q < 8; ++q) {
             CSB;              // (one half-step at a time)
-            const CAF nxt = KS * p + q < CHAIN_NB - 1 ? c_advance<c_younger(EPI)>(P, HS0 + KS * p + q) : c_advance<CHAIN_NB - 2>(P, HS0 + KS * p + q);
+            const CAF nxt = 8 * p + q < CHAIN_NB - 1 ? c_advance<c_younger(EPI)>(P, HS0 + 8 * p + q) : c_advance<CHAIN_NB - 2>(P, HS0 + 8 * p + q);
             acc[2 * p] = CMFMA(cur.h0, B[q].hi, acc[2 * p]);
             acc[2 * p] = CMFMA(cur.h0, B[q].lo, acc[2 * p]);
             acc[2 * p] = CMFMA(cur.l0, B[q].hi, acc[2 * p]);
@@ -247,10 +245,10 @@ constexpr int CHAIN_HEAD_PAD = (BWD_HEAD_FLOATS + 3) & ~3;
 // LDS: [head table 4 KB][weight ring CHAIN_NB x 4 KB][per wave: b_d of its tile as 24-bit pieces (12 KB) | the running g_bd sum in fp32 (16 KB)]
 constexpr int CHAIN_RING_OFF = CHAIN_HEAD_PAD * 4;
 constexpr int CHAIN_PARK_OFF = CHAIN_RING_OFF + CHAIN_NB * BWD_HALF_BYTES;
-constexpr int CHAIN_PARK_BD = 16 * 64 * 12, CHAIN_PARK_GBD = 16 * 64 * 16;
-constexpr int CHAIN_LDS_BYTES = CHAIN_PARK_OFF + CHAIN_WAVES * (CHAIN_PARK_BD + CHAIN_PARK_GBD);      // 5 + 32 + 112 KB
+constexpr int CHAIN_PARK_BD = CHAIN_WAVES == 4 ? 16 * 64 * 12 : 0, CHAIN_PARK_GBD = CHAIN_WAVES == 4 ? 16 * 64 * 16 : 16 * 64 * 12;
+constexpr int CHAIN_LDS_BYTES = CHAIN_PARK_OFF + CHAIN_WAVES * (CHAIN_PARK_BD + CHAIN_PARK_GBD);      // 4 + 32 + 112 KB
 
-__global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(ChainArgs a) {
+__global__ void __launch_bounds__(64 * CHAIN_WAVES, CHAIN_WAVES / 4) mlp_bwd_chain_kernel(ChainArgs a) {
     // (b_d and the g_bd sum are parked in LDS rather than in 128 registers: with them resident the register allocator spilled ~200 values
     //  around every layer's MFMA section; b_d as the 24-bit pieces it was loaded as, which is what leaves room for the weight ring)
     extern __shared__ __attribute__((aligned(16))) float chain_lds[];
@@ -261,7 +259,8 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
     char* const lds = reinterpret_cast<char*>(chain_lds);
     char* const park_bd = lds + CHAIN_PARK_OFF + wave * (CHAIN_PARK_BD + CHAIN_PARK_GBD) + lane * 12;          // piece (nt, q) of this lane at + (4 nt + q) * 64 * 12
     c_f32x4* const park_gbd = reinterpret_cast<c_f32x4*>(lds + CHAIN_PARK_OFF + wave * (CHAIN_PARK_BD + CHAIN_PARK_GBD) + CHAIN_PARK_BD) + lane;
-    auto ld_bd = [&](int nt) {
+    auto ld_bd = [&](int nt, size_t ro_ = 0) {
+        if (CHAIN_WAVES != 4) return c_unpack(c_ld_tile(a.sv.bd, ro_, nt));       // (not parked: re-read, L2 resident)
         c_f32x16 x;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -274,21 +273,37 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
         return x;
     };
     auto st_bd = [&](int nt, const CRaw& x) {          // (the pieces as they were loaded)
+        if (CHAIN_WAVES != 4) return;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<p24_u32x3_a4*>(park_bd + (4 * nt + q) * 64 * 12) = (p24_u32x3){x.d[3 * q], x.d[3 * q + 1], x.d[3 * q + 2]};
     };
+    char* const park_g24 = lds + CHAIN_PARK_OFF + wave * (CHAIN_PARK_BD + CHAIN_PARK_GBD) + CHAIN_PARK_BD + lane * 12;      // (8 waves: g_bd as 24-bit pieces)
     auto ld_gbd = [&](int nt) {
         c_f32x16 x;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const c_f32x4 v = park_gbd[(nt * 4 + q) * 64];
-            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+            if (CHAIN_WAVES == 4) {
+                const c_f32x4 v = park_gbd[(nt * 4 + q) * 64];
+                x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+            } else {
+                const p24_u32x3 v = *reinterpret_cast<const p24_u32x3_a4*>(park_g24 + (4 * nt + q) * 64 * 12);
+                const P24Piece pc = {{v.x, v.y, v.z}};
+                float t0, t1, t2, t3;
+                p24_unpack4(pc, t0, t1, t2, t3);
+                x[4 * q] = t0; x[4 * q + 1] = t1; x[4 * q + 2] = t2; x[4 * q + 3] = t3;
+            }
         }
         return x;
     };
     auto st_gbd = [&](int nt, const c_f32x16& x) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) park_gbd[(nt * 4 + q) * 64] = (c_f32x4){x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+        for (int q = 0; q < 4; ++q) {
+            if (CHAIN_WAVES == 4) park_gbd[(nt * 4 + q) * 64] = (c_f32x4){x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+            else {
+                const P24Piece pc = p24_pack4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+                *reinterpret_cast<p24_u32x3_a4*>(park_g24 + (4 * nt + q) * 64 * 12) = (p24_u32x3){pc.d[0], pc.d[1], pc.d[2]};
+            }
+        }
     };
     const int j = lane & 31, h = lane >> 5;
     // (the stream does not depend on the tile: unless its address is laundered per section, every one of its 2048 fragment registers is
@@ -334,35 +349,8 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
         }
 
         c_f32x16 acc[4];
-        CRaw hn[4], hm[4], hx[4], bdr[4];
+        CRaw hn[4], hm[4], hx[4], bcr[4], bdr[4];
         CFrag X[8];
-        // the B operand of the bias net's forward section: k16-step q of this lane = columns col0 + 16 q + 8 h + 0..7 of its sample's gathered features
-        // (four steps whatever the view count -- every wave issues the same 32 loads, c_advance counts them; columns past the row are clamped,
-        //  their weights are zero in the stream)
-        // (one address form for both feature layouts -- a branch per load otherwise: column c of this sample at f_base + c * f_cs)
-        auto ld_feats = [&](int col0, float (&f)[4][8]) {
-            const int s_ = c_opaque(s), h_ = c_opaque(h);     // (laundered: the column offsets do not depend on the tile -- hoisted out of the tile loop they are 64 registers)
-            const size_t f_base = a.feats_tiled ? (size_t)(s_ >> 5) * a.F * 32 + (s_ & 31) : (size_t)s_ * a.ldf;
-            const int f_cs = a.feats_tiled ? 32 : 1;
-            const float* const fb = a.feats + f_base;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int col_ = col0 + 16 * q + 8 * h_ + e, col = col_ < a.F ? col_ : a.F - 1;
-                    f[q][e] = fb[col * f_cs];
-                }
-        };
-        auto add_bias = [&](c_f32x16 (&x)[4], int b0) {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const c_f32x4 b = *reinterpret_cast<const c_f32x4*>(&hw[c_opaque(b0) + 32 * nt + 8 * q + 4 * h]);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) x[nt][4 * q + c] += b[c];
-                }
-        };
         float ad[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};      // this lane's share of the adapt / base head outputs
 
         // ---- adapt heads backwards + relu of [views | view_confi]: g_vc
@@ -426,7 +414,6 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
                     }
             }
         };
-        c_f32x16 bc2[4];                                         // the confidence-bias net's section result, then b_c
         {
             CFrag Z[8];
 #pragma unroll
@@ -442,19 +429,11 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) hm[nt] = c_ld_tile(a.sv.h[4], ro, nt);      // for the first trunk epilogue, two sections away
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bdr[nt] = c_ld_tile(a.sv.bd, ro, nt);      // for the epilogue behind the next two sections
-            float fi[4][8];
-            ld_feats(a.n_mvs, fi);                                   // image features: the confidence-bias net's input, for the section after this one
-            c_zero(bc2);
-            launder(); c_section<32, 1, 16 + 16 + 16 + 32>(P, cur, Z, bc2)   /* G_bc stores, h4, b_d and feature loads */;
-            small_out(bc2, a.n_mvs, a.n_img);
-            // ---- confidence-bias net FORWARD: b_c = W_c [image features] + b (models.py:151)
-            CFrag Bi[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Bi[q] = c_split8(fi[q]);
-            c_zero(bc2);
-            launder(); c_section<40, 2, 0, 4>(P, cur, Bi, bc2);
-            add_bias(bc2, BWD_HEAD_BIAS);
+            for (int nt = 0; nt < 4; ++nt) { bcr[nt] = c_ld_tile(a.sv.bc, ro, nt); bdr[nt] = c_ld_tile(a.sv.bd, ro, nt); }      // for the epilogue behind this section
+            c_f32x16 a2[4];
+            c_zero(a2);
+            launder(); c_section<32, 1, 64>(P, cur, Z, a2)               /* G_bc stores, h4, b_c and b_d loads */;
+            small_out(a2, a.n_mvs, a.n_img);
         }
         CSB;
 
@@ -462,7 +441,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
         {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const c_f32x16 bct = bc2[nt], bdt = c_unpack(bdr[nt]), h5_ = c_unpack(hn[nt]);
+                const c_f32x16 bct = c_unpack(bcr[nt]), bdt = c_unpack(bdr[nt]), h5_ = c_unpack(hn[nt]);
                 c_f32x16 gxv, gy, gb;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -499,7 +478,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const c_f32x16 hcur_ = c_unpack(hraw[nt]);
-                const c_f32x16 bdt = ld_bd(nt);
+                const c_f32x16 bdt = ld_bd(nt, ro);
                 c_f32x16 gb = ld_gbd(nt), gy;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -531,17 +510,17 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
             CSB;                                                                                          \
             trunk_epi(a.G_y[(L) - 1], CUR);                                                               \
         }
-        UCNERF_CHAIN_LAYER(48, 5, hm, hn, 48)   // uses h4 (requested before the confidence-bias net's section), requests h2; in front: gx, G_y[5] stores, h3 loads
-        UCNERF_CHAIN_LAYER(64, 4, hx, hm, 32)   // uses h3, requests h1; in front of each: a set's loads (while there are any), G_y stores
-        UCNERF_CHAIN_LAYER(80, 3, hn, hx, 32)   // uses h2, requests h0
-        UCNERF_CHAIN_LAYER(96, 2, hm, hn, 32)   // uses h1
-        UCNERF_CHAIN_LAYER(112, 1, hx, hn, 16)  // uses h0
+        UCNERF_CHAIN_LAYER(40, 5, hm, hn, 48)   // uses h4 (requested before the confidence-bias net's section), requests h2; in front: gx, G_y[5] stores, h3 loads
+        UCNERF_CHAIN_LAYER(56, 4, hx, hm, 32)   // uses h3, requests h1; in front of each: a set's loads (while there are any), G_y stores
+        UCNERF_CHAIN_LAYER(72, 3, hn, hx, 32)   // uses h2, requests h0
+        UCNERF_CHAIN_LAYER(88, 2, hm, hn, 32)   // uses h1
+        UCNERF_CHAIN_LAYER(104, 1, hx, hn, 16)  // uses h0
 #undef UCNERF_CHAIN_LAYER
 
         // ---- depth-bias net: g_bd = sum_l g_pre_l * y_l with y_l = h_l / b_d on the active units; then its transposed layer
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const c_f32x16 bdt = ld_bd(nt), gb = ld_gbd(nt);
+            const c_f32x16 bdt = ld_bd(nt, ro), gb = ld_gbd(nt);
             c_f32x16 g;
 #pragma unroll
             for (int r = 0; r < 16; ++r) g[r] = gb[r] != 0.f ? gb[r] / bdt[r] : 0.f;
@@ -552,7 +531,7 @@ __global__ void __launch_bounds__(64 * CHAIN_WAVES, 1) mlp_bwd_chain_kernel(Chai
         {
             c_f32x16 a2[4];
             c_zero(a2);
-            launder(); c_section<128, 1, 32>(P, cur, X, a2)              /* G_y[0] and G_bd stores */;
+            launder(); c_section<120, 1, 32>(P, cur, X, a2)              /* G_y[0] and G_bd stores */;
             small_out(a2, 0, a.n_mvs);
         }
 
@@ -581,23 +560,21 @@ int launch_pack_bwd(int n_src, const float* flat, float* stream_out, hipStream_t
     BwdPackArgs a;
     memset(&a, 0, sizeof(a));
     int hs = 0, i = 0;
-    auto sec = [&](int pairs, long long base, int ld, int col0, int rows, long long base_hi, int fwd = 0) {
+    auto sec = [&](int pairs, long long base, int ld, int col0, int rows, long long base_hi) {
         a.sec[i].hs0 = hs; a.sec[i].pairs = pairs; a.sec[i].ld = ld; a.sec[i].col0 = col0; a.sec[i].rows = rows; a.sec[i].base = base; a.sec[i].base_hi = base_hi;
-        a.sec[i].fwd = fwd; a.sec[i].ks = fwd ? 4 : 8;
-        hs += a.sec[i].ks * pairs; ++i;
+        hs += 8 * pairs; ++i;
     };
     sec(2, L.p_vw, KV, 0, 128, L.p_vcw);                    // [views | view_confi]^T, feature part of their input
     sec(2, L.p_fw, 128, 0, 128, -1);                        // feature_linear^T
     sec(1, L.p_bcw, 8 * v, 0, 8 * v, -1);                   // confidence-bias net^T
-    sec(2, L.p_bcw, 8 * v, 0, 8 * v, -1, 1);                // confidence-bias net, forward (<= 64 inputs)
     sec(2, L.p_lw[5], 128 + MLP_PE_PTS, MLP_PE_PTS, 128, -1);   // layer 5, hidden part of [pe | h4]
     for (int l = 4; l >= 1; --l) sec(2, L.p_lw[l], 128, 0, 128, -1);
     sec(1, L.p_bdw, 24 + 4 * v, 0, 24 + 4 * v, -1);         // depth-bias net^T
-    if (hs != BWD_HALF_STEPS || i != BWD_N_SEC) return fail(UCNERF_EINVAL, "mlp_bwd: stream schedule mismatch");
+    if (hs != BWD_HALF_STEPS || i != 9) return fail(UCNERF_EINVAL, "mlp_bwd: stream schedule mismatch");
     a.flat = flat;
     a.out = reinterpret_cast<unsigned short*>(stream_out);
     a.head = stream_out + (size_t)BWD_HALF_STEPS * BWD_HALF_BYTES / 4;
-    a.p_crw = L.p_crw; a.p_a1w = L.p_a1w; a.p_rw = L.p_rw; a.p_aw = L.p_aw; a.p_crb = L.p_crb; a.p_a1b = L.p_a1b; a.p_rb = L.p_rb; a.p_ab = L.p_ab; a.p_bcb = L.p_bcb;
+    a.p_crw = L.p_crw; a.p_a1w = L.p_a1w; a.p_rw = L.p_rw; a.p_aw = L.p_aw; a.p_crb = L.p_crb; a.p_a1b = L.p_a1b; a.p_rb = L.p_rb; a.p_ab = L.p_ab;
     hipLaunchKernelGGL(pack_bwd_kernel, dim3(BWD_HALF_STEPS), dim3(256), 0, st, a);
     return check_launch("mlp_bwd pack");
 }
@@ -627,6 +604,6 @@ int launch_mlp_bwd_chain(int n_src, int m, const float* raw, const float* g_raw,
     return check_launch("mlp_bwd chain");
 }
 
-const char* build_flags_mlp_bwd_chain() { return "mlp_bwd_chain: (no compile-time switches) "; }
+const char* build_flags_mlp_bwd_chain() { return "mlp_bwd_chain: " UCNERF_FLAG(UCNERF_CHAIN_WAVES); }
 
 }  // namespace ucnerf

@@ -93,7 +93,7 @@ struct MlpSaved {
     int p24;
     float* bd;      // depth-bias net output b_d
     float* h[6];    // trunk activations h_l = relu((W_l x + b_l) * b_d)
-    float* bc;      // confidence-bias net output b_c   (NULL = not kept: the gradient chain computes it again, mlp_bwd_chain.hip)
+    float* bc;      // confidence-bias net output b_c
     float* ft;      // feature_linear output f
     float* vc;      // relu([views_linears | view_confi_linears]([f | dir encoding]))
 };

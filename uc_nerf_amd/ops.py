@@ -633,7 +633,6 @@ def mlp_fwd(pw, wstream, pts, dirs, feats, S, feats_tiled=False, max_blocks=0):
 
 
 KEPT_SETS = ("bd", "h0", "h1", "h2", "h3", "h4", "h5", "bc", "ft", "vc")       # order of the activation sets at the head of the backward workspace
-NOT_KEPT_FOR_CHAIN = ("bc",)        # ... of which the gradient chain (bwd_mode 0) computes these again instead of reading them (csrc/mlp_bwd_chain.hip)
 
 
 def decode_p24(buf, m, cols=128):
@@ -644,9 +643,8 @@ def decode_p24(buf, m, cols=128):
 
 
 def mlp_fwd_train(pw, wstream, pts, dirs, feats, S, bwd_mode=None):
-    """ucnerf_mlp_fwd_train: the forward that keeps its activation sets for ucnerf_mlp_bwd (tests / diagnostics).  Returns (raw, sets): the
-    [m,128] sets decoded to fp32, whatever format the backward mode keeps them in (0 / "chain": 24-bit floats, all but NOT_KEPT_FOR_CHAIN;
-    1 / "layerwise": fp32, all ten)."""
+    """ucnerf_mlp_fwd_train: the forward that keeps its activation sets for ucnerf_mlp_bwd (tests / diagnostics).  Returns (raw, sets): the ten
+    [m,128] sets decoded to fp32, whatever format the backward mode keeps them in (0 / "chain": 24-bit floats, 1 / "layerwise": fp32)."""
     pts, dirs, feats = _f32(pts), _f32(dirs), _f32(feats)
     mode = _backward_mode if bwd_mode is None else BACKWARD_MODES[bwd_mode] if isinstance(bwd_mode, str) else int(bwd_mode)
     m = pts.numel() // 3
@@ -665,8 +663,6 @@ def mlp_fwd_train(pw, wstream, pts, dirs, feats, S, bwd_mode=None):
     per = (m * 128 + 3) // 4 * 4
     sets = {}
     for i, name in enumerate(KEPT_SETS):
-        if mode == 0 and name in NOT_KEPT_FOR_CHAIN:
-            continue
         chunk = ws[i * per:(i + 1) * per]
         sets[name] = decode_p24(chunk, m) if mode == 0 else chunk[: m * 128].view(m, 128).clone()
     return raw, sets
