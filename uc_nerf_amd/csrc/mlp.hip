@@ -629,10 +629,6 @@ int launch_pack_bf16(const ucnerf_mlp_config* cfg, const float* flat, const int3
 int launch_pack_bf16_tab(const ucnerf_mlp_config* cfg, const ParamTable& t, const int32_t* idx, float* out, hipStream_t st);
 int launch_mlp_fwd_bf16x3(const ucnerf_mlp_params* p, hipStream_t st);      // mlp_bf16.hip built with TERMS = 3
 int launch_mlp_fwd_bf16_plain(const ucnerf_mlp_params* p, hipStream_t st);   // ... and with TERMS = 1
-// mlp_fwd_x6.hip (cfg.precision 5: the three-piece training forward; its stream is packed straight from the flat parameters, no index)
-int64_t x6_stream_floats();
-int launch_pack_x6(const ucnerf_mlp_config* cfg, const float* flat, float* out, hipStream_t st);
-constexpr int64_t X6_INDEX_COUNT = 4;       // (a placeholder index: ucnerf_mlp_pack's signature is the same for every precision)
 
 const char* build_flags_mlp_f32() { return "mlp_f32: " UCNERF_FLAG(UCNERF_MLP_WAVES) UCNERF_FLAG(UCNERF_MLP_PRIO) UCNERF_FLAG(UCNERF_MLP_RING) UCNERF_FLAG(UCNERF_MLP_SAVE_NT); }
 
@@ -652,25 +648,20 @@ int64_t ucnerf_mlp_stream_count(const ucnerf_mlp_config* cfg) {
     MlpLayout L;
     if (!cfg || !mlp_layout(cfg->n_src, &L)) return fail(UCNERF_EINVAL, "mlp: n_src must be in 1..8");
     if (cfg->precision >= 1 && cfg->precision <= 3) return bf16_stream_floats(cfg);
-    if (cfg->precision == 5) return x6_stream_floats();
-    if (cfg->precision != 0) return fail(UCNERF_EINVAL, "mlp: precision %d (0 = f32, 1 = bf16x3, 2 = bf16, 3 = bf16x3 with the gather fused, 5 = bf16x6: the training forward)", cfg->precision);
+    if (cfg->precision != 0) return fail(UCNERF_EINVAL, "mlp: precision %d (0 = f32, 1 = bf16x3, 2 = bf16, 3 = bf16x3 with the gather fused)", cfg->precision);
     return L.total;
 }
 
 int64_t ucnerf_mlp_index_count(const ucnerf_mlp_config* cfg) {
     const int64_t n = ucnerf_mlp_stream_count(cfg);
     if (n < 0) return n;
-    return cfg->precision == 5 ? X6_INDEX_COUNT : cfg->precision != 0 ? bf16_index_count(cfg) : n;
+    return cfg->precision != 0 ? bf16_index_count(cfg) : n;
 }
 
 int ucnerf_mlp_pack_index(const ucnerf_mlp_config* cfg, int32_t* idx_host) {
     UCNERF_REQUIRE(cfg && idx_host, "mlp_pack_index: null pointer");
     UCNERF_REQUIRE(cfg->pe_layout == 0 || cfg->pe_layout == 1, "mlp_pack_index: pe_layout %d", cfg->pe_layout);
-    UCNERF_REQUIRE((cfg->precision >= 0 && cfg->precision <= 3) || cfg->precision == 5, "mlp_pack_index: precision %d", cfg->precision);
-    if (cfg->precision == 5) {
-        for (int i = 0; i < X6_INDEX_COUNT; ++i) idx_host[i] = -1;
-        return UCNERF_OK;
-    }
+    UCNERF_REQUIRE(cfg->precision >= 0 && cfg->precision <= 3, "mlp_pack_index: precision %d", cfg->precision);
     if (cfg->precision == 0) {
         UCNERF_REQUIRE(build_pack_index(cfg, idx_host) == 0, "mlp_pack_index: n_src %d outside 1..8", cfg->n_src);
         return UCNERF_OK;
@@ -688,7 +679,6 @@ int ucnerf_mlp_pack_index(const ucnerf_mlp_config* cfg, int32_t* idx_host) {
 
 int ucnerf_mlp_pack(const ucnerf_mlp_config* cfg, const float* flat, const int32_t* idx, float* out, void* stream) {
     UCNERF_REQUIRE(cfg && flat && idx && out, "mlp_pack: null pointer");
-    if (cfg->precision == 5) return launch_pack_x6(cfg, flat, out, (hipStream_t)stream);
     if (cfg->precision != 0) return launch_pack_bf16(cfg, flat, idx, out, (hipStream_t)stream);
     const int64_t n = ucnerf_mlp_stream_count(cfg);
     UCNERF_REQUIRE(n > 0, "mlp_pack: bad config");
@@ -712,7 +702,6 @@ int ucnerf_mlp_pack_tensors(const ucnerf_mlp_config* cfg, int32_t n_tensors, con
         off += tensor_numel_host[j];
     }
     t.start[n_tensors] = (int)off;
-    UCNERF_REQUIRE(cfg->precision != 5, "mlp_pack_tensors: the bf16x6 stream is packed from the flat parameter vector (ucnerf_mlp_pack)");
     UCNERF_REQUIRE(off == n_params, "mlp_pack_tensors: the tensors hold %lld floats, the network has %lld parameters", (long long)off, (long long)n_params);
     if (cfg->precision != 0) return launch_pack_bf16_tab(cfg, t, idx, out, (hipStream_t)stream);
     const int64_t n = ucnerf_mlp_stream_count(cfg);
@@ -728,7 +717,6 @@ int ucnerf_mlp_unpack_grad(const float* g, const int32_t* idx, float* gflat, int
 }
 
 int ucnerf_mlp_fwd(const ucnerf_mlp_params* p, void* stream) {
-    UCNERF_REQUIRE(!p || p->cfg.precision != 5, "mlp_fwd: a weight stream packed with precision 5 (bf16x6) serves the training forward (ucnerf_mlp_fwd_train, bwd_mode 0) and nothing else");
     if (p && (p->cfg.precision == 1 || p->cfg.precision == 3)) return launch_mlp_fwd_bf16x3(p, (hipStream_t)stream);      // (3: refused there with the reason)
     if (p && p->cfg.precision == 2) return launch_mlp_fwd_bf16_plain(p, (hipStream_t)stream);
     return launch_mlp_fwd(p, nullptr, (hipStream_t)stream);

@@ -21,7 +21,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st);
 int launch_mlp_fwd_bf16x3_save(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st);      // mlp_bf16.hip
-int launch_mlp_fwd_x6(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st);              // mlp_fwd_x6.hip
 int launch_embed_strided(int m, int n_freqs, int layout, const float* x, float* out, int out_stride, hipStream_t st);      // rays.hip
 
 // 4 consecutive parameters (parameter tensors are only 4-byte aligned inside the flat vector)
@@ -660,14 +659,13 @@ int ucnerf_mlp_fwd_train(const ucnerf_mlp_params* p, float* bwd_workspace, int32
     UCNERF_REQUIRE(p && bwd_workspace, "mlp_fwd_train: null pointer");
     UCNERF_REQUIRE(bwd_mode == 0 || bwd_mode == 1, "mlp_fwd_train: bwd_mode %d", bwd_mode);
     if (p->m <= 0) return UCNERF_OK;
-    UCNERF_REQUIRE(p->cfg.precision == 0 || p->cfg.precision == 1 || p->cfg.precision == 5, "mlp_fwd_train: the training forward runs in f32, bf16x3 or bf16x6 precision");
+    UCNERF_REQUIRE(p->cfg.precision == 0 || p->cfg.precision == 1, "mlp_fwd_train: the training forward runs in f32 or bf16x3 precision");
     UCNERF_REQUIRE(((uintptr_t)bwd_workspace & 15) == 0, "mlp_fwd_train: workspace must be 16-byte aligned");
     BwdWork w;
     carve_bwd(bwd_workspace, p->m, p->dirs_per_sample ? p->m : p->m / (p->S > 0 ? p->S : 1), &w);
     hipStream_t st = (hipStream_t)stream;
     w.sv.p24 = bwd_mode == 0;                       // the gradient chain reads the sets as 24-bit floats, the layer-by-layer backward as fp32
     if (p->cfg.precision == 1) { RUN(launch_mlp_fwd_bf16x3_save(p, &w.sv, st)); }      // split-bf16 matrix cores
-    else if (p->cfg.precision == 5) { RUN(launch_mlp_fwd_x6(p, &w.sv, st)); }           // three bf16 pieces per operand: fp32-grade (mlp_fwd_x6.hip)
     else RUN(launch_mlp_fwd(p, &w.sv, st));
     // the backward reads the forward's output from its own slot
     if (hipMemcpyAsync(w.raw, p->raw, (size_t)p->m * 4 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -700,7 +698,7 @@ int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     const int ew_blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
 
     // 0. forward with the activations kept; encodings as explicit matrices for the weight-gradient GEMMs
-    UCNERF_REQUIRE(f.cfg.precision == 0 || ((f.cfg.precision == 1 || f.cfg.precision == 5) && bp->saved_valid),
+    UCNERF_REQUIRE(f.cfg.precision == 0 || (f.cfg.precision == 1 && bp->saved_valid),
                    "mlp_bwd: without the activations of ucnerf_mlp_fwd_train (saved_valid) the backward re-runs the forward itself, in f32 "
                    "precision only (pack the weights with precision 0)");
     if (!bp->saved_valid) {

@@ -533,8 +533,7 @@ class PackedWeights:
     """Pack index (host-built by the library, cached on device) + packing of a flat parameter vector."""
     _cache = {}
 
-    PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2, "bf16x3_fused": 3,     # 3: bf16x3 with the gather inside the MLP kernel (render passes only)
-                  "bf16x6": 5}                                               # 5: three bf16 pieces per operand, fp32-grade: the training forward (csrc/mlp_fwd_x6.hip)
+    PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2, "bf16x3_fused": 3}     # 3: bf16x3 with the gather inside the MLP kernel (render passes only)
 
     def __init__(self, n_src, pe_layout, device, precision="f32"):
         self.cfg = L.MlpConfig(n_src, pe_layout, self.PRECISIONS[precision])
