@@ -41,6 +41,10 @@ int ucnerf_device_cus(void);
  * UCNERF_BF16_BW, UCNERF_BF16_NBUF, UCNERF_MLP_WAVES, UCNERF_CHAIN_WAVES, ...; the wrong-result timing switches of rounds 1-3 were taken out of
  * the sources in round 4).  The host side checks the production values (tests/test_abi_host.py). */
 const char* ucnerf_build_flags(void);
+/* Diagnostics: how many ucnerf_render_fused_fwd calls of this process let the gather-fused launch composite (and re-sample) its rays in its own
+ * tail instead of launching K7 / K8 / K9 behind it -- passes of at most a round and a half of 32-sample tiles (csrc/render.hip: tail_fits; the
+ * outputs are bit-identical either way).  The environment variable UCNERF_FUSED_TAIL=0, read at every call, switches that route off. */
+int64_t ucnerf_fused_tail_launches(void);
 /* Digest of the sources, headers and flags this binary was linked from (uc_nerf_amd/build.py: source_hash()): a host can tell a library
  * that does not belong to the tree it sits in (tests/test_abi_host.py), and __graft_entry__.build() rebuilds one that was not linked on
  * the machine it runs on. */

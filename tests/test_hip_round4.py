@@ -251,6 +251,39 @@ def test_step_with_the_small_launches_folded_in_equals_the_old_launch_structure_
         assert torch.equal(ru["rgb"], old["rgb"]) and torch.equal(ru["depth"], old["depth"])
 
 
+@pytest.mark.parametrize("n,coarse_in_tail,fine_in_tail", [(512, True, True), (500, True, True), (700, True, False), (300, False, False), (37, False, False),
+                                                         (4096, False, False)])
+def test_compositing_and_resampling_in_the_tail_of_the_fused_launch_are_bit_identical(n, coarse_in_tail, fine_in_tail, monkeypatch):
+    """Row f1 to the letter for small passes: with at most a round and a half of tiles and (nearly) every CU owning whole rays, the gather-fused launch
+    composites its rays itself and -- coarse pass -- draws the fine depths from them (K3 .. K9 in one launch, csrc/mlp_bf16.hip TAIL instantiation);
+    larger or badly balanced passes keep the separate launches.  Same device functions: every output equal bit for bit; the library's counter says
+    which passes took the route."""
+    from uc_nerf_amd import _lib as L
+    from uc_nerf_amd.pipeline import CoarseFineRenderer, flat_params_of
+    from uc_nerf_amd.synthetic import init_ucnerf_state_dict, make_scene, random_pixels, scene_to
+    scene = scene_to(make_scene(seed=0), torch.device(DEV))
+    sd = init_ucnerf_state_dict(seed=0, n_src=6, sigma_scale=0.05, sigma_bias=0.05)
+    r = CoarseFineRenderer(scene, flat_params_of(sd).to(DEV), 64, 128, precision="bf16x3_fused")
+    xs, ys = random_pixels(4096, 256, 320, seed=0)
+    xs, ys = dev(xs[:n].contiguous()), dev(ys[:n].contiguous())
+    noise = dev(torch.rand(n, 64, generator=torch.Generator().manual_seed(100)))
+    count = L.lib().ucnerf_fused_tail_launches
+    monkeypatch.setenv("UCNERF_FUSED_TAIL", "0")
+    c0 = count()
+    old = r.render(xs, ys, perturb=1.0, noise=noise)
+    old = {k: (v.clone() if torch.is_tensor(v) else {kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in old.items()}
+    assert count() == c0                                   # switched off: the separate launches
+    monkeypatch.delenv("UCNERF_FUSED_TAIL")
+    new = r.render(xs, ys, perturb=1.0, noise=noise)
+    assert count() - c0 == int(coarse_in_tail) + int(fine_in_tail)
+    for k in ("rays_d", "z_coarse", "z_samples", "z_fine", "rgb", "depth", "acc", "weights", "var"):
+        assert torch.equal(new[k], old[k]), k
+    for k in ("rgb", "depth", "weights"):
+        assert torch.equal(new["coarse"][k], old["coarse"][k]), "coarse " + k
+    ru = r.render(xs, ys, perturb=1.0, noise=noise, reuse_coarse=True)
+    assert torch.equal(ru["rgb"], old["rgb"]) and torch.equal(ru["depth"], old["depth"])
+
+
 # ---------------------------------------------------------------------------------------------- sources handed over channel-last, zero copy
 def _bench_scene_channel_last(seed=0):
     from uc_nerf_amd import ops

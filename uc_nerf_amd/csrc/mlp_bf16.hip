@@ -35,6 +35,8 @@
 #include "gather_cl_device.h"
 #include "raygen_device.h"
 #include "p24.h"
+#include "composite_device.h"
+#include "sample_pdf_device.h"
 
 // the LDS-DMA asm below names m0 as a clobber on purpose (it loads the LDS base into it)
 #pragma clang diagnostic ignored "-Winline-asm"
@@ -46,6 +48,11 @@
 // (launch_mlp_fwd_bf16x3) plus the host-side packing shared by both precisions, = 1 the plain-bf16 launcher only.
 #ifndef UCNERF_BF16_BUILD_TERMS
 #define UCNERF_BF16_BUILD_TERMS 3
+#endif
+// A third build (-DUCNERF_BF16_BUILD_TAIL=1, TERMS = 3) holds nothing but the TAIL instantiations of the gather-fused kernel and their launcher
+// (launch_fused_tail): the launch that also composites and re-samples the rays of a small pass -- compiled beside the main object, not after it.
+#ifndef UCNERF_BF16_BUILD_TAIL
+#define UCNERF_BF16_BUILD_TAIL 0
 #endif
 
 namespace ucnerf {
@@ -108,7 +115,7 @@ static bool bf16_layout(int v, Bf16Layout* B) {
 // feature held by element j of lane-half hh in hidden k16-step q = (kt, s): accumulator register 8s + j of row-tile kt
 __host__ __device__ inline int hid_feature16(int kt, int s, int j, int hh) { return 32 * kt + (j & 3) + 8 * (2 * s + (j >> 2)) + 4 * hh; }
 
-#if UCNERF_BF16_BUILD_TERMS == 3
+#if UCNERF_BF16_BUILD_TERMS == 3 && !UCNERF_BF16_BUILD_TAIL
 // ------------------------------------------------------------------------------------------------ host: pack index
 // idx16[e] for every bf16 element e of the stream: flat parameter index | (part << 30) (part 0 = hi, 1 = lo), -1 = zero.
 // Half-steps appear in the order the kernel consumes them (see the schedule in mlp_fwd_bf16_kernel):
@@ -501,11 +508,17 @@ struct FusedGather {
     float* gen_rays_d;       // [n,3] out
     float* gen_z;            // [n,S] out
     float* gen_angle;        // [n,3] out
+    // TAIL instantiation (passes of at most two rounds of tiles): tiles are dealt in whole rays to blocks (tail_rpb rays = tail_rpb * tail_tpr
+    // consecutive tiles per block) and, when its last tile is done, a block composites its rays itself (K7, composite_device.h) and -- coarse
+    // pass -- draws the fine depths from them (K8 + K9, sample_pdf_device.h): one launch for K3 .. K9 of the pass
+    int tail_rpb, tail_tpr, tail_resample;
+    ucnerf_composite_params tail_c;
+    ucnerf_sample_pdf_params tail_s;
 };
 [[maybe_unused]] constexpr int FUSED_MAX_V = 8;    // (seven and eight views: with a two-slot weight ring, fused_ring_slots)
 constexpr int VIEW_TAB = 24;      // floats per source view in the LDS table: w2c (12), K (9), pad
 
-template <bool TILED, int NSRC, int TERMS, int SAVE, bool FUSED = false, bool COORDS = false, bool S16 = false, bool RAYGEN = false>       // RAYGEN (FUSED only): rays and stratified depths generated in the tile prologue; TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only); SAVE: training forward keeping the activation sets (1: fp32, 2: the 24-bit format of p24.h); COORDS (FUSED only): sample coordinates given; S16 (FUSED only): bf16 channel-last sources
+template <bool TILED, int NSRC, int TERMS, int SAVE, bool FUSED = false, bool COORDS = false, bool S16 = false, bool RAYGEN = false, bool TAIL = false>       // TAIL (FUSED only): see FusedGather; RAYGEN (FUSED only): rays and stratified depths generated in the tile prologue; TERMS 3: split-bf16 (fp32-grade), 1: plain bf16 (the hi*hi term only); SAVE: training forward keeping the activation sets (1: fp32, 2: the 24-bit format of p24.h); COORDS (FUSED only): sample coordinates given; S16 (FUSED only): bf16 channel-last sources
 #ifndef UCNERF_BF16_WPS
 #define UCNERF_BF16_WPS 2      // waves per SIMD: 2 -> 256 VGPRs per wave, 1 -> 512
 #endif
@@ -558,8 +571,11 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     // busy in every block -- with at most half of it filled, one wave per SIMD, which renders a tile in 0.70 of the time two waves sharing the
     // SIMD take (58 k against 83 k cycles) -- instead of running some blocks full and leaving others empty.  A wave without a tile only
     // keeps the weight ring turning (idle_tile below): the 512-ray shard of a strongly-scaled batch is 0.5 + 1.5 such rounds.
-    const int tiles_per_round = gridDim.x * BW;
-    const int n_rounds = (n_tiles + tiles_per_round - 1) / tiles_per_round;
+    // (TAIL: block b owns the tiles of its rays, [b * t_blk, (b + 1) * t_blk), eight per round; its last rounds may be partly filled -- waves 0..3,
+    //  one per SIMD, first)
+    const int t_blk = TAIL ? fg.tail_rpb * fg.tail_tpr : 0;
+    const int tiles_per_round = TAIL ? BW : gridDim.x * BW;
+    const int n_rounds = TAIL ? (t_blk + BW - 1) / BW : (n_tiles + tiles_per_round - 1) / tiles_per_round;
 #ifndef UCNERF_BF16_WAVE_MAJOR
 #define UCNERF_BF16_WAVE_MAJOR 1
 #endif
@@ -567,7 +583,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     //  the 32-sample pieces of one ray, which gather from the same corner of the sources -- stay behind one XCD's L2)
     const int nb_ = (int)gridDim.x, bx_ = (int)blockIdx.x;
     const int lblock = (nb_ & 7) == 0 ? (bx_ & 7) * (nb_ >> 3) + (bx_ >> 3) : bx_;
-    const int tile0 = UCNERF_BF16_WAVE_MAJOR ? wave * nb_ + lblock : bx_ * BW + wave;
+    const int tile0 = TAIL ? lblock * t_blk + wave : UCNERF_BF16_WAVE_MAJOR ? wave * nb_ + lblock : bx_ * BW + wave;
 
     // Inputs of a tile are fetched one tile ahead (under the previous tile's head / blend arithmetic, when few registers
     // are live): operands of the depth-bias net (element e of step q = feature 16q + 8h + e; columns past a section's
@@ -835,7 +851,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     for (int round = 0; round < n_rounds; ++round) {                          // block-uniform trip count: every wave joins every barrier
         const int tile = round * tiles_per_round + tile0;
 #if UCNERF_BF16_IDLE_SKIP
-        if (tile >= n_tiles) {                               // (wave-uniform; every later tile of this wave is past the end too)
+        if (tile >= n_tiles || (TAIL && round * BW + wave >= t_blk)) {      // (wave-uniform; every later tile of this wave is past the end too)
             for (int i = 0; i < g.slots; ++i) advance<NB>(P);      // this wave's DMA pieces and barriers of one tile, nothing else
             cur = read_half(P.buf, lane, 0);
             continue;
@@ -1132,6 +1148,32 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         if (h == 0 && s_raw < p.m) reinterpret_cast<f32x4*>(p.raw)[s_raw] = out;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
+    if (TAIL) {
+        // ---- K7 (+ K8, K9) of this block's rays.  Every output of every tile of these rays was stored by a wave of THIS block: the stores have been
+        // acknowledged (vmcnt(0) above), the barrier orders them before the loads below, which miss the CU's vector cache (nobody has read these
+        // lines in this launch) and find them in the XCD's L2.  One wave per ray, the stand-alone kernels' device code: bit-identical outputs.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        typedef PdfShared<128, 512> Sh;                      // (the ring, the constants and the stashes are dead: the rays' LDS arrays take their place)
+        Sh& sh = reinterpret_cast<Sh*>(smem)[wave];
+        float* const wl = reinterpret_cast<float*>(smem + BW * sizeof(Sh)) + wave * (128 + 2);
+        const int S_ = fg.tail_c.S, E_ = composite_lane_samples(S_);
+        for (int r = wave; r < fg.tail_rpb; r += BW) {
+            const int ray = lblock * fg.tail_rpb + r;        // (wave-uniform)
+            if (ray >= fg.tail_c.n) break;
+            float* const keep = fg.tail_resample ? wl : nullptr;
+            if (E_ == 1) composite_ray<1, 0>(fg.tail_c, ray, lane, keep);
+            else if (E_ == 2) composite_ray<2, 0>(fg.tail_c, ray, lane, keep);
+            else if (E_ == 3) composite_ray<3, 0>(fg.tail_c, ray, lane, keep);
+            else composite_ray<4, 0>(fg.tail_c, ray, lane, keep);
+            if (fg.tail_resample) {
+                pdf_sync<true>();
+                sample_pdf_ray<128, 512, true>(fg.tail_s, ray, lane, sh, wl, fg.tail_c.z + (size_t)ray * S_);
+                pdf_sync<true>();                            // (the next ray of this wave re-uses the arrays)
+            }
+        }
+    }
 }
 
 constexpr size_t bf16_smem_bytes(int ring_slots = NBUF) {
@@ -1144,6 +1186,28 @@ constexpr size_t bf16_smem_bytes_fused(int v) {
 static_assert(bf16_smem_bytes_fused(6) <= 160 * 1024 && bf16_smem_bytes_fused(8) <= 160 * 1024, "the fused kernel's LDS image must fit the CU");
 
 // `save` (TERMS = 3 only): the training forward -- the activation sets of MlpSaved are written for ucnerf_mlp_bwd (saved_valid = 1)
+#if UCNERF_BF16_BUILD_TAIL
+// the TAIL instantiations (this build's only code objects): `blocks` = ceil(rays / fg->tail_rpb)
+int launch_fused_tail(const ucnerf_mlp_params* p, const BGeom* g, int n_tiles, const FusedGather* fg, int blocks, hipStream_t st) {
+    MlpSaved sv;
+    memset(&sv, 0, sizeof(sv));
+    const int v = p->cfg.n_src;
+    const size_t smem_f = bf16_smem_bytes_fused(v);
+    static_assert(BW * (sizeof(PdfShared<128, 512>) + (128 + 2) * sizeof(float)) <= bf16_smem_bytes_fused(1), "the rays' LDS arrays re-use the kernel's image");
+    dim3 grid(blocks), block(64 * BW);
+#define X(N)                                                                                                                   \
+    if (v == N) {                                                                                                              \
+        const void* fn = (const void*)mlp_fwd_bf16_kernel<true, N, 3, false, true, false, false, false, true>;                 \
+        if (int rc = ensure_dynamic_lds(fn, (int)smem_f, "mlp_fwd (bf16x3, gather fused, compositing in the tail)")) return rc; \
+        hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, 3, false, true, false, false, false, true>), grid, block, smem_f, st, *p, *g, n_tiles, sv, *fg); \
+    }
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#undef X
+    return check_launch("mlp_fwd (bf16x3, gather fused, compositing in the tail)");
+}
+#else
+int launch_fused_tail(const ucnerf_mlp_params* p, const BGeom* g, int n_tiles, const FusedGather* fg, int blocks, hipStream_t st);      // the TAIL build of this file
+
 static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st, const FusedGather* fuse = nullptr) {
     UCNERF_REQUIRE(p, "mlp_fwd: null params");
     if (p->m == 0) return UCNERF_OK;
@@ -1188,6 +1252,10 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
         UCNERF_REQUIRE(!fg.gen_xs || (!fg.s16 && !fg.pts_in && !fg.near_far && B.v <= 6), "mlp_fwd (gather fused): generated rays go with fp32 source copies, derived "
                        "coordinates, the scene's depth range and at most six source views");
         const size_t smem_f = bf16_smem_bytes_fused(B.v);
+        if (fg.tail_rpb > 0) {      // the launch composites its rays itself (small passes, render.hip): whole rays per block
+            UCNERF_REQUIRE(!fg.pts_in && !fg.s16 && !fg.gen_xs && p->max_blocks <= 0, "mlp_fwd (gather fused): compositing in the tail goes with derived coordinates and fp32 sources");
+            return launch_fused_tail(p, &g, n_tiles, &fg, cdiv(fg.tail_c.n, fg.tail_rpb), st);
+        }
 #define X(N)                                                                                                                   \
         if (B.v == N && !fg.pts_in && fg.s16) {                                                                                \
             const void* fn = (const void*)mlp_fwd_bf16_kernel<true, N, 3, false, true, false, true>;                           \
@@ -1271,7 +1339,9 @@ int launch_mlp_fwd_bf16x3(const ucnerf_mlp_params* p, hipStream_t st) { return l
 int launch_mlp_fwd_bf16x3_save(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st) { return launch_bf16(p, save, st); }
 
 // called by render.hip: gather + PE + MLP of one pass in ONE launch (row f1), from the channel-last sources and (ray, depth)
-int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* repacked, const float* dirs, float* raw, hipStream_t st) {
+// `tail_c` (optional): the launch also composites the pass's rays (and, with `tail_s`, re-samples from them) -- see FusedGather
+int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* repacked, const float* dirs, float* raw, hipStream_t st,
+                                 const ucnerf_composite_params* tail_c, const ucnerf_sample_pdf_params* tail_s) {
     const long long M = (long long)rp->n * rp->S;
     UCNERF_REQUIRE(M < (1ll << 31), "render (gather fused): %lld samples in one pass (limit 2^31 - 1)", M);
     ucnerf_mlp_params m;
@@ -1313,6 +1383,13 @@ int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* re
         while ((1u << l) < (unsigned)rp->S) ++l;
         f.div_m = (unsigned)((((unsigned long long)1 << (31 + l)) + (unsigned)rp->S - 1) / (unsigned)rp->S);
         f.div_sh = l - 1;
+    }
+    if (tail_c) {
+        const int cus = device_cus();
+        if (cus <= 0) return fail(UCNERF_EHIP, "mlp_fwd: no device");
+        f.tail_rpb = cdiv(rp->n, cus); f.tail_tpr = rp->S / 32; f.tail_resample = tail_s ? 1 : 0;
+        f.tail_c = *tail_c;
+        if (tail_s) f.tail_s = *tail_s;
     }
     return launch_bf16(&m, nullptr, st, &f);
 }
@@ -1381,5 +1458,6 @@ int launch_pack_bf16_tab(const ucnerf_mlp_config* cfg, const ParamTable& t, cons
 }
 
 #endif   // UCNERF_BF16_BUILD_TERMS == 3
+#endif   // !UCNERF_BF16_BUILD_TAIL
 
 }  // namespace ucnerf

@@ -2,6 +2,8 @@
 // (network/renderer.py:215-255 with utils/utils.py:716-724 in front).  Host-side orchestration only:
 // every stage is one of the library's own kernels; intermediates live in the caller's workspace.
 #include "common.h"
+#include <atomic>
+#include <cstdlib>
 #include "mlp_layout.h"
 
 namespace ucnerf {
@@ -55,7 +57,8 @@ __global__ void __launch_bounds__(256) render_points_kernel(PointsArgs a) {
 }
 
 int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float* feats, int tiled, float* ndc, hipStream_t st);
-int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* repacked, const float* dirs, float* raw, hipStream_t st);   // mlp_bf16.hip
+int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* repacked, const float* dirs, float* raw, hipStream_t st,
+                                 const ucnerf_composite_params* tail_c, const ucnerf_sample_pdf_params* tail_s);   // mlp_bf16.hip
 
 struct Workspace {
     float *pts, *ndc1, *ndc2, *ndc3, *ndc, *angle, *feats, *raw;
@@ -124,6 +127,35 @@ static size_t carve_bwd_render(float* base, int n, int S, int V, Workspace* w, f
     return o;
 }
 
+static std::atomic<long long> g_tail_launches{0};
+
+// compositing (K7) parameters of the pass, `raw` = where the MLP leaves its outputs
+static void composite_args(const ucnerf_render_params* p, const float* raw, ucnerf_composite_params* c) {
+    memset(c, 0, sizeof(*c));
+    c->n = p->n; c->S = p->S; c->variant = 0; c->white_bkgd = p->white_bkgd;
+    c->raw = raw; c->z = p->z;
+    c->rgb_map = p->rgb_map; c->depth_map = p->depth_map; c->acc_map = p->acc_map; c->weights = p->weights; c->var = p->var;
+    c->u = p->u_sampled; c->wu = p->wu_map;
+}
+
+// May the gather-fused launch composite (and re-sample) its rays in its own tail?  Passes of at most a round and a half of tiles (the shards of a strongly
+// scaled batch: there the two or three latency-bound launches behind the MLP are a tenth of the step), whole 32-sample tiles per ray, the
+// stand-alone kernels' small LDS shapes.  UCNERF_FUSED_TAIL=0 in the environment switches it off (A/B, tests: the outputs are bit-identical).
+static bool tail_fits(const ucnerf_render_params* p, const ucnerf_sample_pdf_params* s) {
+    const char* e = getenv("UCNERF_FUSED_TAIL");
+    if (e && e[0] == '0') return false;
+    const int cus = device_cus();
+    if (cus <= 0 || p->S % 32 != 0 || p->S > 256 || p->max_blocks > 0 || p->sources_cl_bf16 || p->gen_rays || coords_given(p)) return false;
+    if ((long long)p->n * (p->S / 32) * 2 > 3ll * cus * 8) return false;              // more than a round and a half of tiles: nothing to gain (measured: 2048 rays + 1 %)
+    {   // whole rays per block: rays / ceil(rays / CUs) blocks -- all but a tenth of the CUs must get one (37 rays: + 13 % on 37 blocks)
+        const int rpb = cdiv(p->n, cus), blocks = cdiv(p->n, rpb);
+        if (blocks * 10 < cus * 9) return false;
+    }
+    if (s && !(s->from_coarse && s->n == p->n && s->n_merge == p->S && s->n_bins == p->S - 1 && p->S >= 3 && s->n_bins <= 128 && p->S + s->n_samples <= 512 && s->n_samples >= 1 && (s->u_stride == 0 || s->u_stride == s->n_samples) &&
+               (s->samples || s->inds || s->cdf || s->z_sorted) && (!s->merge_rank || s->z_sorted) && s->u)) return false;
+    return true;
+}
+
 static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace* w) {
     const int V = p->cfg.n_src;
     carve(p->workspace, p->n, p->S, V, w);
@@ -131,6 +163,13 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
     const bool keep_feats = p->feats != nullptr;        // caller wants row-major features (for the backward)
     ucnerf_feat_gather_params g;
     float* raw_fused = nullptr;
+    ucnerf_composite_params c;
+    ucnerf_sample_pdf_params s_res;
+    if (p->resample) {                                   // ABI v4: this pass's compositing and the next pass's depths from ONE launch
+        UCNERF_REQUIRE(!p->u_sampled, "render_fused_fwd: resample and the per-sample uncertainty outputs exclude each other");
+        s_res = *p->resample;
+        s_res.weights = nullptr; s_res.z_merge = p->z;
+    }
     if (p->cfg.precision == 3) {                        // row f1: gather + PE + MLP in one launch, no feature buffer at all
         UCNERF_REQUIRE(p->sources_cl && !keep_feats && !p->u_sampled && !p->train_workspace,
                        "render_fused_fwd: precision 3 (gather fused into the MLP kernel) needs the channel-last sources; it keeps no features "
@@ -139,8 +178,12 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
         if (!gen && !p->dir_feat && (rc = launch_dirs(p, st, w))) return rc;
         raw_fused = p->raw ? p->raw : w->raw;
         if (p->ev_mlp_start && (rc = ucnerf_event_record(p->ev_mlp_start, st))) return rc;
-        if ((rc = launch_mlp_fwd_bf16x3_gather(p, p->sources_cl, gen ? w->angle : p->dir_feat ? p->dir_feat : w->angle, raw_fused, st))) return rc;
+        const bool tail = tail_fits(p, p->resample ? &s_res : nullptr);
+        if (tail) composite_args(p, raw_fused, &c);
+        if ((rc = launch_mlp_fwd_bf16x3_gather(p, p->sources_cl, gen ? w->angle : p->dir_feat ? p->dir_feat : w->angle, raw_fused, st, tail ? &c : nullptr,
+                                               tail && p->resample ? &s_res : nullptr))) return rc;
         if (p->ev_mlp_stop && (rc = ucnerf_event_record(p->ev_mlp_stop, st))) return rc;
+        if (tail) { ++g_tail_launches; return UCNERF_OK; }      // K7 (and K8, K9) ran inside the launch
     } else if (p->sources_cl) {                                // fast path: channel-last sources, coordinates derived in-kernel
         g.out_tiled = keep_feats ? (p->feats_tiled ? 1 : 0) : 1;
         g.feats = keep_feats ? p->feats : w->feats;
@@ -170,18 +213,8 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
         if (p->ev_mlp_stop && (rc = ucnerf_event_record(p->ev_mlp_stop, st))) return rc;
     }
 
-    ucnerf_composite_params c;
-    memset(&c, 0, sizeof(c));
-    c.n = p->n; c.S = p->S; c.variant = 0; c.white_bkgd = p->white_bkgd;
-    c.raw = m.raw; c.z = p->z;
-    c.rgb_map = p->rgb_map; c.depth_map = p->depth_map; c.acc_map = p->acc_map; c.weights = p->weights; c.var = p->var;
-    c.u = p->u_sampled; c.wu = p->wu_map;
-    if (p->resample) {                                   // ABI v4: this pass's compositing and the next pass's depths from ONE launch
-        UCNERF_REQUIRE(!p->u_sampled, "render_fused_fwd: resample and the per-sample uncertainty outputs exclude each other");
-        ucnerf_sample_pdf_params s = *p->resample;
-        s.weights = nullptr; s.z_merge = p->z;
-        return ucnerf_composite_sample_pdf(&c, &s, st);
-    }
+    composite_args(p, m.raw, &c);
+    if (p->resample) return ucnerf_composite_sample_pdf(&c, &s_res, st);
     return ucnerf_composite_fwd(&c, st);
 }
 
@@ -190,6 +223,8 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
 using namespace ucnerf;
 
 extern "C" {
+
+int64_t ucnerf_fused_tail_launches(void) { return (int64_t)g_tail_launches.load(); }
 
 int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V) {
     if (n < 0 || S < 1 || V < 1 || V > 8) return fail(UCNERF_EINVAL, "render_workspace: bad sizes n=%d S=%d V=%d", n, S, V);
