@@ -45,6 +45,10 @@ const char* ucnerf_build_flags(void);
  * tail instead of launching K7 / K8 / K9 behind it -- passes of at most a round and a half of 32-sample tiles (csrc/render.hip: tail_fits; the
  * outputs are bit-identical either way).  The environment variable UCNERF_FUSED_TAIL=0, read at every call, switches that route off. */
 int64_t ucnerf_fused_tail_launches(void);
+/* 1 when a pass of n rays x S samples is of the size that takes that route on the current device (the other conditions are the caller's to know:
+ * gather-fused precision, fp32 channel-last sources, derived coordinates, no max_blocks).  A host uses it to decide whether to hand the pass its ray
+ * generation too (gen_rays / gen_depths): on the tail route the blocks generate their own rays at no measurable cost. */
+int32_t ucnerf_fused_tail_fits(int32_t n, int32_t S);
 /* Digest of the sources, headers and flags this binary was linked from (uc_nerf_amd/build.py: source_hash()): a host can tell a library
  * that does not belong to the tree it sits in (tests/test_abi_host.py), and __graft_entry__.build() rebuilds one that was not linked on
  * the machine it runs on. */

@@ -235,7 +235,7 @@ def test_step_with_the_small_launches_folded_in_equals_the_old_launch_structure_
     xs, ys = random_pixels(4096, 256, 320, seed=0)
     xs, ys = dev(xs[:n].contiguous()), dev(ys[:n].contiguous())
     noise = dev(torch.rand(n, 64, generator=torch.Generator().manual_seed(100)))
-    assert r.fold_launches and not r.fold_rays             # the default: compositing + re-sampling folded; rays still a launch (measured faster)
+    assert r.fold_launches and r.fold_rays is None         # the default: compositing + re-sampling folded; rays a launch of their own (measured faster) unless the pass takes the tail route
     r.fold_launches = r.fold_rays = False
     old = r.render(xs, ys, perturb=perturb, noise=noise if perturb > 0 else None)
     old = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in old.items()}
@@ -274,8 +274,15 @@ def test_compositing_and_resampling_in_the_tail_of_the_fused_launch_are_bit_iden
     old = {k: (v.clone() if torch.is_tensor(v) else {kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in old.items()}
     assert count() == c0                                   # switched off: the separate launches
     monkeypatch.delenv("UCNERF_FUSED_TAIL")
+    r.fold_rays = False                                    # rays from their own launch
     new = r.render(xs, ys, perturb=1.0, noise=noise)
     assert count() - c0 == int(coarse_in_tail) + int(fine_in_tail)
+    for k in ("rays_d", "z_coarse", "z_fine", "rgb", "depth", "weights"):
+        assert torch.equal(new[k], old[k]), k
+    r.fold_rays = None                                     # the default: on the tail route the coarse launch's blocks generate their own rays as well
+    c1 = count()
+    new = r.render(xs, ys, perturb=1.0, noise=noise)
+    assert count() - c1 == int(coarse_in_tail) + int(fine_in_tail)
     for k in ("rays_d", "z_coarse", "z_samples", "z_fine", "rgb", "depth", "acc", "weights", "var"):
         assert torch.equal(new[k], old[k]), k
     for k in ("rgb", "depth", "weights"):

@@ -554,7 +554,30 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             const int vi = i / VIEW_TAB, e = i % VIEW_TAB;
             vtab[i] = e < 12 ? fg.w2cs[12 * vi + e] : e < 21 ? fg.Ks[9 * vi + e - 12] : 0.f;
         }
+        if (TAIL && fg.gen_xs) {
+            // ABI v4 gen_rays / gen_depths on the tail route: a block owns whole rays, so it makes THEM first -- ray, view-direction feature and the
+            // stratified depths (raygen_device.h: ucnerf_ray_gen_sample's arithmetic and bits), a handful of values per thread, written where the
+            // tiles below (and the launches behind this one) read them.  The stores are acknowledged before the barrier that follows.
+            const int bx0 = (int)blockIdx.x, nbk = (int)gridDim.x;
+            const int lb = (nbk & 7) == 0 ? (bx0 & 7) * (nbk >> 3) + (bx0 >> 3) : bx0;
+            const int ray0 = lb * fg.tail_rpb, nr = fg.tail_c.n - ray0 < fg.tail_rpb ? fg.tail_c.n - ray0 : fg.tail_rpb;
+            for (int r = threadIdx.x; r < nr; r += 64 * BW) {
+                const int ray = ray0 + r;
+                float wx, wy, wz, ax, ay, az;
+                pinhole_ray(fg.gen_xs[ray], fg.gen_ys[ray], fg.gen_K[0], fg.gen_K[1], fg.gen_K[2], fg.gen_K[3], fg.gen_R, &wx, &wy, &wz);
+                view_dir_feature(wx, wy, wz, fg.gen_Q, &ax, &ay, &az);
+                fg.gen_rays_d[3 * (size_t)ray] = wx; fg.gen_rays_d[3 * (size_t)ray + 1] = wy; fg.gen_rays_d[3 * (size_t)ray + 2] = wz;
+                fg.gen_angle[3 * (size_t)ray] = ax; fg.gen_angle[3 * (size_t)ray + 1] = ay; fg.gen_angle[3 * (size_t)ray + 2] = az;
+            }
+            for (int i = threadIdx.x; i < nr * fg.S; i += 64 * BW) {
+                const size_t k = (size_t)ray0 * fg.S + i;
+                fg.gen_z[k] = stratified_depth(fg.near, fg.far, i % fg.S, fg.S, fg.gen_lindisp, fg.gen_perturb, fg.gen_noise ? fg.gen_noise[k] : 0.f);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        }
         __syncthreads();
+        if (TAIL && fg.gen_xs) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 
     Pipe P;
@@ -1249,13 +1272,13 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
         fg = *fuse;
         UCNERF_REQUIRE(!(fg.s16 && fg.pts_in), "mlp_fwd (gather fused): bf16 channel-last sources are served on derived coordinates only (given coordinates: fp32 copies, "
                        "or the two-kernel pass)");
+        if (fg.tail_rpb > 0) {      // the launch composites its rays itself (small passes, render.hip): whole rays per block, which it also generates when asked to
+            UCNERF_REQUIRE(!fg.pts_in && !fg.s16 && !(fg.gen_xs && fg.near_far) && p->max_blocks <= 0, "mlp_fwd (gather fused): compositing in the tail goes with derived coordinates and fp32 sources");
+            return launch_fused_tail(p, &g, n_tiles, &fg, cdiv(fg.tail_c.n, fg.tail_rpb), st);
+        }
         UCNERF_REQUIRE(!fg.gen_xs || (!fg.s16 && !fg.pts_in && !fg.near_far && B.v <= 6), "mlp_fwd (gather fused): generated rays go with fp32 source copies, derived "
                        "coordinates, the scene's depth range and at most six source views");
         const size_t smem_f = bf16_smem_bytes_fused(B.v);
-        if (fg.tail_rpb > 0) {      // the launch composites its rays itself (small passes, render.hip): whole rays per block
-            UCNERF_REQUIRE(!fg.pts_in && !fg.s16 && !fg.gen_xs && p->max_blocks <= 0, "mlp_fwd (gather fused): compositing in the tail goes with derived coordinates and fp32 sources");
-            return launch_fused_tail(p, &g, n_tiles, &fg, cdiv(fg.tail_c.n, fg.tail_rpb), st);
-        }
 #define X(N)                                                                                                                   \
         if (B.v == N && !fg.pts_in && fg.s16) {                                                                                \
             const void* fn = (const void*)mlp_fwd_bf16_kernel<true, N, 3, false, true, false, true>;                           \

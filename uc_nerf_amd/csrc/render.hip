@@ -141,16 +141,18 @@ static void composite_args(const ucnerf_render_params* p, const float* raw, ucne
 // May the gather-fused launch composite (and re-sample) its rays in its own tail?  Passes of at most a round and a half of tiles (the shards of a strongly
 // scaled batch: there the two or three latency-bound launches behind the MLP are a tenth of the step), whole 32-sample tiles per ray, the
 // stand-alone kernels' small LDS shapes.  UCNERF_FUSED_TAIL=0 in the environment switches it off (A/B, tests: the outputs are bit-identical).
-static bool tail_fits(const ucnerf_render_params* p, const ucnerf_sample_pdf_params* s) {
+static bool tail_size_fits(int n, int S) {
     const char* e = getenv("UCNERF_FUSED_TAIL");
     if (e && e[0] == '0') return false;
     const int cus = device_cus();
-    if (cus <= 0 || p->S % 32 != 0 || p->S > 256 || p->max_blocks > 0 || p->sources_cl_bf16 || p->gen_rays || coords_given(p)) return false;
-    if ((long long)p->n * (p->S / 32) * 2 > 3ll * cus * 8) return false;              // more than a round and a half of tiles: nothing to gain (measured: 2048 rays + 1 %)
-    {   // whole rays per block: rays / ceil(rays / CUs) blocks -- all but a tenth of the CUs must get one (37 rays: + 13 % on 37 blocks)
-        const int rpb = cdiv(p->n, cus), blocks = cdiv(p->n, rpb);
-        if (blocks * 10 < cus * 9) return false;
-    }
+    if (cus <= 0 || n < 1 || S % 32 != 0 || S > 256) return false;
+    if ((long long)n * (S / 32) * 2 > 3ll * cus * 8) return false;              // more than a round and a half of tiles: nothing to gain (measured: 2048 rays + 1 %)
+    // whole rays per block: rays / ceil(rays / CUs) blocks -- all but a tenth of the CUs must get one (37 rays: + 13 % on 37 blocks)
+    const int rpb = cdiv(n, cus), blocks = cdiv(n, rpb);
+    return blocks * 10 >= cus * 9;
+}
+static bool tail_fits(const ucnerf_render_params* p, const ucnerf_sample_pdf_params* s) {
+    if (!tail_size_fits(p->n, p->S) || p->max_blocks > 0 || p->sources_cl_bf16 || coords_given(p)) return false;
     if (s && !(s->from_coarse && s->n == p->n && s->n_merge == p->S && s->n_bins == p->S - 1 && p->S >= 3 && s->n_bins <= 128 && p->S + s->n_samples <= 512 && s->n_samples >= 1 && (s->u_stride == 0 || s->u_stride == s->n_samples) &&
                (s->samples || s->inds || s->cdf || s->z_sorted) && (!s->merge_rank || s->z_sorted) && s->u)) return false;
     return true;
@@ -180,7 +182,9 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
         if (p->ev_mlp_start && (rc = ucnerf_event_record(p->ev_mlp_start, st))) return rc;
         const bool tail = tail_fits(p, p->resample ? &s_res : nullptr);
         if (tail) composite_args(p, raw_fused, &c);
-        if ((rc = launch_mlp_fwd_bf16x3_gather(p, p->sources_cl, gen ? w->angle : p->dir_feat ? p->dir_feat : w->angle, raw_fused, st, tail ? &c : nullptr,
+        // (rays generated inside the launch: the RAYGEN instantiation derives every lane's direction feature itself and uses w->angle as scratch; the
+        //  tail route's blocks write the caller's buffers first and read them like given ones)
+        if ((rc = launch_mlp_fwd_bf16x3_gather(p, p->sources_cl, gen && !tail ? w->angle : p->dir_feat ? p->dir_feat : w->angle, raw_fused, st, tail ? &c : nullptr,
                                                tail && p->resample ? &s_res : nullptr))) return rc;
         if (p->ev_mlp_stop && (rc = ucnerf_event_record(p->ev_mlp_stop, st))) return rc;
         if (tail) { ++g_tail_launches; return UCNERF_OK; }      // K7 (and K8, K9) ran inside the launch
@@ -225,6 +229,7 @@ using namespace ucnerf;
 extern "C" {
 
 int64_t ucnerf_fused_tail_launches(void) { return (int64_t)g_tail_launches.load(); }
+int32_t ucnerf_fused_tail_fits(int32_t n, int32_t S) { return tail_size_fits(n, S) ? 1 : 0; }
 
 int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V) {
     if (n < 0 || S < 1 || V < 1 || V > 8) return fail(UCNERF_EINVAL, "render_workspace: bad sizes n=%d S=%d V=%d", n, S, V);

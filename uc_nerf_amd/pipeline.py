@@ -8,6 +8,7 @@ Library calls per batch (+ the source repack when asked), all on the caller's st
 """
 import torch
 
+from . import _lib as L
 from . import ops
 
 
@@ -25,7 +26,7 @@ class CoarseFineRenderer:
                  precision="f32", fused_min_rounds=0, sources_bf16=False):
         dev = scene["confidence"].device
         self.scene, self.dev = scene, dev
-        self.n_coarse, self.n_fine, self.white_bkgd = n_coarse, n_fine, white_bkgd
+        self.n_coarse, self.n_fine, self.white_bkgd, self.max_blocks = n_coarse, n_fine, white_bkgd, max_blocks
         self.src = ops.GatherSources(scene["vols"], scene["confidence"], scene["imgs"], scene["img_feat"],
                                      scene["w2cs"][1:], scene["intrinsics"][1:], cl_bf16=sources_bf16)
         self.precision = precision          # "f32": exact fp32 MFMA; "bf16x3": split-bf16 matrix cores (inference, within the
@@ -57,10 +58,11 @@ class CoarseFineRenderer:
         # round 4: the small launches around the coarse pass are folded into it -- ray_gen_sample into the gather-fused kernel's prologue, the coarse
         # compositing + sample_pdf + merge into one launch (a 512-ray shard's step is five launches instead of seven); False restores the old structure
         self.fold_launches = True     # coarse compositing + sample_pdf + merge: one launch (-2.5 us per step at 512 and at 4096 rays, same box)
-        # ray_gen_sample inside the gather-fused coarse launch (ABI v4 gen_rays / gen_depths): built, bit-identical, and measured SLOWER than the
-        # 4.8-us launch it removes -- +1.2 us per step at 512 rays, +8 us at 4096 (profiles/r04_experiments.md: five correctly rounded divisions and
-        # a square root per lane and tile, twice, are ~200 vector instructions in a kernel where none is free).  Off by default.
-        self.fold_rays = False
+        # ray_gen_sample inside the gather-fused coarse launch (ABI v4 gen_rays / gen_depths).  Per tile (the RAYGEN instantiation) it is bit-identical
+        # and measured SLOWER than the 4.8-us launch it removes -- +1.2 us per step at 512 rays, +8 us at 4096 (profiles/r04_experiments.md: five
+        # correctly rounded divisions and a square root per lane and tile, twice, are ~200 vector instructions in a kernel where none is free).  On the
+        # tail route of small passes a block owns whole rays and makes them once, in its prologue: free.  None = that case only.
+        self.fold_rays = None
 
     def set_params(self, flat_params):
         self.wstream.copy_(self.pw.pack(flat_params))
@@ -91,7 +93,11 @@ class CoarseFineRenderer:
         cpass = self._pass_for(n * self.n_coarse)
         # fold_rays (gather-fused kernel, up to six source views): the coarse launch generates rays, coarse depths and direction features itself
         # (ABI v4 gen_rays / gen_depths) -- no ray_gen_sample launch
-        gen = self.sampler if (self.fold_rays and cpass.pw.cfg.precision == 3 and cpass.use_cl and self.src.V <= 6) else None
+        fold_rays = self.fold_rays
+        if fold_rays is None:
+            fold_rays = (cpass.pw.cfg.precision == 3 and cpass.use_cl and not self.src.cl_bf16 and not self.max_blocks
+                         and bool(L.lib().ucnerf_fused_tail_fits(n, self.n_coarse)))
+        gen = self.sampler if (fold_rays and cpass.pw.cfg.precision == 3 and cpass.use_cl and self.src.V <= 6) else None
         rays_d, angle, z_c = self.sampler.prepare(xs, ys, perturb, noise) if gen is not None else self.sampler(xs, ys, perturb, noise)
         ev = [(a.h, b.h) for a, b in events] if events else (None, None)
         # the coarse pass's compositing launch draws the fine depths as well (composite + sample_pdf + sorted merge: one launch, ABI v4)
