@@ -220,7 +220,7 @@ def bench_dropin(ctx, scene, sd, steps=40, warmup=10):
     with torch.no_grad():
         # what an UNMODIFIED caller gets: install_dropin() and nothing else (train.py:254-272 calls rendering() under no_grad)
         from uc_nerf_amd import dropin as _dropin
-        dt = ctx.timed(lambda: dropin_call(a, kw, scene, outputs, ev), steps * 4, warmup * 4)
+        dt = ctx.timed(lambda: dropin_call(a, kw, scene, outputs, ev), steps * 4, warmup * 16)      # (first leg of this section: the longer warm-up lets the clock settle on it)
         out["dropin_eval_default"] = {"ms_per_call": dt * 1e3, "value": 1024 / dt, "unit": "rays/s", "rays": 1024, "samples_per_ray": 90,
                                       "precision": _dropin.inference_precision(a), "weight_cache": "verify (re-packed from the live parameters in every call)",
                                       "note": "rendering() after install_dropin() alone: no precision knob touched"}
