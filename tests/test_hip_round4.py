@@ -291,6 +291,46 @@ def test_compositing_and_resampling_in_the_tail_of_the_fused_launch_are_bit_iden
     assert torch.equal(ru["rgb"], old["rgb"]) and torch.equal(ru["depth"], old["depth"])
 
 
+@pytest.mark.parametrize("n,S,M,white", [(768, 32, 64, False), (512, 96, 32, True), (256, 128, 0, False), (256, 256, 0, True), (512, 64, 128, True)])
+def test_tail_route_of_a_single_pass_covers_the_sample_counts_and_outputs_of_the_separate_launches(n, S, M, white, monkeypatch):
+    """One RenderPass call per case, with and without the tail route: S = 32 .. 256 (one to four samples per lane in the compositing wave), the white
+    background, every optional output, re-sampling to M new depths with uniform and random draws.  Bit-identical; the counter proves the route ran."""
+    from uc_nerf_amd import _lib as L, ops
+    from uc_nerf_amd.pipeline import flat_params_of
+    from uc_nerf_amd.synthetic import init_ucnerf_state_dict, make_scene, random_pixels, scene_to
+    scene = scene_to(make_scene(seed=0), torch.device(DEV))
+    sd = init_ucnerf_state_dict(seed=0, n_src=6, sigma_scale=0.05, sigma_bias=0.05)
+    src = ops.GatherSources(scene["vols"], scene["confidence"], scene["imgs"], scene["img_feat"], scene["w2cs"][1:], scene["intrinsics"][1:])
+    pw = ops.PackedWeights.get(6, 0, torch.device(DEV), "bf16x3_fused")
+    rp = ops.RenderPass(src, pw, pw.pack(dev(flat_params_of(sd))), dev(scene["c2w"][:3, 3]), scene["w2cs"][0], scene["intrinsics"][0], scene["w2cs"][0],
+                        scene["near"], scene["far"], white)
+    rp.repack_sources()
+    xs, ys = random_pixels(n, 256, 320, seed=5)
+    rays_d, _, _ = ops.ray_gen(scene["K"].cpu(), scene["c2w"].cpu(), xs=dev(xs), ys=dev(ys))
+    z, _ = ops.sample_stratified(None, S, n=n, near=float(scene["near"]), far=float(scene["far"]), device=torch.device(DEV), perturb=1.0,
+                                 noise=dev(torch.rand(n, S, generator=torch.Generator().manual_seed(S))))
+    ang, _ = ops.dir_feature(rays_d, scene["w2cs"][0])
+    count = L.lib().ucnerf_fused_tail_launches
+    assert L.lib().ucnerf_fused_tail_fits(n, S) == 1
+    for u in ((None,) if M == 0 else (torch.linspace(0., 1., M, device=DEV), dev(torch.rand(n, M, generator=torch.Generator().manual_seed(M))))):
+        res = None if u is None else {"u": u, "want_rank": True}
+        outs = []
+        for tail in (False, True):
+            if tail:
+                monkeypatch.delenv("UCNERF_FUSED_TAIL", raising=False)
+            else:
+                monkeypatch.setenv("UCNERF_FUSED_TAIL", "0")
+            c0 = count()
+            o = rp(rays_d, z, want=("acc", "weights", "var"), keep=("raw",), dir_feat=ang, resample=res)
+            assert count() - c0 == int(tail)
+            outs.append({k: v.clone() for k, v in o.items() if torch.is_tensor(v)})
+        assert set(outs[0]) == set(outs[1]) and {"rgb", "depth", "acc", "weights", "var", "raw"} <= set(outs[0])
+        if res is not None:
+            assert {"samples", "z_sorted", "merge_rank"} <= set(outs[0])
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], outs[1][k]), (k, "uniform" if u is not None and u.dim() == 1 else "random")
+
+
 # ---------------------------------------------------------------------------------------------- sources handed over channel-last, zero copy
 def _bench_scene_channel_last(seed=0):
     from uc_nerf_amd import ops
