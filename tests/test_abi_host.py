@@ -139,6 +139,16 @@ def test_pack_index_is_a_rearrangement_of_the_parameters(L, n_src, layout):
         assert not np.array_equal(idx, idx0) and np.array_equal(np.sort(idx), np.sort(idx0))
 
 
+def test_tail_route_diagnostics_answer_without_a_device(L):
+    """ucnerf_fused_tail_fits / ucnerf_fused_tail_launches (the route on which a small pass composites, re-samples and generates its rays inside the
+    gather-fused launch): callable on a host without a GPU -- no device, no route, nothing counted, no crash."""
+    lib = L.lib()
+    assert lib.ucnerf_fused_tail_launches() == 0
+    if not torch.cuda.is_available():
+        assert lib.ucnerf_fused_tail_fits(512, 64) == 0
+    assert lib.ucnerf_fused_tail_fits(512, 63) == 0 and lib.ucnerf_fused_tail_fits(0, 64) == 0 and lib.ucnerf_fused_tail_fits(512, 512) == 0
+
+
 def test_product_package_never_imports_the_oracle():
     import subprocess
     import sys
