@@ -105,7 +105,10 @@ class FlatStore:
         """Fresh views of the flat gradient `buf`, one per parameter (None where `wanted` is False): what a backward returns to autograd.
         (Fresh on purpose: autograd installs a returned gradient as `p.grad` WITHOUT a copy only when nobody else holds the tensor.)"""
         self._issued = (buf.untyped_storage().data_ptr(), buf.storage_offset(), buf.numel())      # what flat_grad() may hand to a bucket
-        return [buf[o:o + n].view(p.shape) if w else None for p, o, n, w in zip(self.params, self.offsets, self.sizes, wanted)]
+        # (one split for all segments, a view only where a parameter is not a vector: 19 tensor operations instead of 72 -- the 250-ray data-parallel
+        #  step is bound by the host's issue time, DESIGN.md 7)
+        segs = buf[:self.n].split(self.sizes)
+        return [(g if p.dim() == 1 else g.view(p.shape)) if w else None for g, p, w in zip(segs, self.params, wanted)]
 
     def flat_grad(self, room=None):
         """The flat fp32 tensor [>= n + extra + tail] every non-None `p.grad` of this store is a view of (each at its own offset), or None:
