@@ -650,7 +650,8 @@ def main():
                         "note": "512 rays x (64+128) on ONE GPU; each projection divides this run's 4096-ray step by the 512-ray step under the same "
                                 "source rule (with_repack: channel-last source copies rebuilt inside both steps -- the headline rule; constant_sources: "
                                 "rebuilt in neither; zero_copy_sources: sources handed over channel-last, ops.ChannelLastSources, read in place); no collective is in either figure (rendering needs none; the gather of 80 KB of outputs is ignored); "
-                                "NOT a scaling measurement"}
+                                "the 512-ray step is two launches (its passes generate, composite and re-sample their rays inside the gather-fused launch: "
+                                "ucnerf_fused_tail_launches, DESIGN.md 4.4), the 4096-ray step five; NOT a scaling measurement"}
             extra["strong_512"] = guarded(strong_512)
 
             def constant_sources():
