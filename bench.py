@@ -639,6 +639,13 @@ def main():
                 dt40z = ctx.timed(lambda: rz.render(xs, ys, perturb=1.0, noise=noise), 100, 20)
                 oz = rz.render(x5, y5, perturb=1.0, noise=nz5)
                 assert torch.equal(oz["rgb"], ref["rgb"]) and torch.equal(oz["depth"], ref["depth"])
+                # how many passes of one step composite / re-sample / generate their rays inside the gather-fused launch (the library's own counter)
+                from uc_nerf_amd import _lib as _L
+                c0 = _L.lib().ucnerf_fused_tail_launches()
+                renderer.render(x5, y5, perturb=1.0, noise=nz5, repack=False)
+                tail5 = int(_L.lib().ucnerf_fused_tail_launches() - c0)
+                renderer.render(xs, ys, perturb=1.0, noise=noise, repack=False)
+                tail40 = int(_L.lib().ucnerf_fused_tail_launches() - c0) - tail5
                 full = rays == 4096
                 return {"ms_per_step": dt5 * 1e3, "ms_per_step_with_repack": dt5r * 1e3, "ms_per_step_zero_copy_sources": dt5z * 1e3,
                         "ms_per_step_4096_zero_copy_sources": dt40z * 1e3, "zero_copy_equals_repacked_route": True, "rays": n,
@@ -647,6 +654,7 @@ def main():
                         "projected_speedup_at_8_gpus": {"with_repack": dt40r / dt5r if full else None, "constant_sources": dt40 / dt5 if full else None,
                                                         "zero_copy_sources": dt40z / dt5z if full else None},
                         "target_ms_per_step_for_6x": {"with_repack": dt40r / 6 * 1e3, "constant_sources": dt40 / 6 * 1e3, "zero_copy_sources": dt40z / 6 * 1e3},
+                        "passes_on_the_tail_route": {"512_rays": tail5, "4096_rays": tail40},
                         "note": "512 rays x (64+128) on ONE GPU; each projection divides this run's 4096-ray step by the 512-ray step under the same "
                                 "source rule (with_repack: channel-last source copies rebuilt inside both steps -- the headline rule; constant_sources: "
                                 "rebuilt in neither; zero_copy_sources: sources handed over channel-last, ops.ChannelLastSources, read in place); no collective is in either figure (rendering needs none; the gather of 80 KB of outputs is ignored); "
