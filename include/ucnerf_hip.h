@@ -42,7 +42,7 @@ int ucnerf_device_cus(void);
  * the sources in round 4).  The host side checks the production values (tests/test_abi_host.py). */
 const char* ucnerf_build_flags(void);
 /* Diagnostics: how many ucnerf_render_fused_fwd calls of this process let the gather-fused launch composite (and re-sample) its rays in its own
- * tail instead of launching K7 / K8 / K9 behind it -- passes of at most a round and a half of 32-sample tiles (csrc/render.hip: tail_fits; the
+ * tail instead of launching K7 / K8 / K9 behind it -- passes of at most three rounds of 32-sample tiles (csrc/render.hip: tail_fits; the
  * outputs are bit-identical either way).  The environment variable UCNERF_FUSED_TAIL=0, read at every call, switches that route off. */
 int64_t ucnerf_fused_tail_launches(void);
 /* 1 when a pass of n rays x S samples is of the size that takes that route on the current device (the other conditions are the caller's to know:

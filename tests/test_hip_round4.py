@@ -251,10 +251,10 @@ def test_step_with_the_small_launches_folded_in_equals_the_old_launch_structure_
         assert torch.equal(ru["rgb"], old["rgb"]) and torch.equal(ru["depth"], old["depth"])
 
 
-@pytest.mark.parametrize("n,coarse_in_tail,fine_in_tail", [(512, True, True), (500, True, True), (700, True, False), (300, False, False), (37, False, False),
+@pytest.mark.parametrize("n,coarse_in_tail,fine_in_tail", [(512, True, True), (500, True, True), (700, True, True), (1024, True, True), (300, False, False), (37, False, False),
                                                          (4096, False, False)])
 def test_compositing_and_resampling_in_the_tail_of_the_fused_launch_are_bit_identical(n, coarse_in_tail, fine_in_tail, monkeypatch):
-    """Row f1 to the letter for small passes: with at most a round and a half of tiles and (nearly) every CU owning whole rays, the gather-fused launch
+    """Row f1 to the letter for small passes: with at most three rounds of tiles and (nearly) every CU owning whole rays, the gather-fused launch
     composites its rays itself and -- coarse pass -- draws the fine depths from them (K3 .. K9 in one launch, csrc/mlp_bf16.hip TAIL instantiation);
     larger or badly balanced passes keep the separate launches.  Same device functions: every output equal bit for bit; the library's counter says
     which passes took the route."""

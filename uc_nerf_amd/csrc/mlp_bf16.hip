@@ -508,7 +508,7 @@ struct FusedGather {
     float* gen_rays_d;       // [n,3] out
     float* gen_z;            // [n,S] out
     float* gen_angle;        // [n,3] out
-    // TAIL instantiation (passes of at most two rounds of tiles): tiles are dealt in whole rays to blocks (tail_rpb rays = tail_rpb * tail_tpr
+    // TAIL instantiation (passes of at most three rounds of tiles): tiles are dealt in whole rays to blocks (tail_rpb rays = tail_rpb * tail_tpr
     // consecutive tiles per block) and, when its last tile is done, a block composites its rays itself (K7, composite_device.h) and -- coarse
     // pass -- draws the fine depths from them (K8 + K9, sample_pdf_device.h): one launch for K3 .. K9 of the pass
     int tail_rpb, tail_tpr, tail_resample;

@@ -138,7 +138,7 @@ static void composite_args(const ucnerf_render_params* p, const float* raw, ucne
     c->u = p->u_sampled; c->wu = p->wu_map;
 }
 
-// May the gather-fused launch composite (and re-sample) its rays in its own tail?  Passes of at most a round and a half of tiles (the shards of a strongly
+// May the gather-fused launch composite (and re-sample) its rays in its own tail?  Passes of at most three rounds of tiles (the shards of a strongly
 // scaled batch: there the two or three latency-bound launches behind the MLP are a tenth of the step), whole 32-sample tiles per ray, the
 // stand-alone kernels' small LDS shapes.  UCNERF_FUSED_TAIL=0 in the environment switches it off (A/B, tests: the outputs are bit-identical).
 static bool tail_size_fits(int n, int S) {
@@ -146,7 +146,12 @@ static bool tail_size_fits(int n, int S) {
     if (e && e[0] == '0') return false;
     const int cus = device_cus();
     if (cus <= 0 || n < 1 || S % 32 != 0 || S > 256) return false;
-    if ((long long)n * (S / 32) * 2 > 3ll * cus * 8) return false;              // more than a round and a half of tiles: nothing to gain (measured: 2048 rays + 1 %)
+    // the largest pass, in half rounds of tiles (a round = CUs x 8 tiles): three rounds.  Measured with the rays generated in the prologue (same box, 64 + 128):
+    // 512 rays -4.5 %, 1024 rays -1.1 % (fine pass = 3 rounds), 2048 rays -0.2 .. -0.6 % (up to 6 rounds), 4096 rays +0.3 % (4 + 12 rounds): the
+    // whole-rays-per-block dealing costs large passes what the folded launches save them.  UCNERF_FUSED_TAIL_HALF_ROUNDS overrides (tuning).
+    static int half_rounds = -1;
+    if (half_rounds < 0) { const char* hr = getenv("UCNERF_FUSED_TAIL_HALF_ROUNDS"); half_rounds = hr && atoi(hr) > 0 ? atoi(hr) : 6; }
+    if ((long long)n * (S / 32) * 2 > (long long)half_rounds * cus * 8) return false;
     // whole rays per block: rays / ceil(rays / CUs) blocks -- all but a tenth of the CUs must get one (37 rays: + 13 % on 37 blocks)
     const int rpb = cdiv(n, cus), blocks = cdiv(n, rpb);
     return blocks * 10 >= cus * 9;
