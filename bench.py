@@ -179,6 +179,29 @@ def guarded(fn, key=None):
         return {key: err} if key else err
 
 
+# ------------------------------------------------------------------------------------------------ sources as a real producer writes them
+def conv_produced_sources(scene, dev, seed=0):
+    """Gather sources that actual torch convolutions wrote in torch's channels_last memory formats -- what the networks in front of the path
+    produce when they run in those formats on this GPU (network/mvs_models.py:624-646: cost_regularization -> volume_feature_no_ref per stage,
+    FeatureNet -> img_feats): one nn.Conv3d(8, 8, 3) per cascade volume in channels_last_3d, one nn.Conv2d(8, 8, 3) over the V feature maps in
+    channels_last, the images as a channels_last [V,3,H,W] stack.  Each is its OWN allocation with whatever strides MIOpen returns (recorded).
+    Returns (dict(vols, imgs, img_feat), record)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    c3 = torch.nn.Conv3d(8, 8, 3, padding=1).to(dev).to(memory_format=torch.channels_last_3d)
+    c2 = torch.nn.Conv2d(8, 8, 3, padding=1).to(dev).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for m in (c3, c2):
+            m.weight.copy_(torch.randn(m.weight.shape, generator=g).to(dev) * 0.1)
+            m.bias.copy_(torch.randn(m.bias.shape, generator=g).to(dev) * 0.1)
+        vols = [c3(v.contiguous(memory_format=torch.channels_last_3d)) for v in scene["vols"]]
+        feat = c2(scene["img_feat"][:, 0].contiguous(memory_format=torch.channels_last)).unsqueeze(1)       # [V,1,8,H,W], as the reference shapes it
+        imgs = scene["imgs"][0].contiguous(memory_format=torch.channels_last).unsqueeze(0)                 # [1,V,3,H,W]
+    rec = {"vol_strides": [list(v.stride()) for v in vols], "img_feat_stride": list(feat.stride()), "imgs_stride": list(imgs.stride()),
+           "vols_channels_last_3d": [bool(v.is_contiguous(memory_format=torch.channels_last_3d)) for v in vols],
+           "separate_allocations": len({t.untyped_storage().data_ptr() for t in vols + [feat, imgs]}) == 5}
+    return {"vols": vols, "imgs": imgs, "img_feat": feat}, rec
+
+
 # ------------------------------------------------------------------------------------------------ live-path (drop-in) workloads
 def dropin_setup(scene, sd, dev):
     import uc_nerf_amd
@@ -203,6 +226,56 @@ def dropin_call(a, kw, scene, outputs, batch, confidence=None, vols=None, img_fe
                               img_feat=scene["img_feat"] if img_feat is None else img_feat,
                               confidence=scene["confidence"] if confidence is None else confidence,
                               network_fn=kw["network_fn"], network_query_fn=kw["network_query_fn"], white_bkgd=kw["white_bkgd"])
+
+
+def bench_eval_image(ctx, scene, a, kw, outputs, ms_per_call_default, images=3):
+    """The reference's evaluation loop, literally (train.py:251-275): per 256 x 320 image, 80 chunks of build_rays_test -> rendering -> .cpu() (x2),
+    then the cat / reshape / clamp of the image -- through the drop-in modules, on the synthetic scene.  Every .cpu() drains the stream, so
+    the host's issue time of a chunk is NOT hidden behind the GPU: this is what an unmodified caller waits for."""
+    import utils.utils as U
+    import network.renderer as renderer
+    dev = ctx.dev
+    H, W, chunk = scene["H"], scene["W"], 1024
+    near_fars = torch.tensor([[scene["near"], scene["far"]]] * scene["w2cs"].shape[0], device=dev)
+    tgt_to_world, world_to_ref, intrinsic = scene["c2w"], scene["w2cs"][0], scene["intrinsics"][0]
+    n_chunks = H * W // chunk + int(H * W % chunk > 0)
+    split = {"build_rays_test": 0.0, "rendering": 0.0, "cpu": 0.0}
+
+    def image(timing=False):
+        pose_ref = {"w2cs": scene["w2cs"].clone(), "intrinsics": scene["intrinsics"].clone()}
+        rgbs, depth_preds = [], []
+        for chunk_idx in range(n_chunks):
+            t0 = time.perf_counter()
+            rays_pts, rays_dir, rays_NDC, depth_candidates, rays_o, ndc_parameters = U.build_rays_test(
+                H, W, tgt_to_world, world_to_ref, intrinsic, near_fars, near_fars[-1], a.N_samples, pad=0, chunk=chunk, idx=chunk_idx, outputs=outputs)
+            t1 = time.perf_counter()
+            rgb, depth_pred = renderer.rendering(a, pose_ref, rays_pts, rays_NDC, depth_candidates, rays_dir, outputs, scene["imgs"],
+                                                 near_fars=near_fars[0], img_feat=scene["img_feat"], confidence=scene["confidence"],
+                                                 ndc_parameters=ndc_parameters, network_fn=kw["network_fn"], network_query_fn=kw["network_query_fn"],
+                                                 white_bkgd=kw["white_bkgd"])
+            t2 = time.perf_counter()
+            rgbs.append(rgb.cpu())
+            depth_preds.append(depth_pred.cpu())
+            if timing:
+                t3 = time.perf_counter()
+                split["build_rays_test"] += t1 - t0; split["rendering"] += t2 - t1; split["cpu"] += t3 - t2
+        return torch.clamp(torch.cat(rgbs).reshape(H, W, 3).permute(2, 0, 1), 0, 1), torch.cat(depth_preds).reshape(H, W)
+
+    with torch.no_grad():
+        for _ in range(2):
+            rgb_img, depth_img = image()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(images):
+            rgb_img, depth_img = image()
+        dt = (time.perf_counter() - t0) / images
+        image(timing=True)
+    assert tuple(rgb_img.shape) == (3, H, W) and torch.isfinite(rgb_img).all() and torch.isfinite(depth_img).all()
+    return {"ms_per_image": dt * 1e3, "value": H * W / dt, "unit": "rays/s", "chunks": n_chunks, "rays_per_chunk": chunk, "samples_per_ray": a.N_samples,
+            "ms_80_rendering_calls_alone": 80 * ms_per_call_default,
+            "host_wall_ms_per_image_by_call": {k: v * 1e3 for k, v in split.items()},
+            "note": "the loop of train.py:251-275 through the drop-in modules, unmodified: build_rays_test -> rendering -> rgb.cpu(), depth.cpu() per 1024-pixel "
+                    "chunk; host_wall_ms_per_image_by_call = wall time spent inside each call (the .cpu() wait contains the chunk's GPU time)"}
 
 
 def bench_dropin(ctx, scene, sd, steps=40, warmup=10):
@@ -251,6 +324,7 @@ def bench_dropin(ctx, scene, sd, steps=40, warmup=10):
             rp_ms = out["render_pass_1024x90_" + prec]["ms_per_call"]
             out["dropin_eval_" + prec]["speed_vs_render_pass"] = rp_ms / out["dropin_eval_" + prec]["ms_per_call"]
             out["dropin_eval_" + prec]["speed_vs_render_pass_versions_cache"] = rp_ms / out["dropin_eval_" + prec]["ms_per_call_versions_cache"]
+    out["dropin_eval_image"] = guarded(lambda: bench_eval_image(ctx, scene, a, kw, outputs, out["dropin_eval_default"]["ms_per_call"]))
     # training: 2000 rays x 90 samples, forward + loss + backward into the network AND the gather sources + Adam (train.py:147-188, 85-92)
     vols = [v.detach().clone().requires_grad_(True) for v in scene["vols"]]
     img_feat = scene["img_feat"].detach().clone().requires_grad_(True)
@@ -287,6 +361,35 @@ def bench_dropin(ctx, scene, sd, steps=40, warmup=10):
                            "note": "rendering() forward (activations kept) + img/depth loss + backward into MLP parameters, cascade volumes, "
                                    "img_feats and confidence + Adam step; parameters and gradients live flat (uc_nerf_amd/flat.py): no concatenation, "
                                    "no per-tensor gradient copies; the weight stream is repacked once per step"}
+    # the same step with the sources as a real producer's convolutions write them (channels_last_3d volumes, channels_last feature maps: read in place,
+    # their gradients accumulated channel-last with the inputs' strides -- no scratch memset, no transposing add)
+    def train_channels_last():
+        prod, rec = conv_produced_sources(scene, dev)
+        vols_c = [v.detach().requires_grad_(True) for v in prod["vols"]]
+        feat_c = prod["img_feat"].detach().requires_grad_(True)
+        sc = dict(scene, imgs=prod["imgs"])
+        res = {}
+        for n_rays, seed in ((2000, 4), (250, 5)):
+            tr = live_path_batch(scene, outputs, n_rays, 90, seed=seed)
+            target = torch.rand(n_rays, 3, device=dev)
+
+            def step_c():
+                opt.zero_grad(set_to_none=True)
+                for t in vols_c + [feat_c, conf]:
+                    t.grad = None
+                rgb, depth = dropin_call(a, kw, sc, outputs, tr, confidence=conf, vols=vols_c, img_feat=feat_c)
+                loss = torch.mean((rgb - target) ** 2) * 5.0 + 0.05 * torch.mean((depth - 2.0) ** 2)
+                loss.backward()
+                opt.step()
+                return loss
+            res[n_rays] = ctx.timed(step_c, steps * (1 if n_rays == 2000 else 2), warmup * (1 if n_rays == 2000 else 2))
+            assert torch.isfinite(step_c()).all()
+        from uc_nerf_amd import dropin as _dr
+        ok = all(v.grad is not None and all(n == 1 or x == y for n, x, y in zip(v.shape, v.grad.stride(), v.stride())) for v in vols_c) and feat_c.grad is not None
+        return dict(rec, ms_per_step=res[2000] * 1e3, ms_per_step_250=res[250] * 1e3, read_in_place=list(_dr.session_of(net).src.inplace),
+                    gradients_have_the_inputs_strides=bool(ok),
+                    note="dropin_train with conv-produced channels_last(_3d) sources handed to rendering() as they are")
+    out["dropin_train_channels_last"] = guarded(train_channels_last)
     # the training side of the strong-scaling point: configs[4]'s 2000-ray batch over 8 GPUs = 250 rays per rank, measured on this one GPU
     step250 = make_step(250, opt, 5)
     dt250 = ctx.timed(step250, steps * 2, warmup * 2)
@@ -639,6 +742,22 @@ def main():
                 dt40z = ctx.timed(lambda: rz.render(xs, ys, perturb=1.0, noise=noise), 100, 20)
                 oz = rz.render(x5, y5, perturb=1.0, noise=nz5)
                 assert torch.equal(oz["rgb"], ref["rgb"]) and torch.equal(oz["depth"], ref["depth"])
+                # ... and with the sources as REAL torch convolutions write them (nn.Conv3d in channels_last_3d, nn.Conv2d in channels_last: each tensor its
+                # own allocation, recognised by stride, ABI v5) against the SAME values handed over channel-major and repacked in every step
+                prod, prec_ = conv_produced_sources(scene, dev)
+                rt_ = CoarseFineRenderer(dict(scene, **prod), flat_params_of(sd).to(dev), args.coarse, args.fine, max_blocks=args.max_blocks, precision=args.precision)
+                major = {"vols": [v.contiguous() for v in prod["vols"]], "imgs": prod["imgs"].contiguous(), "img_feat": prod["img_feat"].contiguous()}
+                rm_ = CoarseFineRenderer(dict(scene, **major), flat_params_of(sd).to(dev), args.coarse, args.fine, max_blocks=args.max_blocks, precision=args.precision)
+                dt5t = ctx.timed(lambda: rt_.render(x5, y5, perturb=1.0, noise=nz5), 300, 60)
+                dt40t = ctx.timed(lambda: rt_.render(xs, ys, perturb=1.0, noise=noise), 100, 20)
+                dt5m = ctx.timed(lambda: rm_.render(x5, y5, perturb=1.0, noise=nz5, repack=True), 300, 60)
+                ot, om = rt_.render(x5, y5, perturb=1.0, noise=nz5), rm_.render(x5, y5, perturb=1.0, noise=nz5, repack=True)
+                tcl = dict(prec_, read_in_place=list(rt_.src.inplace), zero_copy=bool(rt_.src.zero_copy), ms_per_step=dt5t * 1e3, ms_per_step_4096=dt40t * 1e3,
+                           ms_per_step_same_values_repacked=dt5m * 1e3, projected_speedup_at_8_gpus=dt40t / dt5t if rays == 4096 else None,
+                           equals_repacked_route=bool(torch.equal(ot["rgb"], om["rgb"]) and torch.equal(ot["depth"], om["depth"])),
+                           note="sources produced by nn.Conv3d(...).to(memory_format=channels_last_3d) / nn.Conv2d(...).to(memory_format=channels_last) on this GPU, "
+                                "handed to the renderer as they are: read in place when the strides are the channel-last ones (read_in_place: vol1, vol2, vol3, img_feat, "
+                                "imgs), repacked per source otherwise; projection = this run's 4096-ray step over its 512-ray step under the same rule")
                 # how many passes of one step composite / re-sample / generate their rays inside the gather-fused launch (the library's own counter)
                 from uc_nerf_amd import _lib as _L
                 c0 = _L.lib().ucnerf_fused_tail_launches()
@@ -654,7 +773,7 @@ def main():
                         "projected_speedup_at_8_gpus": {"with_repack": dt40r / dt5r if full else None, "constant_sources": dt40 / dt5 if full else None,
                                                         "zero_copy_sources": dt40z / dt5z if full else None},
                         "target_ms_per_step_for_6x": {"with_repack": dt40r / 6 * 1e3, "constant_sources": dt40 / 6 * 1e3, "zero_copy_sources": dt40z / 6 * 1e3},
-                        "passes_on_the_tail_route": {"512_rays": tail5, "4096_rays": tail40},
+                        "passes_on_the_tail_route": {"512_rays": tail5, "4096_rays": tail40}, "torch_channels_last": tcl,
                         "note": "512 rays x (64+128) on ONE GPU; each projection divides this run's 4096-ray step by the 512-ray step under the same "
                                 "source rule (with_repack: channel-last source copies rebuilt inside both steps -- the headline rule; constant_sources: "
                                 "rebuilt in neither; zero_copy_sources: sources handed over channel-last, ops.ChannelLastSources, read in place); no collective is in either figure (rendering needs none; the gather of 80 KB of outputs is ignored); "
@@ -760,6 +879,19 @@ def main():
                                  "counts the MLP's flops only -- the kernel-only figure is two_kernel_pass.roofline"
                                  if args.precision == "bf16x3_fused" else ""))
                         if terms == 3 else "plain bf16: NOT within the 1e-4 parity bar, see parity_vs_f32")
+            if terms == 3:
+                # what the three-MFMA formulation reaches on an MI355X board with this kernel's own instruction mix and nothing else (no gather, no
+                # encoding, no DMA, no barrier): measured by scripts/micro/headline_ceiling.hip on one box next to the kernel, READ BACK from the
+                # committed artifact (the micro-benchmark takes 30 s of its own; it is not run here)
+                cpath = os.path.join(ROOT, "profiles", "r05_headline_ceiling.json")
+                if os.path.exists(cpath):
+                    with open(cpath) as f:
+                        ceil = json.load(f)["ceiling_executed_tflops"]
+                    roof.update(frac_of_measured_ceiling=ex / ceil["iii_plus_valu_5_per_mfma"],
+                                measured_ceiling={"executed_tflops": ceil["iii_plus_valu_5_per_mfma"], "with_one_barrier_per_ring_slot": ceil["iv_plus_barrier_per_slot"],
+                                                  "bare_3_mfma_loop": ceil["i_bare_3mfma"], "as_frac_of_peak_algorithmic": ceil["iii_plus_valu_5_per_mfma"] / 3.003 / peak,
+                                                  "source": "profiles/r05_headline_ceiling.json (.md): power-limited loops with the kernel's instruction ratios, "
+                                                            "same geometry, measured on an earlier box of this round; not measured in this run"})
         line = {
             "metric": "rendered rays/sec (coarse+fine, 64+128 samples)",
             "value": global_rays * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,

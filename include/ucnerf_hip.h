@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UCNERF_ABI_VERSION 4
+#define UCNERF_ABI_VERSION 5
 
 #define UCNERF_OK 0
 #define UCNERF_EINVAL (-1)   /* bad argument (null pointer, unsupported size/config) */
@@ -46,7 +46,7 @@ const char* ucnerf_build_flags(void);
  * outputs are bit-identical either way).  The environment variable UCNERF_FUSED_TAIL=0, read at every call, switches that route off. */
 int64_t ucnerf_fused_tail_launches(void);
 /* 1 when a pass of n rays x S samples is of the size that takes that route on the current device (the other conditions are the caller's to know:
- * gather-fused precision, fp32 channel-last sources, derived coordinates, no max_blocks).  A host uses it to decide whether to hand the pass its ray
+ * gather-fused precision, fp32 channel-last sources, no max_blocks).  A host uses it to decide whether to hand the pass its ray
  * generation too (gen_rays / gen_depths): on the tail route the blocks generate their own rays at no measurable cost. */
 int32_t ucnerf_fused_tail_fits(int32_t n, int32_t S);
 /* Digest of the sources, headers and flags this binary was linked from (uc_nerf_amd/build.py: source_hash()): a host can tell a library
@@ -142,6 +142,35 @@ typedef struct {
 } ucnerf_sample_cascade_params;
 int ucnerf_sample_cascade(const ucnerf_sample_cascade_params* p, void* stream);
 
+/* a1 + a3 + a4 of the EVALUATION loop in one launch (ABI v5) -- utils/utils.py:600-739 (build_rays_test), called once per 1024-pixel chunk by
+ * train.py:251-256: rays through pixels grid_start .. grid_start + n - 1 of the flattened HxW grid (get_rays_mvs, isRandom=False), the three
+ * per-ray cascade ranges read from the stages' depth hypotheses at (row, col) // (4, 2, 1) (first and last plane), 3 x S/3 uniform depths
+ * sorted and stratified-jittered, the world points and their four normalised copies (get_ndc_coordinate).  Same values as ucnerf_ray_gen ->
+ * ucnerf_sample_cascade -> ucnerf_ndc_project, bit for bit.  The camera matrices and the scene range are read from DEVICE memory -- the caller
+ * holds them as device tensors, nothing is read back to the host per chunk. */
+typedef struct {
+    int32_t n, S;              /* rays of the chunk; samples per ray (multiple of 3, <= 768) */
+    int32_t H, W, grid_start;
+    int32_t dv_d[3], dv_h[3], dv_w[3];   /* sizes of depth_values[k] */
+    const float* K;            /* [3,3] intrinsics of the rendered view (device) */
+    const float* c2w;          /* [>=3,4] camera-to-world of the rendered view (device, rows 4 floats apart) */
+    const float* w2c_ref;      /* [>=3,4] reference view (device) */
+    const float* K_ref;        /* [3,3] (device) */
+    const float* near_far_ref; /* [2] scene range (near, far) (device) */
+    const float* depth_values[3];  /* [D_k,h_k,w_k] hypotheses of cascade stage k + 1 (device) */
+    const float* t_rand;       /* [n,S] uniform draws, or NULL for no jitter */
+    float* rays_o;             /* [3] out or NULL: c2w[:3,3] */
+    float* rays_d;             /* [n,3] out */
+    float* near_far;           /* [n,6] out or NULL: (near_1, far_1, near_2, far_2, near_3, far_3) per ray */
+    float* z;                  /* [n,S] out */
+    float* pts;                /* [n,S,3] out */
+    float* ndc1;               /* [n,S,3] out: stage copies and the scene-normalised copy */
+    float* ndc2;
+    float* ndc3;
+    float* ndc;
+} ucnerf_build_rays_test_params;
+int ucnerf_build_rays_test(const ucnerf_build_rays_test_params* p, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * a4  world -> reference-view normalised coordinates -- utils/utils.py:323-373 (get_ndc_coordinate).
  *     p_cam = p R^T + T; |z|<1e-4 -> 1e-4; q = p_cam K^T; xy = q.xy/q.z / inv_scale;
@@ -179,6 +208,30 @@ typedef struct {
     float* out;           /* [m, 3 + 6*n_freqs] */
 } ucnerf_embed_params;
 int ucnerf_embed(const ucnerf_embed_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ABI v5: the gather sources in the layout the fast kernels read ("channel-last": one voxel / pixel = contiguous channels), EACH IN ITS OWN
+ * ALLOCATION -- what a producer's convolutions write when they run in torch's channels_last / channels_last_3d memory formats
+ * (network/mvs_models.py:624-646: cost_regularization -> volume_feature_no_ref per stage, FeatureNet -> img_feats; new tensors every training
+ * step, train.py:136-163), read IN PLACE.  ucnerf_gather_repack builds the same layouts from the reference's channel-major tensors for the
+ * sources that are not handed over this way.
+ *   vol[k]    [D,h,w,8]           = the memory of a [1,8,D,h,w] tensor in channels_last_3d            16-byte aligned
+ *   img_feat  [V,H,W,8]           = a [V,8,H,W] tensor in channels_last                                16-byte aligned
+ *   imgs      [V,H,W,rgb_stride]  rgb_stride = 3 (a [V,3,H,W] tensor in channels_last; 4-byte aligned) or 4 (r,g,b,pad: what the repack writes)
+ * bf16 = 1: every array holds bf16 instead of fp32 (rgb_stride must be 4; SURVEY.md 8 configs[4] "bf16 features").
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* vol[3];
+    const void* img_feat;
+    const void* imgs;
+    int32_t rgb_stride;
+    int32_t bf16;
+} ucnerf_cl_sources;
+/* Gradients of the differentiable ones among them, in the same layouts (fp32, 16-byte aligned, ACCUMULATED into: zero them first); any may be NULL */
+typedef struct {
+    float* vol[3];      /* [D,h,w,8] */
+    float* img_feat;    /* [V,H,W,8] */
+} ucnerf_cl_grads;
 
 /* ------------------------------------------------------------------------------------------------
  * a7  feature gather -- network/renderer.py:177-212 (gen_pts_feats) = utils/utils.py:833-893
@@ -226,11 +279,10 @@ typedef struct {
                                         lanes add the 32 contiguous bytes of one corner instead of eight scattered
                                         cache lines) and added to g_vol / g_img_feat by a transposing pass.  Contents
                                         are overwritten.  NULL: atomics go straight to the channel-major outputs. */
-    float* g_sources_cl;             /* ABI v4, optional: a gradient buffer in the CHANNEL-LAST SOURCE LAYOUT (that of ucnerf_gather_repack, fp32:
-                                        [D,h,w,8] per volume, then [V,H,W,12] pixels = (r,g,b,f0..f7,pad)), 16-byte aligned.  The volume and
-                                        image-feature gradients are ACCUMULATED there (zero it first; the r,g,b,pad slots are never written) and
-                                        g_vol / g_img_feat / scratch are ignored: no scratch, no memset, no transposing pass -- for callers whose
-                                        sources already live channel-last (ucnerf_render_params.sources_cl handed over zero-copy) */
+    ucnerf_cl_grads g_cl;            /* ABI v5, per source: a gradient array in the CHANNEL-LAST layout of ucnerf_cl_sources.  A source whose entry is
+                                        set has its gradient ACCUMULATED there (zero it first) and its g_vol[k] / g_img_feat entry is ignored: no
+                                        scratch, no memset, no transposing pass for it -- for callers whose sources live channel-last
+                                        (ucnerf_render_params.cl handed over in place).  Entries left NULL take the route above. */
 } ucnerf_feat_gather_bwd_params;
 int ucnerf_feat_gather_bwd(const ucnerf_feat_gather_bwd_params* p, void* stream);
 int64_t ucnerf_feat_gather_bwd_scratch_floats(const ucnerf_feat_gather_params* p);
@@ -490,11 +542,15 @@ typedef struct {
     const float* w2cs;         /* [V,12] source views */
     const float* intrinsics;   /* [V,9] */
     const float* wstream;
-    const float* sources_cl;   /* optional: channel-last copies of the sources (ucnerf_gather_repack) -- or the sources THEMSELVES, for a producer
-                                  that writes that layout (zero copy: vol / imgs / img_feat may then be NULL).  When given and
-                                  `feats` is NULL, the pass uses the fast gather that reads them and derives the
+    ucnerf_cl_sources cl;      /* optional (ABI v5; all five pointers or none): the sources channel-last, each in its own allocation -- handed over
+                                  in place by a producer that writes that layout (vol / imgs / img_feat above may then be NULL) and / or built by
+                                  ucnerf_gather_repack.  When given and `feats` is NULL, the pass uses the fast gather that reads them and derives the
                                   sample coordinates itself; vol/imgs/img_feat are then not touched.  REQUIRED when
-                                  cfg.precision == 3 (the gather then runs inside the MLP kernel: no feature buffer) */
+                                  cfg.precision == 3 (the gather then runs inside the MLP kernel: no feature buffer).
+                                  cl.bf16 = 1 (bf16 copies, ucnerf_gather_repack with the same flag: 16-byte voxels and feature pixels, 8-byte colours,
+                                  values rounded to nearest even) -- SURVEY.md 8 configs[4] "fp32 MLP / bf16 features": half the bytes of every
+                                  gather corner, features within bf16 rounding of the fp32 sources'.  Forward only reads differ; the backward
+                                  accumulates source gradients in fp32 as before.  With cfg.precision == 3: derived coordinates only */
     /* workspace: ucnerf_render_workspace_floats(n, S, V) floats */
     float* workspace;
     /* outputs */
@@ -527,10 +583,6 @@ typedef struct {
     int32_t feats_tiled;       /* layout of `feats` when it is kept: 0 row-major [n*S,F]; 1 the MLP's tile layout [ceil(n*S/32)][F][32]
                                   (ceil(n*S/32)*32*F floats) -- what the training forward reads three times faster (coalesced 128-byte
                                   rows instead of 4-byte pieces of 388-byte rows) and ucnerf_render_fused_bwd (bwd_mode 0) accepts */
-    int32_t sources_cl_bf16;   /* 1: `sources_cl` holds bf16 copies (ucnerf_gather_repack with the same flag: 16-byte voxels, 24-byte pixels,
-                                  values rounded to nearest even) -- SURVEY.md 8 configs[4] "fp32 MLP / bf16 features": half the bytes of every
-                                  gather corner, features within bf16 rounding of the fp32 sources'.  Forward only reads differ; the backward
-                                  accumulates source gradients in fp32 as before.  With cfg.precision == 3: derived coordinates only */
     int32_t train_bwd_mode;    /* with train_workspace: the bwd_mode of the coming ucnerf_render_fused_bwd call (it fixes the format the
                                   activations are kept in, see ucnerf_mlp_fwd_train) */
     /* ABI v4: the launches around a coarse pass folded into it (data/ray_utils.py:199-224 chains them; at 512 rays per GPU each ~5-us launch
@@ -546,11 +598,13 @@ typedef struct {
 } ucnerf_render_params;
 int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream);
-/* Channel-last repack of the gather sources named in `p` (vol[3] -> [D,h,w,8] each, imgs + img_feat ->
- * [V,H,W,12] = (r,g,b,f0..f7,0); fp32, or bf16 when p->sources_cl_bf16) into `dst` (ucnerf_gather_repack_floats(p) floats, 16-byte aligned).  Redo it
- * whenever the sources change (once per image in evaluation, once per step in training): ~150 MB of traffic. */
+/* Channel-last repack of the gather sources named in `p` (vol[3] -> [D,h,w,8] each, img_feat -> [V,H,W,8], imgs -> [V,H,W,4] = (r,g,b,0); fp32, or
+ * bf16 when p->cl.bf16) into `dst` (ucnerf_gather_repack_floats(p) floats, 16-byte aligned), and the pointers of the result into `out` (rgb_stride 4,
+ * bf16 as asked).  PER SOURCE: an entry of p->cl that is already set -- a source handed over in place -- is kept as it is (copied to `out`, nothing
+ * read or written for it, no room taken in dst; with p->cl.bf16 the in-place entries must hold bf16 too); its reference-layout pointer may be NULL.
+ * Redo it whenever the repacked sources change (once per image in evaluation, once per step in training): ~150 MB of traffic for all five. */
 int64_t ucnerf_gather_repack_floats(const ucnerf_render_params* p);
-int ucnerf_gather_repack(const ucnerf_render_params* p, float* dst, void* stream);
+int ucnerf_gather_repack(const ucnerf_render_params* p, float* dst, ucnerf_cl_sources* out, void* stream);
 
 /* Backward of one render pass: d(rgb_map, depth_map) -> d(parameters), d(volumes, img_feat, confidence).
  * fwd.raw and fwd.feats must point at the buffers the forward call filled (keep them); all g_* outputs are
@@ -569,8 +623,8 @@ typedef struct {
     int32_t saved_valid;           /* 1: the forward call was given this `workspace` as fwd.train_workspace (it kept the
                                       MLP activations there), so the backward does not repeat the network forward */
     int32_t bwd_mode;              /* ucnerf_mlp_bwd_params.bwd_mode */
-    float* g_sources_cl;           /* ABI v4, optional: ucnerf_feat_gather_bwd_params.g_sources_cl -- source gradients accumulated in the channel-last
-                                      source layout (g_vol / g_img_feat / gather_scratch are then ignored; g_conf as before) */
+    ucnerf_cl_grads g_cl;          /* ABI v5, per source: ucnerf_feat_gather_bwd_params.g_cl -- source gradients accumulated in the channel-last
+                                      layout of the in-place sources (that source's g_vol / g_img_feat entry is then ignored; g_conf as before) */
 } ucnerf_render_bwd_params;
 int64_t ucnerf_render_bwd_workspace_floats(int32_t n, int32_t S, int32_t V);
 int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* p, void* stream);

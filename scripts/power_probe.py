@@ -26,7 +26,20 @@ ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--tag", default="")
 args = ap.parse_args()
 
-HW = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+def _own_hwmon():
+    """hwmon directories of THE card torch's device 0 is (matched by PCI bus id: the host's other cards run other people's jobs); all cards when
+    the id cannot be matched."""
+    every = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+    try:
+        pr = torch.cuda.get_device_properties(0)
+        bus = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        own = [h for h in every if bus in os.path.realpath(h.split("/hwmon/")[0]).lower()]
+        return own or every
+    except Exception:      # noqa: BLE001
+        return every
+
+
+HW = _own_hwmon()
 
 
 def rd(path):

@@ -242,7 +242,7 @@ def test_bf16_source_copies_equal_fp32_copies_of_bf16_rounded_sources_and_stay_a
     full = {k: full[k].clone() for k in ("rgb", "depth", "acc")}
     r16 = CoarseFineRenderer(scene_to(scene, d), flat, 64, 128, precision=precision, sources_bf16=True)
     got = r16.render(xs_d, ys_d)
-    assert r16.pass_.p.sources_cl_bf16 == 1
+    assert r16.pass_.p.cl.bf16 == 1
     got = {k: got[k].clone() for k in ("rgb", "depth", "acc")}
     ref = CoarseFineRenderer(scene_to(_rounded(scene), d), flat, 64, 128, precision=precision).render(xs_d, ys_d)
     for k in ("rgb", "depth", "acc"):

@@ -1,0 +1,335 @@
+"""Round 5 on the GPU.
+
+  * ABI v5: gather sources channel-last, EACH IN ITS OWN ALLOCATION -- the tensors actual torch convolutions write in the channels_last /
+    channels_last_3d memory formats (the producers of network/mvs_models.py:624-646, new every step in train.py:136-163) -- read in place,
+    recognised per source by stride; forward bit-identical to the repacked route, gradients returned with the inputs' strides;
+  * round 4's advisor findings: a graphed step replays on NEW source values; FlatAdam leaves frozen tensors alone; the "versions" weight cache
+    sees FlatAdam steps.
+"""
+import types
+
+import pytest
+import torch
+
+from conftest import load_golden
+from test_hip_configs import dev
+from test_hip_round4 import _call, _mods, _net, _qfn
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_strides(a, b):
+    """Equal strides on every dimension that has more than one element (torch leaves the others arbitrary)."""
+    return all(n == 1 or x == y for n, x, y in zip(a.shape, a.stride(), b.stride()))
+DEV = "cuda:0"
+
+
+def _conv_sources(scene, seed=0):
+    """Sources as nn.Conv3d / nn.Conv2d running in channels_last(_3d) write them on this GPU (what bench.py's conv_produced_sources does)."""
+    g = torch.Generator().manual_seed(seed)
+    c3 = torch.nn.Conv3d(8, 8, 3, padding=1).to(DEV).to(memory_format=torch.channels_last_3d)
+    c2 = torch.nn.Conv2d(8, 8, 3, padding=1).to(DEV).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for m in (c3, c2):
+            m.weight.copy_(dev(torch.randn(m.weight.shape, generator=g)) * 0.1)
+            m.bias.copy_(dev(torch.randn(m.bias.shape, generator=g)) * 0.1)
+        vols = [c3(v.contiguous(memory_format=torch.channels_last_3d)) for v in scene["vols"]]
+        feat = c2(scene["img_feat"][:, 0].contiguous(memory_format=torch.channels_last)).unsqueeze(1)
+        imgs = scene["imgs"][0].contiguous(memory_format=torch.channels_last).unsqueeze(0)
+    return vols, imgs, feat
+
+
+def _scene():
+    from uc_nerf_amd.synthetic import make_scene, scene_to
+    return scene_to(make_scene(seed=0), torch.device(DEV))
+
+
+def test_conv_outputs_in_channels_last_formats_are_read_in_place():
+    """What MIOpen really returns: a Conv3d in channels_last_3d writes [D,h,w,8] memory, a Conv2d in channels_last [V,H,W,8]; five separate
+    allocations; every one recognised and read in place -- no repack buffer exists -- and the render equals the repacked route of the same
+    values bit for bit on every kernel route (network/mvs_models.py:624-646, utils/utils.py:742-799,833-893)."""
+    from uc_nerf_amd import ops
+    from uc_nerf_amd.pipeline import CoarseFineRenderer, flat_params_of
+    from uc_nerf_amd.synthetic import init_ucnerf_state_dict, random_pixels
+    scene = _scene()
+    vols, imgs, feat = _conv_sources(scene)
+    for v in vols:
+        assert v.is_contiguous(memory_format=torch.channels_last_3d) and ops.cl_volume_view(v) is not None, v.stride()
+    assert ops.cl_img_feat_view(feat) is not None, feat.stride()
+    assert ops.cl_imgs_view(imgs) is not None and ops.cl_imgs_view(imgs)[1] == 3, imgs.stride()
+    assert len({t.untyped_storage().data_ptr() for t in vols + [imgs, feat]}) == 5
+    sd = init_ucnerf_state_dict(seed=0, n_src=6, sigma_scale=0.05, sigma_bias=0.05)
+    flat = flat_params_of(sd).to(DEV)
+    major = dict(scene, vols=[v.contiguous() for v in vols], imgs=imgs.contiguous(), img_feat=feat.contiguous())
+    for n in (512, 700, 2048):
+        xs, ys = random_pixels(n, 256, 320, seed=n)
+        noise = dev(torch.rand(n, 64, generator=torch.Generator().manual_seed(100)))
+        for prec in ("bf16x3_fused", "bf16x3", "f32"):
+            ra = CoarseFineRenderer(major, flat, 64, 128, precision=prec)
+            rb = CoarseFineRenderer(dict(scene, vols=vols, imgs=imgs, img_feat=feat), flat, 64, 128, precision=prec)
+            assert rb.src.zero_copy and rb.src.inplace == [True] * 5 and not any(ra.src.inplace)
+            a = ra.render(dev(xs), dev(ys), perturb=1.0, noise=noise)
+            b = rb.render(dev(xs), dev(ys), perturb=1.0, noise=noise)
+            assert rb.src._cl is None                                   # nothing was repacked
+            for k in ("rgb", "depth", "acc", "weights", "z_fine"):
+                assert torch.equal(a[k], b[k]), (n, prec, k)
+
+
+@pytest.mark.parametrize("which", [(True, False, True, False, True), (False, True, False, True, False), (True, True, True, True, False), (False, False, False, False, True)])
+def test_sources_are_recognised_one_by_one(which):
+    """Per source: the channel-last ones are read in place, the others repacked into a buffer that holds only them (ucnerf_gather_repack keeps the
+    entries of ucnerf_render_params.cl that are set); same bits as the all-repacked route.  Padded [V,H,W,4] colours are read in place too."""
+    from uc_nerf_amd import _lib as L
+    from uc_nerf_amd.pipeline import CoarseFineRenderer, flat_params_of
+    from uc_nerf_amd.synthetic import init_ucnerf_state_dict, random_pixels
+    scene = _scene()
+    vols, imgs, feat = _conv_sources(scene, seed=1)
+    mix_v = [v if w else v.contiguous() for v, w in zip(vols, which[:3])]
+    mix_f = feat if which[3] else feat.contiguous()
+    if which[4]:                                                                  # colours as padded 16-byte pixels
+        buf = torch.zeros(imgs.shape[1], 256, 320, 4, device=DEV)
+        buf[..., :3] = imgs[0].permute(0, 2, 3, 1)
+        mix_i = buf[..., :3].permute(0, 3, 1, 2).unsqueeze(0)
+    else:
+        mix_i = imgs.contiguous()
+    sd = init_ucnerf_state_dict(seed=0, n_src=6, sigma_scale=0.05, sigma_bias=0.05)
+    flat = flat_params_of(sd).to(DEV)
+    major = dict(scene, vols=[v.contiguous() for v in vols], imgs=imgs.contiguous(), img_feat=feat.contiguous())
+    xs, ys = random_pixels(600, 256, 320, seed=2)
+    for prec in ("bf16x3_fused", "f32"):
+        ra = CoarseFineRenderer(major, flat, 64, 128, precision=prec)
+        rb = CoarseFineRenderer(dict(scene, vols=mix_v, imgs=mix_i, img_feat=mix_f), flat, 64, 128, precision=prec)
+        assert rb.src.inplace == list(which) and not rb.src.zero_copy
+        assert not which[4] or rb.src.rgb_stride == 4
+        a, b = ra.render(dev(xs), dev(ys)), rb.render(dev(xs), dev(ys))
+        for k in ("rgb", "depth", "acc", "weights"):
+            assert torch.equal(a[k], b[k]), (prec, k)
+        # the repack buffer holds exactly the sources that are not in place
+        n_vox = [v.numel() for v in vols]
+        want = sum(n for n, w in zip(n_vox, which[:3]) if not w) + (0 if which[3] else feat.numel()) + (0 if which[4] else 4 * imgs.numel() // 3)
+        assert rb.src._cl.numel() == want
+        p = rb.pass_.p
+        for k in range(3):
+            assert (p.cl.vol[k] == mix_v[k].data_ptr()) == which[k]
+        assert (p.cl.img_feat == mix_f.data_ptr()) == which[3] and (p.cl.imgs == mix_i.data_ptr()) == which[4]
+    assert L.lib().ucnerf_abi_version() == 5
+
+
+@pytest.mark.parametrize("which", [(True,) * 4, (True, False, True, False), (False, True, False, True)])
+def test_training_through_conv_produced_sources(which, sd_v7):
+    """rendering() under autograd on sources that convolutions wrote channel-last (train.py:136-163): forward bit-identical to the channel-major
+    route; the volume / image-feature gradients arrive with the inputs' strides (accumulated channel-last by the gather backward: no scratch, no
+    transposing add for them) and equal the channel-major route's up to float-atomic order -- also when only some sources are channel-last."""
+    mods = _mods()
+    g = load_golden("g10_rendering")
+    qfn = _qfn(mods)
+    gen = torch.Generator().manual_seed(7)
+    r3, r1 = dev(torch.randn(g["z"].shape[0], 3, generator=gen)), dev(torch.randn(g["z"].shape[0], generator=gen))
+    c3 = torch.nn.Conv3d(8, 8, 3, padding=1).to(DEV).to(memory_format=torch.channels_last_3d)
+    c2 = torch.nn.Conv2d(8, 8, 3, padding=1).to(DEV).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        vols_cl = [c3(dev(g["vol%d" % k]).contiguous(memory_format=torch.channels_last_3d)) for k in (1, 2, 3)]
+        feat_cl = c2(dev(g["img_feat"])[:, 0].contiguous(memory_format=torch.channels_last)).unsqueeze(1)
+    seen = {}
+
+    def run(cl):
+        net = _net(mods, 7, sd_v7)
+        vols = [(v if (cl and w) else v.contiguous()).detach().requires_grad_(True) for v, w in zip(vols_cl, which[:3])]
+        img_feat = (feat_cl if (cl and which[3]) else feat_cl.contiguous()).detach().requires_grad_(True)
+        if cl:
+            img_feat.register_hook(lambda gr: seen.update(stride=gr.stride()))
+        conf = dev(g["conf"]).requires_grad_(True)
+        rgb, depth = _call(mods, g, net, qfn, vols=vols, img_feat=img_feat, conf=conf)
+        ((rgb * r3).sum() + (depth * r1).sum()).backward()
+        from uc_nerf_amd import dropin
+        return rgb.detach(), depth.detach(), vols, img_feat, conf, net, dropin.session_of(net)
+
+    rgb_a, d_a, vols_a, if_a, conf_a, net_a, _ = run(False)
+    rgb_b, d_b, vols_b, if_b, conf_b, net_b, sess = run(True)
+    assert sess.src.inplace[:4] == list(which)
+    assert torch.equal(rgb_a, rgb_b) and torch.equal(d_a, d_b)
+    for k, (v, w) in enumerate(zip(vols_b, vols_a)):
+        assert v.grad.shape == v.shape and _same_strides(v.grad, v), (k, v.grad.stride(), v.stride())
+        torch.testing.assert_close(v.grad, w.grad, atol=2e-5 * max(w.grad.abs().max().item(), 1e-6), rtol=1e-4)
+    assert all(n == 1 or a == b for n, a, b in zip(if_b.shape, seen["stride"], if_b.stride())), (seen["stride"], if_b.stride())
+    torch.testing.assert_close(if_b.grad, if_a.grad, atol=2e-5 * max(if_a.grad.abs().max().item(), 1e-6), rtol=1e-4)
+    torch.testing.assert_close(conf_b.grad, conf_a.grad, atol=2e-5 * max(conf_a.grad.abs().max().item(), 1e-6), rtol=1e-4)
+    for (name, p), q in zip(net_a.named_parameters(), net_b.parameters()):
+        if p.grad is None:
+            assert q.grad is None, name
+        else:
+            torch.testing.assert_close(q.grad, p.grad, atol=2e-5 * max(p.grad.abs().max().item(), 1e-6), rtol=1e-4, msg=lambda s_: name + ": " + s_)
+
+
+def test_frozen_sources_cost_no_gradient_buffer(sd_v7):
+    """need = all False for the heavy sources (a frozen MVS network, detached volumes): the backward allocates no source-gradient segment and hands the
+    gather backward no channel-last gradient array (round 4's advisor finding on the zero-copy route)."""
+    mods = _mods()
+    g = load_golden("g10_rendering")
+    qfn = _qfn(mods)
+    net = _net(mods, 7, sd_v7)
+    vols = [dev(g["vol%d" % k]).contiguous(memory_format=torch.channels_last_3d) for k in (1, 2, 3)]
+    torch.cuda.reset_peak_memory_stats()
+    rgb, depth = _call(mods, g, net, qfn, vols=vols)
+    base = torch.cuda.memory_allocated()
+    (rgb.sum() + depth.sum()).backward()
+    torch.cuda.synchronize()
+    assert all(v.grad is None for v in vols)
+    pool = sum(p.grad.numel() for p in net.parameters() if p.grad is not None)
+    assert pool > 0 and torch.cuda.max_memory_allocated() - base < 64 << 20        # (a source-gradient pool alone would be 72 MB on the bench scene; here the scene is tiny: the bound is on what the backward adds)
+
+
+# ---------------------------------------------------------------------------------------------- round 4's advisor findings
+def test_graphed_step_gathers_from_the_sources_of_the_replay(sd_v7):
+    """train_step.GraphedStep: new volumes / image features COPIED INTO the static source tensors between replays are what the replay trains on --
+    the capture records the source repack although the tensors' identity and version said "unchanged" while capturing.  Channel-last (in place)
+    sources need no repack at all.  Compared with the eager step on the same values."""
+    from uc_nerf_amd.flat import FlatAdam
+    from uc_nerf_amd.train_step import GraphedStep
+    mods = _mods()
+    g = load_golden("g10_rendering")
+    qfn = _qfn(mods)
+    gen = torch.Generator().manual_seed(5)
+    target = dev(torch.rand(g["z"].shape[0], 3, generator=gen))
+    V = g["V"]
+    args = types.SimpleNamespace(view_num=V, feat_dim=24 + 12 * (V - 1) + 1, img_downscale=1.0, use_color_volume=False, net_type="v2")
+    w2cs, Ks = dev(g["w2cs"]), dev(g["K"]).repeat(V, 1, 1)
+    ndc = {"stage1": dev(g["ndc1"]), "stage2": dev(g["ndc2"]), "stage3": dev(g["ndc3"]), "ndc": dev(g["ndc"])}
+    pts, z, rays_d, imgs, conf = dev(g["pts"]), dev(g["z"]), dev(g["rays_d"]), dev(g["imgs"]), dev(g["conf"])
+    new_vols = [dev(g["vol%d" % k]) * 0.5 + 0.1 for k in (1, 2, 3)]
+    new_feat = dev(g["img_feat"]) * 0.7 - 0.05
+
+    for channel_last in (False, True):
+        fmt3 = torch.channels_last_3d if channel_last else torch.contiguous_format
+        vols_e = [dev(g["vol%d" % k]).contiguous(memory_format=fmt3) for k in (1, 2, 3)]
+        vols_g = [v.clone(memory_format=torch.preserve_format) for v in vols_e]
+        feat_e, feat_g = dev(g["img_feat"]), dev(g["img_feat"])
+
+        def make(net, opt, vols, feat):
+            vf = {"stage%d" % (k + 1): {"volume_feature_no_ref": vols[k]} for k in range(3)}
+
+            def step():
+                opt.zero_grad(set_to_none=True)
+                rgb, depth = mods.renderer.rendering(args, {"w2cs": w2cs, "intrinsics": Ks}, pts, ndc, z, rays_d, vf, imgs, network_fn=net, img_feat=feat,
+                                                     network_query_fn=qfn, confidence=conf)
+                loss = torch.mean((rgb - target) ** 2) * 5.0 + 0.05 * torch.mean((depth - 2.0) ** 2)
+                loss.backward()
+                opt.step()
+                return loss
+            return step
+
+        net_e, net_g = _net(mods, 7, sd_v7), _net(mods, 7, sd_v7)
+        step_e = make(net_e, FlatAdam(net_e, lr=5e-4), vols_e, feat_e)
+        graphed = GraphedStep(make(net_g, FlatAdam(net_g, lr=5e-4, capturable=True), vols_g, feat_g), warmup=2)
+        for _ in range(2):
+            step_e()
+        # a new batch of sources: written into the tensors both steps read
+        with torch.no_grad():
+            for dst_e, dst_g, src in zip(vols_e, vols_g, new_vols):
+                dst_e.copy_(src)
+                dst_g.copy_(src)
+            feat_e.copy_(new_feat)
+            feat_g.copy_(new_feat)
+        for _ in range(3):
+            le, lg = step_e(), graphed.replay()
+            assert abs(lg.item() - le.item()) < 1e-4 * max(1.0, abs(le.item())), channel_last
+            for (name, a), b in zip(net_e.named_parameters(), net_g.parameters()):
+                torch.testing.assert_close(a, b, atol=2e-5, rtol=0, msg=lambda s_: name + ": " + s_)
+
+
+def test_flat_adam_leaves_frozen_tensors_alone(sd_v7):
+    """A partly frozen network (requires_grad = False on some tensors) through the REAL backward: the kernels write a weight gradient for every tensor
+    they reach, but the frozen segments of the flat gradient are zeroed before anybody can step or reduce them -- FlatAdam makes the step
+    torch.optim.Adam(grad_vars) makes (train.py:85-92 hands Adam whatever requires a gradient)."""
+    from uc_nerf_amd.flat import FlatAdam, FlatStore
+    mods = _mods()
+    g = load_golden("g10_rendering")
+    qfn = _qfn(mods)
+    nets = [_net(mods, 7, sd_v7), _net(mods, 7, sd_v7)]
+    frozen = ("pts_linears.0.", "pts_linears.3.", "views_linears.0.weight", "rgb_linear.bias")
+    for net in nets:
+        for name, p in net.named_parameters():
+            if any(t in name for t in frozen):
+                p.requires_grad_(False)
+    before = {n: p.detach().clone() for n, p in nets[0].named_parameters()}
+    opts = [torch.optim.Adam([p for p in nets[0].parameters() if p.requires_grad], lr=1e-3), FlatAdam(nets[1], lr=1e-3)]
+    for _ in range(3):
+        for net, opt in zip(nets, opts):
+            opt.zero_grad(set_to_none=True)
+            rgb, depth = _call(mods, g, net, qfn)
+            (rgb.sum() + 0.3 * depth.sum()).backward()
+            opt.step()
+    assert FlatStore.of(nets[1]).flat_grad() is not None                       # (the flat route was taken)
+    moved = 0
+    for (name, a), b in zip(nets[0].named_parameters(), nets[1].parameters()):
+        if any(t in name for t in frozen):
+            assert torch.equal(b, before[name]) and torch.equal(a, before[name]), name
+        else:
+            torch.testing.assert_close(b, a, atol=1e-6, rtol=1e-5, msg=lambda s_: name + ": " + s_)
+            moved += int(not torch.equal(a, before[name]))
+    assert moved >= 20
+
+
+def test_versions_weight_cache_sees_flat_adam_steps(sd_v7):
+    """set_weight_cache("versions"): FlatAdam steps a Parameter that shares the flat buffer's storage and version counter, not the per-tensor ones;
+    the cache key includes the buffer's own counter, so an evaluation call after a step renders with the new weights."""
+    import uc_nerf_amd
+    from uc_nerf_amd.flat import FlatAdam
+    mods = _mods()
+    g = load_golden("g10_rendering")
+    qfn = _qfn(mods)
+    net = _net(mods, 7, sd_v7)
+    opt = FlatAdam(net, lr=1e-2)
+    uc_nerf_amd.set_weight_cache("versions")
+    try:
+        with torch.no_grad():
+            r0, _ = _call(mods, g, net, qfn)
+            r0b, _ = _call(mods, g, net, qfn)
+        assert torch.equal(r0, r0b)
+        opt.zero_grad(set_to_none=True)
+        rgb, depth = _call(mods, g, net, qfn)
+        (rgb.sum() + depth.sum()).backward()
+        opt.step()
+        with torch.no_grad():
+            r1, _ = _call(mods, g, net, qfn)
+        uc_nerf_amd.set_weight_cache("verify")
+        with torch.no_grad():
+            r1v, _ = _call(mods, g, net, qfn)
+        assert torch.equal(r1, r1v) and (r1 - r0).abs().max() > 1e-4
+    finally:
+        uc_nerf_amd.set_weight_cache("verify")
+
+
+# ---------------------------------------------------------------------------------------------- the evaluation loop's ray builder in one launch
+@pytest.mark.parametrize("chunk_idx,S", [(0, 90), (7, 90), (79, 90), (3, 30), (11, 192)])
+def test_build_rays_test_in_one_launch_equals_the_three_launches(chunk_idx, S):
+    """ucnerf_build_rays_test (utils/utils.py:600-739 in one launch, matrices read from device memory) against the composition it replaces --
+    ucnerf_ray_gen (grid mode) -> torch indexing of the depth hypotheses -> ucnerf_sample_cascade -> ucnerf_ndc_project -- bit for bit."""
+    from uc_nerf_amd import ops
+    from uc_nerf_amd.synthetic import cascade_outputs
+    from uc_nerf_amd.utils import utils as U
+    scene = _scene()
+    outputs = cascade_outputs(scene)
+    H, W, chunk = scene["H"], scene["W"], 1024
+    start = chunk_idx * chunk
+    n = min(chunk, H * W - start)
+    t_rand = dev(torch.rand(n, S, generator=torch.Generator().manual_seed(chunk_idx)))
+    nf_ref = torch.tensor([scene["near"], scene["far"]], device=DEV)
+    got = ops.build_rays_test(H, W, start, n, S, scene["K"], scene["c2w"], scene["w2cs"][0], scene["intrinsics"][0], nf_ref,
+                              [outputs["stage%d" % k]["depth_values"] for k in (1, 2, 3)], t_rand, want_ranges=True)
+    rays_d, _, pix = ops.ray_gen(scene["K"], scene["c2w"], H=H, W=W, grid_start=start, n=n, device=torch.device(DEV), want_pix=True)
+    ranges = U._stage_ranges(outputs, pix.long())
+    z, pts = ops.sample_cascade(ranges, S, t_rand, scene["c2w"][:3, 3].contiguous(), rays_d)
+    ndc = ops.ndc_project(pts, scene["w2cs"][0], scene["intrinsics"][0], [W - 1, H - 1], U._near_far_dict(ranges, S, scene["near"], scene["far"]))
+    assert torch.equal(got["rays_d"], rays_d) and torch.equal(got["ranges"], ranges) and torch.equal(got["z"], z) and torch.equal(got["pts"], pts)
+    for k in ("stage1", "stage2", "stage3", "ndc"):
+        assert torch.equal(got[k], ndc[k]), k
+    assert torch.equal(got["rays_o"], scene["c2w"][:3, 3])
+    # ... and through the mirror of the reference's function: same tuple, same draws
+    torch.manual_seed(3)
+    a = U.build_rays_test(H, W, scene["c2w"], scene["w2cs"][0], scene["intrinsics"][0], nf_ref.view(1, 2), nf_ref, S, chunk=chunk, idx=chunk_idx, outputs=outputs)
+    torch.manual_seed(3)
+    t2 = torch.rand((n, S), device=DEV)
+    b = ops.build_rays_test(H, W, start, n, S, scene["K"], scene["c2w"], scene["w2cs"][0], scene["intrinsics"][0], nf_ref, [outputs["stage%d" % k]["depth_values"] for k in (1, 2, 3)], t2)
+    assert torch.equal(a[0], b["pts"]) and torch.equal(a[1], b["rays_d"]) and torch.equal(a[3], b["z"]) and tuple(a[4].shape) == (n, 3)
+    assert all(torch.equal(a[2][k], b[k]) for k in ("stage1", "stage2", "stage3", "ndc")) and a[5]["pad"] == 0

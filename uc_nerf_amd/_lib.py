@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UCNERF_LIB") or os.path.join(_HERE, "libucnerf_hip.so")   # override: A/B builds
 
-ABI_VERSION = 4    # UCNERF_ABI_VERSION of include/ucnerf_hip.h this binding mirrors
+ABI_VERSION = 5    # UCNERF_ABI_VERSION of include/ucnerf_hip.h this binding mirrors
 
 fp = C.POINTER(C.c_float)
 i32 = C.c_int32
@@ -49,6 +49,12 @@ class NdcProjectParams(C.Structure):
                 ("out_stage3", vp), ("out_ndc", vp)]
 
 
+class BuildRaysTestParams(C.Structure):
+    _fields_ = [("n", i32), ("S", i32), ("H", i32), ("W", i32), ("grid_start", i32), ("dv_d", i32 * 3), ("dv_h", i32 * 3), ("dv_w", i32 * 3),
+                ("K", vp), ("c2w", vp), ("w2c_ref", vp), ("K_ref", vp), ("near_far_ref", vp), ("depth_values", vp * 3), ("t_rand", vp),
+                ("rays_o", vp), ("rays_d", vp), ("near_far", vp), ("z", vp), ("pts", vp), ("ndc1", vp), ("ndc2", vp), ("ndc3", vp), ("ndc", vp)]
+
+
 class EmbedParams(C.Structure):
     _fields_ = [("m", i32), ("n_freqs", i32), ("layout", i32), ("x", vp), ("out", vp)]
 
@@ -60,9 +66,18 @@ class FeatGatherParams(C.Structure):
                 ("feats", vp), ("u_out", vp)]
 
 
+class ClSources(C.Structure):
+    """ucnerf_cl_sources (ABI v5): the gather sources channel-last, each in its own allocation."""
+    _fields_ = [("vol", vp * 3), ("img_feat", vp), ("imgs", vp), ("rgb_stride", i32), ("bf16", i32)]
+
+
+class ClGrads(C.Structure):
+    _fields_ = [("vol", vp * 3), ("img_feat", vp)]
+
+
 class FeatGatherBwdParams(C.Structure):
     _fields_ = [("fwd", FeatGatherParams), ("g_feats", vp), ("g_vol", vp * 3), ("g_conf", vp), ("g_img_feat", vp),
-                ("scratch", vp), ("g_sources_cl", vp)]
+                ("scratch", vp), ("g_cl", ClGrads)]
 
 
 class MlpConfig(C.Structure):
@@ -125,17 +140,17 @@ class RenderParams(C.Structure):
                 ("rays_d", vp), ("z", vp), ("w2c_ref", f32 * 12), ("K_ref", f32 * 9), ("w2c_dir", f32 * 12),
                 ("near", f32), ("far", f32), ("near_far", vp), ("H", i32), ("W", i32), ("vol_d", i32 * 3),
                 ("vol_h", i32 * 3), ("vol_w", i32 * 3), ("vol", vp * 3), ("conf", vp), ("imgs", vp), ("img_feat", vp),
-                ("w2cs", vp), ("intrinsics", vp), ("wstream", vp), ("sources_cl", vp), ("workspace", vp), ("rgb_map", vp),
+                ("w2cs", vp), ("intrinsics", vp), ("wstream", vp), ("cl", ClSources), ("workspace", vp), ("rgb_map", vp),
                 ("depth_map", vp), ("acc_map", vp), ("weights", vp), ("var", vp), ("raw", vp), ("feats", vp),
                 ("ev_mlp_start", vp), ("ev_mlp_stop", vp), ("train_workspace", vp), ("dir_feat", vp), ("u_sampled", vp),
-                ("wu_map", vp), ("pts_in", vp), ("ndc1_in", vp), ("ndc2_in", vp), ("ndc3_in", vp), ("ndc_in", vp), ("feats_tiled", i32), ("sources_cl_bf16", i32), ("train_bwd_mode", i32),
+                ("wu_map", vp), ("pts_in", vp), ("ndc1_in", vp), ("ndc2_in", vp), ("ndc3_in", vp), ("ndc_in", vp), ("feats_tiled", i32), ("train_bwd_mode", i32),
                 ("resample", vp), ("gen_rays", vp), ("gen_depths", vp)]
 
 
 class RenderBwdParams(C.Structure):
     _fields_ = [("fwd", RenderParams), ("g_rgb", vp), ("g_depth", vp), ("flat_params", vp), ("g_flat", vp),
                 ("g_vol", vp * 3), ("g_conf", vp), ("g_img_feat", vp), ("workspace", vp), ("gather_scratch", vp),
-                ("saved_valid", i32), ("bwd_mode", i32), ("g_sources_cl", vp)]
+                ("saved_valid", i32), ("bwd_mode", i32), ("g_cl", ClGrads)]
 
 
 STRUCTS = {
@@ -150,6 +165,7 @@ STRUCTS = {
     "ucnerf_merge_rows_params": MergeRowsParams,
     "ucnerf_cost_volume_params": CostVolumeParams, "ucnerf_depth_regress_params": DepthRegressParams,
     "ucnerf_cost_volume_bwd_params": CostVolumeBwdParams, "ucnerf_depth_regress_bwd_params": DepthRegressBwdParams,
+    "ucnerf_cl_sources": ClSources, "ucnerf_cl_grads": ClGrads, "ucnerf_build_rays_test_params": BuildRaysTestParams,
 }
 
 # every symbol include/ucnerf_hip.h declares: name -> (restype, argtypes)
@@ -174,6 +190,7 @@ SYMBOLS = {
     "ucnerf_ray_gen_sample": (C.c_int, [_P, _P, _P]),
     "ucnerf_sample_cascade": (C.c_int, [_P, _P]),
     "ucnerf_ndc_project": (C.c_int, [_P, _P]),
+    "ucnerf_build_rays_test": (C.c_int, [_P, _P]),
     "ucnerf_embed": (C.c_int, [_P, _P]),
     "ucnerf_feat_gather_fwd": (C.c_int, [_P, _P]),
     "ucnerf_feat_gather_bwd": (C.c_int, [_P, _P]),
@@ -201,7 +218,7 @@ SYMBOLS = {
     "ucnerf_render_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "ucnerf_render_fused_fwd": (C.c_int, [_P, _P]),
     "ucnerf_gather_repack_floats": (C.c_int64, [_P]),
-    "ucnerf_gather_repack": (C.c_int, [_P, _P, _P]),
+    "ucnerf_gather_repack": (C.c_int, [_P, _P, _P, _P]),
     "ucnerf_render_bwd_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "ucnerf_render_fused_bwd": (C.c_int, [_P, _P]),
 }

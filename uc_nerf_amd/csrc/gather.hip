@@ -193,15 +193,14 @@ __global__ void __launch_bounds__(256) feat_gather_bwd_kernel(ucnerf_feat_gather
 
 // ---- channel-last accumulation (scratch given): thread = (sample, channel); the eight lanes of a sample add the 32
 // contiguous bytes of one corner, so an atomic wave-instruction touches 8 cache lines instead of 64.
-// `pix`: floats per pixel of the image-feature region, `pix0`: where a pixel's eight feature gradients start -- (8, 0) in the scratch buffer,
-// (12, 3) in a gradient buffer that has the channel-last SOURCE layout (pixels = r,g,b,f0..f7,pad: ucnerf_feat_gather_bwd_params.g_sources_cl)
-struct ScratchLayout { size_t vol[3], img, total; int pix, pix0; };
-__host__ __device__ inline ScratchLayout scratch_layout(const ucnerf_feat_gather_params& p, bool source_layout = false) {
+// A source whose gradient array is handed over channel-last (ucnerf_feat_gather_bwd_params.g_cl: the layouts of ucnerf_cl_sources) is accumulated
+// THERE instead of in its piece of the scratch buffer -- same kernel, another base pointer.
+struct ScratchLayout { size_t vol[3], img, total; };
+__host__ __device__ inline ScratchLayout scratch_layout(const ucnerf_feat_gather_params& p) {
     ScratchLayout L;
     size_t o = 0;
     for (int k = 0; k < 3; ++k) { L.vol[k] = o; o += 8 * (size_t)p.vol_d[k] * p.vol_h[k] * p.vol_w[k]; }
-    L.pix = source_layout ? 12 : 8; L.pix0 = source_layout ? 3 : 0;
-    L.img = o; o += (size_t)L.pix * p.V * p.H * p.W;
+    L.img = o; o += (size_t)8 * p.V * p.H * p.W;
     L.total = o;
     return L;
 }
@@ -240,12 +239,10 @@ __global__ void __launch_bounds__(256) feat_gather_bwd_cl_kernel(ucnerf_feat_gat
     const int F = 24 + 12 * p.V + 1;
     if (p.unit_mask && !((p.unit_mask >> unit) & 1)) return;            // (uniform per block)
     const float* gf = bp.g_feats + (size_t)s * F;
-    const bool to_sources = bp.g_sources_cl != nullptr;                 // accumulate straight into a gradient buffer in the channel-last source layout
-    float* const acc_buf = to_sources ? bp.g_sources_cl : bp.scratch;
-    const ScratchLayout L = scratch_layout(p, to_sources);
+    const ScratchLayout L = scratch_layout(p);
     if (unit < 3) {
-        if (!to_sources && !bp.g_vol[unit]) return;
-        float* gv = acc_buf + L.vol[unit] + c;
+        if (!bp.g_cl.vol[unit] && !bp.g_vol[unit]) return;
+        float* gv = (bp.g_cl.vol[unit] ? bp.g_cl.vol[unit] : bp.scratch + L.vol[unit]) + c;
         const float* g = (unit == 0 ? p.ndc1 : unit == 1 ? p.ndc2 : p.ndc3) + 3 * (size_t)s;
         const int D = p.vol_d[unit], h = p.vol_h[unit], w = p.vol_w[unit];
         const Lerp ax = axis(g[0] * 2.f - 1.0f, w, false), ay = axis(g[1] * 2.f - 1.0f, h, false),
@@ -265,19 +262,18 @@ __global__ void __launch_bounds__(256) feat_gather_bwd_cl_kernel(ucnerf_feat_gat
         run_atomic_add<8>(gv, dead | (8 * (o11 + ax.i0)), gc * (w11 * ax.w0), sl);
         run_atomic_add<8>(gv, dead | (8 * (o11 + ax.i1)), gc * (w11 * ax.w1), sl);
     } else {
-        if (!to_sources && !bp.g_img_feat) return;
+        if (!bp.g_cl.img_feat && !bp.g_img_feat) return;
         const int v = unit - 4;
         float gx, gy;
         project_view(p, v, s, &gx, &gy);
         const Lerp ax = axis(gx, p.W, true), ay = axis(gy, p.H, true);
         const size_t hw = (size_t)p.H * p.W;
         const int o00 = ay.i0 * p.W + ax.i0, o01 = ay.i0 * p.W + ax.i1, o10 = ay.i1 * p.W + ax.i0, o11 = ay.i1 * p.W + ax.i1;
-        const int ps = L.pix;
-        float* ft = acc_buf + L.img + (size_t)ps * v * hw + L.pix0 + c;
+        float* ft = (bp.g_cl.img_feat ? bp.g_cl.img_feat : bp.scratch + L.img) + (size_t)8 * v * hw + c;
         const float gc = live ? gf[24 + 4 * p.V + 8 * v + c] : 0.f;
         const int dead = live ? 0 : -1;
-        run_atomic_add<8>(ft, dead | (ps * o00), gc * (ay.w0 * ax.w0), sl); run_atomic_add<8>(ft, dead | (ps * o01), gc * (ay.w0 * ax.w1), sl);
-        run_atomic_add<8>(ft, dead | (ps * o10), gc * (ay.w1 * ax.w0), sl); run_atomic_add<8>(ft, dead | (ps * o11), gc * (ay.w1 * ax.w1), sl);
+        run_atomic_add<8>(ft, dead | (8 * o00), gc * (ay.w0 * ax.w0), sl); run_atomic_add<8>(ft, dead | (8 * o01), gc * (ay.w0 * ax.w1), sl);
+        run_atomic_add<8>(ft, dead | (8 * o10), gc * (ay.w1 * ax.w0), sl); run_atomic_add<8>(ft, dead | (8 * o11), gc * (ay.w1 * ax.w1), sl);
     }
 }
 
@@ -346,23 +342,32 @@ int ucnerf_feat_gather_bwd(const ucnerf_feat_gather_bwd_params* bp, void* stream
     if (bp->fwd.m <= 0) return UCNERF_OK;
     hipStream_t st = (hipStream_t)stream;
     const ucnerf_feat_gather_params& f = bp->fwd;
-    if (bp->g_sources_cl) {      // ABI v4: the caller's gradients live in the channel-last source layout -- accumulate there, nothing else to do
-        UCNERF_REQUIRE(((uintptr_t)bp->g_sources_cl & 15) == 0, "feat_gather_bwd: g_sources_cl must be 16-byte aligned");
-        hipLaunchKernelGGL(feat_gather_bwd_cl_kernel, dim3(cdiv((long long)f.m * 8, 256), 3 + f.V), dim3(256), 0, st, *bp);
-        if (bp->g_conf && (8 & (f.unit_mask ? f.unit_mask : ~0)))
-            hipLaunchKernelGGL(conf_bwd_kernel, dim3(cdiv(f.m, 256)), dim3(256), 0, st, *bp);
-        return check_launch("feat_gather_bwd (channel-last gradients)");
-    }
-    if (!bp->scratch) {
+    // per source: accumulate channel-last straight into the caller's gradient array (g_cl, ABI v5), or in the scratch buffer and add transposed
+    const ucnerf_cl_grads& gc = bp->g_cl;
+    const bool any_cl = gc.vol[0] || gc.vol[1] || gc.vol[2] || gc.img_feat;
+    const bool via_scratch = (bp->g_vol[0] && !gc.vol[0]) || (bp->g_vol[1] && !gc.vol[1]) || (bp->g_vol[2] && !gc.vol[2]) || (bp->g_img_feat && !gc.img_feat);
+    if (!bp->scratch && !any_cl) {
         hipLaunchKernelGGL(feat_gather_bwd_kernel, dim3(cdiv(f.m, 256), 4 + f.V), dim3(256), 0, st, *bp);
         return check_launch("feat_gather_bwd");
     }
+    UCNERF_REQUIRE(!via_scratch || bp->scratch, "feat_gather_bwd: channel-last gradients for some sources only: the others need the scratch buffer");
     UCNERF_REQUIRE(((uintptr_t)bp->scratch & 15) == 0, "feat_gather_bwd: scratch must be 16-byte aligned");
+    UCNERF_REQUIRE((((uintptr_t)gc.vol[0] | (uintptr_t)gc.vol[1] | (uintptr_t)gc.vol[2] | (uintptr_t)gc.img_feat) & 15) == 0, "feat_gather_bwd: g_cl arrays must be 16-byte aligned");
     const ScratchLayout L = scratch_layout(f);
-    if (hipMemsetAsync(bp->scratch, 0, L.total * sizeof(float), st) != hipSuccess) return fail(UCNERF_EHIP, "feat_gather_bwd: memset failed");
+    if (via_scratch) {      // zero what the kernel accumulates in: the used pieces of the scratch buffer (contiguous when all four take this route)
+        const size_t vox[3] = {8 * (size_t)f.vol_d[0] * f.vol_h[0] * f.vol_w[0], 8 * (size_t)f.vol_d[1] * f.vol_h[1] * f.vol_w[1], 8 * (size_t)f.vol_d[2] * f.vol_h[2] * f.vol_w[2]};
+        if (!any_cl) {
+            if (hipMemsetAsync(bp->scratch, 0, L.total * sizeof(float), st) != hipSuccess) return fail(UCNERF_EHIP, "feat_gather_bwd: memset failed");
+        } else {
+            for (int k = 0; k < 3; ++k)
+                if (bp->g_vol[k] && !gc.vol[k] && hipMemsetAsync(bp->scratch + L.vol[k], 0, vox[k] * sizeof(float), st) != hipSuccess) return fail(UCNERF_EHIP, "feat_gather_bwd: memset failed");
+            if (bp->g_img_feat && !gc.img_feat && hipMemsetAsync(bp->scratch + L.img, 0, (L.total - L.img) * sizeof(float), st) != hipSuccess) return fail(UCNERF_EHIP, "feat_gather_bwd: memset failed");
+        }
+    }
     hipLaunchKernelGGL(feat_gather_bwd_cl_kernel, dim3(cdiv((long long)f.m * 8, 256), 3 + f.V), dim3(256), 0, st, *bp);
     if (bp->g_conf && (8 & (f.unit_mask ? f.unit_mask : ~0)))      // confidence: straight into the map (one channel), runs combined per wave
         hipLaunchKernelGGL(conf_bwd_kernel, dim3(cdiv(f.m, 256)), dim3(256), 0, st, *bp);
+    if (!via_scratch) return check_launch("feat_gather_bwd (channel-last gradients)");
     const int mask = f.unit_mask ? f.unit_mask : ~0;
     AddTransposedArgs at;
     at.count = 0;
@@ -372,8 +377,8 @@ int ucnerf_feat_gather_bwd(const ucnerf_feat_gather_bwd_params* bp, void* stream
         if (n > n_max) n_max = n;
     };
     for (int k = 0; k < 3; ++k)
-        if (bp->g_vol[k] && (mask & (1 << k))) add(bp->scratch + L.vol[k], bp->g_vol[k], (size_t)f.vol_d[k] * f.vol_h[k] * f.vol_w[k]);
-    if (bp->g_img_feat) {
+        if (bp->g_vol[k] && !gc.vol[k] && (mask & (1 << k))) add(bp->scratch + L.vol[k], bp->g_vol[k], (size_t)f.vol_d[k] * f.vol_h[k] * f.vol_w[k]);
+    if (bp->g_img_feat && !gc.img_feat) {
         const size_t hw = (size_t)f.H * f.W;
         for (int v = 0; v < f.V; ++v)
             if (mask & (1 << (4 + v))) add(bp->scratch + L.img + 8 * (size_t)v * hw, bp->g_img_feat + 8 * (size_t)v * hw, hw);

@@ -1,9 +1,12 @@
 // K3+K4 fast path for the fused render pass: the gather reads CHANNEL-LAST copies of its sources and computes its
 // own sample coordinates from (ray, depth), so nothing per-sample is read except z.
 //
-//   volumes  [8,D,h,w]  -> [D,h,w,8]      one 32-byte voxel = two float4 loads (was 8 scattered dwords)
-//   images + image features [V,3,H,W] + [V,8,H,W] -> [V,H,W,12] = (r,g,b,f0..f7,0): one 48-byte pixel
+//   volumes         [8,D,h,w] -> [D,h,w,8]      one 32-byte voxel = two float4 loads (was 8 scattered dwords)
+//   image features  [V,8,H,W] -> [V,H,W,8]      one 32-byte pixel
+//   images          [V,3,H,W] -> [V,H,W,3 | 4]  one 12-byte load (the repack pads to 16)
 //   confidence stays [H,W]
+// Every source is its own array (ABI v5, ucnerf_cl_sources): the memory of torch's channels_last / channels_last_3d tensors, read in place when
+// the producer writes them, built by repack_sources_kernel otherwise.
 // A trilinear footprint is 8 voxels in 4 x-adjacent pairs: 4 x 64 contiguous bytes instead of 64 scattered
 // 4-byte reads.  Semantics are those of gather.hip (grid_sample restated; reference lines cited there).
 #include "common.h"
@@ -15,8 +18,8 @@ namespace ucnerf {
 // One launch for all four sources (blockIdx.y = source; blocks past a source's size exit): the three volumes and the
 // image stack are 5-13 us of copying each, so four launches were mostly launch latency.
 struct RepackArgs {
-    const float* vol[3]; float4* vol_dst[3]; size_t n_vox[3];
-    const float* imgs; const float* feat; float4* img_dst; int V; size_t hw;
+    const float* vol[3]; float4* vol_dst[3]; size_t n_vox[3];       // (a source with a null destination is skipped: it is read in place)
+    const float* feat; float4* feat_dst; const float* imgs; float4* col_dst; int V; size_t hw;
 };
 
 // two floats -> one dword of two bf16 (round to nearest even), first value in the low half
@@ -26,40 +29,33 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-// S16: the copies hold bf16 (SURVEY.md 8 configs[4] "bf16 features"): a voxel is 16 bytes, a pixel 24 -- half the bytes of every corner
+// S16: the copies hold bf16 (SURVEY.md 8 configs[4] "bf16 features"): a voxel / feature pixel is 16 bytes, a colour 8 -- half the bytes of every corner
+// blockIdx.y: 0..2 volumes, 3 image features, 4 colours
 template <bool S16>
 __global__ void __launch_bounds__(256) repack_sources_kernel(RepackArgs a) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int k = blockIdx.y;
-    if (k < 3) {
-        const size_t n_vox = a.n_vox[k];
-        if (i >= n_vox) return;
-        const float* __restrict__ src = a.vol[k];
+    if (k < 4) {
+        const size_t n_vox = k < 3 ? a.n_vox[k] : a.hw;              // positions per channel plane
+        const size_t n_all = k < 3 ? n_vox : (size_t)a.V * a.hw;
+        float4* dst = k < 3 ? a.vol_dst[k] : a.feat_dst;
+        if (!dst || i >= n_all) return;
+        const float* __restrict__ src = k < 3 ? a.vol[k] + i : a.feat + (i / n_vox) * 8 * n_vox + i % n_vox;
         float c[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) c[q] = src[(size_t)q * n_vox + i];
+        for (int q = 0; q < 8; ++q) c[q] = src[(size_t)q * n_vox];
         if (S16) {
-            reinterpret_cast<uint4*>(a.vol_dst[k])[i] = make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]), pack_bf16x2(c[6], c[7]));
+            reinterpret_cast<uint4*>(dst)[i] = make_uint4(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]), pack_bf16x2(c[6], c[7]));
         } else {
-            a.vol_dst[k][2 * i] = make_float4(c[0], c[1], c[2], c[3]);
-            a.vol_dst[k][2 * i + 1] = make_float4(c[4], c[5], c[6], c[7]);
+            dst[2 * i] = make_float4(c[0], c[1], c[2], c[3]);
+            dst[2 * i + 1] = make_float4(c[4], c[5], c[6], c[7]);
         }
     } else {
         const size_t hw = a.hw;
-        if (i >= (size_t)a.V * hw) return;
-        const size_t v = i / hw, px = i % hw;
-        const float* im = a.imgs + v * 3 * hw + px;
-        const float* ft = a.feat + v * 8 * hw + px;
-        if (S16) {
-            uint2* d = reinterpret_cast<uint2*>(a.img_dst) + 3 * i;         // 24 bytes per pixel
-            d[0] = make_uint2(pack_bf16x2(im[0], im[hw]), pack_bf16x2(im[2 * hw], ft[0]));
-            d[1] = make_uint2(pack_bf16x2(ft[hw], ft[2 * hw]), pack_bf16x2(ft[3 * hw], ft[4 * hw]));
-            d[2] = make_uint2(pack_bf16x2(ft[5 * hw], ft[6 * hw]), pack_bf16x2(ft[7 * hw], 0.f));
-        } else {
-            a.img_dst[3 * i] = make_float4(im[0], im[hw], im[2 * hw], ft[0]);
-            a.img_dst[3 * i + 1] = make_float4(ft[hw], ft[2 * hw], ft[3 * hw], ft[4 * hw]);
-            a.img_dst[3 * i + 2] = make_float4(ft[5 * hw], ft[6 * hw], ft[7 * hw], 0.f);
-        }
+        if (!a.col_dst || i >= (size_t)a.V * hw) return;
+        const float* im = a.imgs + (i / hw) * 3 * hw + i % hw;
+        if (S16) reinterpret_cast<uint2*>(a.col_dst)[i] = make_uint2(pack_bf16x2(im[0], im[hw]), pack_bf16x2(im[2 * hw], 0.f));
+        else a.col_dst[i] = make_float4(im[0], im[hw], im[2 * hw], 0.f);
     }
 }
 
@@ -67,9 +63,11 @@ __global__ void __launch_bounds__(256) repack_sources_kernel(RepackArgs a) {
 struct GatherClArgs {
     int n, S, V, H, W;
     int vol_d[3], vol_h[3], vol_w[3];
-    const float4* vol[3];      // channel-last volumes
+    const float4* vol[3];      // channel-last volumes [D,h,w,8]
     const float* conf;
-    const float4* img;         // [V,H,W,12]
+    const char* feat;          // [V,H,W,8] image features
+    const char* col;           // [V,H,W,col_px / 4] colours (fp32: 12 or 16 bytes per pixel; bf16: 8)
+    unsigned col_px;
     const float* rays_o;       // [3]
     const float* rays_d;       // [n,3]
     const float* z;            // [n,S]
@@ -100,7 +98,7 @@ __device__ __forceinline__ SampleIn sample_in(const GatherClArgs& a, unsigned id
 
 template <bool TILED, bool GIVEN, bool S16>
 __device__ __forceinline__ void gather_cl_unit(const GatherClArgs& a, unsigned idx, int unit, const SampleIn& in) {
-    constexpr unsigned VOX = S16 ? 16u : 32u, PIX = S16 ? 24u : 48u;     // bytes per voxel / pixel of the channel-last copies
+    constexpr unsigned VOX = S16 ? 16u : 32u;                             // bytes per voxel / feature pixel of the channel-last arrays
     const int F = 24 + 12 * a.V + 1;
     const unsigned r = in.r;
     const float z = in.z;
@@ -171,22 +169,28 @@ __device__ __forceinline__ void gather_cl_unit(const GatherClArgs& a, unsigned i
         project_cl(a.w2cs + 12 * vi, a.Ks + 9 * vi, x, y, w, &qx, &qy, &qz);
         const float gx = (qx / qz + 0.0f) / (float)(a.W - 1) * 2.0f - 1.0f, gy = (qy / qz + 0.0f) / (float)(a.H - 1) * 2.0f - 1.0f;
         const LerpCl ax = axis_cl(gx, a.W, true), ay = axis_cl(gy, a.H, true);
-        const char* img = (const char*)a.img + (size_t)vi * a.H * a.W * PIX;
-        const unsigned p00 = (unsigned)(ay.i0 * a.W + ax.i0) * PIX, p10 = (unsigned)(ay.i1 * a.W + ax.i0) * PIX;
-        const unsigned dx = (unsigned)(ax.i1 - ax.i0) * PIX;
+        // pixel indices (view included: the V maps of a source are one array) of the two rows at x0, and the step to x1 (0 at the clamped border)
+        const unsigned i00 = (unsigned)((vi * a.H + ay.i0) * a.W + ax.i0), i10 = (unsigned)((vi * a.H + ay.i1) * a.W + ax.i0);
+        const unsigned dx = (unsigned)(ax.i1 - ax.i0);
         const float w00 = ay.w0 * ax.w0, w01 = ay.w0 * ax.w1, w10 = ay.w1 * ax.w0, w11 = ay.w1 * ax.w1;
-        gf2 c0[2] = {{0, 0}, {0, 0}}, c1[2] = {{0, 0}, {0, 0}}, c2[2] = {{0, 0}, {0, 0}};      // (r g b f0) (f1..f4) (f5 f6 f7 -)
-#define CORNER12(P, WT) { const float w__ = (WT);                                                                                        \
-        if (S16) { const float4 r_ = ld16(img, (P)); const float2 t_ = ld8(img, (P) + 16u);                                              \
-                   FMA4(c0, bf16x4_lo(r_), w__) FMA4(c1, bf16x4_hi(r_), w__) FMA4(c2, bf16x4_lo(make_float4(t_.x, t_.y, 0.f, 0.f)), w__) } \
-        else { FMA4(c0, ld16(img, (P)), w__) FMA4(c1, ld16(img, (P) + 16u), w__) FMA4(c2, ld16(img, (P) + 32u), w__) } }
-        CORNER12(p00, w00) CORNER12(p00 + dx, w01) CORNER12(p10, w10) CORNER12(p10 + dx, w11)
-#undef CORNER12
-        PUT((24 + 4 * vi) * fs, c0[0].x);
-        PUT((24 + 4 * vi + 1) * fs, c0[0].y);
-        PUT((24 + 4 * vi + 2) * fs, c0[1].x);
+        gf2 rg = {0, 0}, c1[2] = {{0, 0}, {0, 0}}, c2[2] = {{0, 0}, {0, 0}};      // (r g) b | (f0..f3) (f4..f7)
+        float bl = 0.f;
+        // same accumulation per channel as ever: corners (y0,x0) (y0,x1) (y1,x0) (y1,x1), one fused multiply-add each
+#define CORNER11(I, WT) { const float w__ = (WT); const unsigned i__ = (I);                                                              \
+        if (S16) { const float4 r_ = ld16(a.feat, i__ * VOX); const float2 t_ = ld8(a.col, i__ * 8u);                                    \
+                   const float4 k_ = bf16x4_lo(make_float4(t_.x, t_.y, 0.f, 0.f));                                                      \
+                   FMA4(c1, bf16x4_lo(r_), w__) FMA4(c2, bf16x4_hi(r_), w__)                                                             \
+                   rg = __builtin_elementwise_fma((gf2){k_.x, k_.y}, (gf2){w__, w__}, rg); bl = __builtin_fmaf(k_.z, w__, bl); }         \
+        else { const gf3u k_ = ld12(a.col, __umul24(i__, a.col_px));                                                                     \
+               FMA4(c1, ld16(a.feat, i__ * VOX), w__) FMA4(c2, ld16(a.feat, i__ * VOX + 16u), w__)                                       \
+               rg = __builtin_elementwise_fma((gf2){k_.x, k_.y}, (gf2){w__, w__}, rg); bl = __builtin_fmaf(k_.z, w__, bl); } }
+        CORNER11(i00, w00) CORNER11(i00 + dx, w01) CORNER11(i10, w10) CORNER11(i10 + dx, w11)
+#undef CORNER11
+        PUT((24 + 4 * vi) * fs, rg.x);
+        PUT((24 + 4 * vi + 1) * fs, rg.y);
+        PUT((24 + 4 * vi + 2) * fs, bl);
         PUT((24 + 4 * vi + 3) * fs, (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.f : 0.f);
-        const float f8[8] = {c0[1].y, c1[0].x, c1[0].y, c1[1].x, c1[1].y, c2[0].x, c2[0].y, c2[1].x};
+        const float f8[8] = {c1[0].x, c1[0].y, c1[1].x, c1[1].y, c2[0].x, c2[0].y, c2[1].x, c2[1].y};
 #pragma unroll
         for (int c = 0; c < 8; ++c) PUT((24 + 4 * a.V + 8 * vi + c) * fs, f8[c]);
     }
@@ -212,109 +216,57 @@ __global__ void __launch_bounds__(256, TILED ? UCNERF_GATHER_WAVES : 1) feat_gat
 }
 
 
-// ------------------------------------------------------------------------------------------------ gather with corner reuse
-// The per-sample kernel above is bound by the bytes its corner reads pull through the CU's vector-memory path (2.1 KB per
-// sample, TA busy 0.83) although consecutive samples of a ray hardly move: a ray crosses a source view along a short epipolar
-// segment (~0.06 px per sample at the bench's poses) and the reference frustum along one (x, y) column.  Here a thread owns a
-// RUN of four consecutive samples, works out their footprints first and then sweeps the sources one 16-byte channel group at
-// a time, keeping the previous sample's corners in registers: it reloads everything when (x0, y0) moved, one z-plane when the
-// depth index advanced by one, nothing otherwise.  Four consecutive samples are 16 contiguous bytes of every tiled feature
-// row, so each feature leaves as one float4 store per thread (eight threads complete a 128-byte line).  blockIdx.y = source view.
-// Arithmetic (projection, weights, accumulation order per channel) is the per-sample kernel's: the features are bit-identical.
-// The four units of the reference frustum (three volumes + confidence) stay on the per-sample kernel: the same scheme for them
-// (one projection per sample, z-plane sliding) was built and needs ~170 live registers per thread -- hipcc spills 350-600 bytes
-// per lane at every occupancy tried, and the source views carry 60 % of the gathered bytes anyway.
-constexpr int RUN = 4;
-constexpr int RUN_THREADS = 256;
-typedef float gf4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ gf4 ld16v(const char* base, unsigned off) { return *(const gf4*)(base + off); }
-#define FMA4V(O, A, WT)                                                                          \
-    { const gf4 a_ = (A); const gf2 w_ = {(WT), (WT)};                                           \
-      O[0] = __builtin_elementwise_fma(a_.xy, w_, O[0]);                                         \
-      O[1] = __builtin_elementwise_fma(a_.zw, w_, O[1]); }
-
-template <bool GIVEN>
-__global__ void __launch_bounds__(RUN_THREADS, 4) feat_gather_run_kernel(GatherClArgs a) {
-    const unsigned base = (blockIdx.x * RUN_THREADS + threadIdx.x) * RUN;
-    if (base >= a.M) return;
-    const int F = 24 + 12 * a.V + 1;
-    float* row = a.feats + ((size_t)(base >> 5) * F) * 32 + (base & 31);       // feature f of samples base..base+3 at row[f * 32 .. +3]
-#define PUT4(FEAT, O) __builtin_nontemporal_store((gf4){(O)[0], (O)[1], (O)[2], (O)[3]}, reinterpret_cast<gf4*>(row + (size_t)(FEAT) * 32));
-    {
-        const int vi = blockIdx.y;
-        const char* img = (const char*)(a.img + (size_t)vi * a.H * a.W * 3);
-        unsigned p00[RUN], p10[RUN], dx[RUN];
-        float w00[RUN], w01[RUN], w10[RUN], w11[RUN], mask[RUN];
-#pragma unroll
-        for (int j = 0; j < RUN; ++j) {
-            const unsigned idx = min(base + j, a.M - 1);
-            float x, y, w;
-            if (GIVEN) { const float* q = a.pts_in + 3 * (size_t)idx; x = q[0]; y = q[1]; w = q[2]; }
-            else { const SampleIn in = sample_in(a, idx); x = a.rays_o[0] + in.z * in.dx; y = a.rays_o[1] + in.z * in.dy; w = a.rays_o[2] + in.z * in.dz; }
-            float qx, qy, qz;
-            project_cl(a.w2cs + 12 * vi, a.Ks + 9 * vi, x, y, w, &qx, &qy, &qz);
-            const float gx = (qx / qz + 0.0f) / (float)(a.W - 1) * 2.0f - 1.0f, gy = (qy / qz + 0.0f) / (float)(a.H - 1) * 2.0f - 1.0f;
-            const LerpCl ax = axis_cl(gx, a.W, true), ay = axis_cl(gy, a.H, true);
-            p00[j] = (unsigned)(ay.i0 * a.W + ax.i0) * 48u; p10[j] = (unsigned)(ay.i1 * a.W + ax.i0) * 48u;
-            dx[j] = (unsigned)(ax.i1 - ax.i0) * 48u;
-            w00[j] = ay.w0 * ax.w0; w01[j] = ay.w0 * ax.w1; w10[j] = ay.w1 * ax.w0; w11[j] = ay.w1 * ax.w1;
-            mask[j] = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.f : 0.f;
-        }
-        const int fc = 24 + 4 * vi, fb = 24 + 4 * a.V + 8 * vi;
-#pragma unroll
-        for (int comp = 0; comp < 3; ++comp) {            // (r g b f0) (f1 f2 f3 f4) (f5 f6 f7 -)
-            const unsigned co = 16u * comp;
-            gf4 p[4];
-            float out[4][RUN];
-#pragma unroll
-            for (int j = 0; j < RUN; ++j) {
-                if (!(j > 0 && p00[j] == p00[j - 1])) {   // (p00 fixes x0, y0 and with them x1, y1)
-                    p[0] = ld16v(img, p00[j] + co); p[1] = ld16v(img, p00[j] + dx[j] + co);
-                    p[2] = ld16v(img, p10[j] + co); p[3] = ld16v(img, p10[j] + dx[j] + co);
-                }
-                gf2 acc[2] = {{0, 0}, {0, 0}};
-                FMA4V(acc, p[0], w00[j]) FMA4V(acc, p[1], w01[j]) FMA4V(acc, p[2], w10[j]) FMA4V(acc, p[3], w11[j])
-                out[0][j] = acc[0].x; out[1][j] = acc[0].y; out[2][j] = acc[1].x; out[3][j] = acc[1].y;
-            }
-            if (comp == 0) { PUT4(fc + 0, out[0]) PUT4(fc + 1, out[1]) PUT4(fc + 2, out[2]) PUT4(fc + 3, mask) PUT4(fb + 0, out[3]) }
-            else if (comp == 1) { PUT4(fb + 1, out[0]) PUT4(fb + 2, out[1]) PUT4(fb + 3, out[2]) PUT4(fb + 4, out[3]) }
-            else { PUT4(fb + 5, out[0]) PUT4(fb + 6, out[1]) PUT4(fb + 7, out[2]) }
-        }
-    }
-#undef PUT4
-}
-
 }  // namespace ucnerf
 
 using namespace ucnerf;
 
 extern "C" {
 
-int64_t ucnerf_gather_repack_floats(const ucnerf_render_params* p) {
-    if (!p) return fail(UCNERF_EINVAL, "gather_repack_floats: null params");
-    int64_t n = 0;
-    for (int k = 0; k < 3; ++k) n += 8ll * p->vol_d[k] * p->vol_h[k] * p->vol_w[k];
-    n += 12ll * p->cfg.n_src * p->H * p->W;
-    return p->sources_cl_bf16 ? (n + 1) / 2 : n;           // (bf16 copies: two values per float; every volume is a multiple of 16 bytes)
+// floats of `dst` a source takes when it is repacked (0 when it is handed over in place)
+static void repack_sizes(const ucnerf_render_params* p, size_t n[5]) {
+    const size_t half = p->cl.bf16 ? 2 : 1;
+    for (int k = 0; k < 3; ++k) n[k] = p->cl.vol[k] ? 0 : (8 * (size_t)p->vol_d[k] * p->vol_h[k] * p->vol_w[k] / half + 3) / 4 * 4;
+    const size_t px = (size_t)p->cfg.n_src * p->H * p->W;
+    n[3] = p->cl.img_feat ? 0 : (8 * px / half + 3) / 4 * 4;
+    n[4] = p->cl.imgs ? 0 : (4 * px / half + 3) / 4 * 4;
 }
 
-int ucnerf_gather_repack(const ucnerf_render_params* p, float* dst, void* stream) {
-    UCNERF_REQUIRE(p && dst, "gather_repack: null pointer");
-    UCNERF_REQUIRE(p->vol[0] && p->vol[1] && p->vol[2] && p->imgs && p->img_feat, "gather_repack: null source");
+int64_t ucnerf_gather_repack_floats(const ucnerf_render_params* p) {
+    if (!p) return fail(UCNERF_EINVAL, "gather_repack_floats: null params");
+    size_t n[5];
+    repack_sizes(p, n);
+    return (int64_t)(n[0] + n[1] + n[2] + n[3] + n[4]);
+}
+
+int ucnerf_gather_repack(const ucnerf_render_params* p, float* dst, ucnerf_cl_sources* out, void* stream) {
+    UCNERF_REQUIRE(p && out, "gather_repack: null pointer");
+    size_t n[5];
+    repack_sizes(p, n);
+    const bool any = n[0] + n[1] + n[2] + n[3] + n[4] > 0;
+    UCNERF_REQUIRE(!any || dst, "gather_repack: null destination");
     UCNERF_REQUIRE(((uintptr_t)dst & 15) == 0, "gather_repack: destination must be 16-byte aligned");
+    UCNERF_REQUIRE(!p->cl.bf16 || !p->cl.imgs || p->cl.rgb_stride == 4, "gather_repack: bf16 colours handed over in place must be padded to 4 values per pixel");
     RepackArgs a;
-    float* o = dst;
+    memset(&a, 0, sizeof(a));
+    ucnerf_cl_sources o = p->cl;
+    o.rgb_stride = p->cl.imgs ? p->cl.rgb_stride : 4;
+    float* q = dst;
     size_t n_max = 0;
     for (int k = 0; k < 3; ++k) {
         a.n_vox[k] = (size_t)p->vol_d[k] * p->vol_h[k] * p->vol_w[k];
-        a.vol[k] = p->vol[k]; a.vol_dst[k] = (float4*)o;
-        o += (p->sources_cl_bf16 ? 4 : 8) * a.n_vox[k];
+        if (!n[k]) continue;
+        UCNERF_REQUIRE(p->vol[k], "gather_repack: null volume %d", k);
+        a.vol[k] = p->vol[k]; a.vol_dst[k] = (float4*)q; o.vol[k] = q; q += n[k];
         if (a.n_vox[k] > n_max) n_max = a.n_vox[k];
     }
-    a.imgs = p->imgs; a.feat = p->img_feat; a.img_dst = (float4*)o; a.V = p->cfg.n_src; a.hw = (size_t)p->H * p->W;
-    if (a.hw * a.V > n_max) n_max = a.hw * a.V;
-    if (p->sources_cl_bf16) hipLaunchKernelGGL(repack_sources_kernel<true>, dim3(cdiv(n_max, 256), 4), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(repack_sources_kernel<false>, dim3(cdiv(n_max, 256), 4), dim3(256), 0, (hipStream_t)stream, a);
+    a.V = p->cfg.n_src; a.hw = (size_t)p->H * p->W;
+    if (n[3]) { UCNERF_REQUIRE(p->img_feat, "gather_repack: null image features"); a.feat = p->img_feat; a.feat_dst = (float4*)q; o.img_feat = q; q += n[3]; }
+    if (n[4]) { UCNERF_REQUIRE(p->imgs, "gather_repack: null images"); a.imgs = p->imgs; a.col_dst = (float4*)q; o.imgs = q; q += n[4]; }
+    if ((n[3] || n[4]) && a.hw * a.V > n_max) n_max = a.hw * a.V;
+    *out = o;
+    if (!any) return UCNERF_OK;
+    if (p->cl.bf16) hipLaunchKernelGGL(repack_sources_kernel<true>, dim3(cdiv(n_max, 256), 5), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(repack_sources_kernel<false>, dim3(cdiv(n_max, 256), 5), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("gather_repack");
 }
 
@@ -322,19 +274,34 @@ int ucnerf_gather_repack(const ucnerf_render_params* p, float* dst, void* stream
 
 namespace ucnerf {
 
-// called by render.hip: gather (+ ndc) for one pass from the repacked sources
-int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float* feats, int tiled, float* ndc, hipStream_t st) {
+// The channel-last sources of a pass, validated (all five arrays, alignment, the sizes the kernels' 32-bit offsets assume)
+int check_cl_sources(const ucnerf_render_params* p, const char* who) {
+    const ucnerf_cl_sources& c = p->cl;
+    UCNERF_REQUIRE(c.vol[0] && c.vol[1] && c.vol[2] && c.img_feat && c.imgs, "%s: the channel-last sources must all be given (ucnerf_gather_repack completes them)", who);
+    for (int k = 0; k < 3; ++k) {
+        UCNERF_REQUIRE(((uintptr_t)c.vol[k] & 15) == 0, "%s: channel-last volume %d must be 16-byte aligned", who, k);
+        UCNERF_REQUIRE(32ull * p->vol_d[k] * p->vol_h[k] * p->vol_w[k] < (1ull << 32), "%s: volume %d exceeds 4 GB", who, k);
+    }
+    UCNERF_REQUIRE(((uintptr_t)c.img_feat & 15) == 0, "%s: channel-last image features must be 16-byte aligned", who);
+    UCNERF_REQUIRE(c.bf16 ? c.rgb_stride == 4 : (c.rgb_stride == 3 || c.rgb_stride == 4), "%s: rgb_stride %d (3 or 4; bf16: 4)", who, c.rgb_stride);
+    UCNERF_REQUIRE(((uintptr_t)c.imgs & (c.bf16 ? 7 : c.rgb_stride == 4 ? 15 : 3)) == 0, "%s: channel-last images are misaligned", who);
+    UCNERF_REQUIRE((unsigned long long)p->cfg.n_src * p->H * p->W < (1ull << 24), "%s: %d x %d x %d pixels (limit 2^24)", who, p->cfg.n_src, p->H, p->W);
+    return UCNERF_OK;
+}
+
+// called by render.hip: gather (+ ndc) for one pass from the channel-last sources
+int launch_gather_cl(const ucnerf_render_params* p, float* feats, int tiled, float* ndc, hipStream_t st) {
+    if (int rc = check_cl_sources(p, "gather_cl")) return rc;
     const bool given = p->pts_in != nullptr;
     GatherClArgs a;
     memset(&a, 0, sizeof(a));
     a.n = p->n; a.S = p->S; a.V = p->cfg.n_src; a.H = p->H; a.W = p->W;
-    const float* o = repacked;
     for (int k = 0; k < 3; ++k) {
         a.vol_d[k] = p->vol_d[k]; a.vol_h[k] = p->vol_h[k]; a.vol_w[k] = p->vol_w[k];
-        a.vol[k] = (const float4*)o;
-        o += (p->sources_cl_bf16 ? 4ull : 8ull) * p->vol_d[k] * p->vol_h[k] * p->vol_w[k];
+        a.vol[k] = (const float4*)p->cl.vol[k];
     }
-    a.img = (const float4*)o;
+    a.feat = (const char*)p->cl.img_feat; a.col = (const char*)p->cl.imgs;
+    a.col_px = p->cl.bf16 ? 8u : 4u * (unsigned)p->cl.rgb_stride;
     a.conf = p->conf; a.rays_o = p->rays_o; a.rays_d = p->rays_d; a.z = p->z; a.near_far = p->near_far;
     a.near = p->near; a.far = p->far;
     memcpy(a.w2c_ref, p->w2c_ref, sizeof(a.w2c_ref));
@@ -353,27 +320,11 @@ int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float
         a.div_sh = l - 1;
     }
     const dim3 grid(cdiv(M, 256), tiled ? 4 + a.V : 1), block(256);
-#ifndef UCNERF_GATHER_RUN
-#define UCNERF_GATHER_RUN 0       // tiled layout: 1 = source views on the corner-reuse kernel (a run of four samples per thread), 0 = one sample per
-                                  // thread for every unit.  Measured (profiles/r02_gather_experiments.md): 3x fewer corner loads, but 36.5 us for the
-                                  // six views against ~32 us on the per-sample kernel at 7 waves per SIMD -- the default stays 0
-#endif
-    if (p->sources_cl_bf16) {
-        UCNERF_REQUIRE(!UCNERF_GATHER_RUN, "gather_cl: the corner-reuse variant reads fp32 copies only");
+    if (p->cl.bf16) {
         if (tiled && !given) hipLaunchKernelGGL((feat_gather_cl_kernel<true, false, true>), grid, block, 0, st, a);
         else if (tiled) hipLaunchKernelGGL((feat_gather_cl_kernel<true, true, true>), grid, block, 0, st, a);
         else if (!given) hipLaunchKernelGGL((feat_gather_cl_kernel<false, false, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((feat_gather_cl_kernel<false, true, true>), grid, block, 0, st, a);
-    }
-    else if (tiled && UCNERF_GATHER_RUN) {
-        const dim3 grid_ref(cdiv(M, 256), 4), grid_r(cdiv(cdiv(M, RUN), RUN_THREADS), a.V), block_r(RUN_THREADS);
-        if (!given) {
-            hipLaunchKernelGGL((feat_gather_cl_kernel<true, false>), grid_ref, block, 0, st, a);        // volumes + confidence (+ ndc, u)
-            hipLaunchKernelGGL((feat_gather_run_kernel<false>), grid_r, block_r, 0, st, a);            // source views
-        } else {
-            hipLaunchKernelGGL((feat_gather_cl_kernel<true, true>), grid_ref, block, 0, st, a);
-            hipLaunchKernelGGL((feat_gather_run_kernel<true>), grid_r, block_r, 0, st, a);
-        }
     }
     else if (tiled && !given) hipLaunchKernelGGL((feat_gather_cl_kernel<true, false>), grid, block, 0, st, a);
     else if (tiled) hipLaunchKernelGGL((feat_gather_cl_kernel<true, true>), grid, block, 0, st, a);
@@ -382,6 +333,6 @@ int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float
     return check_launch("feat_gather_cl");
 }
 
-const char* build_flags_gather_cl() { return "gather_cl: " UCNERF_FLAG(UCNERF_GATHER_RUN) UCNERF_FLAG(UCNERF_GATHER_WAVES); }
+const char* build_flags_gather_cl() { return "gather_cl: " UCNERF_FLAG(UCNERF_GATHER_WAVES); }
 
 }  // namespace ucnerf

@@ -46,6 +46,12 @@ __device__ __forceinline__ float4 ld16(const char* base, unsigned off) {
 __device__ __forceinline__ float2 ld8(const char* base, unsigned off) {
     return *(const float2*)(base + off);
 }
+// 12 bytes at 4-byte alignment: the (r, g, b) of a pixel of a [V,H,W,3] image stack (torch's channels_last of [V,3,H,W]) -- one global_load_dwordx3
+typedef float gf3 __attribute__((ext_vector_type(3)));
+typedef gf3 gf3u __attribute__((aligned(4)));
+__device__ __forceinline__ gf3u ld12(const char* base, unsigned off) {
+    return *(const gf3u*)(base + off);
+}
 // bf16 channel-last copies: eight bf16 in 16 bytes -> the first / second four as floats (a bf16 is the upper half of its float)
 __device__ __forceinline__ float4 bf16x4_lo(const float4& r) {
     const unsigned a = __float_as_uint(r.x), b = __float_as_uint(r.y);

@@ -477,8 +477,11 @@ __device__ __forceinline__ void encode16(const float (&x)[3], int h, float (&pe)
 struct FusedGather {
     int S, V, H, W;
     int vol_d[3], vol_h[3], vol_w[3];
-    unsigned vol_off[3], img_off, view_bytes;      // byte offsets inside the channel-last buffer (all of it < 4 GB)
-    const char* cl;
+    // the channel-last sources, each its own array (ABI v5, ucnerf_cl_sources: read in place or repacked); offsets inside one are 32-bit
+    const char* vol[3];      // [D,h,w,8]
+    const char* feat;        // [V,H,W,8] image features
+    const char* col;         // [V,H,W,col_px / 4] colours
+    unsigned col_px;         // bytes per colour pixel: 12 or 16 (bf16: 8)
     const float* conf;
     const float* rays_o;
     const float* rays_d;
@@ -494,7 +497,7 @@ struct FusedGather {
     const float* pts_in;
     const float* ndc_in[3];
     const float* ndc_enc;
-    int s16;                 // the channel-last copies hold bf16 (ucnerf_render_params.sources_cl_bf16): 16-byte voxels, 24-byte pixels
+    int s16;                 // the channel-last arrays hold bf16 (ucnerf_cl_sources.bf16): 16-byte voxels / feature pixels, 8-byte colours
     // RAYGEN instantiation (ABI v4 gen_rays / gen_depths: ucnerf_ray_gen_sample folded into this launch): pixels and jitter draws in, and the rays,
     // depths and view-direction features the launch generates are WRITTEN for the launches behind it (compositing, re-sampling, the fine pass)
     const float* gen_xs;     // [n] pixel columns / rows
@@ -688,14 +691,18 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             gnf[0] = nf[2 * hl]; gnf[1] = nf[2 * hl + 1]; gnf[2] = nf[4]; gnf[3] = nf[5];
         }
     };
-    constexpr unsigned VOXB = S16 ? 16u : 32u, PIXB = S16 ? 24u : 48u;      // bytes per voxel / pixel of the channel-last copies
-    // (S16: the raw 16-bit values stay in the registers as loaded -- a pixel in slots 3c (16 bytes) and 3c + 1 (8 bytes) -- and become floats where they are consumed)
+    constexpr unsigned VOXB = S16 ? 16u : 32u;              // bytes per voxel / feature pixel of the channel-last arrays
+    // a corner of a source view in slots 3c, 3c + 1 (features) and 3c + 2 (r, g, b); S16: the raw 16-bit values stay in the registers as loaded --
+    // features in slot 3c, colours in 3c + 1 -- and become floats where they are consumed.  fi[].p00 / p10 / dx count PIXELS (view included)
     auto img_loads = [&](int pr) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {                         // (y0,x0) (y0,x1) (y1,x0) (y1,x1)
-            const unsigned o = ((c & 2) ? fi[pr].p10 : fi[pr].p00) + ((c & 1) ? fi[pr].dx : 0u);
-            if (S16) { vi_[pr][3 * c] = ld16(fg.cl, o); const float2 t_ = ld8(fg.cl, o + 16u); vi_[pr][3 * c + 1] = make_float4(t_.x, t_.y, 0.f, 0.f); }
-            else { vi_[pr][3 * c] = ld16(fg.cl, o); vi_[pr][3 * c + 1] = ld16(fg.cl, o + 16u); vi_[pr][3 * c + 2] = ld16(fg.cl, o + 32u); }
+            const unsigned ix = ((c & 2) ? fi[pr].p10 : fi[pr].p00) + ((c & 1) ? fi[pr].dx : 0u);
+            if (S16) { vi_[pr][3 * c] = ld16(fg.feat, ix * VOXB); const float2 t_ = ld8(fg.col, ix * 8u); vi_[pr][3 * c + 1] = make_float4(t_.x, t_.y, 0.f, 0.f); }
+            else {
+                vi_[pr][3 * c] = ld16(fg.feat, ix * VOXB); vi_[pr][3 * c + 1] = ld16(fg.feat, ix * VOXB + 16u);
+                const gf3u k_ = ld12(fg.col, __umul24(ix, fg.col_px)); vi_[pr][3 * c + 2] = make_float4(k_.x, k_.y, k_.z, 0.f);      // (.w is never read)
+            }
         }
     };
     // footprints of the gather, in parts (so that they can be spread over several fills): 0 reference projection (+ the point the
@@ -722,7 +729,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             // (wave-uniform sizes pass through an empty asm: their float forms are otherwise hoisted out of the tile loop into vector registers and spilled)
             const int D = unit == 2 ? sopaque(fg.vol_d[2], so_) : fg.vol_d[unit], hh = unit == 2 ? sopaque(fg.vol_h[2], so_) : fg.vol_h[unit], ww = unit == 2 ? sopaque(fg.vol_w[2], so_) : fg.vol_w[unit];
             const LerpCl ax = axis_cl(u * 2.f - 1.0f, ww, false), ay = axis_cl(v * 2.f - 1.0f, hh, false), az = axis_cl(zn * 2.f - 1.0f, D, false);
-            const unsigned vb = fg.vol_off[unit] + c0;
+            const unsigned vb = c0;                          // (offsets inside the lane's own volume: fg.vol[hl] in the first sweep, fg.vol[2] in the second)
             VolFp f;
             f.o[0] = vb + (unsigned)((az.i0 * hh + ay.i0) * ww + ax.i0) * VOXB; f.o[1] = vb + (unsigned)((az.i0 * hh + ay.i1) * ww + ax.i0) * VOXB;
             f.o[2] = vb + (unsigned)((az.i1 * hh + ay.i0) * ww + ax.i0) * VOXB; f.o[3] = vb + (unsigned)((az.i1 * hh + ay.i1) * ww + ax.i0) * VOXB;
@@ -749,9 +756,8 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             project_cl(mt, mt + 12, x, y, w, &qx, &qy, &qv);
             const float gx = (qx / qv + 0.0f) / (float)(gW - 1) * 2.0f - 1.0f, gy = (qy / qv + 0.0f) / (float)(gH - 1) * 2.0f - 1.0f;
             const LerpCl ax = axis_cl(gx, gW, true), ay = axis_cl(gy, gH, true);
-            const unsigned ib = fg.img_off + (unsigned)vi * fg.view_bytes;
-            fi[pr].p00 = ib + (unsigned)(ay.i0 * gW + ax.i0) * PIXB; fi[pr].p10 = ib + (unsigned)(ay.i1 * gW + ax.i0) * PIXB;
-            fi[pr].dx = (unsigned)(ax.i1 - ax.i0) * PIXB;
+            fi[pr].p00 = (unsigned)((vi * gH + ay.i0) * gW + ax.i0); fi[pr].p10 = (unsigned)((vi * gH + ay.i1) * gW + ax.i0);
+            fi[pr].dx = (unsigned)(ax.i1 - ax.i0);
             fi[pr].w00 = ay.w0 * ax.w0; fi[pr].w01 = ay.w0 * ax.w1; fi[pr].w10 = ay.w1 * ax.w0; fi[pr].w11 = ay.w1 * ax.w1;
             fi[pr].mask = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.f : 0.f;
         }
@@ -779,17 +785,19 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     };
     auto g_issue_first = [&]() {
         SB0;
+        // (the first sweep's volume differs between the lane halves and the two are separate allocations: a per-lane 64-bit base, re-derived here)
+        const char* const va_base = opaque(h) ? fg.vol[1] : fg.vol[0];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {                         // corner c = (z, y, x): the accumulation order of gather_cl.hip
-            const unsigned o = fa.o[c >> 1] + ((c & 1) ? fa.dx : 0u);
-            if (S16) va[2 * c] = ld16(fg.cl, o);
-            else { va[2 * c] = ld16(fg.cl, o); va[2 * c + 1] = ld16(fg.cl, o + 16u); }
+            const char* const o = va_base + (fa.o[c >> 1] + ((c & 1) ? fa.dx : 0u));
+            if (S16) va[2 * c] = *(const float4*)o;
+            else { va[2 * c] = *(const float4*)o; va[2 * c + 1] = *(const float4*)(o + 16); }
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const unsigned o = fb3.o[c >> 1] + ((c & 1) ? fb3.dx : 0u);
-            if (S16) { const float2 t_ = ld8(fg.cl, o); vb3[c] = make_float4(t_.x, t_.y, 0.f, 0.f); }
-            else vb3[c] = ld16(fg.cl, o);
+            if (S16) { const float2 t_ = ld8(fg.vol[2], o); vb3[c] = make_float4(t_.x, t_.y, 0.f, 0.f); }
+            else vb3[c] = ld16(fg.vol[2], o);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) cv[c] = fg.conf[co[c]];
@@ -834,18 +842,21 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         if (NP > 2) img_loads(2);
         SB0;
         auto view_consume = [&](int pr) {
-            gf2 c0[2] = {{0, 0}, {0, 0}}, c1[2] = {{0, 0}, {0, 0}}, c2[2] = {{0, 0}, {0, 0}};      // (r g b f0) (f1..f4) (f5 f6 f7 -)
+            gf2 rg = {0, 0}, c1[2] = {{0, 0}, {0, 0}}, c2[2] = {{0, 0}, {0, 0}};      // (r g) b | (f0..f3) (f4..f7): one fused multiply-add per channel and corner
+            float bl = 0.f;
             const float wt[4] = {fi[pr].w00, fi[pr].w01, fi[pr].w10, fi[pr].w11};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if (S16) { FMA4(c0, bf16x4_lo(vi_[pr][3 * c]), wt[c]) FMA4(c1, bf16x4_hi(vi_[pr][3 * c]), wt[c]) FMA4(c2, bf16x4_lo(vi_[pr][3 * c + 1]), wt[c]) }
-                else { FMA4(c0, vi_[pr][3 * c], wt[c]) FMA4(c1, vi_[pr][3 * c + 1], wt[c]) FMA4(c2, vi_[pr][3 * c + 2], wt[c]) }
+                const float4 k_ = S16 ? bf16x4_lo(vi_[pr][3 * c + 1]) : vi_[pr][3 * c + 2];
+                if (S16) { FMA4(c1, bf16x4_lo(vi_[pr][3 * c]), wt[c]) FMA4(c2, bf16x4_hi(vi_[pr][3 * c]), wt[c]) }
+                else { FMA4(c1, vi_[pr][3 * c], wt[c]) FMA4(c2, vi_[pr][3 * c + 1], wt[c]) }
+                rg = __builtin_elementwise_fma((gf2){k_.x, k_.y}, (gf2){wt[c], wt[c]}, rg); bl = __builtin_fmaf(k_.z, wt[c], bl);
             }
             float* col = pr == 0 ? &nfs[1][4] : &nfs[2 + (pr - 1) / 2][4 * ((pr - 1) & 1)];
-            col[0] = c0[0].x; col[1] = c0[0].y; col[2] = c0[1].x; col[3] = fi[pr].mask;
+            col[0] = rg.x; col[1] = rg.y; col[2] = bl; col[3] = fi[pr].mask;
             f32x4* dst = reinterpret_cast<f32x4*>(bcst_of(pr));
-            dst[0] = (f32x4){c0[1].y, c1[0].x, c1[0].y, c1[1].x};
-            dst[1] = (f32x4){c1[1].y, c2[0].x, c2[0].y, c2[1].x};
+            dst[0] = (f32x4){c1[0].x, c1[0].y, c1[1].x, c1[1].y};
+            dst[1] = (f32x4){c2[0].x, c2[0].y, c2[1].x, c2[1].y};
         };
         view_consume(0);
         SB0;
@@ -1363,28 +1374,25 @@ int launch_mlp_fwd_bf16x3_save(const ucnerf_mlp_params* p, const MlpSaved* save,
 
 // called by render.hip: gather + PE + MLP of one pass in ONE launch (row f1), from the channel-last sources and (ray, depth)
 // `tail_c` (optional): the launch also composites the pass's rays (and, with `tail_s`, re-samples from them) -- see FusedGather
-int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* repacked, const float* dirs, float* raw, hipStream_t st,
+int check_cl_sources(const ucnerf_render_params* p, const char* who);      // gather_cl.hip
+int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* dirs, float* raw, hipStream_t st,
                                  const ucnerf_composite_params* tail_c, const ucnerf_sample_pdf_params* tail_s) {
     const long long M = (long long)rp->n * rp->S;
     UCNERF_REQUIRE(M < (1ll << 31), "render (gather fused): %lld samples in one pass (limit 2^31 - 1)", M);
+    if (int rc = check_cl_sources(rp, "render (gather fused)")) return rc;
     ucnerf_mlp_params m;
     memset(&m, 0, sizeof(m));
     m.cfg = rp->cfg; m.m = (int)M; m.S = rp->S; m.max_blocks = rp->max_blocks; m.dirs = dirs; m.wstream = rp->wstream; m.raw = raw;
     FusedGather f;
     memset(&f, 0, sizeof(f));
     f.S = rp->S; f.V = rp->cfg.n_src; f.H = rp->H; f.W = rp->W;
-    unsigned long long off = 0;
     for (int k = 0; k < 3; ++k) {
         f.vol_d[k] = rp->vol_d[k]; f.vol_h[k] = rp->vol_h[k]; f.vol_w[k] = rp->vol_w[k];
-        f.vol_off[k] = (unsigned)off;
-        off += (rp->sources_cl_bf16 ? 16ull : 32ull) * rp->vol_d[k] * rp->vol_h[k] * rp->vol_w[k];
+        f.vol[k] = reinterpret_cast<const char*>(rp->cl.vol[k]);
     }
-    f.s16 = rp->sources_cl_bf16 ? 1 : 0;
-    f.img_off = (unsigned)off;
-    f.view_bytes = (unsigned)((rp->sources_cl_bf16 ? 24ull : 48ull) * rp->H * rp->W);
-    off += (unsigned long long)f.view_bytes * f.V;
-    UCNERF_REQUIRE(off < (1ull << 32), "render (gather fused): %llu bytes of channel-last sources (limit 4 GB)", off);
-    f.cl = reinterpret_cast<const char*>(repacked);
+    f.s16 = rp->cl.bf16 ? 1 : 0;
+    f.feat = reinterpret_cast<const char*>(rp->cl.img_feat); f.col = reinterpret_cast<const char*>(rp->cl.imgs);
+    f.col_px = rp->cl.bf16 ? 8u : 4u * (unsigned)rp->cl.rgb_stride;
     f.conf = rp->conf; f.rays_o = rp->rays_o; f.rays_d = rp->rays_d; f.z = rp->z; f.near_far = rp->near_far;
     f.near = rp->near; f.far = rp->far;
     memcpy(f.w2c_ref, rp->w2c_ref, sizeof(f.w2c_ref));

@@ -435,6 +435,10 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
     };
     // leaving a pair: this block's partial sums go to the gradient (float atomics on 128-byte row segments)
     auto flush = [&](const WgPair& q) {
+#ifdef UCNERF_WGRAD_EXP_NOFLUSH      // TIMING EXPERIMENT (wrong results; never in the production build): what the float atomics of the flushes cost
+        zero();
+        return;
+#endif
         const int i = lane & 31, hh = lane >> 5;
         // (descriptor fields into scalars first: a select between two FIELDS became a per-lane load of the chosen one, with a vmcnt(0) per atomic)
         float* const gW = q.gW;

@@ -202,6 +202,87 @@ __global__ void __launch_bounds__(64) sample_cascade_kernel(ucnerf_sample_cascad
     }
 }
 
+// ------------------------------------------------------------------------------------------- a1 + a3 + a4 of the evaluation loop, one launch
+// utils/utils.py:600-739 (build_rays_test): one 64-thread block per ray, the arithmetic of ray_gen_one (grid mode), sample_cascade_kernel and
+// ndc_project_kernel in that order on the same values -- bit-identical to the three launches.  Matrices come from device memory (uniform loads).
+__global__ void __launch_bounds__(64) build_rays_test_kernel(ucnerf_build_rays_test_params p) {
+    __shared__ float zs[1024];
+    const int r = blockIdx.x;
+    const int S = p.S, n3 = S / 3;
+    const int idx = p.grid_start + r;
+    const int row = idx / p.W, col = idx % p.W;
+    float wx, wy, wz;
+    pinhole_ray((float)col, (float)row, p.K[0], p.K[2], p.K[4], p.K[5], p.c2w, &wx, &wy, &wz);
+    const float ox = p.c2w[3], oy = p.c2w[7], oz = p.c2w[11];
+    float nf[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {                           // utils/utils.py:659-683: first / last hypothesis plane at the pixel of the stage's resolution
+        const int div = 4 >> k;
+        const size_t px = (size_t)(row / div) * p.dv_w[k] + (col / div), plane = (size_t)p.dv_h[k] * p.dv_w[k];
+        nf[2 * k] = p.depth_values[k][px];
+        nf[2 * k + 1] = p.depth_values[k][(size_t)(p.dv_d[k] - 1) * plane + px];
+    }
+    if (threadIdx.x == 0) {
+        p.rays_d[3 * (size_t)r] = wx; p.rays_d[3 * (size_t)r + 1] = wy; p.rays_d[3 * (size_t)r + 2] = wz;
+        if (p.near_far)
+            for (int k = 0; k < 6; ++k) p.near_far[6 * (size_t)r + k] = nf[k];
+        if (p.rays_o && r == 0) { p.rays_o[0] = ox; p.rays_o[1] = oy; p.rays_o[2] = oz; }
+    }
+    int P = 1;
+    while (P < S) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += 64) {
+        float v = __builtin_inff();
+        if (i < S) {
+            const int k = i / n3, j = i % n3;
+            const float t = linspace01(j, n3);
+            v = nf[2 * k] * (1.0f - t) + nf[2 * k + 1] * t;       // utils/utils.py:396
+        }
+        zs[i] = v;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += 64) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const float a = zs[i], b = zs[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { zs[i] = b; zs[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const float* M = p.w2c_ref;
+    const float* K = p.K_ref;
+    const float near = p.near_far_ref[0], far = p.near_far_ref[1];
+    const float inv_w = (float)(p.W - 1), inv_h = (float)(p.H - 1);
+    for (int s = threadIdx.x; s < S; s += 64) {
+        float z = zs[s];
+        if (p.t_rand) {
+            const float lower = s > 0 ? .5f * (z + zs[s - 1]) : z;      // mids = .5*(z[1:] + z[:-1])
+            const float upper = s + 1 < S ? .5f * (zs[s + 1] + z) : z;
+            z = lower + (upper - lower) * p.t_rand[(size_t)r * S + s];
+        }
+        const size_t o1 = (size_t)r * S + s, o = 3 * o1;
+        p.z[o1] = z;
+        const float x = ox + z * wx, y = oy + z * wy, w = oz + z * wz;
+        p.pts[o] = x; p.pts[o + 1] = y; p.pts[o + 2] = w;
+        const float cx = x * M[0] + y * M[1] + w * M[2] + M[3];      // utils/utils.py:333-367
+        const float cy = x * M[4] + y * M[5] + w * M[6] + M[7];
+        float cz = x * M[8] + y * M[9] + w * M[10] + M[11];
+        if (fabsf(cz) < 1e-4f) cz = 1e-4f;
+        const float qx = cx * K[0] + cy * K[1] + cz * K[2];
+        const float qy = cx * K[3] + cy * K[4] + cz * K[5];
+        const float qz = cx * K[6] + cy * K[7] + cz * K[8];
+        const float u = (qx / qz + 0.0f) / inv_w, v = (qy / qz + 0.0f) / inv_h;
+        p.ndc1[o] = u; p.ndc1[o + 1] = v; p.ndc1[o + 2] = (qz - nf[0]) / (nf[1] - nf[0]);
+        p.ndc2[o] = u; p.ndc2[o + 1] = v; p.ndc2[o + 2] = (qz - nf[2]) / (nf[3] - nf[2]);
+        p.ndc3[o] = u; p.ndc3[o + 1] = v; p.ndc3[o + 2] = (qz - nf[4]) / (nf[5] - nf[4]);
+        p.ndc[o] = u; p.ndc[o + 1] = v; p.ndc[o + 2] = (qz - near) / (far - near);
+    }
+}
+
 // ------------------------------------------------------------------------------------------- a4
 __global__ void ndc_project_kernel(ucnerf_ndc_project_params p) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -327,7 +408,7 @@ int ucnerf_sizeof(const char* name) {
     SZ(ucnerf_embed_params); SZ(ucnerf_feat_gather_params); SZ(ucnerf_feat_gather_bwd_params);
     SZ(ucnerf_mlp_config); SZ(ucnerf_mlp_params); SZ(ucnerf_mlp_bwd_params); SZ(ucnerf_composite_params);
     SZ(ucnerf_composite_bwd_params); SZ(ucnerf_sample_pdf_params); SZ(ucnerf_merge_rows_params); SZ(ucnerf_cost_volume_params); SZ(ucnerf_depth_regress_params); SZ(ucnerf_cost_volume_bwd_params); SZ(ucnerf_depth_regress_bwd_params); SZ(ucnerf_render_params);
-    SZ(ucnerf_render_bwd_params);
+    SZ(ucnerf_render_bwd_params); SZ(ucnerf_cl_sources); SZ(ucnerf_cl_grads); SZ(ucnerf_build_rays_test_params);
 #undef SZ
     return -1;
 }
@@ -402,6 +483,25 @@ int ucnerf_sample_cascade(const ucnerf_sample_cascade_params* p, void* stream) {
     if (p->n <= 0) return UCNERF_OK;
     hipLaunchKernelGGL(sample_cascade_kernel, dim3(p->n), dim3(64), 0, (hipStream_t)stream, *p);
     return check_launch("sample_cascade");
+}
+
+int ucnerf_build_rays_test(const ucnerf_build_rays_test_params* p, void* stream) {
+    UCNERF_REQUIRE(p, "build_rays_test: null params");
+    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->K && p->c2w && p->w2c_ref && p->K_ref && p->near_far_ref && p->depth_values[0] && p->depth_values[1] && p->depth_values[2],
+                   "build_rays_test: null input");
+    UCNERF_REQUIRE(p->rays_d && p->z && p->pts && p->ndc1 && p->ndc2 && p->ndc3 && p->ndc, "build_rays_test: null output");
+    UCNERF_REQUIRE(p->S >= 3 && p->S % 3 == 0 && p->S <= 768, "build_rays_test: S = %d (multiple of 3, <= 768)", p->S);
+    UCNERF_REQUIRE(p->H >= 2 && p->W >= 2 && p->grid_start >= 0 && (long long)p->grid_start + p->n <= (long long)p->H * p->W,
+                   "build_rays_test: pixels %d .. %d of a %d x %d image", p->grid_start, p->grid_start + p->n - 1, p->H, p->W);
+    for (int k = 0; k < 3; ++k) {
+        const int div = 4 >> k;
+        UCNERF_REQUIRE(p->dv_d[k] >= 1 && p->dv_h[k] >= (p->H - 1) / div + 1 && p->dv_w[k] >= (p->W - 1) / div + 1,
+                       "build_rays_test: depth_values[%d] is %d x %d x %d, the image needs at least %d x %d", k, p->dv_d[k], p->dv_h[k], p->dv_w[k],
+                       (p->H - 1) / div + 1, (p->W - 1) / div + 1);
+    }
+    hipLaunchKernelGGL(build_rays_test_kernel, dim3(p->n), dim3(64), 0, (hipStream_t)stream, *p);
+    return check_launch("build_rays_test");
 }
 
 int ucnerf_ndc_project(const ucnerf_ndc_project_params* p, void* stream) {

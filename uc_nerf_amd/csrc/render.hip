@@ -56,8 +56,9 @@ __global__ void __launch_bounds__(256) render_points_kernel(PointsArgs a) {
     a.ndc[o] = u; a.ndc[o + 1] = v; a.ndc[o + 2] = (qz - a.near) / (a.far - a.near);
 }
 
-int launch_gather_cl(const ucnerf_render_params* p, const float* repacked, float* feats, int tiled, float* ndc, hipStream_t st);
-int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* repacked, const float* dirs, float* raw, hipStream_t st,
+int launch_gather_cl(const ucnerf_render_params* p, float* feats, int tiled, float* ndc, hipStream_t st);
+int check_cl_sources(const ucnerf_render_params* p, const char* who);                                              // gather_cl.hip
+int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* dirs, float* raw, hipStream_t st,
                                  const ucnerf_composite_params* tail_c, const ucnerf_sample_pdf_params* tail_s);   // mlp_bf16.hip
 
 struct Workspace {
@@ -93,6 +94,8 @@ static int launch_points(const ucnerf_render_params* p, hipStream_t st, Workspac
 
 // coordinates handed over by the caller (rendering() of the reference receives rays_pts / rays_ndc) instead of derived here
 static inline bool coords_given(const ucnerf_render_params* p) { return p->pts_in != nullptr; }
+// channel-last sources handed over / built (ABI v5: all five arrays or none)
+static inline bool cl_given(const ucnerf_render_params* p) { return p->cl.vol[0] || p->cl.vol[1] || p->cl.vol[2] || p->cl.img_feat || p->cl.imgs; }
 
 static void gather_geometry(const ucnerf_render_params* p, const Workspace* w, ucnerf_feat_gather_params* g) {
     memset(g, 0, sizeof(*g));
@@ -157,7 +160,7 @@ static bool tail_size_fits(int n, int S) {
     return blocks * 10 >= cus * 9;
 }
 static bool tail_fits(const ucnerf_render_params* p, const ucnerf_sample_pdf_params* s) {
-    if (!tail_size_fits(p->n, p->S) || p->max_blocks > 0 || p->sources_cl_bf16 || coords_given(p)) return false;
+    if (!tail_size_fits(p->n, p->S) || p->max_blocks > 0 || p->cl.bf16 || coords_given(p)) return false;
     if (s && !(s->from_coarse && s->n == p->n && s->n_merge == p->S && s->n_bins == p->S - 1 && p->S >= 3 && s->n_bins <= 128 && p->S + s->n_samples <= 512 && s->n_samples >= 1 && (s->u_stride == 0 || s->u_stride == s->n_samples) &&
                (s->samples || s->inds || s->cdf || s->z_sorted) && (!s->merge_rank || s->z_sorted) && s->u)) return false;
     return true;
@@ -178,7 +181,7 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
         s_res.weights = nullptr; s_res.z_merge = p->z;
     }
     if (p->cfg.precision == 3) {                        // row f1: gather + PE + MLP in one launch, no feature buffer at all
-        UCNERF_REQUIRE(p->sources_cl && !keep_feats && !p->u_sampled && !p->train_workspace,
+        UCNERF_REQUIRE(cl_given(p) && !keep_feats && !p->u_sampled && !p->train_workspace,
                        "render_fused_fwd: precision 3 (gather fused into the MLP kernel) needs the channel-last sources; it keeps no features "
                        "and returns no per-sample uncertainty");
         const bool gen = p->gen_rays != nullptr;          // rays, depths and direction features are generated inside the launch (w->angle: its per-sample scratch)
@@ -189,14 +192,14 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
         if (tail) composite_args(p, raw_fused, &c);
         // (rays generated inside the launch: the RAYGEN instantiation derives every lane's direction feature itself and uses w->angle as scratch; the
         //  tail route's blocks write the caller's buffers first and read them like given ones)
-        if ((rc = launch_mlp_fwd_bf16x3_gather(p, p->sources_cl, gen && !tail ? w->angle : p->dir_feat ? p->dir_feat : w->angle, raw_fused, st, tail ? &c : nullptr,
+        if ((rc = launch_mlp_fwd_bf16x3_gather(p, gen && !tail ? w->angle : p->dir_feat ? p->dir_feat : w->angle, raw_fused, st, tail ? &c : nullptr,
                                                tail && p->resample ? &s_res : nullptr))) return rc;
         if (p->ev_mlp_stop && (rc = ucnerf_event_record(p->ev_mlp_stop, st))) return rc;
         if (tail) { ++g_tail_launches; return UCNERF_OK; }      // K7 (and K8, K9) ran inside the launch
-    } else if (p->sources_cl) {                                // fast path: channel-last sources, coordinates derived in-kernel
+    } else if (cl_given(p)) {                                  // fast path: channel-last sources, coordinates derived in-kernel
         g.out_tiled = keep_feats ? (p->feats_tiled ? 1 : 0) : 1;
         g.feats = keep_feats ? p->feats : w->feats;
-        if ((rc = launch_gather_cl(p, p->sources_cl, g.feats, g.out_tiled, w->ndc, st))) return rc;
+        if ((rc = launch_gather_cl(p, g.feats, g.out_tiled, w->ndc, st))) return rc;
     } else {
         if (!coords_given(p) && (rc = launch_points(p, st, w))) return rc;
         gather_geometry(p, w, &g);
@@ -286,13 +289,13 @@ int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* bp, void* stream) {
     mb.saved_valid = bp->saved_valid; mb.bwd_mode = bp->bwd_mode;
     if ((rc = ucnerf_mlp_bwd(&mb, st))) return rc;
 
-    if (bp->g_vol[0] || bp->g_vol[1] || bp->g_vol[2] || bp->g_conf || bp->g_img_feat || bp->g_sources_cl) {
+    if (bp->g_vol[0] || bp->g_vol[1] || bp->g_vol[2] || bp->g_conf || bp->g_img_feat || bp->g_cl.vol[0] || bp->g_cl.vol[1] || bp->g_cl.vol[2] || bp->g_cl.img_feat) {
         ucnerf_feat_gather_bwd_params gb;
         memset(&gb, 0, sizeof(gb));
         gather_geometry(&q, &w, &gb.fwd);
         gb.g_feats = g_feats;
         for (int k = 0; k < 3; ++k) gb.g_vol[k] = bp->g_vol[k];
-        gb.g_conf = bp->g_conf; gb.g_img_feat = bp->g_img_feat; gb.scratch = bp->gather_scratch; gb.g_sources_cl = bp->g_sources_cl;
+        gb.g_conf = bp->g_conf; gb.g_img_feat = bp->g_img_feat; gb.scratch = bp->gather_scratch; gb.g_cl = bp->g_cl;
         if ((rc = ucnerf_feat_gather_bwd(&gb, st))) return rc;
     }
     return UCNERF_OK;
@@ -313,7 +316,7 @@ int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream) {
     if (p->gen_rays) {
         const ucnerf_ray_gen_params* gr = p->gen_rays;
         const ucnerf_sample_stratified_params* gs = p->gen_depths;
-        UCNERF_REQUIRE(p->cfg.precision == 3 && n_given == 0 && !p->near_far && !p->sources_cl_bf16,
+        UCNERF_REQUIRE(p->cfg.precision == 3 && n_given == 0 && !p->near_far && !p->cl.bf16,
                        "render_fused_fwd: generated rays are served by the gather-fused kernel (cfg.precision 3) on derived coordinates, the scene's depth range and fp32 source copies");
         UCNERF_REQUIRE(gr->n == p->n && gs->n == p->n && gs->S == p->S, "render_fused_fwd: gen_rays / gen_depths sizes (%d, %d x %d) differ from the pass's (%d x %d)",
                        gr->n, gs->n, gs->S, p->n, p->S);

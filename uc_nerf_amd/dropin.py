@@ -52,7 +52,9 @@ def set_weight_cache(policy):
                  EMA / clamping code; older optimizers) do not bump a tensor's version counter, so no cache key can see them.
       "versions" the stream is cached and rebuilt only when a parameter's version counter or storage changed (optimizer steps,
                  load_state_dict, ordinary in-place ops).  One launch less per call; for evaluation loops that do not write parameters
-                 through `.data` -- or that call `uc_nerf_amd.dropin.session_of(net).invalidate()` after doing so.
+                 through `.data` -- or that call `uc_nerf_amd.dropin.session_of(net).invalidate()` after doing so.  (torch's FUSED optimizer
+                 kernels -- `torch.optim.Adam(..., fused=True)` -- do not bump version counters either; `flat.FlatAdam` bumps the flat
+                 buffer's by hand after its step, the default foreach Adam of train.py:85-92 bumps them itself.)
     Calls under autograd always pack afresh (once per training step; the backward needs the flat vector of that moment anyway)."""
     global _WEIGHT_CACHE
     if policy not in ("verify", "versions"):
@@ -141,7 +143,9 @@ class FusedSession:
             ent = self.weights[key] = {"sig": None, "ws": pw.pack(flat)}
             return flat, pw, ent["ws"]
         if _WEIGHT_CACHE == "versions":
-            sig = (live.data_ptr(),) + tuple(p._version for p in self.params)
+            # (the flat buffer's own counter too: flat.FlatAdam steps a Parameter that shares the buffer's storage and version counter, not the
+            #  per-tensor ones -- round 4's advisor finding)
+            sig = (live.data_ptr(), live._version) + tuple(p._version for p in self.params)
             if ent is None or ent["sig"] != sig:
                 ent = self.weights[key] = {"sig": sig, "ws": pw.pack(live)}
             return live, pw, ent["ws"]
@@ -167,7 +171,7 @@ class FusedSession:
             return old
         self.src = ops.GatherSources(vols, conf, imgs, img_feat, w2cs, intrinsics, cl_bf16=bf16)
         if heavy_ok:
-            self.src._cl = old._cl
+            self.src._cl, self.src.cl_all = old._cl, old.cl_all
         self.src_sig, self.src_refs = (hsig, lsig), ([r for _, r in heavy], [r for _, r in light])
         return self.src
 
@@ -183,6 +187,11 @@ class FusedSession:
         rp.set_white_bkgd(white_bkgd)
         if not rp.use_cl:
             rp.repack_sources(force=False)           # a copy made for these very sources through another precision's pass is reused
+        if not src.zero_copy and torch.cuda.is_current_stream_capturing():
+            # A step being captured into a HIP graph (train_step.GraphedStep) is replayed on whatever the caller copies into the static source
+            # tensors: the repack must be IN the graph even though the tensors' identity and version say "unchanged" now (round 4's advisor
+            # finding: a replay would otherwise gather from the warm-up's copies).  Sources read in place need nothing.
+            rp.repack_sources(force=True)
         return rp, flat
 
 
@@ -235,7 +244,10 @@ class _FusedRender(torch.autograd.Function):
         grads = [g.reshape(s) if g is not None else None for g, s in zip((gv1, gv2, gv3, gc, gi), ctx.shapes)]
         # views of the ONE flat gradient vector the kernels wrote: autograd installs them as p.grad without a copy (flat.py), so the
         # step's gradients stay one buffer -- what FlatGradBucket all-reduces in place and FlatAdam steps in one launch
-        g_params = store.grad_views(g_flat, [has and req for has, req in zip(sess.grad_mask, ctx.needs_input_grad[15:])])
+        req = ctx.needs_input_grad[15:]
+        if not all(req):                             # frozen tensors: their segments of the flat gradient stay zero (nobody steps or reduces them)
+            store.zero_segments(g_flat, [has and not r for has, r in zip(sess.grad_mask, req)])
+        g_params = store.grad_views(g_flat, [has and r for has, r in zip(sess.grad_mask, req)])
         # (ctx.kept stays: a second backward over the same graph -- retain_graph=True -- finds the kept activations overwritten and
         #  recomputes them through the route above)
         return (None,) * 10 + tuple(grads) + tuple(g_params)

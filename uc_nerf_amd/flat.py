@@ -110,6 +110,14 @@ class FlatStore:
         segs = buf[:self.n].split(self.sizes)
         return [(g if p.dim() == 1 else g.view(p.shape)) if w else None for g, p, w in zip(segs, self.params, wanted)]
 
+    def zero_segments(self, buf, which):
+        """Zeroes the segments of the flat gradient `buf` selected by `which` (one multi-tensor launch): the backward kernels write a weight
+        gradient for EVERY tensor they reach, and a tensor the caller froze (requires_grad = False) must not be stepped by an optimizer
+        (FlatAdam) or reduced by a bucket that takes the buffer whole -- round 4's advisor finding."""
+        segs = [g for g, w in zip(buf[:self.n].split(self.sizes), which) if w]
+        if segs:
+            torch._foreach_zero_(segs)
+
     def flat_grad(self, room=None):
         """The flat fp32 tensor [>= n + extra + tail] every non-None `p.grad` of this store is a view of (each at its own offset), or None:
         gradients produced some other way (the op-by-op route, accumulation into existing grads, two passes summed by autograd)."""
@@ -182,7 +190,11 @@ class FlatAdam(torch.optim.Adam):
         if all(p.grad is None for p in self.store.params):
             return None                            # (nothing was differentiated: torch's Adam skips parameters without a gradient too)
         self._bind()
-        return super().step(closure)
+        out = super().step(closure)
+        # torch's FUSED Adam kernel writes the parameters without bumping their version counter (verified on torch 2.10: `_version` stays put), so
+        # nothing keyed on versions -- dropin.set_weight_cache("versions") -- could see this step: bump the flat buffer's counter by hand (no launch)
+        torch.autograd.graph.increment_version(self.store.flat)
+        return out
 
     def zero_grad(self, set_to_none=True):
         for p in self.store.params:

@@ -259,6 +259,62 @@ def ndc_project(pts, w2c, K, inv_scale, near_far=None, sample_2d=False):
     return outs
 
 
+def _dev_f32(t, name, numel=None, dev=None):
+    """`t` as it is when it is a contiguous float32 tensor on the device (read in place by a kernel); one conversion otherwise."""
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        t = torch.as_tensor(t, dtype=torch.float32, device=dev).contiguous()
+        if not t.is_cuda:
+            raise RuntimeError("uc_nerf_amd: %s must live on a ROCm device" % name)
+    if numel is not None and t.numel() < numel:
+        raise RuntimeError("uc_nerf_amd: %s has %d elements, expected at least %d" % (name, t.numel(), numel))
+    return t
+
+
+def build_rays_test(H, W, grid_start, n, S, K, c2w, w2c_ref, K_ref, near_far_ref, depth_values, t_rand=None, want_ranges=False):
+    """The evaluation loop's ray builder in ONE launch (utils/utils.py:600-739; ucnerf_build_rays_test): rays through pixels grid_start ..
+    grid_start + n - 1 of the HxW grid, cascade ranges from the three depth_values [.., D_k, h_k, w_k], sorted + jittered depths, world points
+    and the four normalised copies.  Every matrix is a DEVICE tensor read in place (K [3,3], c2w [4,4] or [3,4], w2c_ref, K_ref, near_far_ref
+    [2]): nothing is read back to the host.  All outputs are views of one allocation.
+    -> dict(rays_o [3], rays_d [n,3], z [n,S], pts / stage1 / stage2 / stage3 / ndc [n,S,3] (+ ranges [n,6]))."""
+    dev = c2w.device
+    K, c2w, w2c_ref, K_ref = _dev_f32(K, "K", 9, dev), _dev_f32(c2w, "c2w", 12, dev), _dev_f32(w2c_ref, "w2c_ref", 12, dev), _dev_f32(K_ref, "K_ref", 9, dev)
+    near_far_ref = _dev_f32(near_far_ref, "near_far_ref", 2, dev)
+    if c2w.shape[-1] != 4 or w2c_ref.shape[-1] != 4:
+        raise RuntimeError("uc_nerf_amd.build_rays_test: c2w / w2c_ref must have 4 columns")
+    p = L.BuildRaysTestParams()
+    p.n, p.S, p.H, p.W, p.grid_start = int(n), int(S), int(H), int(W), int(grid_start)
+    keep = []
+    for k, dv in enumerate(depth_values):
+        dv = _dev_f32(dv, "depth_values")
+        keep.append(dv)
+        p.dv_d[k], p.dv_h[k], p.dv_w[k] = dv.shape[-3], dv.shape[-2], dv.shape[-1]
+        if dv.numel() != dv.shape[-3] * dv.shape[-2] * dv.shape[-1]:
+            raise RuntimeError("uc_nerf_amd.build_rays_test: depth_values must be [1,D,h,w] (one batch entry)")
+        p.depth_values[k] = dv.data_ptr()
+    if t_rand is not None:
+        t_rand = _f32(t_rand, "t_rand")
+        if t_rand.numel() != n * S:
+            raise RuntimeError("uc_nerf_amd.build_rays_test: t_rand must be [n,S]")
+    m = n * S
+    sizes = (4, 3 * n, 6 * n if want_ranges else 0, m, 3 * m, 3 * m, 3 * m, 3 * m, 3 * m)
+    offs = [0]
+    for sz in sizes:
+        offs.append(offs[-1] + (sz + 3) // 4 * 4)
+    buf = torch.empty(offs[-1], device=dev)
+    base = buf.data_ptr()
+    p.K, p.c2w, p.w2c_ref, p.K_ref, p.near_far_ref, p.t_rand = K.data_ptr(), c2w.data_ptr(), w2c_ref.data_ptr(), K_ref.data_ptr(), near_far_ref.data_ptr(), _ptr(t_rand)
+    p.rays_o, p.rays_d = base, base + 4 * offs[1]
+    p.near_far = base + 4 * offs[2] if want_ranges else None
+    p.z, p.pts, p.ndc1, p.ndc2, p.ndc3, p.ndc = (base + 4 * offs[k] for k in (3, 4, 5, 6, 7, 8))
+    _launch("ucnerf_build_rays_test", p, dev)
+    v3 = lambda k: buf[offs[k]:offs[k] + 3 * m].view(n, S, 3)       # noqa: E731
+    out = {"rays_o": buf[0:3], "rays_d": buf[offs[1]:offs[1] + 3 * n].view(n, 3), "z": buf[offs[3]:offs[3] + m].view(n, S),
+           "pts": v3(4), "stage1": v3(5), "stage2": v3(6), "stage3": v3(7), "ndc": v3(8)}
+    if want_ranges:
+        out["ranges"] = buf[offs[2]:offs[2] + 6 * n].view(n, 6)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ a5
 def embed(x, n_freqs, layout=0):
     x = _f32(x, "x")
@@ -272,45 +328,76 @@ def embed(x, n_freqs, layout=0):
 
 
 # ------------------------------------------------------------------------------------------------ a7
-def _cl_layout(vol_dhw, V, H, W):
-    """Float offsets of the channel-last source buffer the fast gather reads (ucnerf_gather_repack's layout, fp32): three volumes as
-    [D,h,w,8] voxels, then the source views as [V,H,W,12] pixels = (r, g, b, f0..f7, pad).  Returns ([vol offsets], pixel offset, total)."""
-    off, o = [], 0
-    for d, h, w in vol_dhw:
-        off.append(o)
-        o += 8 * d * h * w
-    return off, o, o + 12 * V * H * W
+def _strides_match(t, want):
+    """Strides of `t` equal `want` on every dimension that has more than one element (torch leaves the others arbitrary)."""
+    return all(n == 1 or st == w for n, st, w in zip(t.shape, t.stride(), want))
+
+
+def _cl_ok(t):
+    return torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32
+
+
+def cl_volume_view(v):
+    """`v` ([1,8,D,h,w] or [8,D,h,w]) as the [8,D,h,w] view the kernels can read IN PLACE, when its memory is [D,h,w,8] (what torch calls
+    channels_last_3d: a Conv3d running in that memory format writes it) and 16-byte aligned; None otherwise."""
+    if not _cl_ok(v) or v.dim() not in (4, 5) or (v.dim() == 5 and v.shape[0] != 1):
+        return None
+    t = v[0] if v.dim() == 5 else v
+    c, d, h, w = t.shape
+    if c != 8 or t.data_ptr() % 16 or not _strides_match(t, (1, h * w * 8, w * 8, 8)):
+        return None
+    return t
+
+
+def cl_img_feat_view(f):
+    """`f` ([V,1,8,H,W] or [V,8,H,W]) as the [V,8,H,W] view readable in place: memory [V,H,W,8] (channels_last of [V,8,H,W]), 16-byte aligned."""
+    if not _cl_ok(f) or f.dim() not in (4, 5) or (f.dim() == 5 and f.shape[1] != 1):
+        return None
+    t = f[:, 0] if f.dim() == 5 else f
+    V, c, H, W = t.shape
+    if c != 8 or t.data_ptr() % 16 or not _strides_match(t, (H * W * 8, 1, W * 8, 8)):
+        return None
+    return t
+
+
+def cl_imgs_view(im):
+    """`im` ([1,V,3,H,W] or [V,3,H,W]) as ([V,3,H,W] view, values per pixel) when its memory is [V,H,W,3] (channels_last of [V,3,H,W]) or
+    [V,H,W,4] (padded pixels, 16-byte aligned); None otherwise."""
+    if not _cl_ok(im) or im.dim() not in (4, 5) or (im.dim() == 5 and im.shape[0] != 1):
+        return None
+    t = im[0] if im.dim() == 5 else im
+    V, c, H, W = t.shape
+    if c != 3:
+        return None
+    for px, align in ((3, 4), (4, 16)):
+        if t.data_ptr() % align == 0 and _strides_match(t, (H * W * px, 1, W * px, px)):
+            return t, px
+    return None
 
 
 class ChannelLastSources:
-    """ONE device buffer in the layout the gather kernels read, plus torch VIEWS of it in the reference's shapes -- for a producer that can write
-    its outputs there (or for sources that stay fixed over many steps):
+    """The gather's sources allocated in the layouts the kernels read, as torch tensors in the reference's SHAPES -- a convenience for a producer
+    that can write its outputs there (or for sources that stay fixed over many steps); any tensor with these strides is treated the same way,
+    wherever it was allocated (e.g. the output of an nn.Conv3d running in channels_last_3d):
 
-        vols[k]   [1, 8, D, h, w]   (memory [D,h,w,8]: what torch calls channels_last_3d)       <- volume_feature_no_ref of stage k + 1
-        imgs      [1, V, 3, H, W]   (channels 0..2 of the [V,H,W,12] pixels)                    <- imgs[:, 1:]
-        img_feat  [V, 1, 8, H, W]   (channels 3..10)                                            <- img_feat
+        vols[k]   [1, 8, D, h, w]   memory [D,h,w,8] = torch.channels_last_3d                    <- volume_feature_no_ref of stage k + 1
+        imgs      [1, V, 3, H, W]   memory [V,H,W,3] = torch.channels_last of [V,3,H,W]          <- imgs[:, 1:]
+        img_feat  [V, 1, 8, H, W]   memory [V,H,W,8] = torch.channels_last of [V,8,H,W]          <- img_feat
 
-    Handed to `rendering()` / `GatherSources` (as they are, or `.detach().requires_grad_()` of them), these views are recognised by their
-    pointers and strides: the pass reads the buffer ZERO-COPY -- no per-step repack (25 us, 150 MB of traffic) -- and returns the source
-    gradients in the same layout (views with the inputs' strides: no transposing pass either).  Anything else takes the repack route."""
+    Handed to `rendering()` / `GatherSources` (as they are, or `.detach().requires_grad_()` of them), they are recognised by their strides: the
+    pass reads them ZERO-COPY -- no per-step repack (25 us, 150 MB of traffic) -- and returns the source gradients with the same strides (no
+    transposing pass either).  Every source is recognised on its own: those that do not qualify take the repack route, the others stay in place."""
 
     def __init__(self, vol_dhw, V, H, W, device):
         self.vol_dhw, self.V, self.H, self.W = [tuple(int(x) for x in t) for t in vol_dhw], int(V), int(H), int(W)
-        voff, poff, total = _cl_layout(self.vol_dhw, V, H, W)
-        self.buf = torch.zeros(total, device=device)
-        self.vols, self.imgs, self.img_feat = self.views_of(self.buf)
-
-    def views_of(self, buf):
-        """The (vols, imgs, img_feat) views of a flat buffer of this geometry (the sources' buffer, or a gradient buffer of the same layout)."""
-        voff, poff, total = _cl_layout(self.vol_dhw, self.V, self.H, self.W)
-        vols = [buf[o:o + 8 * d * h * w].view(d, h, w, 8).permute(3, 0, 1, 2).unsqueeze(0) for o, (d, h, w) in zip(voff, self.vol_dhw)]
-        pix = buf[poff:total].view(self.V, self.H, self.W, 12)
-        return vols, pix[..., 0:3].permute(0, 3, 1, 2).unsqueeze(0), pix[..., 3:11].permute(0, 3, 1, 2).unsqueeze(1)
+        self.vols = [torch.zeros(1, 8, d, h, w, device=device).contiguous(memory_format=torch.channels_last_3d) for d, h, w in self.vol_dhw]
+        self.imgs = torch.zeros(V, 3, H, W, device=device).contiguous(memory_format=torch.channels_last).unsqueeze(0)
+        self.img_feat = torch.zeros(V, 8, H, W, device=device).contiguous(memory_format=torch.channels_last).unsqueeze(1)
 
     @classmethod
     def from_reference_layout(cls, vols, imgs, img_feat):
-        """Allocates the buffer for these sources (reference layouts: volumes [1,8,D,h,w], imgs [1,V,3,H,W], img_feat [V,1,8,H,W]) and copies
-        them in -- once; afterwards the views ARE the sources."""
+        """Allocates channel-last tensors for these sources (reference layouts: volumes [1,8,D,h,w], imgs [1,V,3,H,W], img_feat [V,1,8,H,W]) and
+        copies them in -- once; afterwards the new tensors ARE the sources."""
         dhw = [tuple(v.shape[-3:]) for v in vols]
         imgs4 = imgs.reshape(-1, 3, *imgs.shape[-2:])
         c = cls(dhw, imgs4.shape[0], imgs.shape[-2], imgs.shape[-1], imgs.device)
@@ -320,44 +407,6 @@ class ChannelLastSources:
             c.imgs.copy_(imgs.reshape(c.imgs.shape))
             c.img_feat.copy_(img_feat.reshape(c.img_feat.shape))
         return c
-
-
-def _channel_last_alias(vols, imgs, img_feat):
-    """The flat fp32 tensor aliasing ONE buffer that `vols`, `imgs` and `img_feat` are the channel-last views of (ChannelLastSources), or None."""
-    try:
-        if vols is None or imgs is None or img_feat is None or any(v is None for v in vols):
-            return None
-        ts = list(vols) + [imgs, img_feat]
-        if any((not torch.is_tensor(t)) or t.dtype != torch.float32 or not t.is_cuda for t in ts):
-            return None
-        v4 = [t[0] if t.dim() == 5 else t for t in vols]
-        if any(t.dim() != 4 or t.shape[0] != 8 for t in v4):
-            return None
-        im = imgs[0] if imgs.dim() == 5 else imgs
-        ft = img_feat[:, 0] if img_feat.dim() == 5 else img_feat
-        if im.dim() != 4 or ft.dim() != 4 or im.shape[1] != 3 or ft.shape[1] != 8 or im.shape[0] != ft.shape[0] or im.shape[2:] != ft.shape[2:]:
-            return None
-        V, H, W = im.shape[0], im.shape[2], im.shape[3]
-        dhw = [tuple(t.shape[1:]) for t in v4]
-        voff, poff, total = _cl_layout(dhw, V, H, W)
-        base = v4[0].data_ptr()
-        if base % 16:
-            return None
-        for t, o, (d, h, w) in zip(v4, voff, dhw):
-            if t.data_ptr() != base + 4 * o or tuple(t.stride()) != (1, h * w * 8, w * 8, 8):
-                return None
-        pst = (H * W * 12, 1, W * 12, 12)
-        if im.data_ptr() != base + 4 * poff or ft.data_ptr() != base + 4 * (poff + 3) or tuple(im.stride()) != pst or tuple(ft.stride()) != pst:
-            return None
-        stg = v4[0].untyped_storage()
-        if any(t.untyped_storage().data_ptr() != stg.data_ptr() for t in ts):
-            return None
-        off = v4[0].storage_offset()
-        if (off + total) * 4 > stg.nbytes():
-            return None
-        return torch.empty(0, dtype=torch.float32, device=v4[0].device).set_(stg, off, (total,))
-    except (RuntimeError, IndexError, AttributeError):
-        return None
 
 
 class GatherSources:
@@ -373,19 +422,20 @@ class GatherSources:
         self.mask = 0
         dev = None
         self.vols = [None, None, None]
-        # Sources that already live channel-last in ONE buffer of the kernels' layout (ChannelLastSources views): read in place -- no repack,
-        # ever -- and their gradients come back in the same layout.  The reference-layout pointers are then withheld (fill()): an entry
-        # point that reads channel-major sources fails loudly instead of reading the wrong layout.
-        alias = None if cl_bf16 else _channel_last_alias(vols, imgs, img_feat)
-        self.zero_copy = alias is not None
-        if self.zero_copy:
-            self.vols = [(v[0] if v.dim() == 5 else v) for v in vols]                  # [8,D,h,w] views, channel-last in memory
-            self.mask |= 0b111
-            dev = alias.device
-        elif vols is not None:
-            self.vols = [_f32(v, "volume").reshape(v.shape[-4:]) for v in vols]       # [8,D,h,w]
-            for v in self.vols:
-                if v.shape[0] != 8:
+        # PER SOURCE (ABI v5): a tensor whose memory already is the channel-last layout the fast kernels read -- a channels_last_3d volume, a
+        # channels_last feature / image stack, each its own allocation -- is read IN PLACE (no repack, ever) and its gradient comes back with the
+        # same strides.  Its reference-layout pointer is withheld (fill()): an entry point that reads channel-major sources fails loudly instead
+        # of reading the wrong layout.  inplace[k]: 0..2 volumes, 3 img_feat, 4 imgs.
+        self.inplace = [False] * 5
+        self.rgb_stride = 4
+        if vols is not None:
+            if any(v is None for v in vols):
+                raise RuntimeError("uc_nerf_amd: three cascade volumes or none")
+            for k, v in enumerate(vols):
+                t = None if cl_bf16 else cl_volume_view(v)
+                self.inplace[k] = t is not None
+                self.vols[k] = t if t is not None else _f32(v, "volume").reshape(v.shape[-4:])       # [8,D,h,w]
+                if self.vols[k].shape[0] != 8:
                     raise RuntimeError("uc_nerf_amd: cascade volumes must have 8 channels")
             self.mask |= 0b111
             dev = self.vols[0].device
@@ -399,14 +449,19 @@ class GatherSources:
         self.V = 1
         if imgs is not None:
             hw = tuple(imgs.shape[-2:])
-            if self.zero_copy:
-                self.imgs = imgs[0] if imgs.dim() == 5 else imgs                       # [V,3,H,W] / [V,8,H,W] views of the [V,H,W,12] pixels
-                self.img_feat = img_feat[:, 0] if img_feat.dim() == 5 else img_feat
+            t = None if cl_bf16 else cl_imgs_view(imgs)
+            if t is not None:
+                self.imgs, self.rgb_stride = t
+                self.inplace[4] = True
             else:
                 self.imgs = _f32(imgs, "imgs").reshape(-1, 3, *hw)                     # [V,3,H,W]
             self.V = self.imgs.shape[0]
             dev = self.imgs.device
-            if not self.zero_copy:
+            t = None if (cl_bf16 or img_feat is None) else cl_img_feat_view(img_feat)
+            if t is not None and t.shape[0] == self.V and tuple(t.shape[2:]) == hw:
+                self.img_feat = t
+                self.inplace[3] = True
+            else:
                 self.img_feat = (_f32(img_feat, "img_feat").reshape(self.V, 8, *hw) if img_feat is not None
                                  else torch.zeros(self.V, 8, *hw, device=dev))
             self.w2cs = torch.as_tensor(w2cs, dtype=torch.float32)[:, :3, :4].reshape(-1, 12).to(dev).contiguous()
@@ -421,8 +476,17 @@ class GatherSources:
         self.F = 24 + 12 * self.V + 1
         self.device = dev
         self.full = self.mask == (0b1111 | (((1 << self.V) - 1) << 4))
-        self._cl = alias             # channel-last copies read by the fast gather (RenderPass.repack_sources), shared by
-                                     # every RenderPass bound to these sources; zero_copy: the sources' own buffer
+        self.zero_copy = all(self.inplace)          # every source is read in place: nothing to repack, now or later
+        # ucnerf_cl_sources of the in-place sources alone, and of all five once RenderPass.repack_sources has completed them (shared by every
+        # RenderPass bound to these sources); _cl: the buffer the repacked ones live in
+        self.cl_inplace = L.ClSources()
+        for k in range(3):
+            self.cl_inplace.vol[k] = _ptr(self.vols[k]) if self.inplace[k] else None
+        self.cl_inplace.img_feat = _ptr(self.img_feat) if self.inplace[3] else None
+        self.cl_inplace.imgs = _ptr(self.imgs) if self.inplace[4] else None
+        self.cl_inplace.rgb_stride, self.cl_inplace.bf16 = self.rgb_stride, int(self.cl_bf16)
+        self.cl_all = self.cl_inplace if self.zero_copy else None
+        self._cl = None
 
     def fill(self, p):
         p.V, p.H, p.W = self.V, self.H, self.W
@@ -432,9 +496,9 @@ class GatherSources:
                 p.vol_d[k], p.vol_h[k], p.vol_w[k] = v.shape[1], v.shape[2], v.shape[3]
             else:
                 p.vol_d[k] = p.vol_h[k] = p.vol_w[k] = 1
-            p.vol[k] = None if self.zero_copy else _ptr(v)
+            p.vol[k] = None if self.inplace[k] else _ptr(v)
         p.conf = _ptr(self.conf)
-        p.imgs, p.img_feat = (None, None) if self.zero_copy else (_ptr(self.imgs), _ptr(self.img_feat))
+        p.imgs, p.img_feat = (None if self.inplace[4] else _ptr(self.imgs)), (None if self.inplace[3] else _ptr(self.img_feat))
         p.w2cs, p.intrinsics = _ptr(self.w2cs), _ptr(self.intrinsics)
 
 
@@ -465,6 +529,8 @@ def feat_gather_bwd(src, pts, ndc1, ndc2, ndc3, g_feats, need=(True, True, True,
     """Returns grads (g_vol1, g_vol2, g_vol3, g_conf, g_img_feat); entries not needed are None."""
     pts, ndc1, ndc2, ndc3, g_feats = _opt(pts), _opt(ndc1), _opt(ndc2), _opt(ndc3), _f32(g_feats)
     lead = next(t for t in (pts, ndc1, ndc3) if t is not None)
+    if any(src.inplace):
+        raise RuntimeError("uc_nerf_amd.feat_gather_bwd: channel-last sources are served by the render passes (RenderPass.backward)")
     bp = L.FeatGatherBwdParams()
     src.fill(bp.fwd)
     bp.fwd.m = lead.numel() // 3
@@ -1044,10 +1110,8 @@ class RenderPass:
         self.src = src
         src.fill(self.p)
         self.use_cl = False
-        self.p.sources_cl = None
-        self.p.sources_cl_bf16 = int(src.cl_bf16)
-        if src.zero_copy:                            # the sources ARE channel-last: nothing to repack, now or later
-            self.p.sources_cl = _ptr(src._cl)
+        self.p.cl = src.cl_inplace                   # (a copy: the in-place sources, if any; the others' entries stay NULL until repack_sources)
+        if src.zero_copy:                            # every source IS channel-last: nothing to repack, now or later
             self.use_cl = True
 
     def set_weights(self, pw, wstream):
@@ -1059,21 +1123,23 @@ class RenderPass:
         self.p.white_bkgd = int(bool(white_bkgd))
 
     def repack_sources(self, force=True):
-        """(Re)builds the channel-last copies the fast gather reads; call whenever the sources changed.  The copies belong
-        to the sources object: with force=False an existing copy (made through any RenderPass bound to them) is reused."""
+        """(Re)builds the channel-last copies of the sources that are not handed over in place; call whenever those changed.  The copies
+        belong to the sources object: with force=False existing ones (made through any RenderPass bound to them) are reused."""
         src = self.src
-        if src.zero_copy:                            # (never written: the buffer is the caller's)
-            self.p.sources_cl = _ptr(src._cl)
+        if src.zero_copy:                            # (never written: the arrays are the caller's)
+            self.p.cl = src.cl_inplace
             self.use_cl = True
             return
+        self.p.cl = src.cl_inplace
         n = L.lib().ucnerf_gather_repack_floats(C.addressof(self.p))
-        fresh = src._cl is None or src._cl.numel() != n
+        fresh = src._cl is None or src._cl.numel() != n or src.cl_all is None
         if fresh:
             src._cl = torch.empty(n, device=src.device)
+            src.cl_all = L.ClSources()
         if fresh or force:
             with _on(src.device):
-                L.check(L.lib().ucnerf_gather_repack(C.addressof(self.p), _ptr(src._cl), _stream()), "ucnerf_gather_repack")
-        self.p.sources_cl = _ptr(src._cl)
+                L.check(L.lib().ucnerf_gather_repack(C.addressof(self.p), _ptr(src._cl), C.addressof(src.cl_all), _stream()), "ucnerf_gather_repack")
+        self.p.cl = src.cl_all
         self.use_cl = True
 
     @staticmethod
@@ -1217,37 +1283,50 @@ class RenderPass:
         self._saved_for = None
         # ONE zero fill for all accumulated outputs (six separate torch.zeros were six 5-us launches per step): views of a flat buffer,
         # every segment padded to 16 bytes
-        zc = self.src.zero_copy       # sources handed over channel-last: their gradients are accumulated in ONE buffer of the same layout
+        # a source read in place gets its gradient in the SAME layout (channel-last, accumulated straight into it by the gather backward: no scratch,
+        # no transposing pass); the pool segment is then viewed with the source's strides -- what autograd's layout contract asks for
+        src = self.src
+        inp = src.inplace
         shapes = [(max(int(flat_room), self.pw.n_params),)] + \
-                 ([(self.src._cl.numel(),), None, None] if zc else [tuple(v.shape) if need[k] else None for k, v in enumerate(self.src.vols)]) + \
-                 [tuple(self.src.conf.shape) if need[3] else None, None if zc else (tuple(self.src.img_feat.shape) if need[4] else None)]
+                 [tuple(v.shape) if need[k] else None for k, v in enumerate(src.vols)] + \
+                 [tuple(src.conf.shape) if need[3] else None, tuple(src.img_feat.shape) if need[4] else None]
         sizes = [0 if sh is None else (int(torch.Size(sh).numel()) + 3) // 4 * 4 for sh in shapes]
         pool = torch.zeros(sum(sizes), device=dev)
-        outs, off = [], 0
+        segs, off = [], 0
         for sh, sz in zip(shapes, sizes):
-            outs.append(None if sh is None else pool[off:off + int(torch.Size(sh).numel())].view(sh))
+            segs.append(None if sh is None else pool[off:off + int(torch.Size(sh).numel())])
             off += sz
-        g_flat, gv, gc, gi = outs[0], outs[1:4], outs[4], outs[5]
+        g_flat = segs[0]
+        gv = []
+        for k in range(3):
+            if segs[1 + k] is None:
+                gv.append(None)
+            elif inp[k]:
+                c, d, h, w = src.vols[k].shape
+                gv.append(segs[1 + k].view(d, h, w, c).permute(3, 0, 1, 2))
+            else:
+                gv.append(segs[1 + k].view(shapes[1 + k]))
+        gc = None if segs[4] is None else segs[4].view(shapes[4])
+        if segs[5] is None:
+            gi = None
+        elif inp[3]:
+            gi = segs[5].view(src.V, src.H, src.W, 8).permute(0, 3, 1, 2)
+        else:
+            gi = segs[5].view(shapes[5])
         g_depth = _f32(g_depth) if g_depth is not None else None
         bp.g_rgb, bp.g_depth, bp.flat_params, bp.g_flat, bp.workspace = _ptr(g_rgb), _ptr(g_depth), _ptr(flat), _ptr(g_flat), _ptr(ws)
-        bp.g_sources_cl = None
-        if zc:
-            # views of the gradient buffer with the SOURCES' shapes and strides (what autograd's layout contract asks for: installed without a copy)
-            g_cl = gv[0]
-            bp.g_sources_cl = _ptr(g_cl)
-            voff, poff, total = _cl_layout([tuple(v.shape[1:]) for v in self.src.vols], self.src.V, self.src.H, self.src.W)
-            gv = [g_cl[o:o + v.numel()].view(*v.shape[1:], 8).permute(3, 0, 1, 2) if need[k] else None for k, (o, v) in enumerate(zip(voff, self.src.vols))]
-            gi = g_cl[poff:total].view(self.src.V, self.src.H, self.src.W, 12)[..., 3:11].permute(0, 3, 1, 2) if need[4] else None
-            for k in range(3):
-                bp.g_vol[k] = None
-            bp.g_conf, bp.g_img_feat = _ptr(gc), None
-        else:
-            for k in range(3):
-                bp.g_vol[k] = _ptr(gv[k])
-            bp.g_conf, bp.g_img_feat = _ptr(gc), _ptr(gi)
-        gfwd = L.FeatGatherParams()
-        self.src.fill(gfwd)
-        bp.gather_scratch = _ptr(_gather_scratch(self.src, gfwd, dev))
+        for k in range(3):
+            bp.g_vol[k] = None if inp[k] else _ptr(gv[k])
+            bp.g_cl.vol[k] = _ptr(segs[1 + k]) if inp[k] else None
+        bp.g_conf = _ptr(gc)
+        bp.g_img_feat = None if inp[3] else _ptr(gi)
+        bp.g_cl.img_feat = _ptr(segs[5]) if inp[3] else None
+        via_scratch = any(gv[k] is not None and not inp[k] for k in range(3)) or (gi is not None and not inp[3])
+        bp.gather_scratch = None
+        if via_scratch:
+            gfwd = L.FeatGatherParams()
+            src.fill(gfwd)
+            bp.gather_scratch = _ptr(_gather_scratch(src, gfwd, dev))
         _launch("ucnerf_render_fused_bwd", bp, dev)
         return g_flat, gv[0], gv[1], gv[2], gc, gi
 

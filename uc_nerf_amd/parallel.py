@@ -89,13 +89,18 @@ class FlatGradBucket:
     keep grad = None as in the reference.  Nothing else reads device memory: scalars are written into the bucket with a
     device-side copy.
 
-    The cached flags are refreshed (one more read-back) when THIS rank's own pattern of None / not-None gradients differs from the
-    previous step's (a loss term switched on by a schedule, layers unfrozen), in every step on a rank that differentiated nothing at all
-    (an empty shard cannot see such a change locally, and its step time does not matter), and -- because a change on ANOTHER rank alone
-    (a data-dependent branch, a per-rank loss term) is invisible locally -- every `verify_every` steps on every rank (default 16: one
-    read-back per 16 steps): replicas can then disagree about a gradient's existence for at most that many steps, not silently for ever."""
+    **When the reduced flags are read** (`verify_every`).  A pattern change that only ANOTHER rank can see (a data-dependent branch, a per-rank
+    loss term) is invisible locally, and an optimizer step taken on one rank and skipped on another is permanent divergence -- so the default,
+    `verify_every=1`, reads the reduced flags back in EVERY step (144 bytes behind the all-reduce; the one host synchronisation of the step):
+    every rank materialises exactly the gradients some rank produced, in the same step, always.  `verify_every=N > 1` reads them every N steps,
+    when this rank's own None / not-None pattern changed, and in every step on a rank that differentiated nothing; in between, the reduced flags
+    are compared with the cached pattern ON THE DEVICE and the mismatch count travels to pinned host memory behind an event that the NEXT call
+    tests without waiting: a change is then acted on one step late (`late_detections` counts them, a warning is issued) -- for callers that
+    accept that in exchange for a step without a read-back.  `verify_every=0`: never after the first step (a captured HIP graph admits no
+    read-back: train_step.GraphedStep); exact for optimizers that step the flat buffer as ONE parameter (flat.FlatAdam: every rank applies the
+    whole reduced vector, whatever the flags say)."""
 
-    def __init__(self, params, n_scalars=0, verify_every=16, collective_at_one=False):
+    def __init__(self, params, n_scalars=0, verify_every=1, collective_at_one=False):
         from .flat import store_of_param
         self.params = [p for p in params if p.requires_grad]
         self.sizes = [p.numel() for p in self.params]
@@ -129,6 +134,10 @@ class FlatGradBucket:
         self._flag_cache = {}        # local pattern -> device tensor of 0 / 1 flags
         self._step = 0
         self.last_path = None        # "in_place" / "generic": which route the last allreduce took (tests, bench)
+        self.readbacks = 0           # how many steps read the reduced flags back (tests, bench)
+        self.late_detections = 0     # verify_every > 1: pattern changes of another rank found one step late by the device-side check
+        self._pending = None         # (pinned mismatch count, event or None) of the last step's device-side check
+        self._cached_dev = None      # the cached reduced pattern as a device tensor
 
     def _flags_tensor(self, local, dev):
         t = self._flag_cache.get((local, dev))
@@ -166,11 +175,37 @@ class FlatGradBucket:
         if dist.is_initialized() and (dist.get_world_size(group) > 1 or self.collective_at_one):
             dist.all_reduce(buf[:self.numel], op=dist.ReduceOp.SUM, group=group)
         self._step += 1
+        flags = buf[off:off + len(self.params)]
+        if self._pending is not None:                      # last step's device-side comparison, if it has arrived (never waited for)
+            pin, ev = self._pending
+            if ev is None or ev.query():
+                self._pending = None
+                if float(pin) != 0.0:
+                    self.late_detections += 1
+                    self.has_grad = None                   # another rank's pattern changed last step: refresh now
+                    import warnings
+                    warnings.warn("uc_nerf_amd.FlatGradBucket: another rank's gradient pattern changed and was noticed one step late "
+                                  "(verify_every=%d); use verify_every=1 for same-step agreement" % self.verify_every)
         refresh = (self.has_grad is None or local != self.local_flags or not any(local)
                    or (self.verify_every > 0 and self._step % self.verify_every == 0))
         if refresh:
-            self.has_grad = [bool(v > 0) for v in buf[off:off + len(self.params)].tolist()]       # the read-back
+            self.has_grad = [bool(v > 0) for v in flags.tolist()]                  # the read-back
             self.local_flags = local
+            self.readbacks += 1
+            self._cached_dev = None
+        elif self.verify_every > 1 and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            # no read-back this step: compare the reduced flags with the cached pattern on the device; the count reaches the host behind an event
+            if self._cached_dev is None or self._cached_dev.device != dev:
+                self._cached_dev = torch.tensor([1.0 if h else 0.0 for h in self.has_grad], dtype=torch.float32, device=dev)
+            mis = ((flags > 0).to(torch.float32) - self._cached_dev).abs().sum()
+            if dev.type == "cuda":
+                pin = torch.empty((), dtype=torch.float32, pin_memory=True)
+                pin.copy_(mis, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pending = (pin, ev)
+            else:
+                self._pending = (mis, None)
         back = []
         for p, v, has, ins in zip(self.params, views, self.has_grad, self.in_store):
             if p.grad is not None:

@@ -137,26 +137,42 @@ def _near_far_dict(ranges, N_samples, near_ref, far_ref):
     return nf
 
 
+_INV_SCALE = {}
+
+
+def _inv_scale(W, H, device):
+    """torch.tensor([W - 1, H - 1]) on `device` (utils/utils.py:633), made ONCE per image size and device: the reference uploads it in every call
+    -- a host-to-device copy per 1024-pixel chunk; callers only read it."""
+    key = (int(W), int(H), str(device))
+    t = _INV_SCALE.get(key)
+    if t is None:
+        t = _INV_SCALE[key] = torch.tensor([W - 1, H - 1]).to(device)
+    return t
+
+
 def build_rays_test(H, W, tgt_to_world, world_to_ref, intrinsic, near_fars_ref, near_fars, N_samples, pad=0, ref_idx=0,
                     use_cpu=False, chunk=-1, idx=-1, outputs=None):
     """utils/utils.py:600-739 -> (pts [R,S,3], rays_dir [R,3], ndc dict, depth_candidates [R,S], rays_o [R,3],
-    ndc_parameters)."""
+    ndc_parameters).  ONE launch per call (ucnerf_build_rays_test) behind torch's draw of the jitter: pixel -> ray, the three cascade ranges
+    read at px // 4, px // 2, px, the 3 x N_samples/3 depths sorted and jittered, the world points and their four normalised copies; the
+    camera matrices are read from the device tensors handed in (the reference's ops do the same: nothing is read back per chunk)."""
     if use_cpu:
         raise RuntimeError("uc_nerf_amd.build_rays_test: use_cpu=True is not available (GPU-only implementation)")
     device = tgt_to_world.device
-    inv_scale = torch.tensor([W - 1, H - 1]).to(device)
+    inv_scale = _inv_scale(W, H, device)
     intrinsic_render = intrinsic if intrinsic.dim() == 2 else intrinsic.mean(0)
-    rays_o, rays_d, pix = get_rays_mvs(H, W, intrinsic_render, tgt_to_world, isRandom=False, chunk=chunk, idx=idx)
-    n = rays_d.shape[0]
+    total = H * W
+    start, n = (idx * chunk, max(0, min(chunk, total - idx * chunk))) if chunk > 0 else (0, total)
     near_ref, far_ref = near_fars_ref[ref_idx, 0], near_fars_ref[ref_idx, 1]
-    ranges = _stage_ranges(outputs, pix.long())
     t_rand = torch.rand((n, N_samples), device=device)
-    z, pts = ops.sample_cascade(ranges, N_samples, t_rand, rays_o, rays_d)
-    near_far = _near_far_dict(ranges, N_samples, near_ref, far_ref)
-    ndc = get_ndc_coordinate(world_to_ref, intrinsic, pts, inv_scale, near_far)
+    if intrinsic.dim() != 2 or world_to_ref.dim() != 2:
+        raise RuntimeError("uc_nerf_amd.build_rays_test: the reference view's intrinsic must be [3,3] and world_to_ref [4,4]")
+    o = ops.build_rays_test(H, W, start, n, N_samples, intrinsic_render, tgt_to_world, world_to_ref, intrinsic, near_fars_ref[ref_idx],
+                            [outputs["stage%d" % k]['depth_values'] for k in (1, 2, 3)], t_rand)
+    ndc = {"stage1": o["stage1"], "stage2": o["stage2"], "stage3": o["stage3"], "ndc": o["ndc"]}
     ndc_parameters = {'w2c_ref': world_to_ref, 'intrinsic_ref': intrinsic, 'inv_scale': inv_scale, 'near': near_ref,
                       'far': far_ref, 'pad': pad}
-    return pts, rays_d, ndc, z, rays_o.reshape(1, 3).expand(n, -1), ndc_parameters
+    return o["pts"], o["rays_d"], ndc, o["z"], o["rays_o"].reshape(1, 3).expand(n, -1), ndc_parameters
 
 
 def build_rays(args, imgs, mvs_confidence, sparse_depths, coords, pose_ref, w2cs, c2ws, intrinsics, N_rays, N_samples,
