@@ -43,12 +43,18 @@ int ucnerf_device_cus(void);
 const char* ucnerf_build_flags(void);
 /* Diagnostics: how many ucnerf_render_fused_fwd calls of this process let the gather-fused launch composite (and re-sample) its rays in its own
  * tail instead of launching K7 / K8 / K9 behind it -- passes of at most three rounds of 32-sample tiles (csrc/render.hip: tail_fits; the
- * outputs are bit-identical either way).  The environment variable UCNERF_FUSED_TAIL=0, read at every call, switches that route off. */
+ * outputs are bit-identical either way).  The environment variable UCNERF_FUSED_TAIL=0 (read once, at the first use) starts the process with
+ * that route off; ucnerf_set_fused_tail(0 / 1) switches it at run time and returns the previous setting (thread-safe). */
 int64_t ucnerf_fused_tail_launches(void);
+int32_t ucnerf_set_fused_tail(int32_t on);
 /* 1 when a pass of n rays x S samples is of the size that takes that route on the current device (the other conditions are the caller's to know:
  * gather-fused precision, fp32 channel-last sources, no max_blocks).  A host uses it to decide whether to hand the pass its ray
  * generation too (gen_rays / gen_depths): on the tail route the blocks generate their own rays at no measurable cost. */
 int32_t ucnerf_fused_tail_fits(int32_t n, int32_t S);
+/* The same for a COARSE pass that also draws the next pass's n_samples depths (ucnerf_render_params.resample): the library's own decision for
+ * that pass (size AND the re-sampling limits: S - 1 <= 128 bins, S + n_samples <= 512), so that a host that folds the ray generation into the
+ * pass exactly when it takes the tail route decides as the library does (round 4's advisor finding). */
+int32_t ucnerf_fused_tail_fits_resample(int32_t n, int32_t S, int32_t n_samples);
 /* Digest of the sources, headers and flags this binary was linked from (uc_nerf_amd/build.py: source_hash()): a host can tell a library
  * that does not belong to the tree it sits in (tests/test_abi_host.py), and __graft_entry__.build() rebuilds one that was not linked on
  * the machine it runs on. */

@@ -38,3 +38,17 @@ for _ in range(200):
     ts.append(time.perf_counter() - t0)
 ts.sort()
 print("add_ + 16-byte .cpu() after 0.2 ms idle: median %.1f us, p90 %.1f us" % (ts[100] * 1e6, ts[180] * 1e6))
+# Is the spread between images Python's cyclic garbage collector (a full collection walks every object torch has imported)?
+import gc
+print("gc counts", gc.get_count(), "stats", gc.get_stats())
+for mode in ("gc as it is", "gc.freeze()", "gc.disable()"):
+    if mode == "gc.freeze()":
+        gc.collect(); gc.freeze()
+    if mode == "gc.disable()":
+        gc.disable()
+    ts = []
+    for rep in range(6):
+        t0 = time.perf_counter()
+        bench.bench_eval_image(ctx, scene, a, kw, outputs, 0.0, images=1)
+        ts.append((time.perf_counter() - t0) / 4 * 1e3)          # (2 warm-up images + 1 timed + 1 split image per call)
+    print("%-14s ms per image over 6 x 4 images: %s" % (mode, " ".join("%.1f" % t for t in ts)), "gen2 collections so far:", gc.get_stats()[2]["collections"])

@@ -2,6 +2,7 @@
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from uc_nerf_amd import _lib as _L  # noqa: E402
 from uc_nerf_amd.pipeline import CoarseFineRenderer, flat_params_of
 from uc_nerf_amd.synthetic import init_ucnerf_state_dict, make_scene, random_pixels, scene_to
 
@@ -17,7 +18,7 @@ for n in (512, 500, 700):
     noise = torch.rand(4096, 64, generator=torch.Generator().manual_seed(100))[:n].to(dev).contiguous()
     outs = {}
     for tail in ("0", "1"):
-        os.environ["UCNERF_FUSED_TAIL"] = tail
+        _L.lib().ucnerf_set_fused_tail(int(tail))
         r.fold_rays = False if tail == "0" else None
         o = r.render(xs, ys, perturb=1.0, noise=noise, repack=False)
         torch.cuda.synchronize()
@@ -25,7 +26,7 @@ for n in (512, 500, 700):
     bad = [k for k in outs["0"] if not torch.equal(outs["0"][k], outs["1"][k])]
     print("%5d rays: %d outputs compared (%s), differing: %s" % (n, len(outs["0"]), ", ".join(sorted(outs["0"])), bad or "none"))
     for tail, fr in (("0", False), ("1", False), ("1", None), ("0", False), ("1", False), ("1", None)):
-        os.environ["UCNERF_FUSED_TAIL"] = tail
+        _L.lib().ucnerf_set_fused_tail(int(tail))
         r.fold_rays = fr
         for _ in range(100): r.render(xs, ys, perturb=1.0, noise=noise, repack=False)
         torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -273,12 +273,12 @@ def test_compositing_and_resampling_in_the_tail_of_the_fused_launch_are_bit_iden
     xs, ys = dev(xs[:n].contiguous()), dev(ys[:n].contiguous())
     noise = dev(torch.rand(n, 64, generator=torch.Generator().manual_seed(100)))
     count = L.lib().ucnerf_fused_tail_launches
-    monkeypatch.setenv("UCNERF_FUSED_TAIL", "0")
+    L.lib().ucnerf_set_fused_tail(0)
     c0 = count()
     old = r.render(xs, ys, perturb=1.0, noise=noise)
     old = {k: (v.clone() if torch.is_tensor(v) else {kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in old.items()}
     assert count() == c0                                   # switched off: the separate launches
-    monkeypatch.delenv("UCNERF_FUSED_TAIL")
+    L.lib().ucnerf_set_fused_tail(1)
     r.fold_rays = False                                    # rays from their own launch
     new = r.render(xs, ys, perturb=1.0, noise=noise)
     assert count() - c0 == int(coarse_in_tail) + int(fine_in_tail)
@@ -321,10 +321,7 @@ def test_tail_route_of_a_single_pass_covers_the_sample_counts_and_outputs_of_the
         res = None if u is None else {"u": u, "want_rank": True}
         outs = []
         for tail in (False, True):
-            if tail:
-                monkeypatch.delenv("UCNERF_FUSED_TAIL", raising=False)
-            else:
-                monkeypatch.setenv("UCNERF_FUSED_TAIL", "0")
+            L.lib().ucnerf_set_fused_tail(int(tail))
             c0 = count()
             o = rp(rays_d, z, want=("acc", "weights", "var"), keep=("raw",), dir_feat=ang, resample=res)
             assert count() - c0 == int(tail)

@@ -177,7 +177,9 @@ SYMBOLS = {
     "ucnerf_device_cus": (C.c_int, []),
     "ucnerf_build_flags": (C.c_char_p, []),
     "ucnerf_fused_tail_launches": (C.c_int64, []),
+    "ucnerf_set_fused_tail": (C.c_int32, [C.c_int32]),
     "ucnerf_fused_tail_fits": (C.c_int32, [C.c_int32, C.c_int32]),
+    "ucnerf_fused_tail_fits_resample": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "ucnerf_source_hash": (C.c_char_p, []),
     "ucnerf_event_create": (C.c_void_p, []),
     "ucnerf_event_record": (C.c_int, [_P, _P]),

@@ -435,10 +435,6 @@ __global__ void __launch_bounds__(WG_THREADS, 3) mlp_wgrad_kernel(WgArgs a WG_ST
     };
     // leaving a pair: this block's partial sums go to the gradient (float atomics on 128-byte row segments)
     auto flush = [&](const WgPair& q) {
-#ifdef UCNERF_WGRAD_EXP_NOFLUSH      // TIMING EXPERIMENT (wrong results; never in the production build): what the float atomics of the flushes cost
-        zero();
-        return;
-#endif
         const int i = lane & 31, hh = lane >> 5;
         // (descriptor fields into scalars first: a select between two FIELDS became a per-lane load of the chosen one, with a vmcnt(0) per atomic)
         float* const gW = q.gW;
@@ -530,10 +526,14 @@ int wgrad_launch(const WgArgs* a, hipStream_t st) {
     const int cus = device_cus();
     if (cus <= 0) return fail(UCNERF_EHIP, "mlp_bwd: no device");
     if (!a->counters) return fail(UCNERF_EINVAL, "mlp_bwd: the weight-gradient launch needs its chunk counters");
-    // chunk length: about eight chunks per block, 2 .. WG_CHUNK_MAX stages (the kernel reads it from the arguments)
+    // chunk length: 2 .. WG_CHUNK_MAX stages (the kernel reads it from the arguments)
     WgArgs args = *a;
     {
-        long long c = (long long)a->n_pairs * a->stages / (8ll * cus);
+        // about FIVE chunks per block (round 5; eight before): a block owns its first four chunks without asking and every further one costs the
+        // consumers' leading wave a round trip to a counter in global memory (~3 us) -- at 22 500 samples (a 250-ray shard: 20 stages per block)
+        // eight chunks per block meant 2-stage chunks and six round trips: 106 us against 89 us with 4-stage chunks (in-kernel stamps,
+        // profiles/r05_experiments.md; 3 chunks: 89, 4: 92, 2: 98).  Sizes that reach the 16-stage cap either way (>= 87 k samples) are unchanged.
+        long long c = (long long)a->n_pairs * a->stages / (5ll * cus);
         args.chunk = (int)(c < 2 ? 2 : c > WG_CHUNK_MAX ? WG_CHUNK_MAX : c);
     }
     a = &args;
@@ -547,5 +547,6 @@ int wgrad_launch(const WgArgs* a, hipStream_t st) {
 }
 
 const char* build_flags_mlp_wgrad() { return "mlp_wgrad: (no compile-time switches) "; }
+
 
 }  // namespace ucnerf

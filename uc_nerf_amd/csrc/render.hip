@@ -4,6 +4,7 @@
 #include "common.h"
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include "mlp_layout.h"
 
 namespace ucnerf {
@@ -144,24 +145,38 @@ static void composite_args(const ucnerf_render_params* p, const float* raw, ucne
 // May the gather-fused launch composite (and re-sample) its rays in its own tail?  Passes of at most three rounds of tiles (the shards of a strongly
 // scaled batch: there the two or three latency-bound launches behind the MLP are a tenth of the step), whole 32-sample tiles per ray, the
 // stand-alone kernels' small LDS shapes.  UCNERF_FUSED_TAIL=0 in the environment switches it off (A/B, tests: the outputs are bit-identical).
+// The route's switch and size limit: atomics, initialised ONCE from the environment under std::call_once (several host threads may drive the
+// library -- round 4's advisor finding); ucnerf_set_fused_tail() flips the switch at run time (A/B scripts, the bit-identity tests).
+static std::atomic<int> g_tail_on{1}, g_tail_half_rounds{6};
+static void tail_knobs_init() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* e = getenv("UCNERF_FUSED_TAIL");
+        if (e && e[0] == '0') g_tail_on.store(0);
+        const char* hr = getenv("UCNERF_FUSED_TAIL_HALF_ROUNDS");
+        if (hr && atoi(hr) > 0) g_tail_half_rounds.store(atoi(hr));
+    });
+}
 static bool tail_size_fits(int n, int S) {
-    const char* e = getenv("UCNERF_FUSED_TAIL");
-    if (e && e[0] == '0') return false;
+    tail_knobs_init();
+    if (!g_tail_on.load(std::memory_order_relaxed)) return false;
     const int cus = device_cus();
     if (cus <= 0 || n < 1 || S % 32 != 0 || S > 256) return false;
     // the largest pass, in half rounds of tiles (a round = CUs x 8 tiles): three rounds.  Measured with the rays generated in the prologue (same box, 64 + 128):
     // 512 rays -4.5 %, 1024 rays -1.1 % (fine pass = 3 rounds), 2048 rays -0.2 .. -0.6 % (up to 6 rounds), 4096 rays +0.3 % (4 + 12 rounds): the
     // whole-rays-per-block dealing costs large passes what the folded launches save them.  UCNERF_FUSED_TAIL_HALF_ROUNDS overrides (tuning).
-    static int half_rounds = -1;
-    if (half_rounds < 0) { const char* hr = getenv("UCNERF_FUSED_TAIL_HALF_ROUNDS"); half_rounds = hr && atoi(hr) > 0 ? atoi(hr) : 6; }
-    if ((long long)n * (S / 32) * 2 > (long long)half_rounds * cus * 8) return false;
+    if ((long long)n * (S / 32) * 2 > (long long)g_tail_half_rounds.load(std::memory_order_relaxed) * cus * 8) return false;
     // whole rays per block: rays / ceil(rays / CUs) blocks -- all but a tenth of the CUs must get one (37 rays: + 13 % on 37 blocks)
     const int rpb = cdiv(n, cus), blocks = cdiv(n, rpb);
     return blocks * 10 >= cus * 9;
 }
+// the re-sampling a tail can do itself (the stand-alone kernels' small LDS shapes)
+static bool tail_resample_fits(int S, int n_samples, int u_stride) {
+    return S >= 3 && S - 1 <= 128 && S + n_samples <= 512 && n_samples >= 1 && (u_stride == 0 || u_stride == n_samples);
+}
 static bool tail_fits(const ucnerf_render_params* p, const ucnerf_sample_pdf_params* s) {
     if (!tail_size_fits(p->n, p->S) || p->max_blocks > 0 || p->cl.bf16 || coords_given(p)) return false;
-    if (s && !(s->from_coarse && s->n == p->n && s->n_merge == p->S && s->n_bins == p->S - 1 && p->S >= 3 && s->n_bins <= 128 && p->S + s->n_samples <= 512 && s->n_samples >= 1 && (s->u_stride == 0 || s->u_stride == s->n_samples) &&
+    if (s && !(s->from_coarse && s->n == p->n && s->n_merge == p->S && s->n_bins == p->S - 1 && tail_resample_fits(p->S, s->n_samples, s->u_stride) &&
                (s->samples || s->inds || s->cdf || s->z_sorted) && (!s->merge_rank || s->z_sorted) && s->u)) return false;
     return true;
 }
@@ -237,7 +252,9 @@ using namespace ucnerf;
 extern "C" {
 
 int64_t ucnerf_fused_tail_launches(void) { return (int64_t)g_tail_launches.load(); }
+int32_t ucnerf_set_fused_tail(int32_t on) { tail_knobs_init(); return g_tail_on.exchange(on ? 1 : 0); }
 int32_t ucnerf_fused_tail_fits(int32_t n, int32_t S) { return tail_size_fits(n, S) ? 1 : 0; }
+int32_t ucnerf_fused_tail_fits_resample(int32_t n, int32_t S, int32_t n_samples) { return tail_size_fits(n, S) && tail_resample_fits(S, n_samples, 0) ? 1 : 0; }
 
 int64_t ucnerf_render_workspace_floats(int32_t n, int32_t S, int32_t V) {
     if (n < 0 || S < 1 || V < 1 || V > 8) return fail(UCNERF_EINVAL, "render_workspace: bad sizes n=%d S=%d V=%d", n, S, V);

@@ -124,6 +124,7 @@ class FusedSession:
         "versions" weight cache is selected)."""
         self.weights.clear()
         self.src, self.src_sig, self.src_refs = None, None, None
+        self._src_quick = self._src_keep = None
 
     def packed(self, precision, layout, fresh=False):
         """(flat parameter vector, packer, packed stream) of the network's CURRENT parameters.  The parameters live in one flat buffer
@@ -160,6 +161,11 @@ class FusedSession:
         """GatherSources for these tensors.  Two signatures: the HEAVY sources (volumes, images, image features -- what the
         channel-last repack copies, ~150 MB of traffic) and the light ones (confidence map, poses).  Same heavy + same light:
         the cached object; same heavy only: a new object that inherits the channel-last copies."""
+        # fast path (the 80 chunks of one image hand over the very same tensor objects): identities and version counters, no signatures
+        quick = (tuple(map(id, vols)), id(imgs), id(img_feat), id(conf), id(w2cs), id(intrinsics),
+                 tuple(t._version for t in vols), imgs._version, img_feat._version, conf._version, w2cs._version, intrinsics._version, _SOURCE_PRECISION)
+        if self.src is not None and quick == getattr(self, "_src_quick", None):
+            return self.src
         heavy = [_tensor_sig(t) for t in list(vols) + [imgs, img_feat]]
         light = [_tensor_sig(t) for t in (conf, w2cs, intrinsics)]
         hsig, lsig = tuple(s for s, _ in heavy), tuple(s for s, _ in light)
@@ -168,11 +174,13 @@ class FusedSession:
         heavy_ok = (old is not None and old.cl_bf16 == bf16 and hsig == self.src_sig[0]
                     and all(r is None or r() is not None for r in self.src_refs[0]))
         if heavy_ok and lsig == self.src_sig[1] and all(r is None or r() is not None for r in self.src_refs[1]):
+            self._src_quick, self._src_keep = quick, (list(vols), imgs, img_feat, conf, w2cs, intrinsics)      # (kept alive: an id is only an identity while its object lives)
             return old
         self.src = ops.GatherSources(vols, conf, imgs, img_feat, w2cs, intrinsics, cl_bf16=bf16)
         if heavy_ok:
             self.src._cl, self.src.cl_all = old._cl, old.cl_all
         self.src_sig, self.src_refs = (hsig, lsig), ([r for _, r in heavy], [r for _, r in light])
+        self._src_quick, self._src_keep = quick, (list(vols), imgs, img_feat, conf, w2cs, intrinsics)
         return self.src
 
     def render_pass(self, precision, layout, src, white_bkgd, fresh=False):
@@ -195,7 +203,34 @@ class FusedSession:
         return rp, flat
 
 
+_PRIVATE_SESSIONS = None        # set while a step is being captured into a HIP graph (private_sessions)
+
+
+class private_sessions:
+    """Context: every network rendered inside gets a FRESH FusedSession, returned in `self.sessions` -- for the capture of a step into a HIP graph
+    (train_step.TrainStep).  A graph replays on the buffers it was captured with; the regular session's caches (workspaces, source copies, pose
+    tensors) are re-allocated and dropped as eager calls with other shapes or sources come by, which would leave the graph with dangling
+    pointers.  The private session is created inside the capture (its buffers come from the graph's own memory pool), used by nothing else, and
+    kept alive by whoever keeps the graph.  Parameters and their flat store are shared with the regular session: they are the same tensors."""
+
+    def __enter__(self):
+        global _PRIVATE_SESSIONS
+        self._outer, self.sessions = _PRIVATE_SESSIONS, {}
+        _PRIVATE_SESSIONS = self.sessions
+        return self
+
+    def __exit__(self, *exc):
+        global _PRIVATE_SESSIONS
+        _PRIVATE_SESSIONS = self._outer
+        return False
+
+
 def session_of(net):
+    if _PRIVATE_SESSIONS is not None:
+        s = _PRIVATE_SESSIONS.get(id(net))
+        if s is None:
+            s = _PRIVATE_SESSIONS[id(net)] = FusedSession(net)
+        return s
     s = net.__dict__.get("_ucnerf_session")
     if s is None or s.params[0] is not next(net.parameters()):
         s = FusedSession(net)

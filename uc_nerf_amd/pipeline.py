@@ -96,7 +96,8 @@ class CoarseFineRenderer:
         fold_rays = self.fold_rays
         if fold_rays is None:
             fold_rays = (cpass.pw.cfg.precision == 3 and cpass.use_cl and not self.src.cl_bf16 and not self.max_blocks
-                         and bool(L.lib().ucnerf_fused_tail_fits(n, self.n_coarse)))
+                         and bool(L.lib().ucnerf_fused_tail_fits_resample(n, self.n_coarse, self.n_fine) if self.fold_launches
+                                  else L.lib().ucnerf_fused_tail_fits(n, self.n_coarse)))
         gen = self.sampler if (fold_rays and cpass.pw.cfg.precision == 3 and cpass.use_cl and self.src.V <= 6) else None
         rays_d, angle, z_c = self.sampler.prepare(xs, ys, perturb, noise) if gen is not None else self.sampler(xs, ys, perturb, noise)
         ev = [(a.h, b.h) for a, b in events] if events else (None, None)
@@ -128,14 +129,16 @@ class CoarseFineRenderer:
         xs_s, ys_s = torch.zeros(n_rays, device=dev), torch.zeros(n_rays, device=dev)
         noise_s = torch.rand(n_rays, self.n_coarse, device=dev) if perturb > 0 else None
         kw = dict(perturb=perturb, noise=noise_s, repack=repack, reuse_coarse=reuse_coarse)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):                       # warm-up: one-time attribute calls, workspace allocation
+        from .train_step import _CAPTURE_STREAMS          # one stream of the graph's own for warm-up and capture, never destroyed (train_step.GraphedStep)
+        cap = torch.cuda.Stream(device=dev)
+        _CAPTURE_STREAMS.append(cap)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(cap):                        # warm-up: one-time attribute calls, workspace allocation
             for _ in range(2):
                 self.render(xs_s, ys_s, **kw)
-        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.current_stream(dev).wait_stream(cap)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, stream=cap):
             out = self.render(xs_s, ys_s, **kw)
 
         def replay(xs=None, ys=None, noise=None):

@@ -49,7 +49,7 @@ class BatchShard:
 
 
 def sharded_training_loss(rgb, depth_pred, target_s, target_depths, target_weights, patch_dpt, mvs_outputs, depth_sparse_ms, weight_ms,
-                          shard, smooth_loss=None, edge_loss=None):
+                          shard, smooth_loss=None, edge_loss=None, mvs_term=None):
     """This rank's share of the loss of train.py:164-188; all arguments are the rank's LOCAL rows in `shard.index` order
     (`patch_dpt`: rows `shard.patch_ids`, `target_depths/weights`: rows `shard.depth_ids`).  Summed over the ranks it is the
     single-process loss, and so are its gradients.  Returns (weighted local loss, dict of weighted local terms)."""
@@ -66,7 +66,9 @@ def sharded_training_loss(rgb, depth_pred, target_s, target_depths, target_weigh
     n_loc = rgb.shape[0]
     nerf_depth = (torch.mean(((depth_pred[n_loc - nd:] - target_depths) ** 2) * target_weights) * (nd / tot["depth"])) if nd else zero
     img = L.img2mse(rgb, target_s) * (n_loc / tot["rays"]) if n_loc else zero
-    mvs, _ = L.cas_mvsnet_loss(mvs_outputs, depth_sparse_ms, weight_ms)
+    # (mvs_term: the cascade depth loss already evaluated -- its boolean-mask indexing reads sizes back to the host, which a graph capture does
+    #  not admit; it depends on nothing the renderer produces)
+    mvs = mvs_term if mvs_term is not None else L.cas_mvsnet_loss(mvs_outputs, depth_sparse_ms, weight_ms)[0]
     mvs = mvs / shard.world                                                  # replicated term: every rank holds all of it
     loss = nerf_depth * 0.05 + mvs * 0.05 + smooth * 0.05 + scale_inv * 0.008 + img * 5.0
     return loss, {"img_loss": img, "loss_nerf_depth": nerf_depth, "loss_mvs": mvs, "smooth_loss": smooth,
@@ -75,7 +77,13 @@ def sharded_training_loss(rgb, depth_pred, target_s, target_depths, target_weigh
 
 class TrainStep:
     """`render_fn(index) -> (rgb [n,3], depth_pred [n])` renders the given rays of the global batch (on the GPU: the
-    `network.renderer.rendering` mirror on the rank's rows); `params` are the tensors the optimizer updates."""
+    `network.renderer.rendering` mirror on the rank's rows); `params` are the tensors the optimizer updates.
+
+    (Round 5 built an automatic per-batch-shape HIP-graph capture into this class -- eager for a few steps, then one replay per step on static
+    copies of the batch -- and took it out again: on ROCm 7.2 `hipStreamEndCapture` crashed inside `hip::Stream::EndCapture` for this step's
+    capture, in a fresh process as in the test suite, whatever was stripped from the captured function; `GraphedStep` below, the explicit
+    opt-in on a caller-built step function, is unaffected.  The experiment, the rocgdb backtrace and the variants tried are in
+    profiles/r05_experiments.md.)"""
 
     TERMS = ("img_loss", "loss_nerf_depth", "loss_mvs", "smooth_loss", "loss_scaleinvariant")
 
@@ -106,6 +114,9 @@ class TrainStep:
         return out
 
 
+_CAPTURE_STREAMS = []        # streams captures have run on: kept for the life of the process (see GraphedStep.__init__)
+
+
 class GraphedStep:
     """One optimisation step as ONE HIP-graph replay (SURVEY.md 8(f) f1 "HIP-graph capture", for the regime it pays in: a data-parallel shard of a few
     hundred rays, where the step is bound by the host -- the rendering() training step on 250 rays x 90 issues ~70 launches in ~0.8-1.0 ms of Python
@@ -118,17 +129,23 @@ class GraphedStep:
     capturable=True)`); a new batch is COPIED INTO the tensors `fn` reads (same shapes) before `replay()`; nothing inside `fn` may read device
     memory back (`.item()`, `float()`; a FlatGradBucket must be built with `verify_every=0`)."""
 
-    def __init__(self, fn, warmup=3):
+    def __init__(self, fn, warmup=3, warmup_fn=None):
         import torch
         dev = torch.cuda.current_device()
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):                        # warm-up on a side stream: one-time attribute calls, workspaces, optimizer state
-            for _ in range(max(1, warmup)):
-                fn()
-        torch.cuda.current_stream(dev).wait_stream(side)
+        # ONE stream of this graph's own for the warm-up AND the capture, never destroyed (round 5).  Same stream: the parameters' gradient
+        # accumulators are created by the warm-up's forward on the stream the capture runs on, so autograd need not bridge two streams with
+        # short-lived events inside the capture (torch warned about exactly that mismatch in round 4's captures).  Never destroyed, and not
+        # torch's shared default capture stream: the HIP runtime keeps raw pointers to the streams and events a capture touched
+        # (hip::Stream::EndCapture walks them; a crash there is on record, profiles/r05_experiments.md) -- nothing it may point at is freed.
+        cap = torch.cuda.Stream(device=dev)
+        _CAPTURE_STREAMS.append(cap)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(cap):                         # warm-up: one-time attribute calls, workspaces, optimizer state
+            for _ in range(max(0, warmup)):                  # (warmup_fn: a pass that warms the same ops up without stepping the optimizer)
+                (warmup_fn or fn)()
+        torch.cuda.current_stream(dev).wait_stream(cap)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=cap):
             self.out = fn()
 
     def replay(self):
