@@ -228,14 +228,14 @@ def dropin_call(a, kw, scene, outputs, batch, confidence=None, vols=None, img_fe
                               network_fn=kw["network_fn"], network_query_fn=kw["network_query_fn"], white_bkgd=kw["white_bkgd"])
 
 
-def bench_eval_image(ctx, scene, a, kw, outputs, ms_per_call_default, images=3):
+def bench_eval_image(ctx, scene, a, kw, outputs, ms_per_call_default, images=7, chunk=1024):
     """The reference's evaluation loop, literally (train.py:251-275): per 256 x 320 image, 80 chunks of build_rays_test -> rendering -> .cpu() (x2),
     then the cat / reshape / clamp of the image -- through the drop-in modules, on the synthetic scene.  Every .cpu() drains the stream, so
     the host's issue time of a chunk is NOT hidden behind the GPU: this is what an unmodified caller waits for."""
     import utils.utils as U
     import network.renderer as renderer
     dev = ctx.dev
-    H, W, chunk = scene["H"], scene["W"], 1024
+    H, W = scene["H"], scene["W"]
     near_fars = torch.tensor([[scene["near"], scene["far"]]] * scene["w2cs"].shape[0], device=dev)
     tgt_to_world, world_to_ref, intrinsic = scene["c2w"], scene["w2cs"][0], scene["intrinsics"][0]
     n_chunks = H * W // chunk + int(H * W % chunk > 0)
@@ -265,17 +265,22 @@ def bench_eval_image(ctx, scene, a, kw, outputs, ms_per_call_default, images=3):
         for _ in range(2):
             rgb_img, depth_img = image()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        per = []
         for _ in range(images):
+            t0 = time.perf_counter()
             rgb_img, depth_img = image()
-        dt = (time.perf_counter() - t0) / images
+            per.append(time.perf_counter() - t0)
         image(timing=True)
     assert tuple(rgb_img.shape) == (3, H, W) and torch.isfinite(rgb_img).all() and torch.isfinite(depth_img).all()
-    return {"ms_per_image": dt * 1e3, "value": H * W / dt, "unit": "rays/s", "chunks": n_chunks, "rays_per_chunk": chunk, "samples_per_ray": a.N_samples,
-            "ms_80_rendering_calls_alone": 80 * ms_per_call_default,
+    per.sort()
+    dt = per[len(per) // 2]                       # median: the loop drains the stream 160 times per image and follows the host's scheduling noise
+    return {"ms_per_image": dt * 1e3, "ms_per_image_min": per[0] * 1e3, "ms_per_image_max": per[-1] * 1e3, "images_timed": images,
+            "value": H * W / dt, "unit": "rays/s", "chunks": n_chunks, "rays_per_chunk": chunk, "samples_per_ray": a.N_samples,
+            "ms_rendering_calls_alone": n_chunks * ms_per_call_default if chunk == 1024 else None,
             "host_wall_ms_per_image_by_call": {k: v * 1e3 for k, v in split.items()},
-            "note": "the loop of train.py:251-275 through the drop-in modules, unmodified: build_rays_test -> rendering -> rgb.cpu(), depth.cpu() per 1024-pixel "
-                    "chunk; host_wall_ms_per_image_by_call = wall time spent inside each call (the .cpu() wait contains the chunk's GPU time)"}
+            "note": "the loop of train.py:251-275 through the drop-in modules, unmodified: build_rays_test -> rendering -> rgb.cpu(), depth.cpu() per %d-pixel "
+                    "chunk (args.chunk of the reference's own command line); median of %d images; host_wall_ms_per_image_by_call = wall time inside each call "
+                    "during one more image (the .cpu() wait contains the chunk's GPU time)" % (chunk, images)}
 
 
 def bench_dropin(ctx, scene, sd, steps=40, warmup=10):
@@ -325,12 +330,15 @@ def bench_dropin(ctx, scene, sd, steps=40, warmup=10):
             out["dropin_eval_" + prec]["speed_vs_render_pass"] = rp_ms / out["dropin_eval_" + prec]["ms_per_call"]
             out["dropin_eval_" + prec]["speed_vs_render_pass_versions_cache"] = rp_ms / out["dropin_eval_" + prec]["ms_per_call_versions_cache"]
     out["dropin_eval_image"] = guarded(lambda: bench_eval_image(ctx, scene, a, kw, outputs, out["dropin_eval_default"]["ms_per_call"]))
+    # the same loop with the reference's own --chunk option set to the image size: ONE build_rays_test + ONE rendering per image (the fused pass keeps
+    # no per-sample features, so nothing but the coordinates -- 0.44 GB -- scales with the chunk)
+    out["dropin_eval_image_one_chunk"] = guarded(lambda: bench_eval_image(ctx, scene, a, kw, outputs, 0.0, chunk=scene["H"] * scene["W"]))
     # training: 2000 rays x 90 samples, forward + loss + backward into the network AND the gather sources + Adam (train.py:147-188, 85-92)
     vols = [v.detach().clone().requires_grad_(True) for v in scene["vols"]]
     img_feat = scene["img_feat"].detach().clone().requires_grad_(True)
     conf = scene["confidence"].detach().clone().requires_grad_(True)
 
-    def make_step(n_rays, opt, seed):
+    def make_step(n_rays, opt, seed, vols=vols, img_feat=img_feat, scene=scene):
         tr = live_path_batch(scene, outputs, n_rays, 90, seed=seed)
         target = torch.rand(n_rays, 3, device=dev)
 
@@ -428,7 +436,19 @@ def bench_dropin(ctx, scene, sd, steps=40, warmup=10):
             dtg = ctx.timed(g.replay, steps * 2, warmup * 2)
             assert torch.isfinite(g.replay()).all()
             res[n_rays] = dtg
+        # ... and on sources as a producer's convolutions write them (channels_last / channels_last_3d, read in place: no repack, no scratch fill, no
+        # transposing add in the captured step)
+        prod, _ = conv_produced_sources(scene, dev)
+        vols_c = [v.detach().requires_grad_(True) for v in prod["vols"]]
+        feat_c = prod["img_feat"].detach().requires_grad_(True)
+        for n_rays, seed in ((2000, 4), (250, 5)):
+            optg = FlatAdam(net2, lr=5e-4, betas=(0.9, 0.999), capturable=True)
+            g = GraphedStep(make_step(n_rays, optg, seed, vols=vols_c, img_feat=feat_c, scene=dict(scene, imgs=prod["imgs"])))
+            res[("cl", n_rays)] = ctx.timed(g.replay, steps * 2, warmup * 2)
+            assert torch.isfinite(g.replay()).all()
         return {"ms_per_step_2000": res[2000] * 1e3, "ms_per_step_250": res[250] * 1e3, "projected_speedup_at_8_gpus": res[2000] / res[250],
+                "channels_last_sources": {"ms_per_step_2000": res[("cl", 2000)] * 1e3, "ms_per_step_250": res[("cl", 250)] * 1e3,
+                                          "projected_speedup_at_8_gpus": res[("cl", 2000)] / res[("cl", 250)]},
                 "note": "the rendering() training step (forward + loss + backward + FlatAdam) captured into one HIP graph and replayed "
                         "(uc_nerf_amd.train_step.GraphedStep): an opt-in for static batch shapes; NOT a scaling measurement"}
     out["dropin_train_graphed"] = guarded(graphed)

@@ -42,7 +42,8 @@ int ucnerf_device_cus(void);
  * the sources in round 4).  The host side checks the production values (tests/test_abi_host.py). */
 const char* ucnerf_build_flags(void);
 /* Diagnostics: how many ucnerf_render_fused_fwd calls of this process let the gather-fused launch composite (and re-sample) its rays in its own
- * tail instead of launching K7 / K8 / K9 behind it -- passes of at most three rounds of 32-sample tiles (csrc/render.hip: tail_fits; the
+ * tail instead of launching K7 / K8 / K9 behind it -- passes of at most three rounds of 32-sample tiles, derived or given coordinates, any number of
+ * samples per ray up to 256 (csrc/render.hip: tail_fits; the
  * outputs are bit-identical either way).  The environment variable UCNERF_FUSED_TAIL=0 (read once, at the first use) starts the process with
  * that route off; ucnerf_set_fused_tail(0 / 1) switches it at run time and returns the previous setting (thread-safe). */
 int64_t ucnerf_fused_tail_launches(void);
@@ -596,6 +597,10 @@ typedef struct {
     const ucnerf_sample_pdf_params* resample;   /* optional (HOST pointer): the pass's compositing launch also draws the NEXT pass's depths from its
                                   weights -- ucnerf_composite_sample_pdf(this pass's compositing, *resample) instead of ucnerf_composite_fwd;
                                   resample->weights / z_merge may be NULL (implied: this pass's weights and z) */
+    const float* w2c_dir_dev;  /* ABI v5, optional DEVICE pointer to the rotation of the view-direction feature, row-major with 4 columns (a [3,4] or
+                                  [4,4] tensor): used instead of w2c_dir when dir_feat is NULL and this is set -- rendering() holds
+                                  pose_ref['w2cs'][0] on the device and need not read it back.  On the tail route the features are then made
+                                  in the blocks' prologues (no ucnerf_dir_feature launch) */
     const ucnerf_ray_gen_params* gen_rays;      /* optional (HOST pointers, both or none; cfg.precision == 3, derived coordinates, xs / ys pixel lists): the */
     const ucnerf_sample_stratified_params* gen_depths;  /* fused launch generates its own rays and stratified depths -- ucnerf_ray_gen_sample folded into the
                                   kernel's per-tile prologue.  rays_d / z / dir_feat of THIS struct are then buffers the launch FILLS (they must

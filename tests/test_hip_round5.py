@@ -333,3 +333,84 @@ def test_build_rays_test_in_one_launch_equals_the_three_launches(chunk_idx, S):
     b = ops.build_rays_test(H, W, start, n, S, scene["K"], scene["c2w"], scene["w2cs"][0], scene["intrinsics"][0], nf_ref, [outputs["stage%d" % k]["depth_values"] for k in (1, 2, 3)], t2)
     assert torch.equal(a[0], b["pts"]) and torch.equal(a[1], b["rays_d"]) and torch.equal(a[3], b["z"]) and tuple(a[4].shape) == (n, 3)
     assert all(torch.equal(a[2][k], b[k]) for k in ("stage1", "stage2", "stage3", "ndc")) and a[5]["pad"] == 0
+
+
+# ---------------------------------------------------------------------------------------------- rendering()'s chunks in ONE launch
+@pytest.mark.parametrize("n,S,given", [(1024, 90, True), (1000, 90, True), (1024, 90, False), (700, 45, False), (512, 96, True), (512, 33, True), (300, 90, True)])
+def test_tail_route_serves_given_coordinates_and_any_sample_count_bit_identically(n, S, given):
+    """Round 5: the gather-fused launch composites its rays in its own tail also for GIVEN coordinates (what rendering() is handed,
+    network/renderer.py:215-255) and for sample counts that are no multiple of 32 (the 90 cascade samples): a block's tiles start at its own first
+    sample.  And it makes the view-direction features itself from the rotation on the device.  Outputs equal the separate launches' bit for bit."""
+    from uc_nerf_amd import _lib as L
+    from uc_nerf_amd import ops
+    from uc_nerf_amd.pipeline import flat_params_of
+    from uc_nerf_amd.synthetic import cascade_outputs, init_ucnerf_state_dict, live_path_batch
+    scene = _scene()
+    outputs = cascade_outputs(scene)
+    sd = init_ucnerf_state_dict(seed=0, n_src=6, sigma_scale=0.05, sigma_bias=0.05)
+    src = ops.GatherSources(scene["vols"], scene["confidence"], scene["imgs"], scene["img_feat"], scene["w2cs"][1:], scene["intrinsics"][1:])
+    pw = ops.PackedWeights.get(6, 0, torch.device(DEV), "bf16x3_fused")
+    rp = ops.RenderPass(src, pw, pw.pack(flat_params_of(sd).to(DEV)), scene["c2w"][:3, 3].to(DEV), scene["w2cs"][0], scene["intrinsics"][0], scene["w2cs"][0],
+                        scene["near"], scene["far"])
+    rp.repack_sources()
+    b = live_path_batch(scene, outputs, n, S, seed=n + S)
+    coords = {"pts": b["rays_pts"], "stage1": b["rays_ndc"]["stage1"], "stage2": b["rays_ndc"]["stage2"], "stage3": b["rays_ndc"]["stage3"], "ndc": b["rays_ndc"]["ndc"]} if given else None
+    nf = None if given else b["ranges"]
+    ang, _ = ops.dir_feature(b["rays_dir"], scene["w2cs"][0])
+    count = L.lib().ucnerf_fused_tail_launches
+    fits = bool(L.lib().ucnerf_fused_tail_fits(n, S))
+    outs = []
+    for tail, dev_rot in ((0, False), (1, False), (1, True)):
+        L.lib().ucnerf_set_fused_tail(tail)
+        try:
+            c0 = count()
+            kw = dict(w2c_dir_dev=scene["w2cs"][0]) if dev_rot else dict(dir_feat=ang)
+            o = rp(b["rays_dir"], b["depth_candidates"], near_far=nf, want=("acc", "weights", "var"), keep=("raw",), coords=coords, **kw)
+            assert count() - c0 == int(bool(tail) and fits), (tail, fits)
+            outs.append({k: v.clone() for k, v in o.items() if torch.is_tensor(v)})
+        finally:
+            L.lib().ucnerf_set_fused_tail(1)
+    assert fits == (n != 300)                                # (300 rays spread over 150 of the 256 CUs: the separate launches serve them)
+    for other in outs[1:]:
+        for k in ("rgb", "depth", "acc", "weights", "var", "raw"):
+            assert torch.equal(outs[0][k], other[k]), k
+
+
+def test_rendering_under_no_grad_is_one_launch_per_chunk_and_unchanged():
+    """rendering() on an evaluation chunk (train.py:254-272: 1024 pixels x 90 samples, coordinates from build_rays_test): the default route is now
+    ONE launch -- view directions, gather, encoding, MLP, compositing -- with the same bits as the separate launches, and within 2e-5 of the exact kernel."""
+    import uc_nerf_amd
+    from uc_nerf_amd import _lib as L
+    import utils.utils as U
+    from uc_nerf_amd.synthetic import cascade_outputs, init_ucnerf_state_dict
+    mods = _mods()
+    scene = _scene()
+    outputs = cascade_outputs(scene)
+    net = _net(mods, 7, init_ucnerf_state_dict(seed=0, n_src=6, sigma_scale=0.05, sigma_bias=0.05))
+    qfn = _qfn(mods)
+    a = types.SimpleNamespace(view_num=7, feat_dim=97, img_downscale=1.0, use_color_volume=False, net_type="v2")
+    nf = torch.tensor([[scene["near"], scene["far"]]] * 7, device=DEV)
+    torch.manual_seed(11)
+    pts, rd, ndc, z, ro, ndcp = U.build_rays_test(256, 320, scene["c2w"], scene["w2cs"][0], scene["intrinsics"][0], nf, nf[-1], 90, chunk=1024, idx=33, outputs=outputs)
+
+    def call():
+        pose = {"w2cs": scene["w2cs"].clone(), "intrinsics": scene["intrinsics"].clone()}
+        return mods.renderer.rendering(a, pose, pts, ndc, z, rd, outputs, scene["imgs"], img_feat=scene["img_feat"], confidence=scene["confidence"],
+                                       network_fn=net, network_query_fn=qfn, ndc_parameters=ndcp)
+    count = L.lib().ucnerf_fused_tail_launches
+    with torch.no_grad():
+        c0 = count()
+        rgb1, d1 = call()
+        assert count() - c0 == 1
+        L.lib().ucnerf_set_fused_tail(0)
+        try:
+            rgb0, d0 = call()
+        finally:
+            L.lib().ucnerf_set_fused_tail(1)
+        assert torch.equal(rgb0, rgb1) and torch.equal(d0, d1)
+        uc_nerf_amd.set_inference_precision("f32")
+        try:
+            rgbx, dx = call()
+        finally:
+            uc_nerf_amd.set_inference_precision("bf16x3_fused")
+    assert (rgb1 - rgbx).abs().max().item() < 2e-5 and (d1 - dx).abs().max().item() < 4e-5

@@ -144,7 +144,7 @@ class RenderParams(C.Structure):
                 ("depth_map", vp), ("acc_map", vp), ("weights", vp), ("var", vp), ("raw", vp), ("feats", vp),
                 ("ev_mlp_start", vp), ("ev_mlp_stop", vp), ("train_workspace", vp), ("dir_feat", vp), ("u_sampled", vp),
                 ("wu_map", vp), ("pts_in", vp), ("ndc1_in", vp), ("ndc2_in", vp), ("ndc3_in", vp), ("ndc_in", vp), ("feats_tiled", i32), ("train_bwd_mode", i32),
-                ("resample", vp), ("gen_rays", vp), ("gen_depths", vp)]
+                ("resample", vp), ("w2c_dir_dev", vp), ("gen_rays", vp), ("gen_depths", vp)]
 
 
 class RenderBwdParams(C.Structure):

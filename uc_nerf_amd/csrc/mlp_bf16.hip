@@ -515,6 +515,12 @@ struct FusedGather {
     // consecutive tiles per block) and, when its last tile is done, a block composites its rays itself (K7, composite_device.h) and -- coarse
     // pass -- draws the fine depths from them (K8 + K9, sample_pdf_device.h): one launch for K3 .. K9 of the pass
     int tail_rpb, tail_tpr, tail_resample;
+    int tail_spb;            // samples per block = tail_rpb * S: the block's tiles start at ITS first sample (round 5: S need not be a multiple of 32,
+                             // e.g. the 90 cascade samples of rendering()), so a block's last tile may be partly filled
+    // view-direction features made in the block's prologue from the rays' directions (round 5: rendering() hands over rays_d and a rotation that
+    // lives on the device -- no ucnerf_dir_feature launch): angle = (d / |d|) @ Q^T written to tail_dir_out [n,3], which the tiles then read
+    const float* tail_dir_Q;     // [>=3,4] DEVICE, or NULL: the features are given (ucnerf_mlp_params.dirs)
+    float* tail_dir_out;
     ucnerf_composite_params tail_c;
     ucnerf_sample_pdf_params tail_s;
 };
@@ -579,8 +585,21 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
+        if (TAIL && fg.tail_dir_Q) {
+            const int bx0 = (int)blockIdx.x, nbk = (int)gridDim.x;
+            const int lb = (nbk & 7) == 0 ? (bx0 & 7) * (nbk >> 3) + (bx0 >> 3) : bx0;
+            const int ray0 = lb * fg.tail_rpb, nr = fg.tail_c.n - ray0 < fg.tail_rpb ? fg.tail_c.n - ray0 : fg.tail_rpb;
+            for (int r = threadIdx.x; r < nr; r += 64 * BW) {
+                const size_t o = 3 * (size_t)(ray0 + r);
+                float ax, ay, az;
+                view_dir_feature(fg.rays_d[o], fg.rays_d[o + 1], fg.rays_d[o + 2], fg.tail_dir_Q, &ax, &ay, &az);      // (dir_feature_kernel's arithmetic)
+                fg.tail_dir_out[o] = ax; fg.tail_dir_out[o + 1] = ay; fg.tail_dir_out[o + 2] = az;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        }
         __syncthreads();
-        if (TAIL && fg.gen_xs) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (TAIL && (fg.gen_xs || fg.tail_dir_Q)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 
     Pipe P;
@@ -599,7 +618,13 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     // keeps the weight ring turning (idle_tile below): the 512-ray shard of a strongly-scaled batch is 0.5 + 1.5 such rounds.
     // (TAIL: block b owns the tiles of its rays, [b * t_blk, (b + 1) * t_blk), eight per round; its last rounds may be partly filled -- waves 0..3,
     //  one per SIMD, first)
-    const int t_blk = TAIL ? fg.tail_rpb * fg.tail_tpr : 0;
+    const int nb_ = (int)gridDim.x, bx_ = (int)blockIdx.x;
+    const int lblock = (nb_ & 7) == 0 ? (bx_ & 7) * (nb_ >> 3) + (bx_ >> 3) : bx_;
+    const int t_blk = TAIL ? (fg.tail_spb + 31) / 32 : 0;
+    // TAIL: the block's own samples [s_base, s_lim) = its whole rays; tile j of the block covers samples s_base + 32 j ...: with the block's
+    // tiles numbered lblock * t_blk + j, sample = 32 tile + s_off + lane (two block constants, s_off and s_lim, in scalar registers)
+    const int s_off = TAIL ? lblock * (fg.tail_spb - 32 * t_blk) : 0;
+    const int s_lim = TAIL ? ((lblock + 1) * fg.tail_spb < p.m ? (lblock + 1) * fg.tail_spb : p.m) : p.m;
     const int tiles_per_round = TAIL ? BW : gridDim.x * BW;
     const int n_rounds = TAIL ? (t_blk + BW - 1) / BW : (n_tiles + tiles_per_round - 1) / tiles_per_round;
 #ifndef UCNERF_BF16_WAVE_MAJOR
@@ -607,8 +632,6 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
 #endif
     // (workgroups go to the eight XCDs round-robin: block b counts as logical block (b % 8) * (blocks / 8) + b / 8, so that consecutive tiles --
     //  the 32-sample pieces of one ray, which gather from the same corner of the sources -- stay behind one XCD's L2)
-    const int nb_ = (int)gridDim.x, bx_ = (int)blockIdx.x;
-    const int lblock = (nb_ & 7) == 0 ? (bx_ & 7) * (nb_ >> 3) + (bx_ >> 3) : bx_;
     const int tile0 = TAIL ? lblock * t_blk + wave : UCNERF_BF16_WAVE_MAJOR ? wave * nb_ + lblock : bx_ * BW + wave;
 
     // Inputs of a tile are fetched one tile ahead (under the previous tile's head / blend arithmetic, when few registers
@@ -617,7 +640,8 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     // a constant offset again: the per-lane clamp it replaces cost the odd view counts 64-80 bytes of scratch), confidence, point.
     float nfs[4][8], nconf, npx[3];
     // (j and the parked-scalar address are re-derived from `lane` at each use: as loop-long values they get spilled)
-    auto sample_of = [&](int tile) { const int s_raw = tile * 32 + (opaque(lane) & 31); return s_raw < p.m ? s_raw : p.m - 1; };
+    auto s_raw_of = [&](int tile) { return tile * 32 + s_off + (opaque(lane) & 31); };
+    auto sample_of = [&](int tile) { const int s_raw = s_raw_of(tile); return s_raw < s_lim ? s_raw : s_lim - 1; };
     auto feat_base = [&](int s) { return TILED ? p.feats + ((size_t)(s >> 5) * F * 32 + (s & 31)) : p.feats + (size_t)s * g.feat_stride; };
     constexpr int fstride = TILED ? 32 : 1;
     auto fetch = [&](int tile) {
@@ -885,7 +909,7 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
     for (int round = 0; round < n_rounds; ++round) {                          // block-uniform trip count: every wave joins every barrier
         const int tile = round * tiles_per_round + tile0;
 #if UCNERF_BF16_IDLE_SKIP
-        if (tile >= n_tiles || (TAIL && round * BW + wave >= t_blk)) {      // (wave-uniform; every later tile of this wave is past the end too)
+        if (TAIL ? (round * BW + wave >= t_blk || tile * 32 + s_off >= s_lim) : tile >= n_tiles) {      // (wave-uniform; every later tile of this wave is past the end too)
             for (int i = 0; i < g.slots; ++i) advance<NB>(P);      // this wave's DMA pieces and barriers of one tile, nothing else
             cur = read_half(P.buf, lane, 0);
             continue;
@@ -1173,13 +1197,13 @@ __global__ void __launch_bounds__(64 * BW, UCNERF_BF16_WPS) mlp_fwd_bf16_kernel(
         head_part(hadapt, ha, h, acc[3], 3, 0, 16, relu);
         const f32x4 adapt = head_finish(hadapt, ha);
         const float u = ustash_w[opaque(lane)], omu = 1.f - u;
-        const int s_raw = tile * 32 + (opaque(lane) & 31);
+        const int s_raw = s_raw_of(tile);
         f32x4 out;
         out.x = 1.f / (1.f + expf(-(base.x * omu + adapt.x * u)));
         out.y = 1.f / (1.f + expf(-(base.y * omu + adapt.y * u)));
         out.z = 1.f / (1.f + expf(-(base.z * omu + adapt.z * u)));
         out.w = fmaxf(adapt.w * omu + base.w * u, 0.f);
-        if (h == 0 && s_raw < p.m) reinterpret_cast<f32x4*>(p.raw)[s_raw] = out;
+        if (h == 0 && s_raw < s_lim) reinterpret_cast<f32x4*>(p.raw)[s_raw] = out;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
     if (TAIL) {
@@ -1230,10 +1254,15 @@ int launch_fused_tail(const ucnerf_mlp_params* p, const BGeom* g, int n_tiles, c
     static_assert(BW * (sizeof(PdfShared<128, 512>) + (128 + 2) * sizeof(float)) <= bf16_smem_bytes_fused(1), "the rays' LDS arrays re-use the kernel's image");
     dim3 grid(blocks), block(64 * BW);
 #define X(N)                                                                                                                   \
-    if (v == N) {                                                                                                              \
+    if (v == N && !fg->pts_in) {                                                                                               \
         const void* fn = (const void*)mlp_fwd_bf16_kernel<true, N, 3, false, true, false, false, false, true>;                 \
         if (int rc = ensure_dynamic_lds(fn, (int)smem_f, "mlp_fwd (bf16x3, gather fused, compositing in the tail)")) return rc; \
         hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, 3, false, true, false, false, false, true>), grid, block, smem_f, st, *p, *g, n_tiles, sv, *fg); \
+    }                                                                                                                          \
+    if (v == N && fg->pts_in) {      /* coordinates given: what rendering() hands over (network/renderer.py:215-255) */       \
+        const void* fn = (const void*)mlp_fwd_bf16_kernel<true, N, 3, false, true, true, false, false, true>;                  \
+        if (int rc = ensure_dynamic_lds(fn, (int)smem_f, "mlp_fwd (bf16x3, gather fused, given coordinates, compositing in the tail)")) return rc; \
+        hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, N, 3, false, true, true, false, false, true>), grid, block, smem_f, st, *p, *g, n_tiles, sv, *fg); \
     }
     X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #undef X
@@ -1284,7 +1313,7 @@ static int launch_bf16(const ucnerf_mlp_params* p, const MlpSaved* save, hipStre
         UCNERF_REQUIRE(!(fg.s16 && fg.pts_in), "mlp_fwd (gather fused): bf16 channel-last sources are served on derived coordinates only (given coordinates: fp32 copies, "
                        "or the two-kernel pass)");
         if (fg.tail_rpb > 0) {      // the launch composites its rays itself (small passes, render.hip): whole rays per block, which it also generates when asked to
-            UCNERF_REQUIRE(!fg.pts_in && !fg.s16 && !(fg.gen_xs && fg.near_far) && p->max_blocks <= 0, "mlp_fwd (gather fused): compositing in the tail goes with derived coordinates and fp32 sources");
+            UCNERF_REQUIRE(!fg.s16 && !(fg.gen_xs && (fg.near_far || fg.pts_in)) && p->max_blocks <= 0, "mlp_fwd (gather fused): compositing in the tail goes with fp32 sources (and generated rays with derived coordinates)");
             return launch_fused_tail(p, &g, n_tiles, &fg, cdiv(fg.tail_c.n, fg.tail_rpb), st);
         }
         UCNERF_REQUIRE(!fg.gen_xs || (!fg.s16 && !fg.pts_in && !fg.near_far && B.v <= 6), "mlp_fwd (gather fused): generated rays go with fp32 source copies, derived "
@@ -1376,7 +1405,7 @@ int launch_mlp_fwd_bf16x3_save(const ucnerf_mlp_params* p, const MlpSaved* save,
 // `tail_c` (optional): the launch also composites the pass's rays (and, with `tail_s`, re-samples from them) -- see FusedGather
 int check_cl_sources(const ucnerf_render_params* p, const char* who);      // gather_cl.hip
 int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* dirs, float* raw, hipStream_t st,
-                                 const ucnerf_composite_params* tail_c, const ucnerf_sample_pdf_params* tail_s) {
+                                 const ucnerf_composite_params* tail_c, const ucnerf_sample_pdf_params* tail_s, float* tail_dir_out) {
     const long long M = (long long)rp->n * rp->S;
     UCNERF_REQUIRE(M < (1ll << 31), "render (gather fused): %lld samples in one pass (limit 2^31 - 1)", M);
     if (int rc = check_cl_sources(rp, "render (gather fused)")) return rc;
@@ -1418,7 +1447,9 @@ int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* di
     if (tail_c) {
         const int cus = device_cus();
         if (cus <= 0) return fail(UCNERF_EHIP, "mlp_fwd: no device");
-        f.tail_rpb = cdiv(rp->n, cus); f.tail_tpr = rp->S / 32; f.tail_resample = tail_s ? 1 : 0;
+        f.tail_rpb = cdiv(rp->n, cus); f.tail_tpr = cdiv(rp->S, 32); f.tail_resample = tail_s ? 1 : 0;
+        f.tail_spb = f.tail_rpb * rp->S;
+        if (tail_dir_out) { f.tail_dir_Q = rp->w2c_dir_dev; f.tail_dir_out = tail_dir_out; }      // (render.hip: the features are made in the blocks' prologues)
         f.tail_c = *tail_c;
         if (tail_s) f.tail_s = *tail_s;
     }

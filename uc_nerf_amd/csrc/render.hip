@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) render_points_kernel(PointsArgs a) {
 int launch_gather_cl(const ucnerf_render_params* p, float* feats, int tiled, float* ndc, hipStream_t st);
 int check_cl_sources(const ucnerf_render_params* p, const char* who);                                              // gather_cl.hip
 int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* dirs, float* raw, hipStream_t st,
-                                 const ucnerf_composite_params* tail_c, const ucnerf_sample_pdf_params* tail_s);   // mlp_bf16.hip
+                                 const ucnerf_composite_params* tail_c, const ucnerf_sample_pdf_params* tail_s, float* tail_dir_out);   // mlp_bf16.hip
 
 struct Workspace {
     float *pts, *ndc1, *ndc2, *ndc3, *ndc, *angle, *feats, *raw;
@@ -118,6 +118,7 @@ static int launch_dirs(const ucnerf_render_params* p, hipStream_t st, Workspace*
     memset(&d, 0, sizeof(d));
     d.n = p->n; d.has_ref = 1; d.repeat = 1; memcpy(d.w2c_ref, p->w2c_dir, sizeof(d.w2c_ref));
     d.rays_d = p->rays_d; d.angle = w->angle; d.cos_angle = nullptr;
+    d.w2c_ref_dev = p->w2c_dir_dev;                     // (the rotation on the device, when the caller holds it there: rendering()'s pose_ref['w2cs'][0])
     return ucnerf_dir_feature(&d, st);
 }
 
@@ -161,13 +162,13 @@ static bool tail_size_fits(int n, int S) {
     tail_knobs_init();
     if (!g_tail_on.load(std::memory_order_relaxed)) return false;
     const int cus = device_cus();
-    if (cus <= 0 || n < 1 || S % 32 != 0 || S > 256) return false;
+    if (cus <= 0 || n < 1 || S < 1 || S > 256) return false;      // (round 5: any S -- a block's tiles start at its own first sample)
     // the largest pass, in half rounds of tiles (a round = CUs x 8 tiles): three rounds.  Measured with the rays generated in the prologue (same box, 64 + 128):
     // 512 rays -4.5 %, 1024 rays -1.1 % (fine pass = 3 rounds), 2048 rays -0.2 .. -0.6 % (up to 6 rounds), 4096 rays +0.3 % (4 + 12 rounds): the
     // whole-rays-per-block dealing costs large passes what the folded launches save them.  UCNERF_FUSED_TAIL_HALF_ROUNDS overrides (tuning).
-    if ((long long)n * (S / 32) * 2 > (long long)g_tail_half_rounds.load(std::memory_order_relaxed) * cus * 8) return false;
     // whole rays per block: rays / ceil(rays / CUs) blocks -- all but a tenth of the CUs must get one (37 rays: + 13 % on 37 blocks)
     const int rpb = cdiv(n, cus), blocks = cdiv(n, rpb);
+    if ((long long)cdiv(rpb * S, 32) * 2 > (long long)g_tail_half_rounds.load(std::memory_order_relaxed) * 8) return false;      // tiles per block, in half rounds of eight
     return blocks * 10 >= cus * 9;
 }
 // the re-sampling a tail can do itself (the stand-alone kernels' small LDS shapes)
@@ -175,7 +176,7 @@ static bool tail_resample_fits(int S, int n_samples, int u_stride) {
     return S >= 3 && S - 1 <= 128 && S + n_samples <= 512 && n_samples >= 1 && (u_stride == 0 || u_stride == n_samples);
 }
 static bool tail_fits(const ucnerf_render_params* p, const ucnerf_sample_pdf_params* s) {
-    if (!tail_size_fits(p->n, p->S) || p->max_blocks > 0 || p->cl.bf16 || coords_given(p)) return false;
+    if (!tail_size_fits(p->n, p->S) || p->max_blocks > 0 || p->cl.bf16) return false;      // (round 5: given coordinates take the route too)
     if (s && !(s->from_coarse && s->n == p->n && s->n_merge == p->S && s->n_bins == p->S - 1 && tail_resample_fits(p->S, s->n_samples, s->u_stride) &&
                (s->samples || s->inds || s->cdf || s->z_sorted) && (!s->merge_rank || s->z_sorted) && s->u)) return false;
     return true;
@@ -200,15 +201,18 @@ static int run_forward(const ucnerf_render_params* p, hipStream_t st, Workspace*
                        "render_fused_fwd: precision 3 (gather fused into the MLP kernel) needs the channel-last sources; it keeps no features "
                        "and returns no per-sample uncertainty");
         const bool gen = p->gen_rays != nullptr;          // rays, depths and direction features are generated inside the launch (w->angle: its per-sample scratch)
-        if (!gen && !p->dir_feat && (rc = launch_dirs(p, st, w))) return rc;
+        const bool tail = tail_fits(p, p->resample ? &s_res : nullptr);
+        // the view-direction features: given (dir_feat), generated with the rays (gen), made in the tail route's block prologues when the rotation
+        // lives on the device (w2c_dir_dev: no launch of its own), or from ucnerf_dir_feature
+        const bool dirs_in_tail = tail && !gen && !p->dir_feat && p->w2c_dir_dev;
+        if (!gen && !p->dir_feat && !dirs_in_tail && (rc = launch_dirs(p, st, w))) return rc;
         raw_fused = p->raw ? p->raw : w->raw;
         if (p->ev_mlp_start && (rc = ucnerf_event_record(p->ev_mlp_start, st))) return rc;
-        const bool tail = tail_fits(p, p->resample ? &s_res : nullptr);
         if (tail) composite_args(p, raw_fused, &c);
         // (rays generated inside the launch: the RAYGEN instantiation derives every lane's direction feature itself and uses w->angle as scratch; the
         //  tail route's blocks write the caller's buffers first and read them like given ones)
         if ((rc = launch_mlp_fwd_bf16x3_gather(p, gen && !tail ? w->angle : p->dir_feat ? p->dir_feat : w->angle, raw_fused, st, tail ? &c : nullptr,
-                                               tail && p->resample ? &s_res : nullptr))) return rc;
+                                               tail && p->resample ? &s_res : nullptr, dirs_in_tail ? w->angle : nullptr))) return rc;
         if (p->ev_mlp_stop && (rc = ucnerf_event_record(p->ev_mlp_stop, st))) return rc;
         if (tail) { ++g_tail_launches; return UCNERF_OK; }      // K7 (and K8, K9) ran inside the launch
     } else if (cl_given(p)) {                                  // fast path: channel-last sources, coordinates derived in-kernel

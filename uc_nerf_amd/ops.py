@@ -1156,14 +1156,18 @@ class RenderPass:
         p.pts_in, p.ndc1_in, p.ndc2_in, p.ndc3_in, p.ndc_in = (_ptr(t) for t in keep)
         return keep
 
-    def __call__(self, rays_d, z, near_far=None, want=("acc", "weights", "var"), keep=(), events=None, dir_feat=None, coords=None, resample=None, gen=None):
+    def __call__(self, rays_d, z, near_far=None, want=("acc", "weights", "var"), keep=(), events=None, dir_feat=None, coords=None, resample=None, gen=None,
+                 w2c_dir_dev=None):
         """want may also name "u" (per-sample uncertainty u = 1 - sampled confidence [n,S], network/models.py:149) and
         "wu" (its composite sum_i w_i u_i [n]) -- the opt-in uncertainty outputs of SURVEY.md 8(a).
         resample: dict(u=draws [n,M] or [M], want_rank=False) -- the pass's compositing launch also draws the NEXT pass's depths from this pass's
         weights (data/ray_utils.py:216-219: mid-point bins, w[1:-1], sorted merge with z): adds out["samples"] [n,M], out["z_sorted"] [n,S+M]
         (and out["merge_rank"]), the results of sample_pdf(None, out["weights"], u, z_merge=z, from_coarse=True) bit for bit, with no launch of its own.
         gen: a RaySampler whose prepare() returned this call's (rays_d, dir_feat, z): the pass generates them itself (gather-fused kernel only) -- the
-        values of RaySampler.__call__, bit for bit, with no launch of its own."""
+        values of RaySampler.__call__, bit for bit, with no launch of its own.
+        w2c_dir_dev (with dir_feat=None): the rotation of the view-direction feature as a float32 DEVICE tensor ([3,4] or [4,4], contiguous), read by
+        the kernels in place of the by-value w2c_dir -- rendering() holds pose_ref['w2cs'][0] on the device; on the tail route the features are
+        then made inside the pass's one launch."""
         rays_d, z = _f32(rays_d, "rays_d"), _f32(z, "z")
         dir_feat = _f32(dir_feat, "dir_feat") if dir_feat is not None else None
         n, S = z.shape
@@ -1203,6 +1207,12 @@ class RenderPass:
         p.ev_mlp_start, p.ev_mlp_stop = events if events is not None else (None, None)
         p.train_workspace = None
         p.dir_feat = _ptr(dir_feat)
+        p.w2c_dir_dev = None
+        if w2c_dir_dev is not None and dir_feat is None:
+            if not (w2c_dir_dev.is_cuda and w2c_dir_dev.dtype == torch.float32 and w2c_dir_dev.dim() == 2 and w2c_dir_dev.shape[0] >= 3
+                    and w2c_dir_dev.shape[1] == 4 and w2c_dir_dev.is_contiguous()):
+                raise RuntimeError("uc_nerf_amd.RenderPass: w2c_dir_dev must be a contiguous float32 [3,4] or [4,4] tensor on the device")
+            p.w2c_dir_dev = _ptr(w2c_dir_dev)
         p.gen_rays = p.gen_depths = None
         if gen is not None:
             if self.pw.cfg.precision != 3 or coords is not None or near_far is not None or dir_feat is None:
