@@ -873,7 +873,7 @@ def main():
     # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, scripts/pmc_mlp.sh), which
     # cannot run inside this process: the figure is READ BACK from the committed profile and labelled as such
     traffic, traffic_source = None, None
-    for name in (("r04_mlp_bf16_fused_hbm_traffic.json", "r03_mlp_bf16_fused_hbm_traffic.json", "r02_mlp_bf16_fused_hbm_traffic.json") if args.precision == "bf16x3_fused" else
+    for name in (("r05_mlp_bf16_fused_hbm_traffic.json", "r04_mlp_bf16_fused_hbm_traffic.json", "r03_mlp_bf16_fused_hbm_traffic.json", "r02_mlp_bf16_fused_hbm_traffic.json") if args.precision == "bf16x3_fused" else
                  ("r02_mlp_bf16_hbm_traffic.json", "r01_mlp_bf16_hbm_traffic.json") if bf16 else ("r02_mlp_fwd_hbm_traffic.json", "r01_mlp_fwd_hbm_traffic.json")):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):
