@@ -18,6 +18,12 @@ constexpr int CV_MAX_VIEWS = 8, CV_VOX = 32;
 
 struct CvHit { int idx; float mask; };
 
+// Round 5 (counters: the kernels are bound by vector-ALU issue, profiles/r05_mvs_cost_volume_pmc.json): every gather and store through a 32-bit BYTE
+// offset from a block-uniform base -- the address is one scalar pair + one VGPR, one vector add per access instead of a 64-bit shift-and-add chain
+// (the host checks that the source maps and the volume stay below 4 GB).
+__device__ __forceinline__ float cv_ld(const float* base, unsigned byte_off) { return *(const float*)((const char*)base + byte_off); }
+__device__ __forceinline__ void cv_st(float* base, unsigned byte_off, float v) { *(float*)((char*)base + byte_off) = v; }
+
 __device__ __forceinline__ CvHit cv_project(const ucnerf_cost_volume_params& p, int view, int pix, int Wp, float depth) {
     const float x = (float)(pix % Wp - p.pad), y = (float)(pix / Wp - p.pad);          // create_meshgrid - pad  (utils.py:1128-1134)
     const float sx = (float)(p.W - 1) / 2.f, sy = (float)(p.H - 1) / 2.f;
@@ -55,16 +61,16 @@ __global__ void __launch_bounds__(CV_VOX * CV_MAX_VIEWS) cost_volume_wide_kernel
     for (int i = 0; i < p.V; ++i) msum += smask[i][vox];
     const float count = 1.0f / msum;
     if (p.count && ln == 0 && live) p.count[t] = count;
-    const unsigned hw = (unsigned)p.H * p.W, chw = hw * p.C;                           // (host checks V*C*H*W < 2^31)
+    const unsigned hw4 = (unsigned)p.H * p.W * 4u, chw4 = hw4 * p.C;                   // bytes (host checks V*C*H*W*4 < 2^32)
     for (int c = ln; c < p.C; c += CV_MAX_VIEWS) {
         float s = 0.f, q = 0.f;
         for (int i = 0; i < p.V; ++i) {
-            const float v = p.feats[i * chw + c * hw + (unsigned)sidx[i][vox]];
+            const float v = cv_ld(p.feats, i * chw4 + c * hw4 + 4u * (unsigned)sidx[i][vox]);
             s = s + v;                                                                 // volume_sum, volume_sq_sum in view order (:620-621)
             q = q + v * v;
         }
         const float mean = s * count;
-        if (live) p.variance[(size_t)c * total + t] = q * count - mean * mean;         // :624
+        if (live) cv_st(p.variance, (unsigned)c * (total * 4u) + 4u * t, q * count - mean * mean);         // :624
     }
 }
 
@@ -74,14 +80,14 @@ __global__ void __launch_bounds__(256) cost_volume_narrow_kernel(ucnerf_cost_vol
     const unsigned t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const float depth = p.depth_values[t];
-    unsigned idx[CV_MAX_VIEWS];
+    unsigned idx[CV_MAX_VIEWS];                                                        // BYTE offsets of the voxel's pixel in every view's channel 0
     float msum = 1.f;
-    const unsigned hw = (unsigned)p.H * p.W, chw = hw * p.C;
+    const unsigned hw4 = (unsigned)p.H * p.W * 4u, chw4 = hw4 * p.C;
 #pragma unroll
     for (int i = 0; i < CV_MAX_VIEWS; ++i)
         if (i < p.V) {
             const CvHit h = cv_project(p, i, (int)(t % plane), Wp, depth);
-            idx[i] = i * chw + (unsigned)h.idx;
+            idx[i] = i * chw4 + 4u * (unsigned)h.idx;
             msum += h.mask;
         }
     const float count = 1.0f / msum;
@@ -91,12 +97,12 @@ __global__ void __launch_bounds__(256) cost_volume_narrow_kernel(ucnerf_cost_vol
 #pragma unroll
         for (int i = 0; i < CV_MAX_VIEWS; ++i)
             if (i < p.V) {
-                const float v = p.feats[idx[i] + c * hw];
+                const float v = cv_ld(p.feats, idx[i] + c * hw4);
                 s = s + v;
                 q = q + v * v;
             }
         const float mean = s * count;
-        p.variance[(size_t)c * total + t] = q * count - mean * mean;
+        cv_st(p.variance, (unsigned)c * (total * 4u) + 4u * t, q * count - mean * mean);
     }
 }
 
@@ -276,7 +282,7 @@ int ucnerf_cost_volume(const ucnerf_cost_volume_params* p, void* stream) {
                    p->C, p->H, p->W, p->D, p->pad);
     UCNERF_REQUIRE(p->feats && p->proj && p->depth_values && p->variance, "cost_volume: null pointer");
     const long long total = (long long)p->D * (p->H + 2 * p->pad) * (p->W + 2 * p->pad);
-    UCNERF_REQUIRE(total < (1ll << 31) && (long long)p->V * p->C * p->H * p->W < (1ll << 31), "cost_volume: volume / maps too large for 32-bit indices");
+    UCNERF_REQUIRE(total * p->C < (1ll << 30) && (long long)p->V * p->C * p->H * p->W < (1ll << 30), "cost_volume: volume / maps of 4 GB and more (32-bit byte offsets)");
     if (p->C > 16) hipLaunchKernelGGL(cost_volume_wide_kernel, dim3(cdiv(total, CV_VOX)), dim3(CV_VOX * CV_MAX_VIEWS), 0, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(cost_volume_narrow_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, *p);
     return check_launch("cost_volume");
