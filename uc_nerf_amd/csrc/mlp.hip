@@ -592,8 +592,7 @@ int launch_mlp_fwd(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t
         g.feat_bytes = (unsigned)fbytes;
     }
     {   // half a tile by default: 2304 MFMAs * 64 cycles shared by two waves ~ 295k cycles per tile
-        static int stagger = -1;
-        if (stagger < 0) { const char* e = getenv("UCNERF_MLP_STAGGER"); stagger = e ? atoi(e) : 0; }   // measured on MI355X: 0 is best (A/B in DESIGN.md)
+        static const int stagger = [] { const char* e = getenv("UCNERF_MLP_STAGGER"); return e ? atoi(e) : 0; }();   // (read once, thread-safe; measured on MI355X: 0 is best)
         g.stagger = n_tiles > blocks * 4 ? stagger : 0;          // nothing to hide when waves 4..7 have no partner work
     }
     UCNERF_REQUIRE(p->cfg.pe_layout == 0 || p->cfg.pe_layout == 1, "mlp_fwd: pe_layout %d", p->cfg.pe_layout);

@@ -213,19 +213,6 @@ int build_pack_index_bf16(const ucnerf_mlp_config* cfg, int32_t* idx) {
     return hidx == 2 * (int64_t)B.slots ? 0 : -1;
 }
 
-__global__ void pack_bf16_kernel(const float* __restrict__ flat, const int32_t* __restrict__ idx, unsigned short* __restrict__ out, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t k = idx[i];
-    unsigned short r = 0;
-    if (k >= 0) {
-        const float w = flat[k & 0x3fffffff];
-        const __bf16 hi = (__bf16)w;
-        const __bf16 val = (k >> 30) ? (__bf16)(w - (float)hi) : hi;
-        r = __builtin_bit_cast(unsigned short, val);
-    }
-    out[i] = r;
-}
 
 #endif   // UCNERF_BF16_BUILD_TERMS == 3 (host-side packing)
 
@@ -1472,18 +1459,37 @@ int64_t bf16_stream_floats(const ucnerf_mlp_config* cfg) {
     return B.total_bytes / 4;
 }
 
-__global__ void pack_f32_kernel(const float* __restrict__ flat, const int32_t* __restrict__ idx, float* __restrict__ out, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const int32_t k = idx[i]; out[i] = k >= 0 ? flat[k] : 0.f; }
+}
+
+// ONE launch for the whole stream from the flat parameter vector (round 5: the evaluation loop re-packs in every rendering() call -- two launches were
+// 5 us of GPU time and two launches' host time per 1024-pixel chunk): blocks [0, nb16) convert the bf16 half-steps, the rest copy the fp32 constants
+__global__ void pack_all_flat_kernel(const float* __restrict__ flat, const int32_t* __restrict__ idx, unsigned short* __restrict__ out16, int64_t n16,
+                                     float* __restrict__ outc, int nc, int nb16) {
+    if ((int)blockIdx.x < nb16) {
+        const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= n16) return;
+        const int32_t k = idx[i];
+        unsigned short r = 0;
+        if (k >= 0) {
+            const float w = flat[k & 0x3fffffff];
+            const __bf16 hi = (__bf16)w;
+            const __bf16 val = (k >> 30) ? (__bf16)(w - (float)hi) : hi;
+            r = __builtin_bit_cast(unsigned short, val);
+        }
+        out16[i] = r;
+    } else {
+        const int i = ((int)blockIdx.x - nb16) * blockDim.x + threadIdx.x;
+        if (i < nc) { const int32_t k = idx[n16 + i]; outc[i] = k >= 0 ? flat[k] : 0.f; }
+    }
 }
 
 int launch_pack_bf16(const ucnerf_mlp_config* cfg, const float* flat, const int32_t* idx, float* out, hipStream_t st) {
     Bf16Layout B;
     UCNERF_REQUIRE(bf16_layout(cfg->n_src, &B), "mlp_pack: n_src %d outside 1..8", cfg->n_src);
     const int64_t n16 = (int64_t)B.slots * (SLOT_BYTES / 2);
-    hipLaunchKernelGGL(pack_bf16_kernel, dim3(cdiv(n16, 256)), dim3(256), 0, st, flat, idx, reinterpret_cast<unsigned short*>(out), n16);
-    hipLaunchKernelGGL(pack_f32_kernel, dim3(cdiv(CONST_FLOATS, 256)), dim3(256), 0, st, flat, idx + n16,
-                       reinterpret_cast<float*>(reinterpret_cast<char*>(out) + B.const_off_bytes), CONST_FLOATS);
+    const int nb16 = cdiv(n16, 256), nbc = cdiv(CONST_FLOATS, 256);
+    hipLaunchKernelGGL(pack_all_flat_kernel, dim3(nb16 + nbc), dim3(256), 0, st, flat, idx, reinterpret_cast<unsigned short*>(out), n16,
+                       reinterpret_cast<float*>(reinterpret_cast<char*>(out) + B.const_off_bytes), CONST_FLOATS, nb16);
     return check_launch("mlp_pack (bf16x3)");
 }
 
