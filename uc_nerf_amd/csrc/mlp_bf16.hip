@@ -1459,8 +1459,6 @@ int64_t bf16_stream_floats(const ucnerf_mlp_config* cfg) {
     return B.total_bytes / 4;
 }
 
-}
-
 // ONE launch for the whole stream from the flat parameter vector (round 5: the evaluation loop re-packs in every rendering() call -- two launches were
 // 5 us of GPU time and two launches' host time per 1024-pixel chunk): blocks [0, nb16) convert the bf16 half-steps, the rest copy the fp32 constants
 __global__ void pack_all_flat_kernel(const float* __restrict__ flat, const int32_t* __restrict__ idx, unsigned short* __restrict__ out16, int64_t n16,
