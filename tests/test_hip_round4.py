@@ -47,14 +47,14 @@ def _qfn(mods):
     return lambda pts, vd, f, fn: mods.renderer.run_network_mvs(pts, vd, f, fn, embed_fn=e_p, embeddirs_fn=e_d)
 
 
-def _call(mods, g, net, qfn, vols=None, img_feat=None, conf=None):
+def _call(mods, g, net, qfn, vols=None, img_feat=None, conf=None, imgs=None):
     V = g["V"]
     args = types.SimpleNamespace(view_num=V, feat_dim=24 + 12 * (V - 1) + 1, img_downscale=1.0, use_color_volume=False, net_type="v2")
     vols = vols if vols is not None else [dev(g["vol%d" % k]) for k in (1, 2, 3)]
     vf = {"stage%d" % (i + 1): {"volume_feature_no_ref": vols[i]} for i in range(3)}
     pose = {"w2cs": dev(g["w2cs"]).clone(), "intrinsics": dev(g["K"]).repeat(V, 1, 1)}
     ndc = {"stage1": dev(g["ndc1"]), "stage2": dev(g["ndc2"]), "stage3": dev(g["ndc3"]), "ndc": dev(g["ndc"])}
-    return mods.renderer.rendering(args, pose, dev(g["pts"]), ndc, dev(g["z"]), dev(g["rays_d"]), vf, dev(g["imgs"]), network_fn=net,
+    return mods.renderer.rendering(args, pose, dev(g["pts"]), ndc, dev(g["z"]), dev(g["rays_d"]), vf, imgs if imgs is not None else dev(g["imgs"]), network_fn=net,
                                    img_feat=img_feat if img_feat is not None else dev(g["img_feat"]), network_query_fn=qfn,
                                    confidence=conf if conf is not None else dev(g["conf"]))
 

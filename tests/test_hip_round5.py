@@ -161,6 +161,47 @@ def test_training_through_conv_produced_sources(which, sd_v7):
             torch.testing.assert_close(q.grad, p.grad, atol=2e-5 * max(p.grad.abs().max().item(), 1e-6), rtol=1e-4, msg=lambda s_: name + ": " + s_)
 
 
+def test_four_view_scene_through_channel_last_sources():
+    """The Hamlyn-style configuration (view_num 4: three source views, configs[3]) on channel-last sources in place: the no-grad render equals the
+    channel-major one bit for bit and the golden vectors to 1e-4; under autograd the source gradients agree with the channel-major route."""
+    from test_oracle_golden import sd_v4_for_g16
+    from uc_nerf_amd import dropin
+    mods = _mods()
+    g = load_golden("g16_rendering_v4")
+    sd = sd_v4_for_g16(g)
+    qfn = _qfn(mods)
+    vols_cl = [dev(g["vol%d" % k]).contiguous(memory_format=torch.channels_last_3d) for k in (1, 2, 3)]
+    feat = dev(g["img_feat"])
+    feat_cl = feat[:, 0].contiguous(memory_format=torch.channels_last).unsqueeze(1)
+    imgs = dev(g["imgs"])
+    imgs_cl = imgs[0].contiguous(memory_format=torch.channels_last).unsqueeze(0)
+    net = _net(mods, g["V"], sd)
+    with torch.no_grad():
+        rgb_a, d_a = _call(mods, g, net, qfn)
+        rgb_b, d_b = _call(mods, g, net, qfn, vols=vols_cl, img_feat=feat_cl, imgs=imgs_cl)
+    sess = dropin.session_of(net)
+    assert sess.src.zero_copy and sess.src.inplace == [True] * 5
+    assert torch.equal(rgb_a, rgb_b) and torch.equal(d_a, d_b)
+    from test_hip_configs import close
+    close(rgb_b, g["rgb_first" if "rgb_first" in g else "rgb"], 1e-4); close(d_b, g["depth_first" if "depth_first" in g else "depth"], 1e-4)
+    gen = torch.Generator().manual_seed(3)
+    r3, r1 = dev(torch.randn(g["z"].shape[0], 3, generator=gen)), dev(torch.randn(g["z"].shape[0], generator=gen))
+
+    def run(cl):
+        net = _net(mods, g["V"], sd)
+        vols = [(v if cl else v.contiguous()).detach().requires_grad_(True) for v in vols_cl]
+        f = (feat_cl if cl else feat).detach().requires_grad_(True)
+        rgb, depth = _call(mods, g, net, qfn, vols=vols, img_feat=f, imgs=imgs_cl if cl else imgs)
+        ((rgb * r3).sum() + (depth * r1).sum()).backward()
+        return vols, f
+
+    va, fa = run(False)
+    vb, fb = run(True)
+    for a, b in zip(va + [fa], vb + [fb]):
+        assert _same_strides(b.grad, b)
+        torch.testing.assert_close(b.grad, a.grad, atol=2e-5 * max(a.grad.abs().max().item(), 1e-6), rtol=1e-4)
+
+
 def test_frozen_sources_cost_no_gradient_buffer(sd_v7):
     """need = all False for the heavy sources (a frozen MVS network, detached volumes): the backward allocates no source-gradient segment and hands the
     gather backward no channel-last gradient array (round 4's advisor finding on the zero-copy route)."""
