@@ -219,9 +219,13 @@ int build_pack_index_bf16(const ucnerf_mlp_config* cfg, int32_t* idx) {
 // ------------------------------------------------------------------------------------------------ device helpers
 struct Frag { bf16x8 hi, lo; };
 
-// (hi, lo) split of eight activations.  hi is the TRUNCATED bf16 (top 16 bits: one v_and gives it as a float, one
-// v_perm_b32 packs two of them), lo = bf16_rne(x - hi), exact before its rounding: 5 VALU per pair of values against
-// 7 for a round-to-nearest hi.  |lo| < 2^-7 |x| (not 2^-8), so the dropped lo*lo term is 2^-16 relative.
+// (hi, lo) split of eight activations: hi = bf16_rne(x), lo = bf16_rne(x - hi) (the difference is exact before its rounding): one v_cvt_pk_bf16_f32
+// per pair for each, a shift and a mask to read the pair's hi back as floats, one packed subtract -- 5 VALU per pair.  Worst case |lo| <= 2^-8 |x|,
+// the part of x neither term holds <= 2^-16 |x|, the dropped lo*lo term of a product 2^-16 relative (the weights are split the same way on packing).
+// (Rounds 1-4 took hi by TRUNCATION -- v_perm + two v_and, also 5 VALU: |lo| < 2^-7 |x|, the activations' share of all that one bit worse.  Round 5's differential
+//  fuzzer, tests/fuzz_render.py, put the renders of that split at up to 2.5e-4 from the oracle on networks with an unscaled density head --
+//  4 of 43 such cases above the 1e-4 bar; with the rounded hi the median error halves (2.9e-5 -> 1.9e-5, 90th percentile 9.3e-5 -> 4.7e-5)
+//  for +0.7 % of the headline kernel's time, profiles/r05_experiments.md.)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ Frag split8(const float (&x)[8]) {
@@ -229,10 +233,10 @@ __device__ __forceinline__ Frag split8(const float (&x)[8]) {
     Frag f;
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
-        const unsigned b0 = __builtin_bit_cast(unsigned, x[j]), b1 = __builtin_bit_cast(unsigned, x[j + 1]);
-        const unsigned packed = __builtin_amdgcn_perm(b1, b0, 0x07060302u);      // [hi(x[j+1]) | hi(x[j])]
+        const bf16x2 hp = {(__bf16)x[j], (__bf16)x[j + 1]};
+        const unsigned packed = __builtin_bit_cast(unsigned, hp);                 // [hi(x[j+1]) | hi(x[j])]
         hi[j >> 1] = packed;
-        const f32x2 h = {__builtin_bit_cast(float, b0 & 0xffff0000u), __builtin_bit_cast(float, b1 & 0xffff0000u)};
+        const f32x2 h = {__builtin_bit_cast(float, packed << 16), __builtin_bit_cast(float, packed & 0xffff0000u)};
         const f32x2 l = (f32x2){x[j], x[j + 1]} - h;
         f.lo[j] = (__bf16)l.x;
         f.lo[j + 1] = (__bf16)l.y;
