@@ -470,3 +470,13 @@ def test_differential_fuzz_of_the_render_pass_against_the_oracle():
     for tag in ("fused", "given"):
         assert s["rays_above_bar"][tag] <= 1e-3 * s["rays"], s["rays_above_bar"]
         assert max(s["worst"][tag + "_rgb"], s["worst"][tag + "_depth"], s["worst"][tag + "_acc"]) <= 3e-4, s["worst"]
+
+
+def test_differential_fuzz_of_the_resampling_launch():
+    """tests/fuzz_sampling.py on a fixed set of 80 random cases (2..700 bin edges, 1..300 draws, degenerate weight rows, draws on cdf entries, ties in
+    the merge, the from_coarse form): cdf, int64 indices, samples, the sorted merge and its rank, all bit for bit against the oracle's restatement of
+    torch-CPU's arithmetic (data/ray_utils.py:98-141,216-219) -- and, where the cdf is not monotone, against torch-CPU's own binary search."""
+    import fuzz_sampling
+    s = fuzz_sampling.run(cases=80, seed=5, verbose=False)
+    assert not s["failures"], s["failures"]
+    assert s["rows"] > 3000
