@@ -480,3 +480,16 @@ def test_differential_fuzz_of_the_resampling_launch():
     s = fuzz_sampling.run(cases=80, seed=5, verbose=False)
     assert not s["failures"], s["failures"]
     assert s["rows"] > 3000
+
+
+def test_differential_fuzz_of_the_backward_against_oracle_autograd():
+    """tests/fuzz_grads.py on a fixed set of 12 random cases: ucnerf_render_fused_bwd (both training precisions, sources channel-major and channel-last
+    in place, coordinates derived and given) against torch autograd through the oracle's rendering (network/renderer.py:215-255) RE-RUN ON THE DEVICE'S
+    SIDES OF EVERY RELU (read back from the training forward's kept activations): every element of the 30 network gradients, the three volumes', the
+    image features' and the confidence map's within the tests' bar with no outlier allowance, and every side that differs from the float64 oracle's
+    sits at an argument within rounding noise of zero."""
+    import fuzz_grads
+    s = fuzz_grads.run(cases=12, seed=2, verbose=False)
+    assert s["failures"] == 0, [r["bad"] for r in s["rows"] if r["bad"]]
+    assert s["outside"] == {"f32": 0, "bf16x3": 0} and s["far_flips"] == {"f32": 0, "bf16x3": 0}
+    assert s["worst"]["f32"] <= 3e-4 and s["elements"] > 5e6
