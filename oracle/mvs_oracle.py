@@ -88,7 +88,7 @@ def depth_regress(prob_pre, depth_values, prob_init=None, pad=0):
     p = torch.softmax(prob_pre, dim=0)
     depth = torch.sum(p * depth_values, 0)
     # 4 * avg_pool3d over a window of 4 along depth, padded (1, 2): sum of p[d-1 .. d+2]
-    pp = torch.cat([torch.zeros_like(p[:1]), p, torch.zeros_like(p[:2])], 0)
+    pp = torch.cat([p.new_zeros((1,) + p.shape[1:]), p, p.new_zeros((2,) + p.shape[1:])], 0)      # (explicit shapes: D = 1 has no p[:2])
     sum4 = 4 * ((pp[0:D] + pp[1:D + 1] + pp[2:D + 2] + pp[3:D + 3]) / 4)
     idx = torch.sum(p * torch.arange(D, dtype=p.dtype).view(D, 1, 1), 0).long().clamp(0, D - 1)
     conf = torch.gather(sum4, 0, idx.unsqueeze(0)).squeeze(0).clamp(0, 1)

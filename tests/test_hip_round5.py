@@ -493,3 +493,22 @@ def test_differential_fuzz_of_the_backward_against_oracle_autograd():
     assert s["failures"] == 0, [r["bad"] for r in s["rows"] if r["bad"]]
     assert s["outside"] == {"f32": 0, "bf16x3": 0} and s["far_flips"] == {"f32": 0, "bf16x3": 0}
     assert s["worst"]["f32"] <= 3e-4 and s["elements"] > 5e6
+
+
+def test_differential_fuzz_of_the_evaluation_ray_builder():
+    """tests/fuzz_builders.py on a fixed set of 40 random cases: ucnerf_build_rays_test (one launch) against the oracle's composition of the reference's
+    steps (utils/utils.py:248-271,600-739) -- random image sizes, chunk positions (the ragged last chunk included), sample counts, hypothesis counts
+    and ranges, cameras; a stage with one hypothesis (near == far) must give the reference's infinities and NaNs in the same places."""
+    import fuzz_builders
+    s = fuzz_builders.run(cases=40, seed=4, verbose=False)
+    assert not s["failures"], s["failures"]
+    assert s["rays"] > 5000
+
+
+def test_differential_fuzz_of_the_cost_volume_and_depth_regression():
+    """tests/fuzz_mvs.py on a fixed set of 15 random cases (network/mvs_models.py:599-646): 1..8 source views, 1..32 channels, odd map
+    sizes, 1..48 hypotheses, padding, cameras from nearly identical to far apart -- variance volume, in-view count, the gradient into the feature maps,
+    probabilities, depth, confidence and the gradient at the logits against oracle/mvs_oracle.py, with the nearest-neighbour allowance of the fixture tests."""
+    import fuzz_mvs
+    s = fuzz_mvs.run(cases=15, seed=6, verbose=False)
+    assert not s["failures"], s["failures"]
