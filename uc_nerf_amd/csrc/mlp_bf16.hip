@@ -225,7 +225,7 @@ struct Frag { bf16x8 hi, lo; };
 // (Rounds 1-4 took hi by TRUNCATION -- v_perm + two v_and, also 5 VALU: |lo| < 2^-7 |x|, the activations' share of all that one bit worse.  Round 5's differential
 //  fuzzer, tests/fuzz_render.py, put the renders of that split at up to 2.5e-4 from the oracle on networks with an unscaled density head --
 //  4 of 43 such cases above the 1e-4 bar; with the rounded hi the median error halves (2.9e-5 -> 1.9e-5, 90th percentile 9.3e-5 -> 4.7e-5)
-//  for +0.7 % of the headline kernel's time, profiles/r05_experiments.md.)
+//  for +0.2 % of the headline kernel's time, profiles/r05_experiments.md.)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ Frag split8(const float (&x)[8]) {
@@ -233,7 +233,7 @@ __device__ __forceinline__ Frag split8(const float (&x)[8]) {
     Frag f;
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
-        const bf16x2 hp = {(__bf16)x[j], (__bf16)x[j + 1]};
+        const bf16x2 hp = __builtin_convertvector((f32x2){x[j], x[j + 1]}, bf16x2);      // ONE v_cvt_pk_bf16_f32 (two scalar conversions were not merged)
         const unsigned packed = __builtin_bit_cast(unsigned, hp);                 // [hi(x[j+1]) | hi(x[j])]
         hi[j >> 1] = packed;
         const f32x2 h = {__builtin_bit_cast(float, packed << 16), __builtin_bit_cast(float, packed & 0xffff0000u)};

@@ -110,7 +110,7 @@ struct CAF { c_bf16x8 h0, l0, h1, l1; };
 
 // (hi, lo) split of eight values: hi = truncated bf16, lo = bf16_rne(x - hi) 
 // (the forward's split8, mlp_bf16.hip, rounds hi to nearest since round 5 -- the renders answer to an absolute 1e-4 bar; the gradients' bar is relative
-//  and they keep the truncated hi, which measured 0.7 % faster in the forward kernel)
+//  and they keep the truncated hi, which measured 0.2 % faster in the forward kernel)
 __device__ __forceinline__ CFrag c_split8(const float (&x)[8]) {
     c_u32x4 hi;
     CFrag f;
