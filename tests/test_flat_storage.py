@@ -268,3 +268,18 @@ def test_two_ranks_reduce_the_vector_in_place_and_an_empty_shard_still_gets_the_
         torch.testing.assert_close(g1, 0.5 * _grad_values(st, mask, 2.0))
         assert none1 == [not m for m in mask]                            # ... and still holds every gradient the other rank produced
     assert dist.is_available()
+
+
+def test_a_reflattened_buffer_is_a_new_generation_whatever_its_address():
+    """The "versions" weight cache (dropin.FusedSession.packed) keys on FlatStore.generation: every re-flattening counts up, because neither the new
+    buffer's address (the allocator may hand the freed one out again) nor its version counter (36 copies after every flatten) tells the buffers apart."""
+    net = _net()
+    st = FlatStore.of(net)
+    g0, v0 = st.generation, st.flat._version
+    net.double()
+    net.float()                                   # re-points every p.data: UCNeRF._apply re-flattens each time
+    st.sync()
+    g1 = st.generation
+    assert g1 > g0 and st.flat._version == v0 and st.flat.dtype == torch.float32
+    st.sync()
+    assert st.generation == g1                   # nothing moved: the same buffer, the same generation

@@ -512,3 +512,49 @@ def test_differential_fuzz_of_the_cost_volume_and_depth_regression():
     import fuzz_mvs
     s = fuzz_mvs.run(cases=15, seed=6, verbose=False)
     assert not s["failures"], s["failures"]
+
+
+def test_pending_backward_keeps_its_forward_time_weight_stream(sd_v7):
+    """A training forward, then the parameters change in place (an optimizer step of another loss) and a no_grad render of the SAME precision runs, then
+    the first call's backward: it must differentiate through the weights its forward used.  (The no_grad route re-packs its cached stream in place; a
+    training forward's stream therefore never enters that cache.)"""
+    import uc_nerf_amd
+    mods = _mods()
+    g = load_golden("g10_rendering")
+    qfn = _qfn(mods)
+    gen = torch.Generator().manual_seed(11)
+    r3, r1 = dev(torch.randn(g["z"].shape[0], 3, generator=gen)), dev(torch.randn(g["z"].shape[0], generator=gen))
+
+    def grads(disturb):
+        net = _net(mods, 7, sd_v7)
+        rgb, depth = _call(mods, g, net, qfn)
+        loss = (rgb * r3).sum() + (depth * r1).sum()
+        if disturb:
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.mul_(1.25)
+                _call(mods, g, net, qfn)
+        loss.backward()
+        return [p.grad.clone() for p in net.parameters() if p.grad is not None]
+
+    uc_nerf_amd.install_dropin(precision="f32")
+    try:
+        a, b = grads(False), grads(True)
+    finally:
+        uc_nerf_amd.install_dropin()
+    assert len(a) == len(b) == 30
+    for x, y in zip(a, b):
+        torch.testing.assert_close(y, x, atol=2e-5 * max(x.abs().max().item(), 1e-6), rtol=1e-4)
+
+
+def test_stateful_fuzz_of_the_dropin_against_fresh_networks():
+    """tests/fuzz_dropin.py: one long-lived network + session driven through random sequences of renders, training steps (Adam / FlatAdam), delayed
+    backwards, in-place weight writes, load_state_dict, CPU round trips, source writes / replacements / layout switches and knob changes must answer
+    every call like a freshly built network.  The first case is the one that found a stale "versions" weight cache in round 5 (a re-flattened
+    parameter buffer at the old buffer's address with the old version count): seed 1 case 361."""
+    import fuzz_dropin
+    s = fuzz_dropin.run(steps=60, seed=1, verbose=False, only=361)
+    assert not s["failures"], s["failures"]
+    s = fuzz_dropin.run(cases=25, steps=50, seed=7, verbose=False)
+    assert not s["failures"], s["failures"]
+    assert s["renders"] > 300 and s["trains"] > 150

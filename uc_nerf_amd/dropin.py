@@ -140,13 +140,16 @@ class FusedSession:
         pw = ops.PackedWeights.get(self.n_src, layout, dev, precision)
         ent = self.weights.get(key)
         if fresh:
+            # (the stream belongs to this call's autograd context until its backward has run: it is never entered in the cache, where a later
+            #  no_grad call of the same precision would re-pack it in place -- with other values, had an optimizer stepped in between)
             flat = live.clone()
-            ent = self.weights[key] = {"sig": None, "ws": pw.pack(flat)}
-            return flat, pw, ent["ws"]
+            return flat, pw, pw.pack(flat)
         if _WEIGHT_CACHE == "versions":
             # (the flat buffer's own counter too: flat.FlatAdam steps a Parameter that shares the buffer's storage and version counter, not the
             #  per-tensor ones -- round 4's advisor finding)
-            sig = (live.data_ptr(), live._version) + tuple(p._version for p in self.params)
+            # (and the store's generation, not the buffer's address: after a re-flattening -- module.to(), .float(), a CPU round trip -- the new
+            #  buffer may sit where the old one did, with the same version count; round 5's stateful fuzzer, tests/fuzz_dropin.py, found exactly that)
+            sig = (self.store.generation, live._version) + tuple(p._version for p in self.params)
             if ent is None or ent["sig"] != sig:
                 ent = self.weights[key] = {"sig": sig, "ws": pw.pack(live)}
             return live, pw, ent["ws"]

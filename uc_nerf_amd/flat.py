@@ -81,6 +81,9 @@ class FlatStore:
                 p.data = seg
         self.flat = flat
         self._ptrs = [p.data_ptr() for p in self.params]      # (sync()'s fast check)
+        # which flat buffer this is, counted up and never reused: an ADDRESS is no identity across re-flattenings (the old buffer is freed and the
+        # allocator may hand the same address out again -- with the same version count, which starts from the 36 copies above every time)
+        self.generation = getattr(self, "generation", 0) + 1
         return flat
 
     def sync(self):
