@@ -11,6 +11,7 @@ One case = one small scene and ONE network object driven through a random sequen
   weights     parameters scaled in place / load_state_dict / a round trip through the CPU (re-flattens the store)
   sources     the volumes / images / features written in place; replaced by new tensors; switched between channel-major and channel-last
               (channels_last_3d / channels_last) layouts; only the confidence map or only the poses changed
+  scene       the script turns to a second scene of another size (and later back): two sets of sources alternate through one session
   knobs       inference precision (bf16x3_fused / bf16x3 / f32), weight-cache policy (verify / versions), the one-launch tail route on / off
 After every render the same call is made on a FRESH network (new module, state_dict copied in, new session) with fresh clones of the sources:
 no_grad outputs must be bit-identical; a training call's rgb / depth bit-identical and its gradients equal up to float-atomic order
@@ -59,12 +60,13 @@ def _layout(t, cl, kind):
     return t[0].contiguous(memory_format=torch.channels_last).unsqueeze(0)
 
 
-def grads_equal(x, y):
+def grads_equal(x, y, m_all):
     """Equal up to float-atomic order: 2e-5 max|g| + 1e-4 relative per element; a ONE-element tensor (the bias of a density head: a sum over all samples
-    that cancels, re-ordered by every launch's atomics -- two fresh networks differ by up to 2e-4 of it) 1e-3 relative."""
+    that cancels, re-ordered by every launch's atomics -- two fresh networks differ by up to 2e-4 of it, more when it happens to cancel to nearly
+    nothing) 1e-3 relative + 2e-5 of the step's largest gradient element `m_all`."""
     m = max(y.abs().max().item(), 1e-6)
     if y.numel() == 1:
-        return bool(((x - y).abs() <= 1e-3 * m).all())
+        return bool(((x - y).abs() <= 1e-3 * m + 2e-5 * m_all).all())
     return bool(((x - y).abs() <= 2e-5 * m + 1e-4 * y.abs()).all())
 
 
@@ -93,7 +95,7 @@ def run(cases=12, steps=40, seed=0, verbose=True, only=None, magnify=False):
         src = dict(vols=[_layout(v, False, "vol") for v in scene["vols"]], img_feat=_layout(scene["img_feat"], False, "feat"),
                    imgs=_layout(scene["imgs"], False, "imgs"), conf=scene["confidence"].clone(), w2cs=scene["w2cs"].clone(), intr=scene["intrinsics"].clone())
         knobs = dict(precision="bf16x3_fused", cache="verify", tail=1)
-        log = []
+        log, other = [], None
 
         def apply_knobs():
             uc_nerf_amd.set_inference_precision(knobs["precision"])
@@ -123,7 +125,7 @@ def run(cases=12, steps=40, seed=0, verbose=True, only=None, magnify=False):
         try:
             apply_knobs()
             for k in range(steps):
-                op = rng.choice(["render", "render", "render", "train", "delayed", "weights", "sources", "sources", "knobs"])
+                op = rng.choice(["render", "render", "render", "train", "delayed", "weights", "sources", "sources", "knobs", "scene"])
                 if op == "render":
                     b = batch_of(k)
                     got = call(net, src, b, False)
@@ -161,12 +163,13 @@ def run(cases=12, steps=40, seed=0, verbose=True, only=None, magnify=False):
                     (rgb_a, d_a, g_a), (rgb_b, d_b, g_b) = outs
                     if not (torch.equal(rgb_a, rgb_b) and torch.equal(d_a, d_b)):
                         raise AssertionError("training forward differs from a fresh network's")
+                    m_all = max(float(y.abs().max()) for y in g_b if y is not None)
                     for gi, (x, y) in enumerate(zip(g_a, g_b)):
                         if (x is None) != (y is None):
                             raise AssertionError("gradient present on one side only")
                         if x is not None:
                             m = max(y.abs().max().item(), 1e-6)
-                            if not grads_equal(x, y):
+                            if not grads_equal(x, y, m_all):
                                 # the floor: the same step on a SECOND fresh network (float atomics add in a different order every launch)
                                 n3, s3 = fresh()
                                 if need:
@@ -208,12 +211,13 @@ def run(cases=12, steps=40, seed=0, verbose=True, only=None, magnify=False):
                     trains += 1
                     log.append("delayed backward n=%d S=%d" % tuple(b["depth_candidates"].shape))
                     third = None
+                    m_all = max(float(y.abs().max()) for y in outs[1] if y is not None)
                     for gi, (x, y) in enumerate(zip(*outs)):
                         if (x is None) != (y is None):
                             raise AssertionError("delayed backward: gradient present on one side only")
                         if x is not None:
                             m = max(y.abs().max().item(), 1e-6)
-                            if not grads_equal(x, y):
+                            if not grads_equal(x, y, m_all):
                                 if third is None:                      # the floor: a second immediate backward on a network in the forward-time state
                                     for p in n2.parameters():
                                         p.grad = None
@@ -260,6 +264,18 @@ def run(cases=12, steps=40, seed=0, verbose=True, only=None, magnify=False):
                         src["w2cs"] = src["w2cs"].clone()
                         src["w2cs"][1:, 0, 3] += 0.001
                     log.append("sources how=%d cl=%s" % (how, "".join(str(int(x)) for x in cl)))
+                elif op == "scene":
+                    # the script turns to its OTHER scene (a validation view of another size, say) and later back: the sources of the one it leaves
+                    # are neither touched nor freed
+                    if other is None:
+                        H2, W2 = 4 * int(rng.randint(8, 25)), 4 * int(rng.randint(8, 33))
+                        sc2 = scene_to(make_scene(seed=s + 500, H=H2, W=W2, V=V, small_volumes=bool(rng.rand() < 0.5)), torch.device(DEV))
+                        cl2 = [bool(rng.rand() < 0.5) for _ in range(5)]
+                        src2 = dict(vols=[_layout(v, k_, "vol") for v, k_ in zip(sc2["vols"], cl2[:3])], img_feat=_layout(sc2["img_feat"], cl2[3], "feat"),
+                                    imgs=_layout(sc2["imgs"], cl2[4], "imgs"), conf=sc2["confidence"].clone(), w2cs=sc2["w2cs"].clone(), intr=sc2["intrinsics"].clone())
+                        other = (sc2, cascade_outputs(sc2, seed=s + 500), src2, cl2, H2, W2)
+                    (scene, outputs, src, cl, H, W), other = other, (scene, outputs, src, cl, H, W)
+                    log.append("scene -> %dx%d cl=%s" % (H, W, "".join(str(int(x)) for x in cl)))
                 elif op == "knobs":
                     knobs["precision"] = str(rng.choice(["bf16x3_fused", "bf16x3_fused", "bf16x3", "f32"]))
                     knobs["cache"] = str(rng.choice(["verify", "versions"]))

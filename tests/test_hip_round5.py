@@ -558,3 +558,13 @@ def test_stateful_fuzz_of_the_dropin_against_fresh_networks():
     s = fuzz_dropin.run(cases=25, steps=50, seed=7, verbose=False)
     assert not s["failures"], s["failures"]
     assert s["renders"] > 300 and s["trains"] > 150
+
+
+def test_stateful_fuzz_of_the_coarse_fine_pipeline_and_its_route_equivalences():
+    """tests/fuzz_pipeline.py: one CoarseFineRenderer per case through random renders (1..4096 rays, jitter, random draws, reuse_coarse), new weights,
+    sources written in place, route knobs (folded launches, in-kernel rays, tail route) and source layouts -- every render bit-identical to a freshly
+    built renderer with the same settings AND to the plain route (nothing folded, no tail, channel-major sources, fine pass re-evaluating all depths)."""
+    import fuzz_pipeline
+    s = fuzz_pipeline.run(cases=60, steps=25, seed=9, verbose=False)
+    assert not s["failures"], s["failures"]
+    assert s["renders"] > 500
