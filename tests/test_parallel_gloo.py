@@ -318,3 +318,51 @@ def test_sharded_training_step_reproduces_the_single_process_gradient():
         assert abs(res[0]["terms"][0] - parts["img_loss"].item()) < 1e-6
     one = _f3_rank(0, 1)                                                 # world = 1 is the reference's step
     torch.testing.assert_close(one["grads"], want, atol=1e-7, rtol=1e-6)
+
+
+def test_sharded_loss_sums_to_the_single_process_loss_over_random_layouts():
+    """Property behind row f3, over 60 random batch layouts and world sizes 1..9 (more ranks than patches or sparse-depth rays included: empty shards):
+    the ranks' weighted losses SUM to the single-process loss of train.py:164-188 (utils.loss.training_loss), term by term, and so do the gradients
+    with respect to the rendered colours and depths.  One process, no collective: the shards are evaluated one after the other."""
+    import numpy as np
+    from uc_nerf_amd.train_step import BatchShard, sharded_training_loss
+    from uc_nerf_amd.utils import loss as L
+    for case in range(60):
+        rng = np.random.RandomState(case)
+        g = torch.Generator().manual_seed(case)
+        ps = int(rng.choice([2, 3, 4, 8]))
+        patch_num = int(rng.randint(2, 12))
+        n_rays = patch_num * ps * ps + int(rng.randint(0, 60))
+        n_depth = int(rng.randint(1, 40))
+        N = n_rays + n_depth
+        world = int(rng.randint(1, 10))
+        rgb = torch.rand(N, 3, generator=g).requires_grad_(True)
+        depth = (1 + 3 * torch.rand(N, generator=g)).requires_grad_(True)
+        target_s, t_d, t_w = torch.rand(N, 3, generator=g), 1 + 3 * torch.rand(n_depth, generator=g), 2 * torch.rand(n_depth, generator=g)
+        dpt = torch.rand(patch_num, ps, ps, 1, generator=g)
+        gt, w, mvs = {}, {}, {}
+        for k, (h, ww) in {"stage1": (4, 5), "stage2": (8, 10), "stage3": (16, 20)}.items():
+            m = torch.rand(1, h, ww, generator=g) < 0.4
+            gt[k] = torch.where(m, 1 + 3 * torch.rand(1, h, ww, generator=g), torch.zeros(1, h, ww))
+            w[k] = torch.where(m, 0.1 + torch.rand(1, h, ww, generator=g), torch.zeros(1, h, ww))
+            mvs[k] = {"depth": 1 + 3 * torch.rand(1, h, ww, generator=g)}
+        loss, parts = L.training_loss(rgb, depth, target_s, t_d, t_w, dpt, mvs, gt, w, n_rays=n_rays, patch_num=patch_num, patch_size=ps)
+        loss.backward()
+        want = (rgb.grad.clone(), depth.grad.clone())
+        rgb.grad = depth.grad = None
+        total, terms, seen = 0.0, {}, torch.zeros(N, dtype=torch.long)
+        for rank in range(world):
+            sh = BatchShard(n_rays, N, patch_num, ps, rank, world)
+            idx = sh.index
+            seen[idx] += 1
+            l_r, p_r = sharded_training_loss(rgb[idx], depth[idx], target_s[idx], t_d[sh.depth_ids], t_w[sh.depth_ids], dpt[sh.patch_ids], mvs, gt, w, sh)
+            l_r.backward()
+            total += float(l_r.detach())
+            for k, v in p_r.items():
+                terms[k] = terms.get(k, 0.0) + float(v.detach())
+        assert bool((seen == 1).all()), (case, world)                       # every ray on exactly one rank
+        assert abs(total - float(loss)) < 1e-5 * max(1.0, abs(float(loss))), (case, world, total, float(loss))
+        for k in ("img_loss", "loss_nerf_depth", "smooth_loss", "loss_scaleinvariant", "loss_mvs"):
+            assert abs(terms[k] - float(parts[k])) < 2e-5 * max(1.0, abs(float(parts[k]))), (case, world, k, terms[k], float(parts[k]))
+        torch.testing.assert_close(rgb.grad, want[0], atol=1e-6, rtol=1e-4)
+        torch.testing.assert_close(depth.grad, want[1], atol=1e-6, rtol=1e-4)
