@@ -13,6 +13,9 @@
  *   - every function is asynchronous on `stream` (a hipStream_t passed as void*), allocates nothing,
  *     is re-entrant, and returns 0 on success or a negative UCNERF_E* code; ucnerf_last_error() returns
  *     a thread-local description of the last failure;
+ *   - arguments are checked before anything is launched: a NULL params pointer, a NULL required array, a size outside the documented range and a
+ *     NEGATIVE count are UCNERF_EINVAL; a count of ZERO rays / samples / rows is an empty batch -- success, nothing launched, no pointer read
+ *     (torch hands empty tensors to the reference's functions the same way);
  *   - "sample" = one depth sample on one ray; M = N_rays * S samples, ray-major (sample s of ray r at
  *     index r*S + s).
  */

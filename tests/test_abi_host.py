@@ -227,3 +227,17 @@ def test_gradient_chain_counted_waits_never_exceed_the_operations_actually_issue
         assert seq[a_i][1] >= 6
         checked += 1
     assert checked == 128
+
+
+def test_entry_points_refuse_null_and_empty_arguments_without_crashing():
+    """Every (params*, stream) entry point of include/ucnerf_hip.h, in a child process (a crash must not take the test run with it): NULL params, an all-zero
+    struct, positive sizes with NULL arrays, negative and absurd sizes with dummy arrays -- an error code and a message every time (an all-zero struct
+    may also be an empty batch: success), never a crash, never a launch.  110 calls; runs without a GPU."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "abi_null_probe.py")], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, "the probe died (exit %d): %s" % (r.returncode, r.stderr[-2000:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["calls"] >= 100 and not out["problems"], out["problems"]

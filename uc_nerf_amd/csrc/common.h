@@ -29,6 +29,10 @@ inline int check_launch(const char* what) {
 #define UCNERF_REQUIRE(cond, ...) \
     do { if (!(cond)) return ::ucnerf::fail(UCNERF_EINVAL, __VA_ARGS__); } while (0)
 
+// An empty batch is a no-op; a NEGATIVE count is the caller's error (round 5: every entry point used to take it for an empty batch).
+#define UCNERF_COUNT(n) \
+    do { if ((n) < 0) return ::ucnerf::fail(UCNERF_EINVAL, "%s: negative count %lld", __func__, (long long)(n)); if ((n) == 0) return UCNERF_OK; } while (0)
+
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 struct Mat34 { float m[12]; };

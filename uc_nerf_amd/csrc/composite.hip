@@ -89,14 +89,14 @@ extern "C" {
 
 int ucnerf_composite_fwd(const ucnerf_composite_params* p, void* stream) {
     UCNERF_REQUIRE(p, "composite_fwd: null params");
-    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->n);
     UCNERF_REQUIRE(p->raw && p->z && p->rgb_map && p->depth_map, "composite_fwd: null pointer");
     UCNERF_REQUIRE(p->S >= 1 && p->S <= 1024, "composite_fwd: S = %d outside 1..1024", p->S);
     UCNERF_REQUIRE(p->variant == 0 || (p->variant == 1 && p->rays_d), "composite_fwd: variant %d (variant 1 needs rays_d)", p->variant);
     UCNERF_REQUIRE(!p->var || (p->variant == 0 && p->S >= 2), "composite_fwd: var needs the live variant and S >= 2");
     UCNERF_REQUIRE(((uintptr_t)p->raw & 15) == 0, "composite_fwd: raw must be 16-byte aligned");
     UCNERF_REQUIRE(!p->wu || p->u, "composite_fwd: wu (sum of w*u) needs the per-sample uncertainty u");
-    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->n);
     hipStream_t st = (hipStream_t)stream;
     const int E = composite_lane_samples(p->S);      // (shared with the launch fused with the re-sampling: same lane split, same weights)
     if (E <= 1) launch_fwd<1>(*p, st);
@@ -110,13 +110,13 @@ int ucnerf_composite_fwd(const ucnerf_composite_params* p, void* stream) {
 
 int ucnerf_composite_bwd(const ucnerf_composite_bwd_params* bp, void* stream) {
     UCNERF_REQUIRE(bp, "composite_bwd: null params");
-    if (bp->fwd.n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(bp->fwd.n);
     UCNERF_REQUIRE(bp->fwd.raw && bp->fwd.z && bp->g_raw, "composite_bwd: null pointer");
     const ucnerf_composite_params& p = bp->fwd;
     UCNERF_REQUIRE(p.variant == 0, "composite_bwd: only the live variant (network/renderer.py) has a backward");
     UCNERF_REQUIRE(p.S >= 1 && p.S <= 1024, "composite_bwd: S = %d outside 1..1024", p.S);
     UCNERF_REQUIRE(((uintptr_t)p.raw & 15) == 0 && ((uintptr_t)bp->g_raw & 15) == 0, "composite_bwd: raw/g_raw must be 16-byte aligned");
-    if (p.n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p.n);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(cdiv(p.n, 4)), block(256);
     const int E = cdiv(p.S, 64);

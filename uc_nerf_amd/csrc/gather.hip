@@ -320,7 +320,7 @@ extern "C" {
 
 int ucnerf_feat_gather_fwd(const ucnerf_feat_gather_params* p, void* stream) {
     UCNERF_REQUIRE(p, "feat_gather_fwd: null params");
-    if (p->m <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->m);
     int rc = check_geometry(p, "feat_gather_fwd");
     if (rc) return rc;
     const int mask = p->unit_mask ? p->unit_mask : ~0;
@@ -328,18 +328,18 @@ int ucnerf_feat_gather_fwd(const ucnerf_feat_gather_params* p, void* stream) {
     UCNERF_REQUIRE(!(mask & 8) || p->conf, "feat_gather_fwd: null confidence");
     UCNERF_REQUIRE(!(mask & (((1 << p->V) - 1) << 4)) || (p->imgs && p->img_feat), "feat_gather_fwd: null images / image features");
     UCNERF_REQUIRE(p->feats, "feat_gather_fwd: null output");
-    if (p->m <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->m);
     hipLaunchKernelGGL(feat_gather_fwd_kernel, dim3(cdiv(p->m, 256), 4 + p->V), dim3(256), 0, (hipStream_t)stream, *p);
     return check_launch("feat_gather_fwd");
 }
 
 int ucnerf_feat_gather_bwd(const ucnerf_feat_gather_bwd_params* bp, void* stream) {
     UCNERF_REQUIRE(bp, "feat_gather_bwd: null params");
-    if (bp->fwd.m <= 0) return UCNERF_OK;
+    UCNERF_COUNT(bp->fwd.m);
     UCNERF_REQUIRE(bp->g_feats, "feat_gather_bwd: null g_feats");
     int rc = check_geometry(&bp->fwd, "feat_gather_bwd");
     if (rc) return rc;
-    if (bp->fwd.m <= 0) return UCNERF_OK;
+    UCNERF_COUNT(bp->fwd.m);
     hipStream_t st = (hipStream_t)stream;
     const ucnerf_feat_gather_params& f = bp->fwd;
     // per source: accumulate channel-last straight into the caller's gradient array (g_cl, ABI v5), or in the scratch buffer and add transposed

@@ -658,7 +658,7 @@ int64_t ucnerf_mlp_bwd_workspace_floats(const ucnerf_mlp_config* cfg, int32_t m)
 int ucnerf_mlp_fwd_train(const ucnerf_mlp_params* p, float* bwd_workspace, int32_t bwd_mode, void* stream) {
     UCNERF_REQUIRE(p && bwd_workspace, "mlp_fwd_train: null pointer");
     UCNERF_REQUIRE(bwd_mode == 0 || bwd_mode == 1, "mlp_fwd_train: bwd_mode %d", bwd_mode);
-    if (p->m <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->m);
     UCNERF_REQUIRE(p->cfg.precision == 0 || p->cfg.precision == 1, "mlp_fwd_train: the training forward runs in f32 or bf16x3 precision");
     UCNERF_REQUIRE(((uintptr_t)bwd_workspace & 15) == 0, "mlp_fwd_train: workspace must be 16-byte aligned");
     BwdWork w;
@@ -676,7 +676,7 @@ int ucnerf_mlp_fwd_train(const ucnerf_mlp_params* p, float* bwd_workspace, int32
 int ucnerf_mlp_bwd(const ucnerf_mlp_bwd_params* bp, void* stream) {
     UCNERF_REQUIRE(bp, "mlp_bwd: null params");
     const ucnerf_mlp_params& f = bp->fwd;
-    if (f.m <= 0) return UCNERF_OK;
+    UCNERF_COUNT(f.m);
     UCNERF_REQUIRE(f.pts && f.dirs && f.feats && f.wstream && bp->g_raw && bp->flat_params && bp->g_flat && bp->g_feats &&
                        bp->workspace, "mlp_bwd: null pointer");
     UCNERF_REQUIRE(!f.feats_tiled || (bp->bwd_mode == 0 && !f.encoded), "mlp_bwd: features in the tile layout are read by the gradient chain (bwd_mode 0) only");

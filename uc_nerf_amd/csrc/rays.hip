@@ -353,7 +353,7 @@ __global__ void embed_kernel(ucnerf_embed_params p, int out_stride) {
 // rows `out_stride` floats apart (mlp_bwd.hip: the weight-gradient launch reads its fp32 operands in 16-byte pieces -- dense rows of 63 / 27
 // floats put every piece on an unaligned address)
 int launch_embed_strided(int m, int n_freqs, int layout, const float* x, float* out, int out_stride, hipStream_t st) {
-    if (m <= 0) return UCNERF_OK;
+    UCNERF_COUNT(m);
     ucnerf_embed_params p;
     p.m = m; p.n_freqs = n_freqs; p.layout = layout; p.x = x; p.out = out;
     hipLaunchKernelGGL(embed_kernel, dim3(cdiv((long long)m * (n_freqs + 1), 256)), dim3(256), 0, st, p, out_stride);
@@ -443,19 +443,19 @@ int ucnerf_ray_gen_sample(const ucnerf_ray_gen_params* rg, const ucnerf_sample_s
 
 int ucnerf_ndc_rays(const ucnerf_ndc_rays_params* p, void* stream) {
     UCNERF_REQUIRE(p, "ndc_rays: null params");
-    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->n);
     UCNERF_REQUIRE(p->rays_o && p->rays_d && p->out_o && p->out_d, "ndc_rays: null pointer");
     UCNERF_REQUIRE(p->variant == 0 || p->variant == 1, "ndc_rays: variant %d", p->variant);
-    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->n);
     hipLaunchKernelGGL(ndc_rays_kernel, dim3(cdiv(p->n, 256)), dim3(256), 0, (hipStream_t)stream, *p);
     return check_launch("ndc_rays");
 }
 
 int ucnerf_dir_feature(const ucnerf_dir_feature_params* p, void* stream) {
     UCNERF_REQUIRE(p, "dir_feature: null params");
-    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->n);
     UCNERF_REQUIRE(p->rays_d && p->angle, "dir_feature: null pointer");
-    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->n);
     hipLaunchKernelGGL(dir_feature_kernel, dim3(cdiv((long long)p->n * (p->repeat > 1 ? p->repeat : 1), 256)), dim3(256), 0,
                        (hipStream_t)stream, *p);
     return check_launch("dir_feature");
@@ -463,12 +463,12 @@ int ucnerf_dir_feature(const ucnerf_dir_feature_params* p, void* stream) {
 
 int ucnerf_sample_stratified(const ucnerf_sample_stratified_params* p, void* stream) {
     UCNERF_REQUIRE(p, "sample_stratified: null params");
-    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->n);
     UCNERF_REQUIRE(p->z, "sample_stratified: null z");
     UCNERF_REQUIRE(p->rays || !p->pts, "sample_stratified: pts output needs the rays array");
     UCNERF_REQUIRE(p->S >= 1, "sample_stratified: S = %d", p->S);
     UCNERF_REQUIRE(!(p->perturb > 0.f) || p->noise, "sample_stratified: perturb > 0 needs noise draws");
-    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->n);
     hipLaunchKernelGGL(sample_stratified_kernel, dim3(cdiv((long long)p->n * p->S, 256)), dim3(256), 0,
                        (hipStream_t)stream, *p);
     return check_launch("sample_stratified");
@@ -476,18 +476,18 @@ int ucnerf_sample_stratified(const ucnerf_sample_stratified_params* p, void* str
 
 int ucnerf_sample_cascade(const ucnerf_sample_cascade_params* p, void* stream) {
     UCNERF_REQUIRE(p, "sample_cascade: null params");
-    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->n);
     UCNERF_REQUIRE(p->near_far && p->z, "sample_cascade: null pointer");
     UCNERF_REQUIRE(p->S >= 3 && p->S % 3 == 0 && p->S <= 768, "sample_cascade: S = %d (multiple of 3, <= 768)", p->S);
     UCNERF_REQUIRE(!p->pts || (p->rays_o && p->rays_d), "sample_cascade: pts needs rays_o and rays_d");
-    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->n);
     hipLaunchKernelGGL(sample_cascade_kernel, dim3(p->n), dim3(64), 0, (hipStream_t)stream, *p);
     return check_launch("sample_cascade");
 }
 
 int ucnerf_build_rays_test(const ucnerf_build_rays_test_params* p, void* stream) {
     UCNERF_REQUIRE(p, "build_rays_test: null params");
-    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->n);
     UCNERF_REQUIRE(p->K && p->c2w && p->w2c_ref && p->K_ref && p->near_far_ref && p->depth_values[0] && p->depth_values[1] && p->depth_values[2],
                    "build_rays_test: null input");
     UCNERF_REQUIRE(p->rays_d && p->z && p->pts && p->ndc1 && p->ndc2 && p->ndc3 && p->ndc, "build_rays_test: null output");
@@ -506,7 +506,7 @@ int ucnerf_build_rays_test(const ucnerf_build_rays_test_params* p, void* stream)
 
 int ucnerf_ndc_project(const ucnerf_ndc_project_params* p, void* stream) {
     UCNERF_REQUIRE(p, "ndc_project: null params");
-    if (p->m <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->m);
     UCNERF_REQUIRE(p->pts, "ndc_project: null pts");
     UCNERF_REQUIRE(p->nf_stride == 0 || p->nf_stride == 1, "ndc_project: nf_stride %d", p->nf_stride);
     if (p->sample_2d) {
@@ -517,18 +517,18 @@ int ucnerf_ndc_project(const ucnerf_ndc_project_params* p, void* stream) {
                            (!p->out_stage3 || (p->near_3 && p->far_3)),
                        "ndc_project: stage output without its near/far arrays");
     }
-    if (p->m <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->m);
     hipLaunchKernelGGL(ndc_project_kernel, dim3(cdiv(p->m, 256)), dim3(256), 0, (hipStream_t)stream, *p);
     return check_launch("ndc_project");
 }
 
 int ucnerf_embed(const ucnerf_embed_params* p, void* stream) {
     UCNERF_REQUIRE(p, "embed: null params");
-    if (p->m <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->m);
     UCNERF_REQUIRE(p->x && p->out, "embed: null pointer");
     UCNERF_REQUIRE(p->n_freqs >= 0 && p->n_freqs <= 30, "embed: n_freqs %d", p->n_freqs);
     UCNERF_REQUIRE(p->layout == 0 || p->layout == 1, "embed: layout %d", p->layout);
-    if (p->m <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->m);
     hipLaunchKernelGGL(embed_kernel, dim3(cdiv((long long)p->m * (p->n_freqs + 1), 256)), dim3(256), 0,
                        (hipStream_t)stream, *p, 3 + 6 * p->n_freqs);
     return check_launch("embed");

@@ -278,7 +278,7 @@ int64_t ucnerf_render_bwd_workspace_floats(int32_t n, int32_t S, int32_t V) {
 int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* bp, void* stream) {
     UCNERF_REQUIRE(bp, "render_fused_bwd: null params");
     const ucnerf_render_params* p = &bp->fwd;
-    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->n);
     UCNERF_REQUIRE(p->rays_o && p->rays_d && p->z && p->wstream && p->raw && p->feats && bp->g_rgb && bp->flat_params && bp->g_flat &&
                        bp->workspace, "render_fused_bwd: null pointer (fwd.raw and fwd.feats must hold the forward's outputs)");
     UCNERF_REQUIRE(((uintptr_t)bp->workspace & 15) == 0, "render_fused_bwd: workspace must be 16-byte aligned");
@@ -324,7 +324,7 @@ int ucnerf_render_fused_bwd(const ucnerf_render_bwd_params* bp, void* stream) {
 
 int ucnerf_render_fused_fwd(const ucnerf_render_params* p, void* stream) {
     UCNERF_REQUIRE(p, "render_fused_fwd: null params");
-    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->n);
     UCNERF_REQUIRE(p->rays_o && p->rays_d && p->z && p->workspace && p->wstream && p->rgb_map && p->depth_map,
                    "render_fused_fwd: null pointer");
     UCNERF_REQUIRE(p->S >= 1 && p->S <= 1024, "render_fused_fwd: S = %d outside 1..1024", p->S);

@@ -51,7 +51,7 @@ using namespace ucnerf;
 
 extern "C" int ucnerf_sample_pdf(const ucnerf_sample_pdf_params* p, void* stream) {
     UCNERF_REQUIRE(p, "sample_pdf: null params");
-    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->n);
     UCNERF_REQUIRE(p->weights && p->u, "sample_pdf: null pointer");
     if (p->from_coarse)
         UCNERF_REQUIRE(p->z_merge && p->n_merge == p->n_bins + 1, "sample_pdf: from_coarse needs z_merge with n_merge == n_bins + 1");
@@ -64,7 +64,7 @@ extern "C" int ucnerf_sample_pdf(const ucnerf_sample_pdf_params* p, void* stream
     UCNERF_REQUIRE(!p->z_sorted || p->n_merge == 0 || p->z_merge, "sample_pdf: z_sorted with n_merge > 0 needs z_merge");
     UCNERF_REQUIRE(p->samples || p->inds || p->cdf || p->z_sorted, "sample_pdf: no outputs requested");
     UCNERF_REQUIRE(!p->merge_rank || p->z_sorted, "sample_pdf: merge_rank needs z_sorted");
-    if (p->n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(p->n);
     if (p->n_bins <= 128 && p->n_merge + p->n_samples <= 512)
         hipLaunchKernelGGL((sample_pdf_kernel<128, 512>), dim3(p->n), dim3(64), 0, (hipStream_t)stream, *p);
     else
@@ -74,7 +74,7 @@ extern "C" int ucnerf_sample_pdf(const ucnerf_sample_pdf_params* p, void* stream
 
 extern "C" int ucnerf_composite_sample_pdf(const ucnerf_composite_params* c, const ucnerf_sample_pdf_params* s, void* stream) {
     UCNERF_REQUIRE(c && s, "composite_sample_pdf: null params");
-    if (c->n <= 0) return UCNERF_OK;
+    UCNERF_COUNT(c->n);
     UCNERF_REQUIRE(c->raw && c->z && c->rgb_map && c->depth_map, "composite_sample_pdf: null compositing pointer");
     UCNERF_REQUIRE(c->variant == 0 && !c->u && !c->wu, "composite_sample_pdf: the live compositing variant without uncertainty inputs");
     UCNERF_REQUIRE(!c->var || c->S >= 2, "composite_sample_pdf: var needs S >= 2");
@@ -106,7 +106,9 @@ extern "C" int ucnerf_composite_sample_pdf(const ucnerf_composite_params* c, con
 
 extern "C" int ucnerf_merge_rows(const ucnerf_merge_rows_params* p, void* stream) {
     UCNERF_REQUIRE(p, "merge_rows: null params");
-    if (p->n <= 0 || p->na + p->nb <= 0) return UCNERF_OK;
+    UCNERF_REQUIRE(p->na >= 0 && p->nb >= 0, "merge_rows: negative row length");
+    UCNERF_COUNT(p->n);
+    UCNERF_COUNT(p->na + p->nb);
     UCNERF_REQUIRE(p->rank && p->out && (p->a || p->na == 0) && (p->b || p->nb == 0), "merge_rows: null pointer");
     UCNERF_REQUIRE(p->width >= 1 && p->width <= 8, "merge_rows: width = %d outside 1..8", p->width);
     UCNERF_REQUIRE(p->width != 4 || ((((uintptr_t)p->a | (uintptr_t)p->b | (uintptr_t)p->out) & 15) == 0), "merge_rows: 4-float rows must be 16-byte aligned");
