@@ -10,7 +10,8 @@ One case = one small scene and ONE network object driven through a random sequen
               forward in between -- the gradients must be those of an immediate backward
   weights     parameters scaled in place / load_state_dict / a round trip through the CPU (re-flattens the store)
   sources     the volumes / images / features written in place; replaced by new tensors; switched between channel-major and channel-last
-              (channels_last_3d / channels_last) layouts; only the confidence map or only the poses changed
+              (channels_last_3d / channels_last) layouts or handed over as strided slices of wider allocations; only the confidence map or only
+              the poses changed; (a third of the batches arrive as non-contiguous views as well)
   scene       the script turns to a second scene of another size (and later back): two sets of sources alternate through one session
   knobs       inference precision (bf16x3_fused / bf16x3 / f32), weight-cache policy (verify / versions), the one-launch tail route on / off
 After every render the same call is made on a FRESH network (new module, state_dict copied in, new session) with fresh clones of the sources:
@@ -120,7 +121,18 @@ def run(cases=12, steps=40, seed=0, verbose=True, only=None, magnify=False):
             n = int(rng.choice([1, 31, 64, 100, 257, 700, 1024]))
             S = int(rng.choice([30, 45, 90]))
             chunk = None if rng.rand() < 0.5 else int(rng.randint(0, max(1, H * W // n)))
-            return live_path_batch(scene, outputs, n, S, seed=s * 100 + k, chunk_idx=chunk)
+            b = live_path_batch(scene, outputs, n, S, seed=s * 100 + k, chunk_idx=chunk)
+            if rng.rand() < 0.3:
+                # the same values behind other strides: slices of wider allocations, every second column, an expanded direction
+                def wide(t):
+                    w_ = torch.zeros(t.shape[:-1] + (t.shape[-1] + 3,), device=t.device)
+                    w_[..., :t.shape[-1]] = t
+                    return w_[..., :t.shape[-1]]
+                z2 = torch.zeros(n, 2 * S, device=DEV)
+                z2[:, ::2] = b["depth_candidates"]
+                b = dict(b, rays_pts=wide(b["rays_pts"]), rays_ndc={k_: wide(v) for k_, v in b["rays_ndc"].items()}, depth_candidates=z2[:, ::2],
+                         rays_dir=wide(b["rays_dir"]))
+            return b
 
         try:
             apply_knobs()
@@ -244,8 +256,16 @@ def run(cases=12, steps=40, seed=0, verbose=True, only=None, magnify=False):
                         opt = None                                 # (optimizer state points at the old parameter storage; a script would rebuild it too)
                     log.append("weights how=%d" % how)
                 elif op == "sources":
-                    how = int(rng.randint(0, 5))
-                    if how == 0:                                   # written in place
+                    how = int(rng.randint(0, 6))
+                    if how == 5:                                   # neither channel-major nor channel-last: slices of wider allocations (copied by the library)
+                        def sliced(t):
+                            w_ = torch.zeros(t.shape[:-1] + (t.shape[-1] + 2,), device=t.device)
+                            w_[..., 1:-1] = t
+                            return w_[..., 1:-1]
+                        src["vols"] = [sliced(v.contiguous()) for v in src["vols"]]
+                        src["img_feat"], src["imgs"], src["conf"] = sliced(src["img_feat"].contiguous()), sliced(src["imgs"].contiguous()), sliced(src["conf"])
+                        cl = [False] * 5
+                    elif how == 0:                                 # written in place
                         i = int(rng.randint(0, 5))
                         t = (src["vols"] + [src["img_feat"], src["imgs"]])[i]
                         with torch.no_grad():

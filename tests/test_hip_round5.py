@@ -568,3 +568,43 @@ def test_stateful_fuzz_of_the_coarse_fine_pipeline_and_its_route_equivalences():
     s = fuzz_pipeline.run(cases=60, steps=25, seed=9, verbose=False)
     assert not s["failures"], s["failures"]
     assert s["renders"] > 500
+
+
+def test_empty_batches_go_through_every_route():
+    """Zero rays (the empty last chunk of a script that slices its pixels, an empty shard of a sharded batch): rendering() under no_grad in every
+    precision and under autograd, and the evaluation ray builder, return empty outputs -- and the backward of an empty batch leaves zero gradients --
+    as torch hands empty tensors through the reference's own functions (network/renderer.py:215-255)."""
+    import uc_nerf_amd
+    import fuzz_dropin as FD
+    from uc_nerf_amd import ops
+    from uc_nerf_amd.synthetic import cascade_outputs, init_ucnerf_state_dict, live_path_batch, make_scene, scene_to
+    mods = FD._mods()
+    V = 4
+    scene = scene_to(make_scene(seed=0, H=64, W=80, V=V, small_volumes=True), torch.device(DEV))
+    outputs = cascade_outputs(scene)
+    net = FD._net(mods, V, init_ucnerf_state_dict(seed=0, n_src=V - 1, sigma_scale=0.05, sigma_bias=0.05))
+    qfn = _qfn(mods)
+    args = types.SimpleNamespace(view_num=V, feat_dim=24 + 12 * (V - 1) + 1, img_downscale=1.0, use_color_volume=False, net_type="v2")
+    b = live_path_batch(scene, outputs, 8, 30, seed=1)
+    e = dict(rays_pts=b["rays_pts"][:0], rays_ndc={k: v[:0] for k, v in b["rays_ndc"].items()}, depth_candidates=b["depth_candidates"][:0], rays_dir=b["rays_dir"][:0])
+
+    def call(grad):
+        vf = {"stage%d" % (i + 1): {"volume_feature_no_ref": scene["vols"][i]} for i in range(3)}
+        pose = {"w2cs": scene["w2cs"].clone(), "intrinsics": scene["intrinsics"].clone()}
+        with torch.enable_grad() if grad else torch.no_grad():
+            return mods.renderer.rendering(args, pose, e["rays_pts"], e["rays_ndc"], e["depth_candidates"], e["rays_dir"], vf, scene["imgs"], network_fn=net,
+                                           img_feat=scene["img_feat"], network_query_fn=qfn, confidence=scene["confidence"])
+    try:
+        for prec in ("bf16x3_fused", "bf16x3", "f32"):
+            uc_nerf_amd.set_inference_precision(prec)
+            rgb, d = call(False)
+            assert tuple(rgb.shape) == (0, 3) and tuple(d.shape) == (0,)
+    finally:
+        uc_nerf_amd.set_inference_precision("bf16x3_fused")
+    rgb, d = call(True)
+    assert tuple(rgb.shape) == (0, 3) and tuple(d.shape) == (0,)
+    (rgb.sum() + d.sum()).backward()
+    assert all(p.grad is None or not torch.count_nonzero(p.grad) for p in net.parameters())
+    out = ops.build_rays_test(64, 80, 0, 0, 30, scene["K"], scene["c2w"], scene["w2cs"][0], scene["intrinsics"][0], torch.tensor([1., 4.], device=DEV),
+                              [outputs["stage%d" % k]["depth_values"] for k in (1, 2, 3)])
+    assert tuple(out["z"].shape) == (0, 30) and tuple(out["pts"].shape) == (0, 30, 3)
