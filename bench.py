@@ -645,13 +645,15 @@ def main():
             msf = sum(a.elapsed_ms(b) for st in evf for a, b in st)
             achf = samples_per_step * args.steps * FLOP_PER_SAMPLE / (msf * 1e-3) / 1e12
             of = rf.render(xs, ys, perturb=1.0, noise=noise)
-            same = (of["z_fine"] - out["z_fine"]).abs().amax(-1) < 1e-4
+            # (bit-equal fine depths: a depth that moved by 1e-5 can carry a sample across a source image's border -- a mask flip worth 1e-2 of rgb on
+            #  this synthetic scene -- so "nearly equal" depths say nothing about the two kernels' arithmetic)
+            same = (of["z_fine"] == out["z_fine"]).all(-1)
             exf = achf * BF16X3_EXECUTED_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE
             return {"value": global_rays / dtf, "unit": "rays/s", "ms_per_step": dtf * 1e3, "precision": prec,
                     "roofline": {"bound": "mfma", "kernel": "mlp_fwd_bf16_kernel" + ("" if fused_is_headline else " (gather fused)"),
                                  "achieved": achf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achf / PEAK_BF16_MFMA_TFLOPS,
                                  "executed": exf, "executed_frac": exf / PEAK_BF16_MFMA_TFLOPS, "avg_launch_ms": msf / (2 * args.steps)},
-                    "max_abs_rgb_vs_headline_on_rays_with_equal_depths": (of["rgb"] - out["rgb"]).abs().amax(-1)[same].max().item(),
+                    "max_abs_rgb_vs_headline_on_rays_with_equal_depths": (of["rgb"] - out["rgb"]).abs().amax(-1)[same].max().item() if bool(same.any()) else None,
                     "rays_with_equal_fine_depths": same.float().mean().item(),
                     "note": ("NOT the headline: the two-kernel pass (feat_gather_cl -> tiled feature buffer -> mlp_fwd_bf16); its MLP launch does "
                              "no gather, so its roofline fraction is the kernel-only figure" if fused_is_headline else

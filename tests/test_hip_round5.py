@@ -608,3 +608,13 @@ def test_empty_batches_go_through_every_route():
     out = ops.build_rays_test(64, 80, 0, 0, 30, scene["K"], scene["c2w"], scene["w2cs"][0], scene["intrinsics"][0], torch.tensor([1., 4.], device=DEV),
                               [outputs["stage%d" % k]["depth_values"] for k in (1, 2, 3)])
     assert tuple(out["z"].shape) == (0, 30) and tuple(out["pts"].shape) == (0, 30, 3)
+
+
+def test_differential_fuzz_of_the_stand_alone_network_launch():
+    """tests/fuzz_mlp.py on a fixed set of 40 random cases: ucnerf_mlp_fwd and ucnerf_embed against the oracle (network/models.py:50-54,138-184;
+    utils/run_nerf_helpers.py:52-53) -- 1..7 source views, ragged sample counts, both encoding layouts, directions per ray or per sample, features
+    row-major or tiled, all three arithmetics; bars scaled by the float32 oracle's own distance from the float64 one where the input is ill-conditioned."""
+    import fuzz_mlp
+    s = fuzz_mlp.run(cases=40, seed=8, verbose=False)
+    assert not s["failures"], s["failures"]
+    assert s["worst"]["embed"] <= 2e-6 and s["samples"] > 20000
