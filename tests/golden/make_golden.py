@@ -745,8 +745,78 @@ def g15():
     save("g15_losses", **arrs)
 
 
+# ------------------------------------------------------------------ G18 the training ray builder (utils/utils.py:400-597)
+def g18():
+    """build_rays as train.py:147-163 calls it (with_depth=True), on a tiny scene, with every random draw RECORDED in call order -- torch.multinomial
+    (the two confidence-weighted patch picks), np.random.randint (the patch shifts), torch.randint (the uniform pixels), torch.rand (the jitter) -- so that
+    a replay of the same draws through another implementation must reproduce every output, whatever device its generator lives on."""
+    import types
+    g = torch.Generator().manual_seed(118)
+    H, W, V, NS = 24, 32, 3, 12
+    patch_num, ps, n_rays = 4, 4, 90
+    args = types.SimpleNamespace(patch_num=patch_num, patch_size=ps)
+    imgs = torch.rand(1, V, 3, H, W, generator=g)
+    conf = torch.rand(H, W, generator=g).clamp(1e-3, 1 - 1e-3)
+    outputs = {}
+    for k, (d, D) in (("stage1", (4, 5)), ("stage2", (2, 4)), ("stage3", (1, 3))):
+        lo = 1.0 + torch.rand(1, 1, H // d, W // d, generator=g)
+        steps = torch.linspace(0, 1, D).view(1, D, 1, 1)
+        hi = lo + 0.4 + torch.rand(1, 1, H // d, W // d, generator=g)
+        outputs[k] = {"depth_values": (lo * (1 - steps) + hi * steps).contiguous(), "prob_volume": torch.softmax(torch.randn(1, D, H // d, W // d, generator=g), 1)}
+    K = torch.tensor([[30., 0, 16], [0, 30, 12], [0, 0, 1]])
+    c2ws = torch.stack([rand_pose(g) for _ in range(V)])
+    w2cs = torch.inverse(c2ws)
+    intrinsics = K.repeat(V, 1, 1)
+    near_fars = torch.tensor([[1.0, 4.0]] * V)
+    pose_ref = {"w2cs": w2cs.clone(), "intrinsics": intrinsics.clone(), "near_fars": near_fars}
+    n_sparse = 7
+    coords = torch.stack([torch.randint(0, H, (n_sparse,), generator=g), torch.randint(0, W, (n_sparse,), generator=g)], -1).float()     # (row, col)
+    sparse = torch.zeros(H, W)
+    sparse[coords[:, 0].long(), coords[:, 1].long()] = 1.0 + 2.0 * torch.rand(n_sparse, generator=g)
+    draws = []
+    orig = (torch.multinomial, np.random.randint, torch.randint, torch.rand)
+
+    def rec(kind, fn):
+        def wrapped(*a, **k):
+            out = fn(*a, **k)
+            draws.append((kind, torch.as_tensor(out).clone()))
+            return out
+        return wrapped
+    torch.multinomial, np.random.randint, torch.randint, torch.rand = rec("multinomial", orig[0]), rec("np_randint", orig[1]), rec("randint", orig[2]), rec("rand", orig[3])
+    # get_rays_with_random_patches (utils/utils.py:196-199) slices a transposed mesh grid, moves the slice `.to(device)` and calls `.view(-1)` on it: on the
+    # GPU the reference runs on, the move is a copy and the copy is contiguous; on this container's CPU the move is the identity and `.view` raises.  The
+    # capture therefore lets `.view` fall back to `.reshape` (the same values the GPU path sees) for the duration of the call.
+    view = torch.Tensor.view
+
+    def view_or_reshape(self, *shape, **kw):
+        try:
+            return view(self, *shape, **kw)
+        except RuntimeError:
+            return self.reshape(*shape)
+    torch.Tensor.view = view_or_reshape
+    try:
+        torch.manual_seed(18)
+        np.random.seed(18)
+        out = ref.utils.build_rays(args, imgs, conf, sparse, coords, pose_ref, w2cs, c2ws, intrinsics, n_rays, NS, with_depth=True, outputs=outputs)
+    finally:
+        torch.multinomial, np.random.randint, torch.randint, torch.rand = orig
+        torch.Tensor.view = view
+    pts, rays_d, colors, ndc, z, rays_o, rays_depths, par, pix = out
+    assert rays_depths is None
+    arrs = dict(H=H, W=W, V=V, NS=NS, patch_num=patch_num, patch_size=ps, n_rays=n_rays, imgs=imgs, conf=conf, K=K, c2ws=c2ws, w2cs=w2cs, near_fars=near_fars,
+                coords=coords, sparse=sparse, pts=pts, rays_d=rays_d, colors=colors, z=z, rays_o=rays_o, pix=pix,
+                ndc1=ndc["stage1"], ndc2=ndc["stage2"], ndc3=ndc["stage3"], ndc=ndc["ndc"], n_draws=len(draws),
+                draw_kinds=np.array([k for k, _ in draws]))
+    for i, (_, v) in enumerate(draws):
+        arrs["draw_%03d" % i] = v
+    for k in ("stage1", "stage2", "stage3"):
+        arrs[k + "_depth_values"] = outputs[k]["depth_values"]
+        arrs[k + "_prob_volume"] = outputs[k]["prob_volume"]
+    save("g18_build_rays", **arrs)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12_g13, g14, g15, g16, g17):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12_g13, g14, g15, g16, g17, g18):
         if not only or fn.__name__ in only:
             fn()

@@ -313,6 +313,53 @@ def test_build_rays_training_sampler_contract(mods):
                               200, NS, with_depth=False, outputs=outputs)
 
 
+def test_build_rays_replays_the_reference_draw_for_draw(mods, monkeypatch):
+    """utils/utils.py:400-597 as train.py:147-163 calls it.  G18 holds the reference's outputs on a tiny scene together with EVERY random draw it made, in
+    call order: two torch.multinomial picks (confidence / uncertainty patches), eight np.random.randint patch shifts, two torch.randint draws (the
+    uniform pixels: columns, then rows) and one torch.rand (the depth jitter).  The mirror is fed the same draws through the same primitives -- a
+    primitive asked for out of order, or with another shape, fails the test -- and must reproduce rays, colours, depths, points and all four coordinate
+    sets; i.e. under one seed on one device it consumes the generators exactly as the reference does."""
+    import numpy as np
+    g = load_golden("g18_build_rays")
+    H, W, V, NS = int(g["H"]), int(g["W"]), int(g["V"]), int(g["NS"])
+    kinds = [str(k) for k in np.asarray(g["draw_kinds"]).tolist()]
+    draws = [g["draw_%03d" % i] for i in range(int(g["n_draws"]))]
+    pos = [0]
+
+    def next_draw(kind, device=None, shape=None):
+        i = pos[0]
+        assert i < len(kinds) and kinds[i] == kind, "draw %d: the reference made a %s draw here, the mirror asks for %s" % (i, kinds[i] if i < len(kinds) else "no", kind)
+        pos[0] += 1
+        v = draws[i]
+        v = v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v))
+        if shape is not None:
+            assert tuple(v.shape) == tuple(shape), "draw %d (%s): shape %s asked, the reference drew %s" % (i, kind, tuple(shape), tuple(v.shape))
+        return v.to(device) if device is not None else v
+
+    def _size(a, k):
+        sz = k.get("size", a[-1] if a else None)
+        return tuple(sz) if isinstance(sz, (tuple, list, torch.Size)) else (int(sz),)
+
+    monkeypatch.setattr(torch, "multinomial", lambda inp, n, *a, **k: next_draw("multinomial", inp.device, (n,)))
+    monkeypatch.setattr(np.random, "randint", lambda *a, **k: int(next_draw("np_randint")))
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: next_draw("randint", k.get("device"), _size(a, k)))
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: next_draw("rand", k.get("device"), a[0] if len(a) == 1 and isinstance(a[0], (tuple, list, torch.Size)) else a))
+    outputs = {k: {"depth_values": dev(g[k + "_depth_values"]), "prob_volume": dev(g[k + "_prob_volume"])} for k in ("stage1", "stage2", "stage3")}
+    pose_ref = {"w2cs": dev(g["w2cs"]).clone(), "intrinsics": dev(g["K"]).repeat(V, 1, 1), "near_fars": dev(g["near_fars"])}
+    args = types.SimpleNamespace(patch_num=int(g["patch_num"]), patch_size=int(g["patch_size"]))
+    out = mods.utils.build_rays(args, dev(g["imgs"]), dev(g["conf"]), dev(g["sparse"]), dev(g["coords"]), pose_ref, dev(g["w2cs"]), dev(g["c2ws"]),
+                                dev(g["K"]).repeat(V, 1, 1), int(g["n_rays"]), NS, with_depth=True, outputs=outputs)
+    monkeypatch.undo()
+    assert pos[0] == len(kinds), "the mirror made %d of the reference's %d draws" % (pos[0], len(kinds))
+    pts, rd, colors, ndc, z, ro, rdep, par, pix = out
+    assert rdep is None and torch.equal(pix.cpu(), g["pix"])
+    assert torch.equal(colors.cpu(), g["colors"])
+    close(rd, g["rays_d"]); close(ro, g["rays_o"])
+    close(z, g["z"], 1e-6, 1e-6); close(pts, g["pts"], 1e-5, 1e-5)
+    for k, name in (("stage1", "ndc1"), ("stage2", "ndc2"), ("stage3", "ndc3"), ("ndc", "ndc")):
+        close(ndc[k], g[name], 2e-5, 2e-5)
+
+
 def test_create_ucnerf_contract(mods):
     args = types.SimpleNamespace(multires=10, multires_views=4, i_embed=0, netdepth=6, netwidth=128, feat_dim=97, net_type="v2",
                                  view_num=7, netchunk=1024, perturb=1.0, N_samples=90, use_viewdirs=True, white_bkgd=False,

@@ -353,3 +353,44 @@ def test_g17_uncertainty_outputs_on_the_g10_and_g11_scenes(sd_v7):
     close(ref["coarse"]["u_sampled"], u17["g11_c_u"], 1e-6, 0); close(ref["u_sampled"], u17["g11_f_u"], 1e-6, 0)
     ok = (g["ys"] > 0) & (g["ys"] < g["H"] - 1)          # rows 0 / H-1 sit on the in-mask discontinuity (see test_g11)
     close(ref["coarse"]["wu"][ok], u17["g11_c_wu"][ok], 2e-5, 1e-4); close(ref["wu"][ok], u17["g11_f_wu"][ok], 2e-5, 1e-4)
+
+
+def test_g18_training_ray_builder_downstream_of_the_pixel_picks():
+    """G18 = the reference's build_rays (utils/utils.py:400-597) with every random draw recorded.  Given the pixels it picked and its jitter draws, the
+    oracle's pieces reproduce its rays, colours, cascade depths, points and normalised coordinates -- and the picks themselves follow from the
+    recorded draws (patch cells from the multinomial picks, shifts from numpy, uniform pixels from randint, sparse-depth pixels last)."""
+    g = load_golden("g18_build_rays")
+    H, W, NS, ps, patch_num = g["H"], g["W"], g["NS"], g["patch_size"], g["patch_num"]
+    draws = [g["draw_%03d" % i] for i in range(g["n_draws"])]
+    # the pixel list from the draws
+    rows, cols, k = [], [], 0
+    for half in range(2):
+        sel = draws[k]; k += 1
+        for j in range(patch_num // 2):
+            cr = min(max(int(sel[j]) // W // ps, 0), H // ps - 2)
+            cc = min(max(int(sel[j]) % W // ps, 0), W // ps - 2)
+            r0, c0 = cr * ps + int(draws[k]), cc * ps + int(draws[k + 1]); k += 2
+            rr, cc_ = torch.arange(r0, min(r0 + ps, H)), torch.arange(c0, min(c0 + ps, W))
+            rows.append(rr.repeat_interleave(cc_.numel())); cols.append(cc_.repeat(rr.numel()))
+    xs_u, ys_u = draws[k], draws[k + 1]
+    rows += [ys_u, g["coords"][:, 0].long()]; cols += [xs_u, g["coords"][:, 1].long()]
+    pix = torch.stack([torch.cat(rows), torch.cat(cols)])
+    assert torch.equal(pix, g["pix"])
+    t_rand = draws[k + 2]
+    _, rd, _ = O.get_rays_mvs_pixels(pix[1].float(), pix[0].float(), g["K"], g["c2ws"][0])
+    close(rd, g["rays_d"])
+    assert torch.equal(g["imgs"][0, 0][:, pix[0], pix[1]].t(), g["colors"])
+    nf = {}
+    for kk, d in (("1", 4), ("2", 2), ("3", 1)):
+        dv = g["stage%s_depth_values" % kk]
+        pr, pc = torch.div(pix[0], d, rounding_mode="trunc"), torch.div(pix[1], d, rounding_mode="trunc")
+        nf["near_" + kk], nf["far_" + kk] = dv[0, 0, pr, pc].unsqueeze(1), dv[0, -1, pr, pc].unsqueeze(1)
+    z = O.cascade_depth_candidates(nf["near_1"], nf["far_1"], nf["near_2"], nf["far_2"], nf["near_3"], nf["far_3"], NS, t_rand)
+    close(z, g["z"])
+    pts = g["c2ws"][0][:3, 3].reshape(1, 1, 3) + z.unsqueeze(-1) * rd.unsqueeze(1)
+    close(pts, g["pts"])
+    nfe = {k_: v.expand(-1, NS).unsqueeze(-1) for k_, v in nf.items()}
+    nfe["near"], nfe["far"] = g["near_fars"][0, 0], g["near_fars"][0, 1]
+    ndc = O.get_ndc_coordinate(g["w2cs"][0], g["K"], pts, torch.tensor([W - 1, H - 1]), nfe)
+    for k_, name in (("stage1", "ndc1"), ("stage2", "ndc2"), ("stage3", "ndc3"), ("ndc", "ndc")):
+        close(ndc[k_], g[name], 1e-5, 1e-5)
