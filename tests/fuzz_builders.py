@@ -26,18 +26,22 @@ from oracle import ucnerf_oracle as O                                           
 DEV = "cuda:0"
 
 
-def worst(got, want, atol, rtol):
-    """max over elements of |got - want| / (atol + rtol |want|): <= 1 passes."""
+def worst(got, want, atol, rtol, exact=None):
+    """max over elements of |got - want| / (atol + rtol |want| + 8 |want - exact|): <= 1 passes.  `exact`: the same quantity from the oracle run in
+    float64 -- where the float32 oracle itself is far from it (a sample next to the reference camera's plane: the projection divides by a depth that is
+    the small difference of large terms) no float32 evaluation can be held to the plain bar."""
     got, want = got.detach().cpu().double(), want.double()
     if not want.numel():
         return 0.0
+    slack = 8 * (want - exact.double()).abs() if exact is not None else torch.zeros_like(want)
+    slack = torch.where(torch.isfinite(slack), slack, torch.zeros_like(slack))
     fin = torch.isfinite(want)
     # a stage with ONE depth hypothesis has near == far: the reference divides by zero there (utils/utils.py:333-347) and the kernel must give the
     # same infinities and NaNs in the same places
     same_kind = (torch.isnan(want) & torch.isnan(got)) | (torch.isinf(want) & (got == want))
     if not bool((fin | same_kind).all()) or not bool(torch.isfinite(got[fin]).all()):
         return float("inf")
-    return float(((got[fin] - want[fin]).abs() / (atol + rtol * want[fin].abs())).max()) if fin.any() else 0.0
+    return float(((got[fin] - want[fin]).abs() / (atol + rtol * want[fin].abs() + slack[fin])).max()) if fin.any() else 0.0
 
 
 def run(cases=200, seed=0, verbose=True):
@@ -86,6 +90,8 @@ def run(cases=200, seed=0, verbose=True):
         nfe = {k: v.expand(-1, S).unsqueeze(-1) for k, v in nf.items()}
         nfe["near"], nfe["far"] = nf_ref[0], nf_ref[1]
         ndc = O.get_ndc_coordinate(w2c_ref, K_ref, pts, torch.tensor([W - 1, H - 1]), nfe)
+        ndc64 = O.get_ndc_coordinate(w2c_ref.double(), K_ref.double(), pts.double(), torch.tensor([W - 1, H - 1], dtype=torch.float64),
+                                     {k_: (v.double() if torch.is_tensor(v) else v) for k_, v in nfe.items()})
         # ---- device: one launch
         got = ops.build_rays_test(H, W, start, n, S, K.to(dev), c2w.to(dev), w2c_ref.to(dev), K_ref.to(dev), nf_ref.to(dev), [d.to(dev) for d in dvs],
                                   t_rand.to(dev), want_ranges=True)
@@ -93,7 +99,7 @@ def run(cases=200, seed=0, verbose=True):
         w = {"rays_d": worst(got["rays_d"], rd, 1e-6, 1e-6), "z": worst(got["z"], z, 1e-6, 1e-6), "pts": worst(got["pts"], pts, 1e-5, 1e-5),
              "ranges": 0.0 if torch.equal(got["ranges"].cpu(), ranges) else float("inf"), "rays_o": 0.0 if torch.equal(got["rays_o"].cpu(), ro) else float("inf")}
         for k in ("stage1", "stage2", "stage3", "ndc"):
-            w[k] = worst(got[k], ndc[k], 2e-5, 2e-5)
+            w[k] = worst(got[k], ndc[k], 2e-5, 2e-5, exact=ndc64[k])
         for k, v in w.items():
             worst_all[k] = max(worst_all.get(k, 0.0), v)
         rays += n
