@@ -20,7 +20,6 @@ no_grad outputs must be bit-identical; a training call's rgb / depth bit-identic
 held to three times the difference between TWO fresh networks running the same step before it counts as a failure).  No oracle involved: this checks state, not arithmetic (the other fuzzers do that).
 """
 import argparse
-import copy
 import os
 import sys
 import time
