@@ -588,6 +588,106 @@ def main():
     achieved = samples_per_step * args.steps * FLOP_PER_SAMPLE / (mlp_ms * 1e-3) / 1e12
     bf16 = args.precision != "f32"
 
+    import threading
+    line_once = threading.Lock()
+
+    def finish(extra_, final=True):
+        """Builds the ONE JSON line and prints it (rank 0).  final=False: called by the watchdog below when the secondary measurements of an N > 1 run
+        did not come back -- the headline, measured before them, still goes out (nothing here then touches the GPU or a collective)."""
+        if not line_once.acquire(blocking=False):      # (the watchdog and the main thread never both print)
+            return
+        psnr_vs_f32 = None
+        if args.precision == "bf16" and final:         # outside the parity bar by construction: report the distance to the exact render
+            r32 = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, precision="f32")
+            ref = r32.pass_(out["rays_d"], out["z_fine"])            # same fine depths: isolates the network arithmetic
+            mse = torch.mean((out["rgb"] - ref["rgb"]) ** 2).item()
+            psnr_vs_f32 = {"psnr_db": -10.0 * math.log10(max(mse, 1e-20)),
+                           "max_abs_rgb": (out["rgb"] - ref["rgb"]).abs().max().item(),
+                           "max_abs_depth": (out["depth"] - ref["depth"]).abs().max().item()}
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+        # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, scripts/pmc_mlp.sh), which
+        # cannot run inside this process: the figure is READ BACK from the committed profile and labelled as such
+        traffic, traffic_source = None, None
+        for name in (("r05_mlp_bf16_fused_hbm_traffic.json", "r04_mlp_bf16_fused_hbm_traffic.json", "r03_mlp_bf16_fused_hbm_traffic.json", "r02_mlp_bf16_fused_hbm_traffic.json") if args.precision == "bf16x3_fused" else
+                     ("r02_mlp_bf16_hbm_traffic.json", "r01_mlp_bf16_hbm_traffic.json") if bf16 else ("r02_mlp_fwd_hbm_traffic.json", "r01_mlp_fwd_hbm_traffic.json")):
+            tpath = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get("bytes_per_launch")
+                traffic_source = "profiles/%s (rocprofv3 PMC passes of this command on an earlier box; not measured in this run)" % name
+                break
+
+        if rank == 0:
+            roof = {"bound": "mfma", "kernel": ("mlp_fwd_bf16_kernel (FUSED instantiation: feature gather + encoding + MLP)" if args.precision == "bf16x3_fused"
+                                                else "mlp_fwd_bf16_kernel" if bf16 else "mlp_fwd_kernel"), "achieved": achieved,
+                    "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
+                    "avg_launch_ms": mlp_ms / launches, "flop_per_launch_avg": samples_per_step * FLOP_PER_SAMPLE / 2}
+            if bf16:
+                # achieved / frac count ALGORITHMIC flops (one multiply-accumulate per weight and sample) against the dense bf16
+                # peak; the split evaluation executes three bf16 MFMA products per algorithmic one (fp32-grade accuracy), so the
+                # matrix pipe itself runs at `executed` TFLOP/s
+                terms = 3 if args.precision in ("bf16x3", "bf16x3_fused") else 1
+                ex = achieved * BF16X3_EXECUTED_FLOP_PER_SAMPLE / 3 * terms / FLOP_PER_SAMPLE
+                roof.update(executed=ex, executed_frac=ex / peak,
+                            note=("bf16x3: 3 bf16 MFMAs per algorithmic MAC; algorithmic ceiling = peak/3.003 = 832 TFLOP/s"
+                                  + ("; this launch also does the pass's feature gather (no separate gather kernel, no feature buffer): `achieved` "
+                                     "counts the MLP's flops only -- the kernel-only figure is two_kernel_pass.roofline"
+                                     if args.precision == "bf16x3_fused" else ""))
+                            if terms == 3 else "plain bf16: NOT within the 1e-4 parity bar, see parity_vs_f32")
+                if terms == 3:
+                    # what the three-MFMA formulation reaches on an MI355X board with this kernel's own instruction mix and nothing else (no gather, no
+                    # encoding, no DMA, no barrier): measured by scripts/micro/headline_ceiling.hip on one box next to the kernel, READ BACK from the
+                    # committed artifact (the micro-benchmark takes 30 s of its own; it is not run here)
+                    cpath = os.path.join(ROOT, "profiles", "r05_headline_ceiling.json")
+                    if os.path.exists(cpath):
+                        with open(cpath) as f:
+                            ceil = json.load(f)["ceiling_executed_tflops"]
+                        roof.update(frac_of_measured_ceiling=ex / ceil["iii_plus_valu_5_per_mfma"],
+                                    measured_ceiling={"executed_tflops": ceil["iii_plus_valu_5_per_mfma"], "with_one_barrier_per_ring_slot": ceil["iv_plus_barrier_per_slot"],
+                                                      "bare_3_mfma_loop": ceil["i_bare_3mfma"], "as_frac_of_peak_algorithmic": ceil["iii_plus_valu_5_per_mfma"] / 3.003 / peak,
+                                                      "source": "profiles/r05_headline_ceiling.json (.md): power-limited loops with the kernel's instruction ratios, "
+                                                                "same geometry, measured on an earlier box of this round; not measured in this run"})
+            line = {
+                "metric": "rendered rays/sec (coarse+fine, 64+128 samples)",
+                "value": global_rays * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "clock_settle_steps": settle, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                "scaling": args.scaling, "vs_baseline": None,
+                "dtype": {"f32": "f32", "bf16x3": "f32 via split-bf16 (bf16x3) MFMA, f32 accumulate",
+                          "bf16x3_fused": "f32 via split-bf16 (bf16x3) MFMA, f32 accumulate (feature gather fused into the MLP kernel)",
+                          "bf16": "bf16 operands, f32 accumulate"}[args.precision], "data": "synthetic",
+                "config": {"workload": "configs[1] shapes: %d rays/GPU x (%d coarse + %d fine -> %d merged) samples, V=7 views "
+                                       "256x320, cascade volumes 48x64x80/32x128x160/8x256x320, UCNeRF D=6 W=128 random init"
+                                       % (rays, args.coarse, args.fine, args.coarse + args.fine),
+                           "global_rays": global_rays, "parallelism": "ray-sharded x%d, no data-path collective" % world,
+                           "precision": args.precision},
+                "roofline": roof,
+                "mlp_share_of_step": mlp_ms / (dt * 1e3),
+                "ranks_seen": ctx.dist.get_world_size() if ctx.dist is not None else 1,
+                **({"hip_graph_ms_per_step": graph_ms} if graph_ms is not None else {}),
+            }
+            if psnr_vs_f32 is not None:
+                line["parity_vs_f32"] = psnr_vs_f32
+            line.update(extra_)
+            if args.cpu_rays > 0 and world == 1 and final:      # (N = 1 only: the CPU legs take 10-30 s, during which other ranks would sit at the closing barrier)
+                line["parity_vs_oracle"] = guarded(lambda: parity_vs_oracle(scene_cpu, sd, out, xs_all[:rays], ys_all[:rays], noise.cpu(), args.coarse, args.fine))
+                line["cpu_baseline"] = cpu_baseline(scene_cpu, sd, args.cpu_rays, args.coarse, args.fine)
+            print(json.dumps(line), flush=True)
+
+    # N > 1: the secondary measurements below contain collectives (barriers, the gradient all-reduce).  Should one of them not come back -- a rank that
+    # failed alone leaves the others waiting in a barrier -- the headline measured above must still reach the driver: a watchdog thread (it runs while
+    # the main thread sits in a blocking HIP / RCCL call: those release the GIL) prints the line with what there is and ends the process.
+    secondaries_done = threading.Event()
+    if world > 1:
+        limit = float(os.environ.get("UCNERF_BENCH_SECONDARY_LIMIT_S", "240"))
+
+        def watchdog():
+            if not secondaries_done.wait(limit):
+                try:
+                    finish({"secondaries": {"error": "did not finish within %.0f s on rank %d: the line carries the headline only" % (limit, rank)}}, final=False)
+                finally:
+                    os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+
     extra = {}
     secondary = not args.no_reuse
     if secondary:
@@ -863,83 +963,13 @@ def main():
         if world == 1 and ctx.dist is not None:       # UCNERF_BENCH_GROUP_AT_1: the data-parallel step through a one-rank process group
             extra["train_dp"] = guarded(lambda: bench_train_dp(ctx, scene, sd, 2000))
 
-    psnr_vs_f32 = None
-    if args.precision == "bf16":         # outside the parity bar by construction: report the distance to the exact render
-        r32 = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, precision="f32")
-        ref = r32.pass_(out["rays_d"], out["z_fine"])            # same fine depths: isolates the network arithmetic
-        mse = torch.mean((out["rgb"] - ref["rgb"]) ** 2).item()
-        psnr_vs_f32 = {"psnr_db": -10.0 * math.log10(max(mse, 1e-20)),
-                       "max_abs_rgb": (out["rgb"] - ref["rgb"]).abs().max().item(),
-                       "max_abs_depth": (out["depth"] - ref["depth"]).abs().max().item()}
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-    # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, scripts/pmc_mlp.sh), which
-    # cannot run inside this process: the figure is READ BACK from the committed profile and labelled as such
-    traffic, traffic_source = None, None
-    for name in (("r05_mlp_bf16_fused_hbm_traffic.json", "r04_mlp_bf16_fused_hbm_traffic.json", "r03_mlp_bf16_fused_hbm_traffic.json", "r02_mlp_bf16_fused_hbm_traffic.json") if args.precision == "bf16x3_fused" else
-                 ("r02_mlp_bf16_hbm_traffic.json", "r01_mlp_bf16_hbm_traffic.json") if bf16 else ("r02_mlp_fwd_hbm_traffic.json", "r01_mlp_fwd_hbm_traffic.json")):
-        tpath = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get("bytes_per_launch")
-            traffic_source = "profiles/%s (rocprofv3 PMC passes of this command on an earlier box; not measured in this run)" % name
-            break
-
-    if rank == 0:
-        roof = {"bound": "mfma", "kernel": ("mlp_fwd_bf16_kernel (FUSED instantiation: feature gather + encoding + MLP)" if args.precision == "bf16x3_fused"
-                                            else "mlp_fwd_bf16_kernel" if bf16 else "mlp_fwd_kernel"), "achieved": achieved,
-                "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
-                "avg_launch_ms": mlp_ms / launches, "flop_per_launch_avg": samples_per_step * FLOP_PER_SAMPLE / 2}
-        if bf16:
-            # achieved / frac count ALGORITHMIC flops (one multiply-accumulate per weight and sample) against the dense bf16
-            # peak; the split evaluation executes three bf16 MFMA products per algorithmic one (fp32-grade accuracy), so the
-            # matrix pipe itself runs at `executed` TFLOP/s
-            terms = 3 if args.precision in ("bf16x3", "bf16x3_fused") else 1
-            ex = achieved * BF16X3_EXECUTED_FLOP_PER_SAMPLE / 3 * terms / FLOP_PER_SAMPLE
-            roof.update(executed=ex, executed_frac=ex / peak,
-                        note=("bf16x3: 3 bf16 MFMAs per algorithmic MAC; algorithmic ceiling = peak/3.003 = 832 TFLOP/s"
-                              + ("; this launch also does the pass's feature gather (no separate gather kernel, no feature buffer): `achieved` "
-                                 "counts the MLP's flops only -- the kernel-only figure is two_kernel_pass.roofline"
-                                 if args.precision == "bf16x3_fused" else ""))
-                        if terms == 3 else "plain bf16: NOT within the 1e-4 parity bar, see parity_vs_f32")
-            if terms == 3:
-                # what the three-MFMA formulation reaches on an MI355X board with this kernel's own instruction mix and nothing else (no gather, no
-                # encoding, no DMA, no barrier): measured by scripts/micro/headline_ceiling.hip on one box next to the kernel, READ BACK from the
-                # committed artifact (the micro-benchmark takes 30 s of its own; it is not run here)
-                cpath = os.path.join(ROOT, "profiles", "r05_headline_ceiling.json")
-                if os.path.exists(cpath):
-                    with open(cpath) as f:
-                        ceil = json.load(f)["ceiling_executed_tflops"]
-                    roof.update(frac_of_measured_ceiling=ex / ceil["iii_plus_valu_5_per_mfma"],
-                                measured_ceiling={"executed_tflops": ceil["iii_plus_valu_5_per_mfma"], "with_one_barrier_per_ring_slot": ceil["iv_plus_barrier_per_slot"],
-                                                  "bare_3_mfma_loop": ceil["i_bare_3mfma"], "as_frac_of_peak_algorithmic": ceil["iii_plus_valu_5_per_mfma"] / 3.003 / peak,
-                                                  "source": "profiles/r05_headline_ceiling.json (.md): power-limited loops with the kernel's instruction ratios, "
-                                                            "same geometry, measured on an earlier box of this round; not measured in this run"})
-        line = {
-            "metric": "rendered rays/sec (coarse+fine, 64+128 samples)",
-            "value": global_rays * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "clock_settle_steps": settle, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x3": "f32 via split-bf16 (bf16x3) MFMA, f32 accumulate",
-                      "bf16x3_fused": "f32 via split-bf16 (bf16x3) MFMA, f32 accumulate (feature gather fused into the MLP kernel)",
-                      "bf16": "bf16 operands, f32 accumulate"}[args.precision], "data": "synthetic",
-            "config": {"workload": "configs[1] shapes: %d rays/GPU x (%d coarse + %d fine -> %d merged) samples, V=7 views "
-                                   "256x320, cascade volumes 48x64x80/32x128x160/8x256x320, UCNeRF D=6 W=128 random init"
-                                   % (rays, args.coarse, args.fine, args.coarse + args.fine),
-                       "global_rays": global_rays, "parallelism": "ray-sharded x%d, no data-path collective" % world,
-                       "precision": args.precision},
-            "roofline": roof,
-            "mlp_share_of_step": mlp_ms / (dt * 1e3),
-            "ranks_seen": ctx.dist.get_world_size() if ctx.dist is not None else 1,
-            **({"hip_graph_ms_per_step": graph_ms} if graph_ms is not None else {}),
-        }
-        if psnr_vs_f32 is not None:
-            line["parity_vs_f32"] = psnr_vs_f32
-        line.update(extra)
-        if args.cpu_rays > 0:           # (rank 0 only; at N > 1 the other ranks wait at the closing barrier)
-            line["parity_vs_oracle"] = guarded(lambda: parity_vs_oracle(scene_cpu, sd, out, xs_all[:rays], ys_all[:rays], noise.cpu(), args.coarse, args.fine))
-            line["cpu_baseline"] = cpu_baseline(scene_cpu, sd, args.cpu_rays, args.coarse, args.fine)
-        print(json.dumps(line), flush=True)
+    secondaries_done.set()
+    finish(extra)
     if ctx.dist is not None:
+        if world > 1:                # the line is out: a closing barrier that does not come back must not keep the launcher waiting
+            t_ = threading.Timer(60.0, lambda: os._exit(0))
+            t_.daemon = True
+            t_.start()
         ctx.dist.barrier()
         ctx.dist.destroy_process_group()
 
