@@ -97,6 +97,45 @@ __device__ __forceinline__ void run_atomic_add(float* base, int key, float v, in
     }
     if (head && key >= 0 && s != 0.f) atomicAdd(base + key, s);
 }
+
+// The same over TWO batches of positions held by the same lanes (batch A = positions 0 .. N-1, batch B = N .. 2N-1 of one run dimension: a wave covers
+// 2N consecutive samples): a run that crosses from A's last position into B's first is issued ONCE, by its head in A.  Twice the window of
+// run_atomic_add for the same lanes -- views' runs are ~16 samples long, the finest volume's ~11 (round 5).
+template <int STRIDE>
+__device__ __forceinline__ void run_atomic_add2(float* base, int key_a, float v_a, int key_b, float v_b, int pos) {
+    constexpr int N = 64 / STRIDE;
+    const int lane = threadIdx.x & 63, col = lane % STRIDE;
+    // ---- batch B on its own
+    const int kpb = __shfl_up(key_b, STRIDE), knb = __shfl_down(key_b, STRIDE);
+    int end_b = pos == N - 1 || knb != key_b;
+    float s_b = v_b;
+#pragma unroll
+    for (int d = 1; d < N; d <<= 1) {
+        const float sn = __shfl_down(s_b, STRIDE * d);
+        const int en = __shfl_down(end_b, STRIDE * d);
+        if (!end_b) { s_b += sn; end_b = en; }
+    }
+    // ---- the run at B's first position, seen from A's last
+    const int key_b0 = __shfl(key_b, col);
+    const float s_b0 = __shfl(s_b, col);
+    const int key_a7 = __shfl(key_a, (N - 1) * STRIDE + col);
+    const bool absorbed = key_a7 == key_b0 && key_b0 >= 0;              // (uniform over the lanes of a column)
+    if (pos == N - 1 && absorbed) v_a += s_b0;
+    // ---- batch A
+    const int kpa = __shfl_up(key_a, STRIDE), kna = __shfl_down(key_a, STRIDE);
+    int end_a = pos == N - 1 || kna != key_a;
+    float s_a = v_a;
+#pragma unroll
+    for (int d = 1; d < N; d <<= 1) {
+        const float sn = __shfl_down(s_a, STRIDE * d);
+        const int en = __shfl_down(end_a, STRIDE * d);
+        if (!end_a) { s_a += sn; end_a = en; }
+    }
+    const bool head_a = pos == 0 || kpa != key_a;
+    const bool head_b = (pos == 0 ? !absorbed : kpb != key_b);
+    if (head_a && key_a >= 0 && s_a != 0.f) atomicAdd(base + key_a, s_a);
+    if (head_b && key_b >= 0 && s_b != 0.f) atomicAdd(base + key_b, s_b);
+}
 #endif
 
 }  // namespace ucnerf

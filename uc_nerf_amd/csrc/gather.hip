@@ -228,52 +228,80 @@ __global__ void __launch_bounds__(256) conf_bwd_kernel(ucnerf_feat_gather_bwd_pa
     run_atomic_add<1>(bp.g_conf, dead | (ay.i1 * p.W + ax.i1), gc * (ay.w1 * ax.w1), pos);
 }
 
+// The corner keys (element offsets of channel 0 of the cell, -1 past the end) and weighted gradients of one sample: the 8 corners of a volume's cell, the
+// 4 of a source view's pixel.  (Two functions and two branches in the kernel, not one function returning either: arrays merged across a branch are
+// not scalarised -- the compiler parked them in LDS.)
+struct VolCorners { int key[8]; float val[8]; };
+struct ViewCorners { int key[4]; float val[4]; };
+
+__device__ __forceinline__ VolCorners vol_corners(const ucnerf_feat_gather_bwd_params& bp, int unit, long long s_raw, int c) {
+    const ucnerf_feat_gather_params& p = bp.fwd;
+    const bool live = s_raw < p.m;
+    const size_t s = live ? (size_t)s_raw : (size_t)p.m - 1;
+    const int F = 24 + 12 * p.V + 1;
+    const int dead = live ? 0 : -1;                                     // keys of lanes past the end
+    const float* g = (unit == 0 ? p.ndc1 : unit == 1 ? p.ndc2 : p.ndc3) + 3 * s;
+    const int D = p.vol_d[unit], h = p.vol_h[unit], w = p.vol_w[unit];
+    const Lerp ax = axis(g[0] * 2.f - 1.0f, w, false), ay = axis(g[1] * 2.f - 1.0f, h, false),
+               az = axis(g[2] * 2.f - 1.0f, D, false);
+    const int o00 = (az.i0 * h + ay.i0) * w, o01 = (az.i0 * h + ay.i1) * w,
+              o10 = (az.i1 * h + ay.i0) * w, o11 = (az.i1 * h + ay.i1) * w;
+    const float w00 = az.w0 * ay.w0, w01 = az.w0 * ay.w1, w10 = az.w1 * ay.w0, w11 = az.w1 * ay.w1;
+    const float gc = live ? bp.g_feats[s * F + 8 * unit + c] : 0.f;
+    // same products as the direct path (weights folded in the same order); zero-weight corners add nothing
+    VolCorners r;
+    r.key[0] = dead | (8 * (o00 + ax.i0)); r.val[0] = gc * (w00 * ax.w0);
+    r.key[1] = dead | (8 * (o00 + ax.i1)); r.val[1] = gc * (w00 * ax.w1);
+    r.key[2] = dead | (8 * (o01 + ax.i0)); r.val[2] = gc * (w01 * ax.w0);
+    r.key[3] = dead | (8 * (o01 + ax.i1)); r.val[3] = gc * (w01 * ax.w1);
+    r.key[4] = dead | (8 * (o10 + ax.i0)); r.val[4] = gc * (w10 * ax.w0);
+    r.key[5] = dead | (8 * (o10 + ax.i1)); r.val[5] = gc * (w10 * ax.w1);
+    r.key[6] = dead | (8 * (o11 + ax.i0)); r.val[6] = gc * (w11 * ax.w0);
+    r.key[7] = dead | (8 * (o11 + ax.i1)); r.val[7] = gc * (w11 * ax.w1);
+    return r;
+}
+
+__device__ __forceinline__ ViewCorners view_corners(const ucnerf_feat_gather_bwd_params& bp, int v, long long s_raw, int c) {
+    const ucnerf_feat_gather_params& p = bp.fwd;
+    const bool live = s_raw < p.m;
+    const int s = live ? (int)s_raw : p.m - 1;
+    const int F = 24 + 12 * p.V + 1;
+    const int dead = live ? 0 : -1;
+    float gx, gy;
+    project_view(p, v, s, &gx, &gy);
+    const Lerp ax = axis(gx, p.W, true), ay = axis(gy, p.H, true);
+    const float gc = live ? bp.g_feats[(size_t)s * F + 24 + 4 * p.V + 8 * v + c] : 0.f;
+    ViewCorners r;
+    r.key[0] = dead | (8 * (ay.i0 * p.W + ax.i0)); r.val[0] = gc * (ay.w0 * ax.w0);
+    r.key[1] = dead | (8 * (ay.i0 * p.W + ax.i1)); r.val[1] = gc * (ay.w0 * ax.w1);
+    r.key[2] = dead | (8 * (ay.i1 * p.W + ax.i0)); r.val[2] = gc * (ay.w1 * ax.w0);
+    r.key[3] = dead | (8 * (ay.i1 * p.W + ax.i1)); r.val[3] = gc * (ay.w1 * ax.w1);
+    return r;
+}
+
+// thread = (sample pair, channel): a wave covers SIXTEEN consecutive samples -- lane (sl, c) holds samples 16 w + sl and 16 w + 8 + sl of channel c -- and
+// combines runs of equal cells over all sixteen before any atomic is issued (run_atomic_add2: round 5; it was eight samples per wave)
 __global__ void __launch_bounds__(256) feat_gather_bwd_cl_kernel(ucnerf_feat_gather_bwd_params bp) {
     const ucnerf_feat_gather_params& p = bp.fwd;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int s_raw = (int)(t >> 3), c = (int)(t & 7);
-    const int sl = (threadIdx.x >> 3) & 7;                              // sample within the wave
-    const bool live = s_raw < p.m;
-    const int s = live ? s_raw : p.m - 1;
+    const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int c = threadIdx.x & 7, sl = (threadIdx.x >> 3) & 7;       // channel, sample within the batch of eight
+    const long long s_a = wave * 16 + sl, s_b = s_a + 8;              // (past the end: clamped inside the corner functions, keys -1)
     const int unit = blockIdx.y < 3 ? blockIdx.y : blockIdx.y + 1;      // units 0..2 volumes, 4.. views (conf stays on the direct path)
-    const int F = 24 + 12 * p.V + 1;
     if (p.unit_mask && !((p.unit_mask >> unit) & 1)) return;            // (uniform per block)
-    const float* gf = bp.g_feats + (size_t)s * F;
     const ScratchLayout L = scratch_layout(p);
     if (unit < 3) {
         if (!bp.g_cl.vol[unit] && !bp.g_vol[unit]) return;
         float* gv = (bp.g_cl.vol[unit] ? bp.g_cl.vol[unit] : bp.scratch + L.vol[unit]) + c;
-        const float* g = (unit == 0 ? p.ndc1 : unit == 1 ? p.ndc2 : p.ndc3) + 3 * (size_t)s;
-        const int D = p.vol_d[unit], h = p.vol_h[unit], w = p.vol_w[unit];
-        const Lerp ax = axis(g[0] * 2.f - 1.0f, w, false), ay = axis(g[1] * 2.f - 1.0f, h, false),
-                   az = axis(g[2] * 2.f - 1.0f, D, false);
-        const int o00 = (az.i0 * h + ay.i0) * w, o01 = (az.i0 * h + ay.i1) * w,
-                  o10 = (az.i1 * h + ay.i0) * w, o11 = (az.i1 * h + ay.i1) * w;
-        const float w00 = az.w0 * ay.w0, w01 = az.w0 * ay.w1, w10 = az.w1 * ay.w0, w11 = az.w1 * ay.w1;
-        const float gc = live ? gf[8 * unit + c] : 0.f;
-        const int dead = live ? 0 : -1;                                 // keys of lanes past the end
-        // same products as the direct path (weights folded in the same order); zero-weight corners add nothing
-        run_atomic_add<8>(gv, dead | (8 * (o00 + ax.i0)), gc * (w00 * ax.w0), sl);
-        run_atomic_add<8>(gv, dead | (8 * (o00 + ax.i1)), gc * (w00 * ax.w1), sl);
-        run_atomic_add<8>(gv, dead | (8 * (o01 + ax.i0)), gc * (w01 * ax.w0), sl);
-        run_atomic_add<8>(gv, dead | (8 * (o01 + ax.i1)), gc * (w01 * ax.w1), sl);
-        run_atomic_add<8>(gv, dead | (8 * (o10 + ax.i0)), gc * (w10 * ax.w0), sl);
-        run_atomic_add<8>(gv, dead | (8 * (o10 + ax.i1)), gc * (w10 * ax.w1), sl);
-        run_atomic_add<8>(gv, dead | (8 * (o11 + ax.i0)), gc * (w11 * ax.w0), sl);
-        run_atomic_add<8>(gv, dead | (8 * (o11 + ax.i1)), gc * (w11 * ax.w1), sl);
+        const VolCorners A = vol_corners(bp, unit, s_a, c), B = vol_corners(bp, unit, s_b, c);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) run_atomic_add2<8>(gv, A.key[k], A.val[k], B.key[k], B.val[k], sl);
     } else {
         if (!bp.g_cl.img_feat && !bp.g_img_feat) return;
         const int v = unit - 4;
-        float gx, gy;
-        project_view(p, v, s, &gx, &gy);
-        const Lerp ax = axis(gx, p.W, true), ay = axis(gy, p.H, true);
-        const size_t hw = (size_t)p.H * p.W;
-        const int o00 = ay.i0 * p.W + ax.i0, o01 = ay.i0 * p.W + ax.i1, o10 = ay.i1 * p.W + ax.i0, o11 = ay.i1 * p.W + ax.i1;
-        float* ft = (bp.g_cl.img_feat ? bp.g_cl.img_feat : bp.scratch + L.img) + (size_t)8 * v * hw + c;
-        const float gc = live ? gf[24 + 4 * p.V + 8 * v + c] : 0.f;
-        const int dead = live ? 0 : -1;
-        run_atomic_add<8>(ft, dead | (8 * o00), gc * (ay.w0 * ax.w0), sl); run_atomic_add<8>(ft, dead | (8 * o01), gc * (ay.w0 * ax.w1), sl);
-        run_atomic_add<8>(ft, dead | (8 * o10), gc * (ay.w1 * ax.w0), sl); run_atomic_add<8>(ft, dead | (8 * o11), gc * (ay.w1 * ax.w1), sl);
+        float* ft = (bp.g_cl.img_feat ? bp.g_cl.img_feat : bp.scratch + L.img) + (size_t)8 * v * ((size_t)p.H * p.W) + c;
+        const ViewCorners A = view_corners(bp, v, s_a, c), B = view_corners(bp, v, s_b, c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) run_atomic_add2<8>(ft, A.key[k], A.val[k], B.key[k], B.val[k], sl);
     }
 }
 
@@ -364,7 +392,7 @@ int ucnerf_feat_gather_bwd(const ucnerf_feat_gather_bwd_params* bp, void* stream
             if (bp->g_img_feat && !gc.img_feat && hipMemsetAsync(bp->scratch + L.img, 0, (L.total - L.img) * sizeof(float), st) != hipSuccess) return fail(UCNERF_EHIP, "feat_gather_bwd: memset failed");
         }
     }
-    hipLaunchKernelGGL(feat_gather_bwd_cl_kernel, dim3(cdiv((long long)f.m * 8, 256), 3 + f.V), dim3(256), 0, st, *bp);
+    hipLaunchKernelGGL(feat_gather_bwd_cl_kernel, dim3(cdiv((long long)f.m * 4, 256), 3 + f.V), dim3(256), 0, st, *bp);      // (a thread serves two samples)
     if (bp->g_conf && (8 & (f.unit_mask ? f.unit_mask : ~0)))      // confidence: straight into the map (one channel), runs combined per wave
         hipLaunchKernelGGL(conf_bwd_kernel, dim3(cdiv(f.m, 256)), dim3(256), 0, st, *bp);
     if (!via_scratch) return check_launch("feat_gather_bwd (channel-last gradients)");
