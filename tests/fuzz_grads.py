@@ -48,10 +48,11 @@ BAR = {"f32": (3e-4, 3e-3), "bf16x3": (2e-3, 1e-2)}        # per element: |got -
 COARSER = {"f32": 1, "bf16x3": 128}                        # the arithmetic's unit roundoff in units of float32's (2^-24; split-bf16: 2^-17)
 
 
-def outside(got, want, prec="f32"):
-    """(number of elements outside the element-wise bar, worst |error| / max|want|)"""
+def outside(got, want, prec="f32", scale=0.0):
+    """(number of elements outside the element-wise bar, worst |error| / max|want|).  scale: a floor for max|want| -- a bias gradient is the plain sum
+    of what its weight gradient sums with activations as factors, and cancels where that does not: it is held to the larger of the two maxima."""
     got, want = got.detach().cpu().reshape(want.shape), want.detach()
-    m = want.abs().max().item()
+    m = max(want.abs().max().item(), float(scale))
     err = (got - want.to(got.dtype)).abs()
     a, b = BAR[prec]
     out = err > (a * m + 1e-8 + b * want.abs())
@@ -214,7 +215,9 @@ def run(cases=40, seed=0, verbose=True):
                     if torch.count_nonzero(got[k]):
                         b.append(k + ": gradient where the reference has none")
                     continue
-                o_ = outside(got[k], w_, prec)
+                wk = k[:-4] + "weight" if k.endswith(".bias") else None
+                sc = float(want_s[wk].abs().max()) if wk is not None and want_s.get(wk) is not None else 0.0
+                o_ = outside(got[k], w_, prec, sc)
                 elements += w_.numel()
                 if o_[0]:
                     if w64 is None:
