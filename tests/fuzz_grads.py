@@ -216,8 +216,8 @@ def run(cases=40, seed=0, verbose=True):
                         b.append(k + ": gradient where the reference has none")
                     continue
                 wk = k[:-4] + "weight" if k.endswith(".bias") else None
-                sc = float(want_s[wk].abs().max()) if wk is not None and want_s.get(wk) is not None else 0.0
-                o_ = outside(got[k], w_, prec, sc)
+                floor_ = float(want_s[wk].abs().max()) if wk is not None and want_s.get(wk) is not None else 0.0
+                o_ = outside(got[k], w_, prec, floor_)
                 elements += w_.numel()
                 if o_[0]:
                     if w64 is None:
