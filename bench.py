@@ -728,6 +728,33 @@ def main():
                                      "psnr_db_vs_f32": -10.0 * math.log10(max(mse, 1e-20)),
                                      "max_abs_rgb_vs_f32": (op["rgb"] - ref["rgb"]).abs().max().item(),
                                      "note": "NOT the headline and NOT within the 1e-4 parity bar: one bf16 MFMA per product (precision='bf16')"}
+                # the same split with fp16 terms (ucnerf_mlp_config.operand = 1, ABI v6): three f16 MFMAs per product, 11 significant bits per term
+                if ops.split_operand() == "bf16":
+                    ops.set_split_operand("fp16")
+                    try:
+                        rh = CoarseFineRenderer(scene, flat_params_of(sd).to(dev), args.coarse, args.fine, max_blocks=args.max_blocks, precision=args.precision)
+                    finally:
+                        ops.set_split_operand("bf16")
+                    evh = [[(ops.Event(), ops.Event()), (ops.Event(), ops.Event())] for _ in range(args.steps)]
+                    kh = [-args.warmup]
+
+                    def steph():
+                        rh.render(xs, ys, perturb=1.0, noise=noise, events=evh[kh[0]] if kh[0] >= 0 else None)
+                        kh[0] += 1
+                    dth = ctx.timed(steph, args.steps, args.warmup)
+                    msh = sum(a.elapsed_ms(b) for st in evh for a, b in st)
+                    oh = rh.render(xs, ys, perturb=1.0, noise=noise)
+                    refh = r32.pass_(oh["rays_d"], oh["z_fine"])
+                    o3 = renderer.render(xs, ys, perturb=1.0, noise=noise)
+                    ref3 = r32.pass_(o3["rays_d"], o3["z_fine"])
+                    res["fp16_terms"] = {"value": global_rays / dth, "unit": "rays/s", "ms_per_step": dth * 1e3, "avg_launch_ms": msh / (2 * args.steps),
+                                         "max_abs_rgb_vs_f32": (oh["rgb"] - refh["rgb"]).abs().max().item(),
+                                         "max_abs_depth_vs_f32": (oh["depth"] - refh["depth"]).abs().max().item(),
+                                         "headline_max_abs_rgb_vs_f32": (o3["rgb"] - ref3["rgb"]).abs().max().item(),
+                                         "headline_max_abs_depth_vs_f32": (o3["depth"] - ref3["depth"]).abs().max().item(),
+                                         "note": "NOT the headline: the headline's route and precision with fp16 instead of bf16 terms (set_split_operand('fp16'): "
+                                                 "~22-bit products at the same matrix-core rate; fp16's range -- no activation beyond 65 504). Distances: to the "
+                                                 "exact-f32 kernel on the same fine depths, this render's and the headline's"}
             return res
         def other_route():
             """Row f1: the same step on the other route -- the gather inside the MLP kernel (one launch per pass, the default) against

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UCNERF_ABI_VERSION 5
+#define UCNERF_ABI_VERSION 6
 
 #define UCNERF_OK 0
 #define UCNERF_EINVAL (-1)   /* bad argument (null pointer, unsupported size/config) */
@@ -318,6 +318,13 @@ typedef struct {
                                 order that kernel's lane halves produce the bias nets' operands and serves ucnerf_render_fused_fwd
                                 only (channel-last sources, coordinates derived from (ray, depth) or handed over -- pts_in ... ndc_in --,
                                 no kept features, no per-sample uncertainty); ucnerf_mlp_fwd refuses it.  Same arithmetic as 1. */
+    int32_t operand;      /* (ABI v6) the 16-bit terms of precisions 1 .. 3 -- the packed stream and the kernels that read it must agree:
+                             0: bf16 (8 significant bits per term; any float32 range).  The default.
+                             1: fp16 (v_mfma_f32_32x32x16_f16: 11 significant bits per term at the same matrix-core rate, so the three-product
+                                split holds ~22 bits -- rendered outputs at float32 level where the bf16 split is at 16 .. 17 bits).  fp16's RANGE
+                                is the price: an activation or weight beyond 65 504 overflows (float32 itself no longer resolves 1e-4 of a
+                                sigmoid's argument there), and a term below 6e-5 is held with an absolute resolution of 3e-8.  Inference forward
+                                only (ucnerf_mlp_fwd_train refuses it).  Ignored by precision 0. */
 } ucnerf_mlp_config;
 
 /* Sizes: floats in the flat parameter vector, floats (4-byte units) of the packed stream, int32 entries of the pack

@@ -13,7 +13,8 @@ One case = one small scene and ONE network object driven through a random sequen
               (channels_last_3d / channels_last) layouts or handed over as strided slices of wider allocations; only the confidence map or only
               the poses changed; (a third of the batches arrive as non-contiguous views as well)
   scene       the script turns to a second scene of another size (and later back): two sets of sources alternate through one session
-  knobs       inference precision (bf16x3_fused / bf16x3 / f32), weight-cache policy (verify / versions), the one-launch tail route on / off
+  knobs       inference precision (bf16x3_fused / bf16x3 / f32), weight-cache policy (verify / versions), the one-launch tail route on / off, the
+              split's terms (bf16 / fp16)
 After every render the same call is made on a FRESH network (new module, state_dict copied in, new session) with fresh clones of the sources:
 no_grad outputs must be bit-identical; a training call's rgb / depth bit-identical and its gradients equal up to float-atomic order
 (2e-5 max|g| + 1e-4 relative; the one-element gradient of a density head's bias, a sum over all samples that cancels, 1e-3; an element outside that is
@@ -94,13 +95,14 @@ def run(cases=12, steps=40, seed=0, verbose=True, only=None, magnify=False):
         cl = [False] * 5                                  # layout of vol1..3, img_feat, imgs
         src = dict(vols=[_layout(v, False, "vol") for v in scene["vols"]], img_feat=_layout(scene["img_feat"], False, "feat"),
                    imgs=_layout(scene["imgs"], False, "imgs"), conf=scene["confidence"].clone(), w2cs=scene["w2cs"].clone(), intr=scene["intrinsics"].clone())
-        knobs = dict(precision="bf16x3_fused", cache="verify", tail=1)
+        knobs = dict(precision="bf16x3_fused", cache="verify", tail=1, operand="bf16")
         log, other = [], None
 
         def apply_knobs():
             uc_nerf_amd.set_inference_precision(knobs["precision"])
             uc_nerf_amd.set_weight_cache(knobs["cache"])
             L.lib().ucnerf_set_fused_tail(knobs["tail"])
+            uc_nerf_amd.set_split_operand(knobs["operand"])
 
         def call(network, sources, batch, grad):
             vf = {"stage%d" % (i + 1): {"volume_feature_no_ref": sources["vols"][i]} for i in range(3)}
@@ -299,6 +301,7 @@ def run(cases=12, steps=40, seed=0, verbose=True, only=None, magnify=False):
                     knobs["precision"] = str(rng.choice(["bf16x3_fused", "bf16x3_fused", "bf16x3", "f32"]))
                     knobs["cache"] = str(rng.choice(["verify", "versions"]))
                     knobs["tail"] = int(rng.rand() < 0.7)
+                    knobs["operand"] = str(rng.choice(["bf16", "bf16", "fp16"]))
                     apply_knobs()
                     log.append("knobs %s" % knobs)
                 if magnify and op != "render":
@@ -314,6 +317,7 @@ def run(cases=12, steps=40, seed=0, verbose=True, only=None, magnify=False):
         finally:
             uc_nerf_amd.set_inference_precision("bf16x3_fused")
             uc_nerf_amd.set_weight_cache("verify")
+            uc_nerf_amd.set_split_operand("bf16")
             L.lib().ucnerf_set_fused_tail(1)
         if verbose:
             print("case %d (seed %d) V=%d %dx%d: %d steps %s" % (c, s, V, H, W, len(log), "FAIL" if failures and failures[-1].startswith("case %d " % c) else "ok"), flush=True)

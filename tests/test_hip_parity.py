@@ -37,7 +37,7 @@ def flat_params(sd):
 def test_native_library_is_loaded():
     import uc_nerf_amd._lib as L
     lib = L.lib()
-    assert lib.ucnerf_abi_version() == L.ABI_VERSION == 5
+    assert lib.ucnerf_abi_version() == L.ABI_VERSION == 6
     assert lib.ucnerf_device_cus() >= 200          # MI355X: 256 CUs
 
 

@@ -112,7 +112,7 @@ def test_sources_are_recognised_one_by_one(which):
         for k in range(3):
             assert (p.cl.vol[k] == mix_v[k].data_ptr()) == which[k]
         assert (p.cl.img_feat == mix_f.data_ptr()) == which[3] and (p.cl.imgs == mix_i.data_ptr()) == which[4]
-    assert L.lib().ucnerf_abi_version() == 5
+    assert L.lib().ucnerf_abi_version() == 6
 
 
 @pytest.mark.parametrize("which", [(True,) * 4, (True, False, True, False), (False, True, False, True)])
@@ -618,3 +618,65 @@ def test_differential_fuzz_of_the_stand_alone_network_launch():
     s = fuzz_mlp.run(cases=40, seed=8, verbose=False)
     assert not s["failures"], s["failures"]
     assert s["worst"]["embed"] <= 2e-6 and s["samples"] > 20000
+
+
+@pytest.mark.parametrize("fixture", ["g10_rendering", "g16_rendering_v4"])
+def test_fp16_terms_render_the_reference_vectors_at_float32_level(fixture, sd_v7):
+    """ucnerf_mlp_config.operand = 1 (ABI v6): the split precisions with fp16 terms -- the same three matrix-core products per algorithmic one, 11
+    significant bits per term instead of 8.  rendering() under no_grad on G10 / G16 (network/renderer.py:215-255): within float32 rounding of the reference's
+    vectors to 4e-6 / 1e-5 (the bf16 terms are held to 1e-4 and measure 2e-5), on every route (gather fused incl. the one-launch tail, two-kernel pass), and the
+    training forward still packs bf16 terms."""
+    import uc_nerf_amd
+    from uc_nerf_amd import dropin, ops
+    from test_hip_configs import close
+    from test_oracle_golden import sd_v4_for_g16
+    mods = _mods()
+    g = load_golden(fixture)
+    sd = sd_v7 if fixture == "g10_rendering" else sd_v4_for_g16(g)
+    net, qfn = _net(mods, g["V"], sd), _qfn(mods)
+    want_rgb, want_d = g["rgb_first" if "rgb_first" in g else "rgb"], g["depth_first" if "depth_first" in g else "depth"]
+    try:
+        uc_nerf_amd.set_split_operand("fp16")
+        assert ops.split_operand() == "fp16"
+        for prec in ("bf16x3_fused", "bf16x3"):
+            uc_nerf_amd.set_inference_precision(prec)
+            with torch.no_grad():
+                rgb, depth = _call(mods, g, net, qfn)
+            sess = dropin.session_of(net)
+            assert sess.passes[(prec, 0)].pw.operand == 1
+            close(rgb, want_rgb, 4e-6); close(depth, want_d, 1e-5)
+        # a training call: f32 by default -- and the opt-in split training forward keeps bf16 terms whatever the setting
+        uc_nerf_amd.set_training_precision("bf16x3")
+        rgb, depth = _call(mods, g, net, qfn)
+        (rgb.sum() + depth.sum()).backward()
+        assert dropin.session_of(net).passes[("bf16x3", 0)].pw.operand == 0
+        close(rgb.detach(), want_rgb, 1e-4)
+    finally:
+        uc_nerf_amd.set_split_operand("bf16")
+        uc_nerf_amd.set_inference_precision("bf16x3_fused")
+        uc_nerf_amd.set_training_precision("f32")
+    with torch.no_grad():
+        _call(mods, g, net, qfn)
+    assert dropin.session_of(net).passes[("bf16x3_fused", 0)].pw.operand == 0
+
+
+def test_fp16_terms_keep_every_bit_identity_and_refuse_what_they_cannot_serve():
+    """With fp16 terms the route equivalences hold as with bf16 ones (channel-last sources in place == repacked, one-launch tail == two launches, on
+    derived and on given coordinates: tests/fuzz_render.py on 16 random cases under set_split_operand("fp16")), the render fuzz's bar is met with a
+    margin of 5x on every ray (well-conditioned inputs), and ucnerf_mlp_fwd_train refuses the operand loudly."""
+    import uc_nerf_amd
+    import fuzz_render
+    from uc_nerf_amd import ops
+    try:
+        uc_nerf_amd.set_split_operand("fp16")
+        s = fuzz_render.run(cases=16, seed=5, verbose=False)
+        assert s["identity_failures"] == 0 and s["failures"] == 0, [r["bad"] for r in s["rows"] if r["bad"]]
+        assert max(s["worst"]["fused_rgb"], s["worst"]["fused_depth"], s["worst"]["fused_acc"]) <= 2e-5, s["worst"]
+        pw = ops.PackedWeights.get(3, 0, torch.device(DEV), "bf16x3")
+        assert pw.operand == 1
+        m = 64
+        flat = torch.zeros(pw.n_params, device=DEV)
+        with pytest.raises(RuntimeError, match="bf16 terms"):
+            ops.mlp_fwd_train(pw, pw.pack(flat), torch.zeros(m, 3, device=DEV), torch.zeros(m, 3, device=DEV), torch.zeros(m, 24 + 36 + 1, device=DEV), 1)
+    finally:
+        uc_nerf_amd.set_split_operand("bf16")

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UCNERF_LIB") or os.path.join(_HERE, "libucnerf_hip.so")   # override: A/B builds
 
-ABI_VERSION = 5    # UCNERF_ABI_VERSION of include/ucnerf_hip.h this binding mirrors
+ABI_VERSION = 6    # UCNERF_ABI_VERSION of include/ucnerf_hip.h this binding mirrors
 
 fp = C.POINTER(C.c_float)
 i32 = C.c_int32
@@ -81,7 +81,7 @@ class FeatGatherBwdParams(C.Structure):
 
 
 class MlpConfig(C.Structure):
-    _fields_ = [("n_src", i32), ("pe_layout", i32), ("precision", i32)]
+    _fields_ = [("n_src", i32), ("pe_layout", i32), ("precision", i32), ("operand", i32)]
 
 
 class MlpParams(C.Structure):

@@ -15,7 +15,11 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libucnerf_hip.so")
 SOURCES = ["rays.hip", "gather.hip", "gather_cl.hip", "mlp.hip", "mlp_bf16.hip", "mlp_bwd.hip", "mlp_bwd_chain.hip", "mlp_wgrad.hip", "composite.hip", "sample_pdf.hip", "render.hip", "mvs.hip"]
 # (source, object name, extra flags): translation units built more than once with different switches
-VARIANTS = [("mlp_bf16.hip", "mlp_bf16_plain.o", ["-DUCNERF_BF16_BUILD_TERMS=1"]), ("mlp_bf16.hip", "mlp_bf16_tail.o", ["-DUCNERF_BF16_BUILD_TAIL=1"])]
+VARIANTS = [("mlp_bf16.hip", "mlp_bf16_plain.o", ["-DUCNERF_BF16_BUILD_TERMS=1"]), ("mlp_bf16.hip", "mlp_bf16_tail.o", ["-DUCNERF_BF16_BUILD_TAIL=1"]),
+            # the same three builds with fp16 terms (ucnerf_mlp_config.operand == 1, ABI v6): entry points under the suffix _h16
+            ("mlp_bf16.hip", "mlp_h16.o", ["-DUCNERF_OPERAND_FP16=1"]),
+            ("mlp_bf16.hip", "mlp_h16_plain.o", ["-DUCNERF_OPERAND_FP16=1", "-DUCNERF_BF16_BUILD_TERMS=1"]),
+            ("mlp_bf16.hip", "mlp_h16_tail.o", ["-DUCNERF_OPERAND_FP16=1", "-DUCNERF_BF16_BUILD_TAIL=1"])]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mlp_layout.h"), os.path.join(CSRC, "sincos_cw.h"), os.path.join(CSRC, "gather_cl_device.h"), os.path.join(CSRC, "mlp_bwd_parts.h"), os.path.join(CSRC, "p24.h"), os.path.join(CSRC, "composite_device.h"), os.path.join(CSRC, "sample_pdf_device.h"), os.path.join(CSRC, "raygen_device.h"),
            os.path.join(HERE, "..", "include", "ucnerf_hip.h")]
 # -ffp-contract=off: the sample_pdf / sampling kernels reproduce torch-CPU roundings (separate mul and add)

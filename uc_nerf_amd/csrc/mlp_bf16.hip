@@ -60,7 +60,39 @@ namespace ucnerf {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// ucnerf_mlp_config.operand (ABI v6): every build of this file exists twice -- with bf16 terms (UCNERF_OPERAND_FP16 = 0: the entry points below) and with
+// fp16 terms (UCNERF_OPERAND_FP16 = 1: 11-bit hi and lo terms, v_mfma_f32_32x32x16_f16; the same entry points under the suffix _h16, which the
+// bf16 build's entry points forward to when cfg.operand == 1).  fp16 has no range guard: values beyond 65 504 overflow.
+#ifndef UCNERF_OPERAND_FP16
+#define UCNERF_OPERAND_FP16 0
+#endif
+#if UCNERF_OPERAND_FP16
+#define build_pack_index_bf16 build_pack_index_bf16_h16
+#define launch_fused_tail launch_fused_tail_h16
+#define build_flags_mlp_bf16x3 build_flags_mlp_bf16x3_h16
+#define build_flags_mlp_bf16_plain build_flags_mlp_bf16_plain_h16
+#define launch_mlp_fwd_bf16x3 launch_mlp_fwd_bf16x3_h16
+#define launch_mlp_fwd_bf16x3_save launch_mlp_fwd_bf16x3_save_h16
+#define launch_mlp_fwd_bf16x3_gather launch_mlp_fwd_bf16x3_gather_h16
+#define launch_mlp_fwd_bf16_plain launch_mlp_fwd_bf16_plain_h16
+#define bf16_index_count bf16_index_count_h16
+#define bf16_stream_floats bf16_stream_floats_h16
+#define launch_pack_bf16 launch_pack_bf16_h16
+#define launch_pack_bf16_tab launch_pack_bf16_tab_h16
+#define mlp_fwd_bf16_kernel mlp_fwd_h16_kernel                      // (the kernels too: a template's instantiations are weak symbols -- the linker would keep ONE of two
+#define pack_all_flat_kernel pack_all_flat_h16_kernel                //  equally named ones and both operand kinds would run the same code)
+#define pack_all_tab_kernel pack_all_tab_h16_kernel
+#define UCNERF_OPERAND_DISPATCH(cfg_operand, call)
+#else
+// (the fp16 build's entry points; `call` names one of them with this entry point's own arguments)
+#define UCNERF_OPERAND_DISPATCH(cfg_operand, call) do { if ((cfg_operand) == 1) return call; } while (0)
+#endif
+#if UCNERF_OPERAND_FP16
+typedef _Float16 op16;
+#else
+typedef __bf16 op16;
+#endif
+typedef op16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef UCNERF_BF16_HINT_V
 #define UCNERF_BF16_HINT_V 5   // VALU instructions the scheduler may place after each MFMA of a half-step (7 would fill an MFMA's 32 cycles; measured
@@ -76,7 +108,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float sc_mul(float a, float b) { float r = a * b; asm volatile("" : "+v"(r)); return r; }
 __device__ __forceinline__ float sc_sub(float a, float b) { float r = a - b; asm volatile("" : "+v"(r)); return r; }
 __device__ __forceinline__ float sc_fma(float a, float b, float c) { float r = __builtin_fmaf(a, b, c); asm volatile("" : "+v"(r)); return r; }
+#if UCNERF_OPERAND_FP16
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#else
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#endif
 #define SB0 __builtin_amdgcn_sched_barrier(0)
 
 #ifndef UCNERF_BF16_IDLE_SKIP
@@ -227,7 +263,7 @@ struct Frag { bf16x8 hi, lo; };
 //  4 of 43 such cases above the 1e-4 bar; with the rounded hi the median error halves (2.9e-5 -> 1.9e-5, 90th percentile 9.3e-5 -> 4.7e-5)
 //  for +0.2 % of the headline kernel's time, profiles/r05_experiments.md.)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef op16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ Frag split8(const float (&x)[8]) {
     u32x4 hi;
     Frag f;
@@ -236,10 +272,14 @@ __device__ __forceinline__ Frag split8(const float (&x)[8]) {
         const bf16x2 hp = __builtin_convertvector((f32x2){x[j], x[j + 1]}, bf16x2);      // ONE v_cvt_pk_bf16_f32 (two scalar conversions were not merged)
         const unsigned packed = __builtin_bit_cast(unsigned, hp);                 // [hi(x[j+1]) | hi(x[j])]
         hi[j >> 1] = packed;
+#if UCNERF_OPERAND_FP16
+        const f32x2 h = {(float)hp[0], (float)hp[1]};
+#else
         const f32x2 h = {__builtin_bit_cast(float, packed << 16), __builtin_bit_cast(float, packed & 0xffff0000u)};
+#endif
         const f32x2 l = (f32x2){x[j], x[j + 1]} - h;
-        f.lo[j] = (__bf16)l.x;
-        f.lo[j + 1] = (__bf16)l.y;
+        f.lo[j] = (op16)l.x;
+        f.lo[j + 1] = (op16)l.y;
     }
     f.hi = __builtin_bit_cast(bf16x8, hi);
     return f;
@@ -1389,14 +1429,32 @@ const char* build_flags_mlp_bf16_plain() { return "mlp_bf16_plain: " UCNERF_BF16
 #endif
 
 #if UCNERF_BF16_BUILD_TERMS == 3
-int launch_mlp_fwd_bf16x3(const ucnerf_mlp_params* p, hipStream_t st) { return launch_bf16(p, nullptr, st); }
-int launch_mlp_fwd_bf16x3_save(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st) { return launch_bf16(p, save, st); }
+#if !UCNERF_OPERAND_FP16
+int launch_mlp_fwd_bf16x3_h16(const ucnerf_mlp_params* p, hipStream_t st);                   // the fp16-term builds of this file (cfg.operand == 1)
+int launch_mlp_fwd_bf16x3_gather_h16(const ucnerf_render_params* rp, const float* dirs, float* raw, hipStream_t st, const ucnerf_composite_params* tail_c,
+                                     const ucnerf_sample_pdf_params* tail_s, float* tail_dir_out);
+int launch_pack_bf16_h16(const ucnerf_mlp_config* cfg, const float* flat, const int32_t* idx, float* out, hipStream_t st);
+int launch_pack_bf16_tab_h16(const ucnerf_mlp_config* cfg, const ParamTable& t, const int32_t* idx, float* out, hipStream_t st);
+#endif
+int launch_mlp_fwd_bf16x3(const ucnerf_mlp_params* p, hipStream_t st) {
+    UCNERF_REQUIRE(p, "mlp_fwd: null params");
+    UCNERF_REQUIRE(p->cfg.operand == 0 || p->cfg.operand == 1, "mlp_fwd: cfg.operand %d (0 = bf16 terms, 1 = fp16 terms)", p->cfg.operand);
+    UCNERF_OPERAND_DISPATCH(p->cfg.operand, launch_mlp_fwd_bf16x3_h16(p, st));
+    return launch_bf16(p, nullptr, st);
+}
+int launch_mlp_fwd_bf16x3_save(const ucnerf_mlp_params* p, const MlpSaved* save, hipStream_t st) {
+    UCNERF_REQUIRE(p && p->cfg.operand == 0, "mlp_fwd_train: the training forward keeps its activations for a backward that splits them into bf16 terms "
+                   "(cfg.operand 0); fp16 terms serve the inference forward");
+    return launch_bf16(p, save, st);
+}
 
 // called by render.hip: gather + PE + MLP of one pass in ONE launch (row f1), from the channel-last sources and (ray, depth)
 // `tail_c` (optional): the launch also composites the pass's rays (and, with `tail_s`, re-samples from them) -- see FusedGather
 int check_cl_sources(const ucnerf_render_params* p, const char* who);      // gather_cl.hip
 int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* dirs, float* raw, hipStream_t st,
                                  const ucnerf_composite_params* tail_c, const ucnerf_sample_pdf_params* tail_s, float* tail_dir_out) {
+    UCNERF_REQUIRE(rp->cfg.operand == 0 || rp->cfg.operand == 1, "render (gather fused): cfg.operand %d (0 = bf16 terms, 1 = fp16 terms)", rp->cfg.operand);
+    UCNERF_OPERAND_DISPATCH(rp->cfg.operand, launch_mlp_fwd_bf16x3_gather_h16(rp, dirs, raw, st, tail_c, tail_s, tail_dir_out));
     const long long M = (long long)rp->n * rp->S;
     UCNERF_REQUIRE(M < (1ll << 31), "render (gather fused): %lld samples in one pass (limit 2^31 - 1)", M);
     if (int rc = check_cl_sources(rp, "render (gather fused)")) return rc;
@@ -1447,7 +1505,15 @@ int launch_mlp_fwd_bf16x3_gather(const ucnerf_render_params* rp, const float* di
     return launch_bf16(&m, nullptr, st, &f);
 }
 #else
-int launch_mlp_fwd_bf16_plain(const ucnerf_mlp_params* p, hipStream_t st) { return launch_bf16(p, nullptr, st); }
+#if !UCNERF_OPERAND_FP16
+int launch_mlp_fwd_bf16_plain_h16(const ucnerf_mlp_params* p, hipStream_t st);
+#endif
+int launch_mlp_fwd_bf16_plain(const ucnerf_mlp_params* p, hipStream_t st) {
+    UCNERF_REQUIRE(p, "mlp_fwd: null params");
+    UCNERF_REQUIRE(p->cfg.operand == 0 || p->cfg.operand == 1, "mlp_fwd: cfg.operand %d (0 = bf16 terms, 1 = fp16 terms)", p->cfg.operand);
+    UCNERF_OPERAND_DISPATCH(p->cfg.operand, launch_mlp_fwd_bf16_plain_h16(p, st));
+    return launch_bf16(p, nullptr, st);
+}
 #endif
 
 #if UCNERF_BF16_BUILD_TERMS == 3
@@ -1474,8 +1540,8 @@ __global__ void pack_all_flat_kernel(const float* __restrict__ flat, const int32
         unsigned short r = 0;
         if (k >= 0) {
             const float w = flat[k & 0x3fffffff];
-            const __bf16 hi = (__bf16)w;
-            const __bf16 val = (k >> 30) ? (__bf16)(w - (float)hi) : hi;
+            const op16 hi = (op16)w;
+            const op16 val = (k >> 30) ? (op16)(w - (float)hi) : hi;
             r = __builtin_bit_cast(unsigned short, val);
         }
         out16[i] = r;
@@ -1486,6 +1552,8 @@ __global__ void pack_all_flat_kernel(const float* __restrict__ flat, const int32
 }
 
 int launch_pack_bf16(const ucnerf_mlp_config* cfg, const float* flat, const int32_t* idx, float* out, hipStream_t st) {
+    UCNERF_REQUIRE(cfg->operand == 0 || cfg->operand == 1, "mlp_pack: cfg.operand %d (0 = bf16 terms, 1 = fp16 terms)", cfg->operand);
+    UCNERF_OPERAND_DISPATCH(cfg->operand, launch_pack_bf16_h16(cfg, flat, idx, out, st));
     Bf16Layout B;
     UCNERF_REQUIRE(bf16_layout(cfg->n_src, &B), "mlp_pack: n_src %d outside 1..8", cfg->n_src);
     const int64_t n16 = (int64_t)B.slots * (SLOT_BYTES / 2);
@@ -1506,8 +1574,8 @@ __global__ void pack_all_tab_kernel(ParamTable t, const int32_t* __restrict__ id
         unsigned short r = 0;
         if (k >= 0) {
             const float w = param_table_load(&l, k & 0x3fffffff);
-            const __bf16 hi = (__bf16)w;
-            const __bf16 val = (k >> 30) ? (__bf16)(w - (float)hi) : hi;
+            const op16 hi = (op16)w;
+            const op16 val = (k >> 30) ? (op16)(w - (float)hi) : hi;
             r = __builtin_bit_cast(unsigned short, val);
         }
         out16[i] = r;
@@ -1518,6 +1586,8 @@ __global__ void pack_all_tab_kernel(ParamTable t, const int32_t* __restrict__ id
 }
 
 int launch_pack_bf16_tab(const ucnerf_mlp_config* cfg, const ParamTable& t, const int32_t* idx, float* out, hipStream_t st) {
+    UCNERF_REQUIRE(cfg->operand == 0 || cfg->operand == 1, "mlp_pack_tensors: cfg.operand %d (0 = bf16 terms, 1 = fp16 terms)", cfg->operand);
+    UCNERF_OPERAND_DISPATCH(cfg->operand, launch_pack_bf16_tab_h16(cfg, t, idx, out, st));
     Bf16Layout B;
     UCNERF_REQUIRE(bf16_layout(cfg->n_src, &B), "mlp_pack: n_src %d outside 1..8", cfg->n_src);
     const int64_t n16 = (int64_t)B.slots * (SLOT_BYTES / 2);

@@ -132,12 +132,14 @@ class FusedSession:
         fresh=True (calls under autograd): packed now, and `flat` is a SNAPSHOT of the buffer (one 0.7-MB copy) -- the backward takes its
         weight gradients against the parameters of this very forward, whatever an optimizer does in between.
         Otherwise the stream follows the weight-cache policy (set_weight_cache) and `flat` is the live buffer."""
-        key = (precision, layout)
         live = self.store.sync()
         dev = live.device
         if live.dtype != torch.float32:
             raise RuntimeError("uc_nerf_amd: network parameters must be float32")
-        pw = ops.PackedWeights.get(self.n_src, layout, dev, precision)
+        # (the 16-bit terms of the split precisions, ops.set_split_operand: a training forward keeps activations for a backward that splits them into
+        #  bf16 terms, so it is always packed for those)
+        pw = ops.PackedWeights.get(self.n_src, layout, dev, precision, operand=0 if fresh else None)
+        key = (precision, layout, pw.operand)
         ent = self.weights.get(key)
         if fresh:
             # (the stream belongs to this call's autograd context until its backward has run: it is never entered in the cache, where a later

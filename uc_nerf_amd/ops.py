@@ -611,15 +611,34 @@ def set_backward_mode(mode):
     _backward_mode = BACKWARD_MODES[mode]
 
 
+SPLIT_OPERANDS = {"bf16": 0, "fp16": 1}
+_split_operand = SPLIT_OPERANDS[os.environ.get("UCNERF_SPLIT_OPERAND", "bf16")]
+
+
+def set_split_operand(kind):
+    """The 16-bit terms of the split precisions ("bf16x3", "bf16x3_fused", "bf16") from now on (ucnerf_mlp_config.operand, ABI v6): "bf16" (default:
+    8 significant bits per term, float32's range) or "fp16" (11 bits per term at the same matrix-core rate -- the three-product split then holds ~22
+    bits and the renders sit at float32 level, +1.8 % kernel time -- but fp16's range: an activation or weight beyond 65 504 overflows).  Takes effect
+    for every weight stream packed afterwards (PackedWeights.get keys on it); inference only."""
+    global _split_operand
+    if kind not in SPLIT_OPERANDS:
+        raise ValueError("uc_nerf_amd: split operand must be 'bf16' or 'fp16', got %r" % (kind,))
+    _split_operand = SPLIT_OPERANDS[kind]
+
+
+def split_operand():
+    return "fp16" if _split_operand else "bf16"
+
+
 class PackedWeights:
     """Pack index (host-built by the library, cached on device) + packing of a flat parameter vector."""
     _cache = {}
 
     PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2, "bf16x3_fused": 3}     # 3: bf16x3 with the gather inside the MLP kernel (render passes only)
 
-    def __init__(self, n_src, pe_layout, device, precision="f32"):
-        self.cfg = L.MlpConfig(n_src, pe_layout, self.PRECISIONS[precision])
-        self.precision = precision
+    def __init__(self, n_src, pe_layout, device, precision="f32", operand=0):
+        self.cfg = L.MlpConfig(n_src, pe_layout, self.PRECISIONS[precision], 0 if precision == "f32" else int(operand))
+        self.precision, self.operand = precision, self.cfg.operand
         lib = L.lib()
         self.n_params = lib.ucnerf_mlp_param_count(C.addressof(self.cfg))
         self.n_stream = lib.ucnerf_mlp_stream_count(C.addressof(self.cfg))
@@ -634,10 +653,13 @@ class PackedWeights:
         self.device = device
 
     @classmethod
-    def get(cls, n_src, pe_layout, device, precision="f32"):
-        key = (n_src, pe_layout, str(device), precision)
+    def get(cls, n_src, pe_layout, device, precision="f32", operand=None):
+        """operand: None = the module's current setting (set_split_operand); "bf16" / "fp16" / 0 / 1 to pin it."""
+        op = _split_operand if operand is None else SPLIT_OPERANDS.get(operand, operand)
+        op = 0 if precision == "f32" else int(op)
+        key = (n_src, pe_layout, str(device), precision, op)
         if key not in cls._cache:
-            cls._cache[key] = cls(n_src, pe_layout, device, precision)
+            cls._cache[key] = cls(n_src, pe_layout, device, precision, op)
         return cls._cache[key]
 
     def pack(self, flat, out=None):
