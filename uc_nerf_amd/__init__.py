@@ -8,7 +8,7 @@ Layers:
 
 GPU only: there is no CPU or PyTorch fallback; calls on CPU tensors raise.
 """
-__version__ = "0.4.0"
+__version__ = "0.5.0"
 
 
 def set_inference_precision(precision):
