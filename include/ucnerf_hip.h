@@ -322,8 +322,8 @@ typedef struct {
                              0: bf16 (8 significant bits per term; any float32 range).  The default.
                              1: fp16 (v_mfma_f32_32x32x16_f16: 11 significant bits per term at the same matrix-core rate, so the three-product
                                 split holds ~22 bits -- rendered outputs at float32 level where the bf16 split is at 16 .. 17 bits).  fp16's RANGE
-                                is the price: an activation or weight beyond 65 504 overflows (float32 itself no longer resolves 1e-4 of a
-                                sigmoid's argument there), and a term below 6e-5 is held with an absolute resolution of 3e-8.  Inference forward
+                                is the price: the conversions round toward zero, so an activation beyond 131 008 is clamped -- finite, but wrong
+                                (float32 itself resolves no more than 1e-2 of it) -- and a term below 6e-5 is held with an absolute resolution of 3e-8.  Inference forward
                                 only (ucnerf_mlp_fwd_train refuses it).  Ignored by precision 0. */
 } ucnerf_mlp_config;
 

@@ -269,17 +269,27 @@ __device__ __forceinline__ Frag split8(const float (&x)[8]) {
     Frag f;
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
+#if UCNERF_OPERAND_FP16
+        // fp16 terms: BOTH conversions toward zero (v_cvt_pkrtz_f16_f32) -- a value beyond fp16's range then becomes 65 504, never an infinity: an
+        // activation past 131 008 is clamped (wrong, but finite: float32 itself resolves no more than 1e-2 of it), nothing ever turns into a NaN.
+        // hi + lo holds 20 .. 21 bits (a rounded pair would hold 22).
+        const auto hp = __builtin_amdgcn_cvt_pkrtz(x[j], x[j + 1]);
+        const unsigned packed = __builtin_bit_cast(unsigned, hp);                 // [hi(x[j+1]) | hi(x[j])]
+        hi[j >> 1] = packed;
+        const f32x2 h = {(float)hp[0], (float)hp[1]};
+        const f32x2 l = (f32x2){x[j], x[j + 1]} - h;
+        const auto lp = __builtin_amdgcn_cvt_pkrtz(l.x, l.y);
+        f.lo[j] = (op16)lp[0];
+        f.lo[j + 1] = (op16)lp[1];
+#else
         const bf16x2 hp = __builtin_convertvector((f32x2){x[j], x[j + 1]}, bf16x2);      // ONE v_cvt_pk_bf16_f32 (two scalar conversions were not merged)
         const unsigned packed = __builtin_bit_cast(unsigned, hp);                 // [hi(x[j+1]) | hi(x[j])]
         hi[j >> 1] = packed;
-#if UCNERF_OPERAND_FP16
-        const f32x2 h = {(float)hp[0], (float)hp[1]};
-#else
         const f32x2 h = {__builtin_bit_cast(float, packed << 16), __builtin_bit_cast(float, packed & 0xffff0000u)};
-#endif
         const f32x2 l = (f32x2){x[j], x[j + 1]} - h;
         f.lo[j] = (op16)l.x;
         f.lo[j + 1] = (op16)l.y;
+#endif
     }
     f.hi = __builtin_bit_cast(bf16x8, hi);
     return f;

@@ -139,8 +139,10 @@ class FusedSession:
         # (the 16-bit terms of the split precisions, ops.set_split_operand: a training forward keeps activations for a backward that splits them into
         #  bf16 terms, so it is always packed for those)
         pw = ops.PackedWeights.get(self.n_src, layout, dev, precision, operand=0 if fresh else None)
-        key = (precision, layout, pw.operand)
+        key = (precision, layout)
         ent = self.weights.get(key)
+        if ent is not None and ent.get("operand", 0) != pw.operand:       # (the terms changed since: another stream format)
+            ent = None
         if fresh:
             # (the stream belongs to this call's autograd context until its backward has run: it is never entered in the cache, where a later
             #  no_grad call of the same precision would re-pack it in place -- with other values, had an optimizer stepped in between)
@@ -153,11 +155,11 @@ class FusedSession:
             #  buffer may sit where the old one did, with the same version count; round 5's stateful fuzzer, tests/fuzz_dropin.py, found exactly that)
             sig = (self.store.generation, live._version) + tuple(p._version for p in self.params)
             if ent is None or ent["sig"] != sig:
-                ent = self.weights[key] = {"sig": sig, "ws": pw.pack(live)}
+                ent = self.weights[key] = {"sig": sig, "ws": pw.pack(live), "operand": pw.operand}
             return live, pw, ent["ws"]
         # "verify": one launch re-packs the stream IN PLACE from the live buffer
         if ent is None or ent["ws"].device != dev:
-            ent = self.weights[key] = {"sig": None, "ws": torch.empty(pw.n_stream, device=dev)}
+            ent = self.weights[key] = {"sig": None, "ws": torch.empty(pw.n_stream, device=dev), "operand": pw.operand}
         pw.pack(live, out=ent["ws"])
         ent["sig"] = None
         return live, pw, ent["ws"]
