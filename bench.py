@@ -753,7 +753,7 @@ def main():
                                          "headline_max_abs_rgb_vs_f32": (o3["rgb"] - ref3["rgb"]).abs().max().item(),
                                          "headline_max_abs_depth_vs_f32": (o3["depth"] - ref3["depth"]).abs().max().item(),
                                          "note": "NOT the headline: the headline's route and precision with fp16 instead of bf16 terms (set_split_operand('fp16'): "
-                                                 "~22-bit products at the same matrix-core rate; fp16's range -- no activation beyond 65 504). Distances: to the "
+                                                 "~21-bit products at the same matrix-core rate; fp16's range -- activations beyond 131 008 are clamped, never infinite). Distances: to the "
                                                  "exact-f32 kernel on the same fine depths, this render's and the headline's"}
             return res
         def other_route():
