@@ -52,15 +52,19 @@ def set_backward_mode(mode):
     ops.set_backward_mode(mode)
 
 
-def install_dropin(precision=None, training_precision=None):
+def install_dropin(precision=None, training_precision=None, split_operand=None):
     """Registers this package's mirrors under the reference's module names (`network.renderer`,
     `network.models`, `utils.utils`, `utils.run_nerf_helpers`, `data.ray_utils`) so that the reference's
     train.py imports resolve here unchanged.  See INTEGRATION.md.
     precision: MLP arithmetic of `rendering()` under torch.no_grad() (None keeps the default, "bf16x3_fused"; "f32" = exact fp32 MFMA);
-    training_precision: of the training forward (None keeps "f32")."""
+    training_precision: of the training forward (None keeps "f32");
+    split_operand: the 16-bit terms of the split precisions under no_grad, "bf16" or "fp16" (None keeps the current setting: "bf16" unless
+    UCNERF_SPLIT_OPERAND says otherwise) -- set_split_operand."""
     import importlib
     if precision is not None:
         set_inference_precision(precision)
+    if split_operand is not None:
+        set_split_operand(split_operand)
     if training_precision is not None:
         set_training_precision(training_precision)
     import sys
