@@ -241,3 +241,25 @@ def test_entry_points_refuse_null_and_empty_arguments_without_crashing():
     assert r.returncode == 0, "the probe died (exit %d): %s" % (r.returncode, r.stderr[-2000:])
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["calls"] >= 100 and not out["problems"], out["problems"]
+
+
+def test_split_operand_setting_is_part_of_a_packer_identity():
+    """ucnerf_mlp_config.operand (ABI v6) on the host side: the module setting selects the packer (and with it the stream format), "f32" ignores it,
+    an unknown kind is refused, and the struct mirror carries the field where the header has it."""
+    from uc_nerf_amd import _lib as L
+    from uc_nerf_amd import ops
+    assert [f[0] for f in L.MlpConfig._fields_] == ["n_src", "pe_layout", "precision", "operand"]
+    assert L.lib().ucnerf_sizeof(b"ucnerf_mlp_config") == C.sizeof(L.MlpConfig) == 16
+    dev = torch.device("cpu")
+    try:
+        a = ops.PackedWeights.get(6, 0, dev, "bf16x3_fused")
+        ops.set_split_operand("fp16")
+        b = ops.PackedWeights.get(6, 0, dev, "bf16x3_fused")
+        assert a is not b and (a.operand, b.operand) == (0, 1) and a.n_stream == b.n_stream
+        assert ops.PackedWeights.get(6, 0, dev, "f32").operand == 0
+        assert ops.PackedWeights.get(6, 0, dev, "bf16x3_fused", operand="bf16") is a
+        with pytest.raises(ValueError):
+            ops.set_split_operand("tf32")
+    finally:
+        ops.set_split_operand("bf16")
+    assert ops.PackedWeights.get(6, 0, dev, "bf16x3_fused") is a
