@@ -276,12 +276,9 @@ __device__ __forceinline__ Frag split8(const float (&x)[8]) {
         const auto hp = __builtin_amdgcn_cvt_pkrtz(x[j], x[j + 1]);
         const unsigned packed = __builtin_bit_cast(unsigned, hp);                 // [hi(x[j+1]) | hi(x[j])]
         hi[j >> 1] = packed;
-        // x - (float)hi as ONE mixed-precision fma per value (v_fma_mix_f32 reads the fp16 half in place): no conversion back, no packed subtract
-        // (written as asm: the compiler converts the halves back with v_cvt_f32_f16 and subtracts instead)
-        float l0, l1;
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(packed), "v"(x[j]));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(packed), "v"(x[j + 1]));
-        const auto lp = __builtin_amdgcn_cvt_pkrtz(l0, l1);
+        const f32x2 h = {(float)hp[0], (float)hp[1]};
+        const f32x2 l = (f32x2){x[j], x[j + 1]} - h;
+        const auto lp = __builtin_amdgcn_cvt_pkrtz(l.x, l.y);
         f.lo[j] = (op16)lp[0];
         f.lo[j + 1] = (op16)lp[1];
 #else
