@@ -40,7 +40,7 @@ def set_training_precision(precision):
 
 def set_split_operand(kind):
     """The 16-bit terms of the split precisions: "bf16" (default: 8 significant bits per term, float32's range) or "fp16" (11 bits per term at the
-    same matrix-core rate: renders at float32 level, +1–2 % kernel time; fp16's range -- an activation beyond 65 504 overflows) -- ops.set_split_operand."""
+    same matrix-core rate: renders at float32 level, no measurable kernel time (+0.1 %); fp16's range -- an activation beyond 65 504 overflows) -- ops.set_split_operand."""
     from . import ops
     ops.set_split_operand(kind)
 

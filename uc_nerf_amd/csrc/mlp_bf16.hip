@@ -267,6 +267,10 @@ typedef op16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ Frag split8(const float (&x)[8]) {
     u32x4 hi;
     Frag f;
+#if UCNERF_OPERAND_FP16
+    float minus_one = -1.0f;
+    asm volatile("" : "+s"(minus_one));
+#endif
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
 #if UCNERF_OPERAND_FP16
@@ -276,9 +280,12 @@ __device__ __forceinline__ Frag split8(const float (&x)[8]) {
         const auto hp = __builtin_amdgcn_cvt_pkrtz(x[j], x[j + 1]);
         const unsigned packed = __builtin_bit_cast(unsigned, hp);                 // [hi(x[j+1]) | hi(x[j])]
         hi[j >> 1] = packed;
-        const f32x2 h = {(float)hp[0], (float)hp[1]};
-        const f32x2 l = (f32x2){x[j], x[j + 1]} - h;
-        const auto lp = __builtin_amdgcn_cvt_pkrtz(l.x, l.y);
+        // x - (float)hi as ONE mixed-precision fma per value: v_fma_mix_f32 reads the fp16 half in place (no conversion back, no packed subtract: four
+        // vector instructions per pair).  The compiler selects it only for a multiplier it cannot fold -- hence the opaque -1 in a scalar register; it
+        // must be the COMPILER's instruction, not inline asm: the operands come out of MFMA accumulators and only the compiler's hazard recognizer
+        // inserts the wait states such a read needs (an asm version was wrong on a few rays in 10^4, profiles/r05_experiments.md section 13).
+        const float l0 = __builtin_fmaf((float)hp[0], minus_one, x[j]), l1 = __builtin_fmaf((float)hp[1], minus_one, x[j + 1]);
+        const auto lp = __builtin_amdgcn_cvt_pkrtz(l0, l1);
         f.lo[j] = (op16)lp[0];
         f.lo[j + 1] = (op16)lp[1];
 #else

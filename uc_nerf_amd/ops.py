@@ -618,7 +618,7 @@ _split_operand = SPLIT_OPERANDS[os.environ.get("UCNERF_SPLIT_OPERAND", "bf16")]
 def set_split_operand(kind):
     """The 16-bit terms of the split precisions ("bf16x3", "bf16x3_fused", "bf16") from now on (ucnerf_mlp_config.operand, ABI v6): "bf16" (default:
     8 significant bits per term, float32's range) or "fp16" (11 bits per term at the same matrix-core rate -- the three-product split then holds ~22
-    bits and the renders sit at float32 level, +1–2 % kernel time -- but fp16's range: an activation beyond 131 008 is clamped, a term below 6e-5 is held
+    bits and the renders sit at float32 level, no measurable kernel time (+0.1 %) -- but fp16's range: an activation beyond 131 008 is clamped, a term below 6e-5 is held
     to 3e-8 absolute).  Takes effect
     for every weight stream packed afterwards (PackedWeights.get keys on it); inference only."""
     global _split_operand
