@@ -267,7 +267,7 @@ typedef op16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ Frag split8(const float (&x)[8]) {
     u32x4 hi;
     Frag f;
-#if UCNERF_OPERAND_FP16
+#if UCNERF_OPERAND_FP16 && !UCNERF_BF16_BUILD_TAIL
     float minus_one = -1.0f;
     asm volatile("" : "+s"(minus_one));
 #endif
@@ -284,7 +284,13 @@ __device__ __forceinline__ Frag split8(const float (&x)[8]) {
         // vector instructions per pair).  The compiler selects it only for a multiplier it cannot fold -- hence the opaque -1 in a scalar register; it
         // must be the COMPILER's instruction, not inline asm: the operands come out of MFMA accumulators and only the compiler's hazard recognizer
         // inserts the wait states such a read needs (an asm version was wrong on a few rays in 10^4, profiles/r05_experiments.md section 13).
+        // (The tail-route build forms the same value -- x - hi is exact either way -- by converting the half back: its kernels have no scalar register
+        //  to spare for the -1 and spilled three vector registers with it.)
+#if UCNERF_BF16_BUILD_TAIL
+        const float l0 = x[j] - (float)hp[0], l1 = x[j + 1] - (float)hp[1];
+#else
         const float l0 = __builtin_fmaf((float)hp[0], minus_one, x[j]), l1 = __builtin_fmaf((float)hp[1], minus_one, x[j + 1]);
+#endif
         const auto lp = __builtin_amdgcn_cvt_pkrtz(l0, l1);
         f.lo[j] = (op16)lp[0];
         f.lo[j + 1] = (op16)lp[1];
